@@ -1,0 +1,170 @@
+/*
+ * muse_hip.h -- C ABI of libmuse_hip.so, the MI355X (gfx950) engine for the MUSE inner loop.
+ *
+ * This is the drop-in boundary for the hot path of marius311/MuseInference.jl: the per-simulation
+ * chain  sample_x_z -> zhat_at_theta (L-BFGS over z) -> grad_theta logLike  that the reference runs
+ * once per element of the pmap in muse! / get_J! / get_H!.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference repository root).  A Julia maintainer binds
+ * these with `ccall((:sym, libmuse_hip), Cint, (...), ...)` from methods on a HipMuseProblem <:
+ * AbstractMuseProblem (julia/HipMuseInference.jl); the Python host in
+ * museinference.jl_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++/torch types; every call returns 0 on success or a
+ *     negative MUSE_ERR_* code, with a human-readable message from muse_last_error() (thread-local).
+ *   - all floating point is IEEE double ("f64"); vectors are contiguous; batched arrays are row-major
+ *     [element][component].
+ *   - `mem` arguments say where the caller's vectors live: MUSE_MEM_HOST or MUSE_MEM_DEVICE
+ *     (a hipMalloc'd / torch device pointer on the context's device).
+ *   - theta is always passed in the UN-transformed space (src/interface.jl:74-75,96-97,146-147) as a
+ *     host array of ntheta doubles.
+ *   - one context per device; calls on one context are serialised on its stream; distinct contexts
+ *     are independent and may be driven from different threads.
+ *   - there is no CPU fallback: every entry fails with MUSE_ERR_HIP if no gfx950 device is usable.
+ *
+ * Models (the reference takes user closures, src/simple.jl:79-89; closures cannot cross a C ABI, so
+ * the models of BASELINE.json's configs are compiled in):
+ *   MUSE_MODEL_FUNNEL  z_i ~ N(0, e^{theta_k(i)}), x_i ~ N(z_i, 1); ntheta contiguous equal blocks,
+ *                      k(i) = floor(i*ntheta/N).  ntheta = 1 is the reference's funnel
+ *                      (src/simple.jl:59-73, docs/src/index.md:154-168).
+ *   MUSE_MODEL_NOISE   z_i ~ N(0,1), x_i ~ N(z_i, e^theta); ntheta = 1.
+ *   MUSE_MODEL_SMOOTH  z as FUNNEL, x = A z + n with A the periodic (1/4,1/2,1/4) stencil.
+ *
+ * Random streams: simulation `sim` of master seed `seed` always sees the same normals
+ * (Philox4x32-10 keyed by seed, counter = (element, sim)), in every call and on every GPU -- the
+ * reference's split_rng contract (src/util.jl:87-92, src/muse.jl:134,169,323,506).
+ */
+#ifndef MUSE_HIP_H
+#define MUSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUSE_MODEL_FUNNEL 0
+#define MUSE_MODEL_NOISE 1
+#define MUSE_MODEL_SMOOTH 2
+
+#define MUSE_MEM_HOST 0
+#define MUSE_MEM_DEVICE 1
+
+#define MUSE_MAX_THETA 8
+
+/* error codes */
+#define MUSE_OK 0
+#define MUSE_ERR_INVALID (-1) /* bad argument                       */
+#define MUSE_ERR_HIP (-2)     /* HIP runtime failure / no device    */
+#define MUSE_ERR_NODATA (-3)  /* include_data without muse_set_data */
+#define MUSE_ERR_ALLOC (-4)   /* device allocation failed           */
+#define MUSE_ERR_RCCL (-5)    /* RCCL failure                       */
+
+/* starting point of a MAP solve */
+#define MUSE_Z0_ZERO 0 /* zero(z): muse! first iteration (src/muse.jl:151), zhat_guess_from_truth (src/interface.jl:184-186) */
+#define MUSE_Z0_TRUE 1 /* the simulation's own z: get_J! (src/muse.jl:511); the data element starts from zero */
+#define MUSE_Z0_WARM 2 /* the context's resident zhat of the same element: muse! iterations > 1 (src/muse.jl:181) */
+
+/* solver status per element; the host applies the reference's semantics (src/interface.jl:168-171):
+ * status >= MUSE_STATUS_MAXITER is "did not converge" (warning), MUSE_STATUS_NONFINITE is the @error case. */
+#define MUSE_STATUS_G_CONVERGED 0       /* ||grad_z||_inf <= atol */
+#define MUSE_STATUS_X_CONVERGED 1       /* step of exactly zero length (x_abstol = 0) */
+#define MUSE_STATUS_F_CONVERGED 2       /* objective unchanged twice in a row (f_abstol = 0, successive_f_tol = 1) */
+#define MUSE_STATUS_MAXITER 3           /* 1000 iterations */
+#define MUSE_STATUS_LINESEARCH_FAILED 4 /* HagerZhang gave up (LineSearchException) */
+#define MUSE_STATUS_NONFINITE 5         /* non-finite objective or gradient */
+
+/* what Optim's result carries that muse! keeps in `history` (src/muse.jl:171,175,218) */
+typedef struct muse_info {
+    int32_t iterations; /* L-BFGS iterations K */
+    int32_t f_calls;    /* objective+gradient evaluations E */
+    int32_t status;     /* MUSE_STATUS_* */
+    int32_t hist_words; /* sum over iterations of the number of (dx,dg) pairs used by the two-loop recursion */
+    double f_min;       /* -logLike at the returned point */
+    double gnorm;       /* ||grad_z||_inf at the returned point */
+} muse_info;
+
+typedef struct muse_ctx muse_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* Replaces constructing a problem object (SimpleMuseProblem, src/simple.jl:79-89). */
+int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out);
+int muse_ctx_destroy(muse_ctx* ctx);
+const char* muse_last_error(void);
+/* prob.x, the observed data (src/simple.jl:5, used at src/muse.jl:170). */
+int muse_set_data(muse_ctx* ctx, const double* x, int mem);
+/* Run the context's work on a caller-owned hipStream_t (NULL = the context's own stream). */
+int muse_set_stream(muse_ctx* ctx, void* hip_stream);
+/* Storage policy of the solver kernel: -1 automatic, 0 streaming (vectors in HBM), 1 resident
+ * (vectors in registers/LDS, N <= muse_max_resident_n()).  Results are bitwise independent of it. */
+int muse_set_placement(muse_ctx* ctx, int placement);
+int64_t muse_max_resident_n(void);
+int muse_synchronize(muse_ctx* ctx);
+/* Device time in ms of the most recent solver launch (HIP events on the context's stream). */
+int muse_last_kernel_ms(muse_ctx* ctx, float* ms);
+
+/* ---- per-simulation operators (the AbstractMuseProblem interface, src/interface.jl:4-186) ----- */
+/* sample_x_z(prob, rng, theta) -> (;x, z)                       src/interface.jl:92-99, src/simple.jl:95 */
+int muse_sample_x_z(muse_ctx* ctx, uint64_t seed, int64_t sim, const double* theta, double* x_out,
+                    double* z_out, int mem);
+/* logLike_and_grad_z(prob, x, z, theta) -> (logLike, grad_z logLike)      src/interface.jl:68-83, src/simple.jl:94 */
+int muse_logLike_and_grad_z(muse_ctx* ctx, const double* x, const double* z, const double* theta,
+                            double* logLike_out, double* grad_out, int mem);
+/* grad_theta logLike(prob, x, z, theta) -> ntheta doubles (host)            src/interface.jl:41-58, src/simple.jl:92 */
+int muse_grad_theta(muse_ctx* ctx, const double* x, const double* z, const double* theta, double* g_out,
+                    int mem);
+/* zhat_at_theta(prob, x, z0, theta; grad_z_logLike_atol) -> (zhat, info)    src/interface.jl:141-171
+ * L-BFGS (m=10, HagerZhang, InitialStatic(1), scaled H0) on -logLike, stop ||grad||_inf <= atol. */
+int muse_zhat_at_theta(muse_ctx* ctx, const double* x, const double* z0, const double* theta, double atol,
+                       double* z_out, muse_info* info, int mem);
+
+/* ---- batched map bodies (one launch for all elements of the reference's pmap) ----------------- */
+/* The muse! map body (src/muse.jl:169-176) and the get_J! map body (src/muse.jl:508-525):
+ * for every element: x = data | sample_x_z(rng_sim, theta).x ; zhat = zhat_at_theta(x, z0, theta) ;
+ * g = grad_theta(x, zhat, theta).  Elements are [data (if include_data)], sim_begin .. sim_end-1,
+ * in that order; element e's zhat stays resident in the context at slot e (warm start of the next
+ * call, src/muse.jl:181).  g_out is [n][ntheta] host, info_out [n] host (may be NULL). */
+int muse_map_and_score_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                             int include_data, const double* theta, double atol, int z0_mode, double* g_out,
+                             muse_info* info_out);
+/* Same, enqueue only; muse_batch_wait() blocks and copies the results out.  Several batches may be
+ * enqueued before waiting only if they use distinct result areas: `result_area` in [0, 4). */
+int muse_map_and_score_batch_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                                   int include_data, const double* theta, double atol, int z0_mode,
+                                   int result_area);
+int muse_batch_wait(muse_ctx* ctx, int result_area, double* g_out, muse_info* info_out);
+/* Resident MAP state: read back / restore zhat of slots [slot_begin, slot_end) ([n][N], row-major).
+ * Serves save_MAPs (src/muse.jl:139-143,219) and checkpoint/resume (src/muse.jl:134-135,234). */
+int muse_get_zhat(muse_ctx* ctx, int64_t slot_begin, int64_t slot_end, double* out, int mem);
+int muse_set_zhat(muse_ctx* ctx, int64_t slot_begin, int64_t slot_end, const double* in, int mem);
+
+/* The get_H! finite-difference branch (src/muse.jl:407-446 with pjacobian, src/util.jl:9-27, and
+ * fdm = central_fdm(3,1), src/muse.jl:300): for sims sim_begin..sim_end-1 and every theta component j,
+ *   H[sim][:, j] = ( -1/2 f(theta0 - step_j e_j) + 1/2 f(theta0 + step_j e_j) ) / step_j,
+ *   f(theta) = grad_theta( x(theta; the sim's randoms), zhat(x; theta0, start zfid), theta0 ).
+ * fid_mode 0 reproduces the reference (src/muse.jl:417-423: every fiducial warm start is the MAP of
+ * the ONE simulation drawn from the un-split master stream, here stream index `fid_sim`);
+ * fid_mode 1 starts each sim from the MAP of its own fiducial simulation.
+ * Hs_out is [nsims][ntheta][ntheta] host, Hs[s][i][j] = d g_i / d theta_j; info_out
+ * [nsims][ntheta][2] host (may be NULL), last index 0 = plus, 1 = minus. */
+int muse_fd_jacobian_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                           const double* theta0, const double* step, double atol, int fid_mode,
+                           int64_t fid_sim, double* Hs_out, muse_info* info_out);
+
+/* ---- multi-GPU exchange of the per-sim accumulators (RCCL over xGMI) --------------------------- */
+/* Collectives C1-C3 of SURVEY.md §2: gather of per-rank score blocks (so that every rank reduces
+ * mean/var/cov in the reference's sim order, src/muse.jl:183,188,529) and sum of per-rank H
+ * accumulators (src/muse.jl:446).  One communicator per context/rank. */
+#define MUSE_UNIQUE_ID_BYTES 128
+int muse_comm_unique_id(void* id_out /* MUSE_UNIQUE_ID_BYTES, call on rank 0 and broadcast */);
+int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id);
+int muse_comm_destroy(muse_ctx* ctx);
+/* every rank contributes count doubles (host), recv_out is [nranks][count] host */
+int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, double* recv_out);
+/* in-place sum over ranks of count doubles (host) */
+int muse_allreduce_sum(muse_ctx* ctx, double* buf, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSE_HIP_H */

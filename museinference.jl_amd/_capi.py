@@ -1,0 +1,110 @@
+"""ctypes binding of libmuse_hip.so -- exactly the entry points declared in include/muse_hip.h.
+
+There is no fallback: if the shared library is missing or no HIP device is usable, loading /
+context creation raises.  Nothing in this package imports the CPU oracle (oracle/).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MODEL_FUNNEL, MODEL_NOISE, MODEL_SMOOTH = 0, 1, 2
+MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH}
+MEM_HOST, MEM_DEVICE = 0, 1
+Z0_ZERO, Z0_TRUE, Z0_WARM = 0, 1, 2
+MAX_THETA = 8
+UNIQUE_ID_BYTES = 128
+STATUS_NAMES = ("g_converged", "x_converged", "f_converged", "maxiter", "linesearch_failed", "nonfinite")
+STATUS_MAXITER, STATUS_NONFINITE = 3, 5
+
+INFO_DTYPE = np.dtype(
+    [("iterations", "<i4"), ("f_calls", "<i4"), ("status", "<i4"), ("hist_words", "<i4"),
+     ("f_min", "<f8"), ("gnorm", "<f8")]
+)
+
+
+class MuseError(RuntimeError):
+    """A libmuse_hip call returned a negative status."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libmuse_hip error {code}: {msg}")
+        self.code = code
+
+
+# symbol -> (restype, argtypes); keep in sync with include/muse_hip.h (tests check the export list)
+_vp, _i, _i64, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
+SIGNATURES = {
+    "muse_ctx_create": (_i, [_i, _i64, _i, _i, C.POINTER(_vp)]),
+    "muse_ctx_destroy": (_i, [_vp]),
+    "muse_last_error": (C.c_char_p, []),
+    "muse_set_data": (_i, [_vp, _vp, _i]),
+    "muse_set_stream": (_i, [_vp, _vp]),
+    "muse_set_placement": (_i, [_vp, _i]),
+    "muse_max_resident_n": (_i64, []),
+    "muse_synchronize": (_i, [_vp]),
+    "muse_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "muse_sample_x_z": (_i, [_vp, _u64, _i64, _vp, _vp, _vp, _i]),
+    "muse_logLike_and_grad_z": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_d), _vp, _i]),
+    "muse_grad_theta": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "muse_zhat_at_theta": (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i]),
+    "muse_map_and_score_batch": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _vp, _vp]),
+    "muse_map_and_score_batch_async": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _i]),
+    "muse_batch_wait": (_i, [_vp, _i, _vp, _vp]),
+    "muse_get_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
+    "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
+    "muse_fd_jacobian_batch": (_i, [_vp, _u64, _i64, _i64, _vp, _vp, _d, _i, _i64, _vp, _vp]),
+    "muse_comm_unique_id": (_i, [_vp]),
+    "muse_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "muse_comm_destroy": (_i, [_vp]),
+    "muse_allgather_scores": (_i, [_vp, _vp, _i64, _vp]),
+    "muse_allreduce_sum": (_i, [_vp, _vp, _i64]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load_library():
+    """dlopen libmuse_hip.so (built in-tree by build.build_extension) and declare every signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise MuseError(-2, f"{path} is missing: run museinference.jl_amd.build.build_extension() "
+                            "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MuseError(rc, load_library().muse_last_error().decode("utf-8", "replace"))
+
+
+def f8(a, n=None):
+    a = np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64)))
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} doubles, got {a.size}")
+    return a
+
+
+def ptr(a):
+    """void* of a numpy array, a raw integer device pointer, or an object with .data_ptr() (torch)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))

@@ -1,0 +1,1613 @@
+// muse_engine.hip -- MI355X (gfx950) engine for the MUSE inner loop: one persistent workgroup per
+// Monte-Carlo element runs  sample_x_z -> L-BFGS/HagerZhang MAP over z -> grad_theta score
+// entirely on the device, one launch per batch (reference: the pmap bodies of muse!/get_J!/get_H!,
+// src/muse.jl:169-176, :508-525, :426-442; the solver behind zhat_at_theta, src/interface.jl:162-171).
+//
+// Layout of one element's work on the chip
+//   * thread t of the workgroup owns the element pairs q = t + j*T  (elements 2q, 2q+1): 16 B per
+//     lane, 1 KiB per wave-instruction, for every vector in HBM (x, z, g, s, trial gradient,
+//     the 2*m history vectors) -- fully coalesced.
+//   * two storage policies share ONE solver source (the Vec accessors below), so their results are
+//     bitwise identical:
+//       - Resident: z, s and the trial gradient live in registers, x and g in LDS; only the L-BFGS
+//         history (dx, dg pairs) and the final zhat touch HBM.  N <= kMaxResidentN (LDS-bound).
+//       - Streaming: every vector lives in the workgroup's HBM scratch; any N.
+//   * all reductions are fixed-shape (per-thread sequential over j, 64-lane xor butterfly, then the
+//     wave partials summed in wave order by every thread), so a result depends only on
+//     (seed, sim, theta, N): not on the grid, the GPU count or the storage policy.
+//   * no MFMA: this is elementwise + reduction work (0.3-0.5 flop/B); the bound is HBM/LDS traffic
+//     and fp64 transcendental issue in the sampler.
+//
+// The scalar control logic (HagerZhang line search, L-BFGS bookkeeping) is evaluated redundantly
+// and identically by every thread from the broadcast reduction results: no divergence, no
+// single-thread serial sections, one barrier per reduction.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/muse_hip.h"
+#include "rng.hpp"
+
+namespace muse {
+
+constexpr int kM = 10;         // L-BFGS memory (Optim.LBFGS default m)
+constexpr int kMaxIter = 1000;  // Optim.Options default iterations
+constexpr int kMaxTheta = MUSE_MAX_THETA;
+constexpr int kResultAreas = 4;
+constexpr int64_t kMaxResidentN = 10000;
+
+// HagerZhang() defaults of LineSearches.jl
+constexpr double kHzDelta = 0.1, kHzSigma = 0.9, kHzRho = 5.0, kHzEpsilon = 1e-6, kHzGamma = 0.66, kHzPsi3 = 0.1;
+constexpr int kHzLinesearchMax = 50, kHzIterFiniteMax = 52;
+constexpr double kEps = 2.220446049250313e-16;
+
+struct ThetaSet {
+    double theta[kMaxTheta];
+    double sd[kMaxTheta];  // exp(theta/2), host libm
+    double iv[kMaxTheta];  // exp(-theta),  host libm
+};
+
+enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
+enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
+enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2 };
+
+struct BatchArgs {
+    int64_t N, ld;
+    int ntheta, kind;
+    int64_t bnd[kMaxTheta + 1];  // block k = elements [bnd[k], bnd[k+1])
+    uint64_t seed;
+    double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
+    int nproblems, include_data, z0_mode, store_zhat;
+    int64_t sim_begin, fid_slot, slot0;
+    ThetaSet tmap;                 // theta of the MAP problem and of the score
+    const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
+    const double* x_data;          // [ld]
+    const double* x_given;         // BATCH_SINGLE: [ld]
+    double* zhat;                  // [slots][ld]
+    double* scores;                // [nproblems][ntheta]
+    muse_info* info;               // [nproblems]
+    double* scratch;               // per workgroup
+    int64_t scratch_stride;        // doubles per workgroup
+    int* work_counter;
+};
+
+struct ProblemDesc {
+    int64_t sim;
+    int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
+    int64_t zslot, z0slot;         // zslot < 0: zhat not stored
+};
+
+__device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
+    ProblemDesc d;
+    if (a.kind == BATCH_STD) {
+        const bool data = a.include_data && p == 0;
+        d.sim = data ? -1 : a.sim_begin + p - (a.include_data ? 1 : 0);
+        d.x_mode = data ? X_DATA : X_SAMPLE;
+        d.z0_mode = (data && a.z0_mode == Z0_TRUE) ? Z0_ZERO : a.z0_mode;
+        d.tsample = -1;
+        d.zslot = a.store_zhat ? a.slot0 + p : -1;
+        d.z0slot = a.slot0 + p;
+    } else if (a.kind == BATCH_FD) {
+        const int per = 2 * a.ntheta;
+        d.sim = a.sim_begin + p / per;
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_COPY;
+        d.tsample = p % per;
+        d.zslot = -1;
+        d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + p / per;
+    } else {
+        d.sim = -1;
+        d.x_mode = X_GIVEN;
+        d.z0_mode = Z0_WARM;
+        d.tsample = -1;
+        d.zslot = a.slot0;
+        d.z0slot = a.slot0;
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vec accessors: (jj, i) = (register slot, element index).  Register vectors ignore i, memory
+// vectors ignore jj; the solver source is written once against this interface.
+template <int NR>
+struct RegVec {
+    double r[NR > 0 ? NR : 1];
+    __device__ __forceinline__ double get(int jj, int64_t) const { return r[jj]; }
+    __device__ __forceinline__ void set(int jj, int64_t, double v) { r[jj] = v; }
+};
+struct MemVec {
+    double* __restrict__ p;
+    __device__ __forceinline__ double get(int, int64_t i) const { return p[i]; }
+    __device__ __forceinline__ void set(int, int64_t i, double v) { p[i] = v; }
+};
+
+// Element loop of one thread: pairs q = tid + j*T, elements 2q and 2q+1, in increasing j.
+template <int T, int EPT, class F>
+__device__ __forceinline__ void for_elems(int64_t N, int tid, F&& f) {
+    if constexpr (EPT > 0) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int64_t i0 = 2 * ((int64_t)tid + (int64_t)j * T);
+            if (i0 < N) f(2 * j, i0);
+            if (i0 + 1 < N) f(2 * j + 1, i0 + 1);
+        }
+    } else {
+        for (int64_t i0 = 2 * (int64_t)tid; i0 < N; i0 += 2 * (int64_t)T) {
+            f(0, i0);
+            if (i0 + 1 < N) f(1, i0 + 1);
+        }
+    }
+}
+
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+
+// Tell the compiler a value is workgroup-uniform (it is: every lane holds the same bits).  Control
+// flow that depends on it then compiles to scalar branches and its live state to SGPRs.
+__device__ __forceinline__ double uniform(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Fixed-shape all-reduce over the workgroup: KS sums and KM NaN-propagating maxima.
+template <int T, int KS, int KM>
+__device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], double (&m)[KM > 0 ? KM : 1],
+                                                double* red, int& parity, int tid) {
+    constexpr int NW = T / 64, K = KS + KM;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) s[k] += __shfl_xor(s[k], off);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) m[k] = nanmax(m[k], __shfl_xor(m[k], off));
+    }
+    double* buf = red + parity * (NW * 8);
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) buf[wave * K + k] = s[k];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) buf[wave * K + KS + k] = m[k];
+    }
+    __syncthreads();
+    // cross-wave combine without a second barrier: lane l reads wave (l mod NW)'s partial, then an
+    // xor butterfly over NW lanes leaves the total in every lane (same fixed tree for every thread)
+    const int src = (tid & (NW - 1)) * K;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) s[k] = buf[src + k];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) m[k] = buf[src + KS + k];
+#pragma unroll
+    for (int off = NW / 2; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) s[k] += __shfl_xor(s[k], off);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) m[k] = nanmax(m[k], __shfl_xor(m[k], off));
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) s[k] = uniform(s[k]);
+#pragma unroll
+    for (int k = 0; k < KM; ++k) m[k] = uniform(m[k]);
+    parity ^= 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Models.  grad() returns d(-logLike)/dz_i and adds the element's share of -2 logLike (without the
+// constant) to facc; the score is assembled from per-block sums of score_term().
+__device__ __forceinline__ int block_of(const BatchArgs& a, int64_t i) {
+    int k = 0;
+#pragma unroll
+    for (int b = 1; b < kMaxTheta; ++b) k += (b < a.ntheta && i >= a.bnd[b]) ? 1 : 0;
+    return k;
+}
+
+template <int MAXB_>
+struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
+    static constexpr int MAXB = MAXB_;
+    static constexpr bool kStencil = false;
+    static constexpr int kId = MUSE_MODEL_FUNNEL;
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+        z = sd * n1;
+        x = z + n2;
+    }
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+        const double r = x - z;
+        facc += r * r + iv * (z * z);
+        return iv * z - r;
+    }
+    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
+};
+struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
+    static constexpr int MAXB = 1;
+    static constexpr bool kStencil = false;
+    static constexpr int kId = MUSE_MODEL_NOISE;
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+        z = n1;
+        x = n1 + sd * n2;
+    }
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+        const double r = x - z;
+        facc += iv * (r * r) + z * z;
+        return z - iv * r;
+    }
+    __device__ static __forceinline__ double score_term(double x, double z) {
+        const double r = x - z;
+        return r * r;
+    }
+};
+template <int MAXB_>
+struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4); streaming policy only
+    static constexpr int MAXB = MAXB_;
+    static constexpr bool kStencil = true;
+    static constexpr int kId = MUSE_MODEL_SMOOTH;
+    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Storage policies.
+template <int T_>
+struct PlaceStreaming {
+    static constexpr int T = T_, EPT = 0;
+    static constexpr bool kResident = false, kXgLds = false;
+    using VX = MemVec; using VG = MemVec; using VZ = MemVec; using VS = MemVec;
+};
+template <int T_, int EPT_, bool XG_LDS>
+struct PlaceResident {
+    static constexpr int T = T_, EPT = EPT_;
+    static constexpr bool kResident = true, kXgLds = XG_LDS;
+    using VX = typename std::conditional<XG_LDS, MemVec, RegVec<2 * EPT_>>::type;
+    using VG = VX;
+    using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;
+};
+
+struct HzPoint {
+    double a, v, d;  // alpha, phi(alpha), dphi(alpha)
+    int id;          // evaluation sequence number (0 = the point alpha=0)
+};
+
+// ------------------------------------------------------------------------------------------------
+template <class Model, class Place>
+struct Solver {
+    static constexpr int T = Place::T, EPT = Place::EPT, MAXB = Model::MAXB;
+    const BatchArgs& a;
+    const int tid;
+    double* red;
+    double* sh_rho;    // [kM]
+    double* sh_gam;    // [kM]
+    double* sh_alpha;  // [kM]
+    int parity;
+    typename Place::VX x;
+    typename Place::VG g;
+    typename Place::VZ z;
+    typename Place::VS s;
+    double* hist;  // [kM][2][ld] in HBM
+    double iv0, sd0;   // MAXB == 1: coefficients in registers
+    double* sh_sd;     // MAXB > 1: sampling sd[k] in LDS (the MAP iv[k] is read from the LDS argument block)
+    int f_calls;
+    double last_c, last_gmax;
+
+    __device__ Solver(const BatchArgs& a_, int tid_, double* red_, double* shs) : a(a_), tid(tid_), red(red_), parity(0) {
+        sh_rho = shs;
+        sh_gam = shs + kM;
+        sh_alpha = shs + 2 * kM;
+        sh_sd = shs + 3 * kM;
+    }
+    __device__ __forceinline__ double* hdx(int slot) const { return hist + (int64_t)(2 * slot) * a.ld; }
+    __device__ __forceinline__ double* hdg(int slot) const { return hist + (int64_t)(2 * slot + 1) * a.ld; }
+    __device__ __forceinline__ double ivk(int64_t i) const {
+        if constexpr (MAXB == 1) return iv0;
+        else return a.tmap.iv[block_of(a, i)];
+    }
+    __device__ __forceinline__ double sdk(int64_t i) const {
+        if constexpr (MAXB == 1) return sd0;
+        else return sh_sd[block_of(a, i)];
+    }
+    __device__ __forceinline__ int blk(int64_t i) const {
+        if constexpr (MAXB == 1) return 0;
+        else return block_of(a, i);
+    }
+
+    // d(-logLike)/dz_i at the point whose components are given by zt(.), for the stencil model
+    // (streaming only: neighbours come from HBM/L1).  Adds the element's share of -2 logLike to facc.
+    template <class ZT>
+    __device__ __forceinline__ double stencil_grad(ZT&& zt, int64_t i, double& facc) const {
+        const int64_t N = a.N;
+        auto wrap = [&](int64_t k) { return k < 0 ? k + N : (k >= N ? k - N : k); };
+        const int64_t im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
+        const double zm2 = zt(im2), zm1 = zt(im1), z0 = zt(i), zp1 = zt(ip1), zp2 = zt(ip2);
+        const double rm = x.get(0, im1) - (0.5 * zm1 + 0.25 * (zm2 + z0));
+        const double r0 = x.get(0, i) - (0.5 * z0 + 0.25 * (zm1 + zp1));
+        const double rp = x.get(0, ip1) - (0.5 * zp1 + 0.25 * (z0 + zp2));
+        const double ivk = this->ivk(i);
+        facc += r0 * r0 + ivk * (z0 * z0);
+        return ivk * z0 - (0.5 * r0 + 0.25 * (rm + rp));
+    }
+
+    // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
+    //    dphi = grad . s and gmax = ||grad||_inf; the gradient itself is stored (into g) only when
+    //    STORE_G -- a line-search trial needs just the three scalars.  One pass, one barrier.
+    template <bool USE_S, bool STORE_G>
+    __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
+        double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
+        if constexpr (!Model::kStencil) {
+            for_elems<T, EPT>(a.N, tid, [&](int jj, int64_t i) {
+                double zi = z.get(jj, i);
+                double si = 0.0;
+                if constexpr (USE_S) {
+                    si = s.get(jj, i);
+                    zi = zi + c * si;
+                }
+                const double gi = Model::grad(ivk(i), x.get(jj, i), zi, sum[0]);
+                if constexpr (STORE_G) g.set(jj, i, gi);
+                if constexpr (USE_S) sum[1] += gi * si;
+                mx[0] = nanmax(mx[0], fabs(gi));
+            });
+        } else {
+            auto zt = [&](int64_t k) {
+                double v = z.get(0, k);
+                if constexpr (USE_S) v = v + c * s.get(0, k);
+                return v;
+            };
+            for_elems<T, EPT>(a.N, tid, [&](int jj, int64_t i) {
+                const double gi = stencil_grad(zt, i, sum[0]);
+                if constexpr (STORE_G) g.set(jj, i, gi);
+                if constexpr (USE_S) sum[1] += gi * s.get(0, i);
+                mx[0] = nanmax(mx[0], fabs(gi));
+            });
+        }
+        block_allreduce<T, 2, 1>(sum, mx, red, parity, tid);
+        f = 0.5 * (sum[0] + a.f_const);
+        dphi = sum[1];
+        gmax = mx[0];
+        f_calls += 1;
+    }
+
+    // phi(c), dphi(c) of the line search (the NLSolversBase objective cache is last_c/last_phi).
+    __device__ __forceinline__ void phidphi(double c, double& phi, double& dphi) {
+        double gm;
+        eval<true, false>(c, phi, dphi, gm);
+        last_c = c;
+        last_gmax = gm;
+        last_phi = phi;
+    }
+
+    __device__ __forceinline__ static bool finite2(double p, double d) { return isfinite(p) && isfinite(d); }
+    __device__ __forceinline__ static double eps_of(double b) {
+        const double ab = fabs(b);
+        return __longlong_as_double(__double_as_longlong(ab) + 1) - ab;
+    }
+    __device__ __forceinline__ static double nextup(double v) {  // nextfloat for finite v
+        if (v == 0.0) return 4.9406564584124654e-324;
+        const long long b = __double_as_longlong(v);
+        return __longlong_as_double(v > 0.0 ? b + 1 : b - 1);
+    }
+    __device__ __forceinline__ static bool wolfe(double c, double phi_c, double dphi_c, double phi_0, double dphi_0,
+                                                 double phi_lim) {
+        const bool w1 = (kHzDelta * dphi_0 >= (phi_c - phi_0) / c) && (dphi_c >= kHzSigma * dphi_0);
+        const bool w2 = ((2.0 * kHzDelta - 1.0) * dphi_0 >= dphi_c) && (dphi_c >= kHzSigma * dphi_0) && (phi_c <= phi_lim);
+        return w1 || w2;
+    }
+    __device__ __forceinline__ static double secant(const HzPoint& p, const HzPoint& q) {
+        return (p.a * q.d - q.a * p.d) / (q.d - p.d);
+    }
+
+    // HagerZhang line search (LineSearches.jl defaults) from the InitialStatic guess c0, written as a
+    // state machine around ONE evaluation site so that the evaluation pass is instantiated once:
+    //   S_INIT   first trial (shrunk by psi3 while non-finite)
+    //   S_EXPAND bracketing expansion c *= rho           (HZ stages B0-B3)
+    //   S_BIS    bisection of [A,B] with dphi(B) < 0      (HZ stage U3, theta = 1/2)
+    //   S_SEC1/2 the two secant steps of secant2          (HZ stages S1-S4)
+    //   S_MID    bisection step of the main loop when the secant steps shrink too slowly
+    //   S_FINAL  re-evaluation at the accepted step when it was not the last trial (update_g!)
+    // Points carry an evaluation id so that "which endpoint did update() replace" (HZ U0-U3) is an
+    // id comparison, as the index comparisons of the published algorithm.
+    // Returns true on success.  On failure (LineSearchException / failed assertion) alpha is the step
+    // Optim falls back to.  On success last_phi/last_gmax are the scalars at z + alpha s.
+    __device__ bool linesearch(double c0, double phi_0, double dphi_0, double& alpha) {
+        enum { S_INIT, S_EXPAND, S_BIS, S_SEC1, S_SEC2, S_MID, S_FINAL };
+        enum { CONT_BRACKET, CONT_UPD1, CONT_UPD2, CONT_UPD3 };
+        alpha = 0.0;
+        if (!finite2(phi_0, dphi_0)) return false;
+        if (dphi_0 >= kEps * fabs(phi_0)) return false;  // not a descent direction
+        if (dphi_0 >= 0.0 || c0 <= kEps) return true;    // alpha = 0, nothing evaluated
+        const double phi_lim = phi_0 + kHzEpsilon * fabs(phi_0);
+        const HzPoint P0{0.0, phi_0, dphi_0, 0};
+        HzPoint A = P0, B = P0, C = P0, prev = P0, a0 = P0, b0 = P0;
+        double alphamax = INFINITY, cold = 0.0, fail_alpha = 0.0, c = c0;
+        int state = S_INIT, cont = CONT_BRACKET, iter = 1, iterfinite = 1, nid = 1;
+        bool ok = true;
+        for (;;) {
+            double phi, dphi;
+            phidphi(c, phi, dphi);
+            const bool fin = finite2(phi, dphi);
+            switch (state) {
+                case S_INIT:
+                    if (!fin) {
+                        if (iterfinite < kHzIterFiniteMax) { iterfinite += 1; c *= kHzPsi3; continue; }
+                        alpha = 0.0;
+                        goto L_DONE;
+                    }
+                    C = HzPoint{c, phi, dphi, nid++};
+                    goto L_BRACKET_TOP;
+                case S_EXPAND:
+                    if (!fin) {
+                        if (c > nextup(cold) && iterfinite < kHzIterFiniteMax) {
+                            alphamax = c;
+                            iterfinite += 1;
+                            c = (cold + c) / 2.0;
+                            continue;
+                        }
+                        alpha = cold;
+                        goto L_DONE;
+                    }
+                    C = HzPoint{c, phi, dphi, nid++};
+                    iter += 1;
+                    goto L_BRACKET_TOP;
+                case S_BIS: {
+                    if (!fin) goto L_FAIL;
+                    const HzPoint D{c, phi, dphi, nid++};
+                    if (D.d >= 0.0) { B = D; goto L_BISECT_RETURN; }
+                    if (D.v <= phi_lim) A = D;
+                    else B = D;
+                    goto L_BISECT_TOP;
+                }
+                case S_SEC1:
+                    if (!fin) goto L_FAIL;
+                    C = HzPoint{c, phi, dphi, nid++};
+                    if (wolfe(c, phi, dphi, phi_0, dphi_0, phi_lim)) { alpha = c; goto L_DONE; }
+                    cont = CONT_UPD1;
+                    goto L_UPDATE;
+                case S_SEC2:
+                    if (!fin) goto L_FAIL;
+                    C = HzPoint{c, phi, dphi, nid++};
+                    if (wolfe(c, phi, dphi, phi_0, dphi_0, phi_lim)) { alpha = c; goto L_DONE; }
+                    cont = CONT_UPD2;
+                    goto L_UPDATE;
+                case S_MID:
+                    if (!fin) goto L_FAIL;
+                    C = HzPoint{c, phi, dphi, nid++};
+                    cont = CONT_UPD3;
+                    goto L_UPDATE;
+                default:  // S_FINAL
+                    return ok;
+            }
+        L_BRACKET_TOP:
+            if (!(iter < kHzLinesearchMax)) { alpha = 0.0; goto L_FAIL_KEEP; }  // never bracketed
+            if (C.d >= 0.0) {
+                A = prev;  // the latest point with phi <= phi_lim and dphi < 0 (HZ look-back)
+                B = C;
+                iter += 1;
+                goto L_MAIN_TOP;
+            } else if (C.v > phi_lim) {
+                A = P0;
+                B = C;
+                cont = CONT_BRACKET;
+                fail_alpha = 0.0;
+                goto L_BISECT_ENTER;
+            } else {
+                cold = C.a;
+                if (nextup(cold) >= alphamax) { alpha = cold; goto L_DONE; }
+                prev = C;
+                c = cold * kHzRho;
+                if (c > alphamax) c = alphamax;
+                iterfinite = 1;
+                state = S_EXPAND;
+                continue;
+            }
+        L_UPDATE:  // HZ stages U0-U3 on (A, B) with the new point C
+            if (!(A.d < 0.0 && A.v <= phi_lim && B.d >= 0.0 && B.a > A.a)) goto L_FAIL;
+            if (C.a < A.a || C.a > B.a) goto L_UPDATE_RETURN;
+            if (C.d >= 0.0) { B = C; goto L_UPDATE_RETURN; }
+            if (C.v <= phi_lim) { A = C; goto L_UPDATE_RETURN; }
+            B = C;
+        L_BISECT_ENTER:
+            if (!(A.d < 0.0 && A.v <= phi_lim && B.d < 0.0 && B.v > phi_lim && B.a > A.a)) goto L_FAIL;
+        L_BISECT_TOP:
+            if (B.a - A.a > eps_of(B.a)) {
+                c = (A.a + B.a) / 2.0;
+                state = S_BIS;
+                continue;
+            }
+        L_BISECT_RETURN:
+            if (cont == CONT_BRACKET) { iter += 1; goto L_MAIN_TOP; }
+        L_UPDATE_RETURN:
+            if (cont == CONT_UPD1) {
+                const bool updB = (B.id == C.id), updA = (A.id == C.id);
+                double c2 = C.a;
+                if (updB) c2 = secant(b0, B);
+                else if (updA) c2 = secant(a0, A);
+                if ((updA || updB) && A.a <= c2 && c2 <= B.a) {
+                    c = c2;
+                    state = S_SEC2;
+                    continue;
+                }
+            }
+            if (cont == CONT_UPD3) { iter += 1; goto L_MAIN_TOP; }
+            // after secant2 (CONT_UPD1 without a second step, or CONT_UPD2)
+            if (!(B.a > A.a)) { alpha = A.a; goto L_FAIL_KEEP; }
+            if (B.a - A.a < kHzGamma * (b0.a - a0.a)) {
+                if (nextup(a0.v) >= b0.v && nextup(A.v) >= B.v) { alpha = A.a; goto L_DONE; }  // flat
+                iter += 1;
+                goto L_MAIN_TOP;
+            }
+            fail_alpha = A.a;
+            c = (A.a + B.a) / 2.0;
+            state = S_MID;
+            continue;
+        L_MAIN_TOP:
+            if (!(iter < kHzLinesearchMax)) { alpha = A.a; goto L_FAIL_KEEP; }
+            a0 = A;
+            b0 = B;
+            if (!(b0.a > a0.a)) { alpha = a0.a; goto L_FAIL_KEEP; }
+            if (b0.a - a0.a <= eps_of(b0.a)) { alpha = a0.a; goto L_DONE; }
+            fail_alpha = a0.a;
+            if (!(a0.d < 0.0 && b0.d >= 0.0)) goto L_FAIL;
+            c = secant(a0, b0);
+            if (!isfinite(c)) goto L_FAIL;
+            state = S_SEC1;
+            continue;
+        L_FAIL:
+            alpha = fail_alpha;
+        L_FAIL_KEEP:
+            ok = false;
+        L_DONE:
+            // update_g!: NLSolversBase re-evaluates unless z + alpha s is the point evaluated last
+            if (!ok) return false;
+            if (alpha == last_c) return true;
+            c = alpha;
+            state = S_FINAL;
+        }
+    }
+
+    // -- one element: sample/load x, MAP by L-BFGS, score.
+    __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
+        const ProblemDesc d = describe(a, p);
+        const int64_t N = a.N, ld = a.ld;
+        iv0 = a.tmap.iv[0];
+        sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.tmap.sd[0];
+        if constexpr (MAXB > 1) {
+            // FD batches sample at a theta that differs from the MAP theta
+            if (tid < MAXB) sh_sd[tid] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tid] : a.tmap.sd[tid];
+            __syncthreads();
+        }
+        // bind storage
+        double* zmem = nullptr;
+        if constexpr (Place::kResident) {
+            hist = wg_scratch;
+            if constexpr (Place::kXgLds) {
+                x.p = lds_x;
+                g.p = lds_g;
+            }
+        } else {
+            x.p = wg_scratch;
+            g.p = wg_scratch + ld;
+            s.p = wg_scratch + 2 * ld;
+            zmem = d.zslot >= 0 ? a.zhat + d.zslot * ld : wg_scratch + 3 * ld;
+            z.p = zmem;
+            hist = wg_scratch + 4 * ld;
+        }
+        const double* z0src = a.zhat + d.z0slot * ld;
+        const bool z_in_place = (!Place::kResident) && (d.z0_mode == Z0_WARM || d.z0_mode == Z0_COPY) && (z0src == zmem);
+
+        // ---- x and the starting point ---------------------------------------------------------
+        if (d.x_mode == X_SAMPLE) {
+            const uint64_t sim = (uint64_t)d.sim;
+            if constexpr (Place::kResident && Place::kXgLds) {
+                // Sampler as a ROLLED loop over this thread's pairs (one or two Philox/Box-Muller
+                // chains in flight, not 2*EPT): x goes straight to LDS, the true z is staged in the
+                // (still unused) g area and picked up into registers below.
+#pragma unroll 1
+                for (int64_t i0 = 2 * (int64_t)tid; i0 < N; i0 += 2 * (int64_t)T) {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int64_t i = i0 + v;
+                        if (i < N) {
+                            const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+                            double zt, xt;
+                            Model::sample(sdk(i), np.n1, np.n2, zt, xt);
+                            x.p[i] = xt;
+                            g.p[i] = zt;
+                        }
+                    }
+                }
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
+                    else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.p[i]);
+                    else z.set(jj, i, z0src[i]);
+                });
+            } else {
+            for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+                double zt, xt;
+                if constexpr (Model::kStencil) {
+                    zt = sdk(i) * np.n1;
+                    xt = np.n2;        // noise now, + A z after the barrier
+                    s.set(jj, i, zt);   // true z staged in the direction buffer
+                } else {
+                    Model::sample(sdk(i), np.n1, np.n2, zt, xt);
+                }
+                x.set(jj, i, xt);
+                if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
+                else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
+                else if (!z_in_place) z.set(jj, i, z0src[i]);
+            });
+            }
+            if constexpr (Model::kStencil) {
+                __syncthreads();
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    const int64_t im = i == 0 ? N - 1 : i - 1, ip = i == N - 1 ? 0 : i + 1;
+                    const double az = 0.5 * s.get(0, i) + 0.25 * (s.get(0, im) + s.get(0, ip));
+                    x.set(jj, i, az + x.get(jj, i));
+                });
+            }
+        } else {
+            const double* xs = d.x_mode == X_DATA ? a.x_data : a.x_given;
+            for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                x.set(jj, i, xs[i]);
+                if (d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE) z.set(jj, i, 0.0);
+                else if (!z_in_place) z.set(jj, i, z0src[i]);
+            });
+        }
+        __syncthreads();
+
+        // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
+        f_calls = 0;
+        last_c = NAN;
+        double f, dphi_unused, gmax;
+        eval<false, true>(0.0, f, dphi_unused, gmax);
+        int iterations = 0, pseudo = 0, hist_words = 0, counter_f_tol = 0;
+        int status = MUSE_STATUS_MAXITER;
+        bool done = false;
+        if (!isfinite(f) || !isfinite(gmax)) { status = MUSE_STATUS_NONFINITE; done = true; }
+        else if (gmax <= a.atol) { status = MUSE_STATUS_G_CONVERGED; done = true; }
+
+        double dot0 = 0.0;      // dot(dx_newest, g) prepared by the update pass
+        bool have_pair = false;  // the update pass of the previous iteration stored a usable pair
+        while (!done && iterations < kMaxIter) {
+            iterations += 1;
+            pseudo += 1;
+            // ---- twoloop!: s = -H g ------------------------------------------------------------
+            const int upper = pseudo - 1, lower = (pseudo - kM) > 1 ? (pseudo - kM) : 1;
+            const int h = upper >= lower ? upper - lower + 1 : 0;
+            double dphi_0;
+            if (h == 0 || !have_pair) {
+                double sum[1] = {0.0}, mx[1] = {0.0};
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    const double gi = g.get(jj, i), si = -gi;
+                    s.set(jj, i, si);
+                    sum[0] += gi * si;
+                });
+                block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                dphi_0 = sum[0];
+            } else {
+                hist_words += h;
+                double dot = dot0;
+                // backward pass (q lives in s; the update pass left q = g there)
+                for (int index = upper; index >= lower; --index) {
+                    const int slot = (index - 1) % kM;
+                    const double al = sh_rho[slot] * dot;
+                    if (tid == 0) sh_alpha[slot] = al;
+                    const double* __restrict__ dgp = hdg(slot);
+                    double sum[1] = {0.0}, mx[1] = {0.0};
+                    if (index > lower) {
+                        const double* __restrict__ dxn = hdx((index - 2) % kM);
+                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                            const double qi = s.get(jj, i) - al * dgp[i];
+                            s.set(jj, i, qi);
+                            sum[0] += dxn[i] * qi;
+                        });
+                    } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
+                        const double gam = sh_gam[(upper - 1) % kM];
+                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                            const double qi = s.get(jj, i) - al * dgp[i];
+                            const double si = gam * qi;
+                            s.set(jj, i, si);
+                            sum[0] += dgp[i] * si;
+                        });
+                    }
+                    block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                    dot = sum[0];
+                }
+                // forward pass
+                for (int index = lower; index <= upper; ++index) {
+                    const int slot = (index - 1) % kM;
+                    const double beta = sh_rho[slot] * dot;
+                    const double coef = sh_alpha[slot] - beta;
+                    const double* __restrict__ dxp = hdx(slot);
+                    double sum[1] = {0.0}, mx[1] = {0.0};
+                    if (index < upper) {
+                        const double* __restrict__ dgn = hdg(index % kM);
+                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                            const double si = s.get(jj, i) + dxp[i] * coef;
+                            s.set(jj, i, si);
+                            sum[0] += dgn[i] * si;
+                        });
+                    } else {
+                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                            const double si = (s.get(jj, i) + dxp[i] * coef) * -1.0;
+                            s.set(jj, i, si);
+                            sum[0] += g.get(jj, i) * si;
+                        });
+                    }
+                    block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                    dot = sum[0];
+                }
+                dphi_0 = dot;
+            }
+            // ---- perform_linesearch!: reset a non-descent direction ------------------------------
+            if (dphi_0 >= 0.0) {
+                pseudo = 1;
+                double sum[1] = {0.0}, mx[1] = {0.0};
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    const double gi = g.get(jj, i), si = -gi;
+                    s.set(jj, i, si);
+                    sum[0] += gi * si;
+                });
+                block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                dphi_0 = sum[0];
+            }
+            const double phi_0 = f, f_prev = f;
+            last_c = NAN;  // no trial evaluated yet in this line search
+            last_phi = f;
+            last_gmax = gmax;
+            double alpha;
+            const bool ls_ok = linesearch(1.0, phi_0, dphi_0, alpha);
+            // ---- update_g! / assess_convergence: the scalars at z + alpha s are those of the last
+            //      evaluation (or of the current point when the step is a no-op) ---------------------
+            const double f_new = last_phi, gmax_new = last_gmax;
+            const bool g_conv = gmax_new <= a.atol;
+            const bool f_conv = fabs(f_new - f_prev) <= 0.0;
+            const int cft = f_conv ? counter_f_tol + 1 : 0;
+            const bool stop_hint = !ls_ok || g_conv || cft > 1 || !isfinite(gmax_new);
+            // ---- fused update pass: z += alpha s; gradient at the new point recomputed (bit-equal
+            //      to the trial evaluation); (dx, dg) stored; g <- new gradient; q <- g -----------------
+            const int slot_new = (pseudo - 1) % kM;
+            double* __restrict__ dxs = hdx(slot_new);
+            double* __restrict__ dgs = hdg(slot_new);
+            const bool keep = !stop_hint;
+            double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
+            if constexpr (!Model::kStencil) {
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    const double zo = z.get(jj, i);
+                    const double dxi = alpha * s.get(jj, i);
+                    const double zn = zo + dxi;
+                    z.set(jj, i, zn);
+                    mx[0] = nanmax(mx[0], fabs(zn - zo));
+                    if (keep) {
+                        double unused = 0.0;
+                        const double gn = Model::grad(ivk(i), x.get(jj, i), zn, unused);
+                        const double dgi = gn - g.get(jj, i);
+                        sum[0] += dxi * dgi;
+                        sum[1] += dgi * dgi;
+                        sum[2] += dxi * gn;
+                        dxs[i] = dxi;
+                        dgs[i] = dgi;
+                        g.set(jj, i, gn);
+                        s.set(jj, i, gn);
+                    }
+                });
+            } else {
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    const double zo = z.get(jj, i);
+                    const double dxi = alpha * s.get(jj, i);
+                    const double zn = zo + dxi;
+                    z.set(jj, i, zn);
+                    mx[0] = nanmax(mx[0], fabs(zn - zo));
+                    if (keep) dxs[i] = dxi;
+                });
+                if (keep) {
+                    __syncthreads();  // neighbours' z must be complete before the stencil reads them
+                    auto zt = [&](int64_t k) { return z.get(0, k); };
+                    for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                        double unused = 0.0;
+                        const double gn = stencil_grad(zt, i, unused);
+                        const double dxi = dxs[i];
+                        const double dgi = gn - g.get(jj, i);
+                        sum[0] += dxi * dgi;
+                        sum[1] += dgi * dgi;
+                        sum[2] += dxi * gn;
+                        dgs[i] = dgi;
+                        g.set(jj, i, gn);
+                        s.set(jj, i, gn);
+                    });
+                }
+            }
+            block_allreduce<T, 3, 1>(sum, mx, red, parity, tid);
+            if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
+                status = MUSE_STATUS_LINESEARCH_FAILED;
+                f = last_phi;
+                gmax = last_gmax;
+                break;
+            }
+            f = f_new;
+            gmax = gmax_new;
+            counter_f_tol = cft;
+            const bool x_conv = mx[0] <= 0.0;
+            done = stop_hint || x_conv;
+            if (g_conv) status = MUSE_STATUS_G_CONVERGED;
+            else if (x_conv) status = MUSE_STATUS_X_CONVERGED;
+            else if (cft > 1) status = MUSE_STATUS_F_CONVERGED;
+            if (!isfinite(gmax)) status = MUSE_STATUS_NONFINITE;
+            // ---- update_h!: rho = 1/(dx.dg); an infinite rho drops the history ----------------------
+            have_pair = false;
+            if (keep) {
+                const double rho_it = 1.0 / sum[0];
+                if (isinf(rho_it)) {
+                    pseudo = 0;
+                } else {
+                    if (tid == 0) {
+                        sh_rho[slot_new] = rho_it;
+                        sh_gam[slot_new] = sum[0] / sum[1];
+                    }
+                    have_pair = true;
+                }
+                dot0 = sum[2];
+            }
+        }
+
+        // ---- zhat out, score -------------------------------------------------------------------
+        if constexpr (Place::kResident) {
+            if (d.zslot >= 0) {
+                double* __restrict__ zo = a.zhat + d.zslot * ld;
+                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) { zo[i] = z.get(jj, i); });
+            }
+        }
+        {
+            double acc[MAXB], mx[1] = {0.0};
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
+            for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                const double t = Model::score_term(x.get(jj, i), z.get(jj, i));
+                if constexpr (MAXB == 1) {
+                    acc[0] += t;
+                } else {
+                    const int k = blk(i);
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
+                }
+            });
+            block_allreduce<T, MAXB, 0>(acc, mx, red, parity, tid);
+            if (tid == 0) {
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) {
+                    if (b < a.ntheta) {
+                        const double cnt = (double)(a.bnd[b + 1] - a.bnd[b]);
+                        a.scores[(int64_t)p * a.ntheta + b] = 0.5 * (a.tmap.iv[b] * acc[b] - cnt);
+                    }
+                }
+                muse_info inf;
+                inf.iterations = iterations;
+                inf.f_calls = f_calls;
+                inf.status = (status <= MUSE_STATUS_F_CONVERGED && !isfinite(f)) ? MUSE_STATUS_NONFINITE : status;
+                inf.hist_words = hist_words;
+                inf.f_min = f;
+                inf.gnorm = gmax;
+                a.info[p] = inf;
+            }
+        }
+    }
+    double last_phi;
+};
+
+constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS copy of the kernel arguments
+
+// The argument block is read from an LDS copy of the kernarg segment, not from the by-value
+// parameter: hipcc materialises a by-value aggregate in scratch as soon as any select/phi of two
+// field addresses is formed, and every access then becomes a scratch access.  LDS loads at uniform
+// addresses are uniform values, so control flow on them stays scalar.
+template <class Model, class Place>
+__global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Place::T;
+    // LDS carve (all offsets multiples of 16 B): reduction scratch, L-BFGS scalars, ticket, args, x, g
+    double* red = reinterpret_cast<double*>(smem);      // [2][T/64][8]
+    double* shs = red + 2 * (T / 64) * 8;                // rho, gamma, alpha [3][kM]; sd [kMaxTheta]; pad
+    int* ticket = reinterpret_cast<int*>(shs + 40);      // [4]
+    double* args_lds = shs + 42;                         // [kArgsDoubles]
+    const int tid = threadIdx.x;
+    {
+        typedef __attribute__((address_space(4))) const uint32_t* kernarg_ptr;
+        kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(args_lds);
+        for (int w = tid; w < (int)(sizeof(BatchArgs) / 4); w += T) dst[w] = kp[w];
+    }
+    __syncthreads();
+    const BatchArgs& a = *reinterpret_cast<const BatchArgs*>(args_lds);
+    double* lds_x = args_lds + kArgsDoubles;
+    double* lds_g = lds_x + a.ld;
+    double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) ticket[0] = atomicAdd(a.work_counter, 1);
+        __syncthreads();
+        const int p = __builtin_amdgcn_readfirstlane(ticket[0]);
+        if (p >= a.nproblems) break;
+        Solver<Model, Place> sv(a, tid, red, shs);
+        sv.run(p, wg_scratch, lds_x, lds_g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-simulation operator kernels (API parity with the reference's per-sim interface; not the
+// performance path).
+template <int MODEL>
+__global__ void __launch_bounds__(256) sample_kernel(BatchArgs a, uint64_t sim, double* __restrict__ x,
+                                                     double* __restrict__ z) {
+    const int64_t N = a.N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = a.ntheta > 1 ? block_of(a, i) : 0;
+        const double sdk = a.tmap.sd[k];
+        const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+        if (MODEL == MUSE_MODEL_NOISE) {
+            z[i] = np.n1;
+            x[i] = np.n1 + sdk * np.n2;
+        } else if (MODEL == MUSE_MODEL_FUNNEL) {
+            const double zi = sdk * np.n1;
+            z[i] = zi;
+            x[i] = zi + np.n2;
+        } else {
+            z[i] = sdk * np.n1;
+            x[i] = np.n2;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) smooth_finish_kernel(int64_t N, const double* __restrict__ z,
+                                                            const double* __restrict__ noise, double* __restrict__ x) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t im = i == 0 ? N - 1 : i - 1, ip = i == N - 1 ? 0 : i + 1;
+        x[i] = (0.5 * z[i] + 0.25 * (z[im] + z[ip])) + noise[i];
+    }
+}
+
+// logLike and grad_z logLike (note the sign: the solver works with -logLike), plus the per-block score
+// sums; one workgroup, fixed-shape reduction (same element->thread map as the solver).
+template <class Model>
+__global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double* __restrict__ xin,
+                                                       const double* __restrict__ zin, double* __restrict__ gout,
+                                                       double* __restrict__ out /* [0]=logLike, [1..]=score */) {
+    __shared__ double red[2 * 16 * 8];
+    constexpr int T = 1024, MAXB = Model::MAXB;
+    const int tid = threadIdx.x;
+    int parity = 0;
+    const int64_t N = a.N;
+    double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
+    double acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
+    auto wrap = [&](int64_t i) { return i < 0 ? i + N : (i >= N ? i - N : i); };
+    for_elems<T, 0>(N, tid, [&](int, int64_t i) {
+        const int k = MAXB > 1 ? block_of(a, i) : 0;
+        const double ivk = a.tmap.iv[k];
+        double gi;
+        if constexpr (Model::kStencil) {
+            const int64_t im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
+            const double zm2 = zin[im2], zm1 = zin[im1], z0 = zin[i], zp1 = zin[ip1], zp2 = zin[ip2];
+            const double rm = xin[im1] - (0.5 * zm1 + 0.25 * (zm2 + z0));
+            const double r0 = xin[i] - (0.5 * z0 + 0.25 * (zm1 + zp1));
+            const double rp = xin[ip1] - (0.5 * zp1 + 0.25 * (z0 + zp2));
+            sum[0] += r0 * r0 + ivk * (z0 * z0);
+            gi = ivk * z0 - (0.5 * r0 + 0.25 * (rm + rp));
+        } else {
+            gi = Model::grad(ivk, xin[i], zin[i], sum[0]);
+        }
+        if (gout) gout[i] = -gi;
+        const double t = Model::score_term(xin[i], zin[i]);
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
+    });
+    block_allreduce<T, 2, 0>(sum, mx, red, parity, tid);
+    block_allreduce<T, MAXB, 0>(acc, mx, red, parity, tid);
+    if (tid == 0) {
+        out[0] = -(0.5 * (sum[0] + a.f_const));
+        for (int b = 0; b < MAXB; ++b)
+            if (b < a.ntheta) out[1 + b] = 0.5 * (a.tmap.iv[b] * acc[b] - (double)(a.bnd[b + 1] - a.bnd[b]));
+    }
+}
+
+}  // namespace muse
+
+// ================================================================================================
+// Host side: context, workspace, launches, C ABI.
+// ================================================================================================
+using namespace muse;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(MUSE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+struct muse_ctx {
+    int model = 0, ntheta = 1, device = 0, placement = -1, num_cus = 0;
+    int64_t N = 0, ld = 0;
+    int64_t bnd[kMaxTheta + 1] = {0};
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    double* x_data = nullptr;
+    bool has_data = false;
+    double* zhat = nullptr;
+    int64_t zhat_slots = 0;
+    double* scratch = nullptr;
+    size_t scratch_doubles = 0;
+    int* counter = nullptr;
+    double* tmp = nullptr;  // 3 vectors for the per-sim operator entry points
+    ThetaSet* tsample_dev = nullptr;
+    ThetaSet* tsample_pin = nullptr;
+    // result areas: device + pinned host, each [cap] scores and infos
+    double* scores_dev[kResultAreas] = {nullptr};
+    muse_info* info_dev[kResultAreas] = {nullptr};
+    double* scores_pin[kResultAreas] = {nullptr};
+    muse_info* info_pin[kResultAreas] = {nullptr};
+    int64_t res_cap[kResultAreas] = {0};
+    int64_t res_n[kResultAreas] = {0};
+    double* small_dev = nullptr;  // 16 doubles
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
+    double* comm_buf = nullptr;
+    size_t comm_buf_doubles = 0;
+};
+
+static void make_thetaset(const muse_ctx* c, const double* theta, ThetaSet& t) {
+    memset(&t, 0, sizeof(t));
+    for (int k = 0; k < c->ntheta; ++k) {
+        t.theta[k] = theta[k];
+        t.sd[k] = exp(0.5 * theta[k]);
+        t.iv[k] = exp(-theta[k]);
+    }
+}
+static double theta_const(const muse_ctx* c, const double* theta) {
+    double cst = 0.0;
+    for (int k = 0; k < c->ntheta; ++k) cst += (double)(c->bnd[k + 1] - c->bnd[k]) * theta[k];
+    return cst;
+}
+
+enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4 };
+
+// Workgroup size is a function of N alone (256 threads for N <= 512, else 512), so that the
+// streaming and the resident policy reduce in the same order and give bitwise equal results.
+static int choose_place(const muse_ctx* c) {
+    const bool small = c->N <= 512;
+    if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN) return small ? P_S256 : P_S512;
+    if (small) return P_R256x1;
+    if (c->N <= 4096) return P_R512x4;
+    return P_R512x10;
+}
+static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 256 : 512; }
+static int place_wgs_per_cu(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 4 : (pl == P_R512x10 ? 1 : 2); }
+static size_t place_lds(const muse_ctx* c, int pl) {
+    size_t fixed = (size_t)(2 * (place_threads(pl) / 64) * 8 + 42 + kArgsDoubles) * sizeof(double);
+    if (pl == P_R512x10) fixed += (size_t)2 * c->ld * sizeof(double);
+    return fixed;
+}
+static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512) ? 4 + 2 * kM : 2 * kM; }
+
+static int ensure_zhat(muse_ctx* c, int64_t slots) {
+    if (slots <= c->zhat_slots) return MUSE_OK;
+    double* nz = nullptr;
+    if (hipMalloc(&nz, (size_t)slots * c->ld * sizeof(double)) != hipSuccess)
+        return fail(MUSE_ERR_ALLOC, "hipMalloc(zhat) failed");
+    HIPCHK(hipMemsetAsync(nz, 0, (size_t)slots * c->ld * sizeof(double), c->stream));
+    if (c->zhat) {
+        HIPCHK(hipMemcpyAsync(nz, c->zhat, (size_t)c->zhat_slots * c->ld * sizeof(double), hipMemcpyDeviceToDevice,
+                              c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->zhat));
+    }
+    c->zhat = nz;
+    c->zhat_slots = slots;
+    return MUSE_OK;
+}
+static int ensure_scratch(muse_ctx* c, size_t doubles) {
+    if (doubles <= c->scratch_doubles) return MUSE_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->scratch) HIPCHK(hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_doubles = 0;
+    if (hipMalloc(&c->scratch, doubles * sizeof(double)) != hipSuccess)
+        return fail(MUSE_ERR_ALLOC, "hipMalloc(scratch) failed");
+    c->scratch_doubles = doubles;
+    return MUSE_OK;
+}
+static int ensure_results(muse_ctx* c, int area, int64_t n) {
+    if (n <= c->res_cap[area]) return MUSE_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->scores_dev[area]) HIPCHK(hipFree(c->scores_dev[area]));
+    if (c->info_dev[area]) HIPCHK(hipFree(c->info_dev[area]));
+    if (c->scores_pin[area]) HIPCHK(hipHostFree(c->scores_pin[area]));
+    if (c->info_pin[area]) HIPCHK(hipHostFree(c->info_pin[area]));
+    const int64_t cap = n + n / 2 + 16;
+    HIPCHK(hipMalloc(&c->scores_dev[area], (size_t)cap * kMaxTheta * sizeof(double)));
+    HIPCHK(hipMalloc(&c->info_dev[area], (size_t)cap * sizeof(muse_info)));
+    HIPCHK(hipHostMalloc(&c->scores_pin[area], (size_t)cap * kMaxTheta * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->info_pin[area], (size_t)cap * sizeof(muse_info), hipHostMallocDefault));
+    c->res_cap[area] = cap;
+    return MUSE_OK;
+}
+
+template <class Model, class Place>
+static int launch_one(muse_ctx* c, const BatchArgs& a, int grid, size_t lds) {
+    auto kern = map_score_kernel<Model, Place>;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Place::T), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return MUSE_OK;
+}
+template <class Model>
+static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_t lds) {
+    if constexpr (Model::kStencil) {
+        if (pl == P_S256) return launch_one<Model, PlaceStreaming<256>>(c, a, grid, lds);
+        return launch_one<Model, PlaceStreaming<512>>(c, a, grid, lds);
+    } else {
+        switch (pl) {
+            case P_R256x1: return launch_one<Model, PlaceResident<256, 1, false>>(c, a, grid, lds);
+            case P_R512x4: return launch_one<Model, PlaceResident<512, 4, false>>(c, a, grid, lds);
+            case P_R512x10: return launch_one<Model, PlaceResident<512, 10, true>>(c, a, grid, lds);
+            case P_S256: return launch_one<Model, PlaceStreaming<256>>(c, a, grid, lds);
+            default: return launch_one<Model, PlaceStreaming<512>>(c, a, grid, lds);
+        }
+    }
+}
+
+// Fill the common fields and launch the solver for `a.nproblems` elements.
+static int launch_batch(muse_ctx* c, BatchArgs& a) {
+    a.N = c->N;
+    a.ld = c->ld;
+    a.ntheta = c->ntheta;
+    for (int k = 0; k <= kMaxTheta; ++k) a.bnd[k] = c->bnd[k];
+    a.x_data = c->x_data;
+    a.zhat = c->zhat;
+    a.work_counter = c->counter;
+    const int pl = choose_place(c);
+    int grid = c->num_cus * place_wgs_per_cu(pl);
+    if (grid > a.nproblems) grid = a.nproblems;
+    if (grid < 1) grid = 1;
+    a.scratch_stride = place_scratch_vectors(pl) * c->ld;
+    int rc = ensure_scratch(c, (size_t)grid * a.scratch_stride);
+    if (rc) return rc;
+    a.scratch = c->scratch;
+    const size_t lds = place_lds(c, pl);
+    HIPCHK(hipMemsetAsync(c->counter, 0, 16, c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (c->model == MUSE_MODEL_NOISE) rc = launch_place<NoiseModel>(c, a, pl, grid, lds);
+    else if (c->model == MUSE_MODEL_FUNNEL)
+        rc = c->ntheta == 1 ? launch_place<FunnelModel<1>>(c, a, pl, grid, lds)
+                            : launch_place<FunnelModel<kMaxTheta>>(c, a, pl, grid, lds);
+    else rc = launch_place<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    return MUSE_OK;
+}
+
+extern "C" {
+
+const char* muse_last_error(void) { return g_err.c_str(); }
+int64_t muse_max_resident_n(void) { return kMaxResidentN; }
+
+int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out) {
+    if (!out) return fail(MUSE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (model < 0 || model > 2) return fail(MUSE_ERR_INVALID, "unknown model");
+    if (N < 1) return fail(MUSE_ERR_INVALID, "N must be >= 1");
+    if (ntheta < 1 || ntheta > kMaxTheta) return fail(MUSE_ERR_INVALID, "ntheta must be in [1, MUSE_MAX_THETA]");
+    if (model == MUSE_MODEL_NOISE && ntheta != 1) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_NOISE has ntheta = 1");
+    if (ntheta > N) return fail(MUSE_ERR_INVALID, "ntheta must be <= N");
+    if (model == MUSE_MODEL_SMOOTH && N < 5) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_SMOOTH needs N >= 5");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(MUSE_ERR_HIP, "no HIP device available (libmuse_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MUSE_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    muse_ctx* c = new muse_ctx();
+    c->model = model;
+    c->N = N;
+    c->ld = (N + 1) & ~(int64_t)1;
+    c->ntheta = ntheta;
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    for (int k = 0; k <= kMaxTheta; ++k) {
+        const int kk = k < ntheta ? k : ntheta;
+        c->bnd[k] = ((int64_t)kk * N + ntheta - 1) / ntheta;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipMalloc(&c->x_data, (size_t)c->ld * sizeof(double)));
+    HIPCHK(hipMalloc(&c->counter, 16));
+    HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
+    HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
+    HIPCHK(hipMalloc(&c->tsample_dev, 2 * kMaxTheta * sizeof(ThetaSet)));
+    HIPCHK(hipHostMalloc(&c->tsample_pin, 2 * kMaxTheta * sizeof(ThetaSet), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipMemsetAsync(c->x_data, 0, (size_t)c->ld * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->tmp, 0, (size_t)3 * c->ld * sizeof(double), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return MUSE_OK;
+}
+
+int muse_comm_destroy(muse_ctx* ctx);
+
+// accessors for muse_comm.cpp (the context layout is private to this file)
+int muse_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+int muse_ctx_comm_slot(muse_ctx* c, void*** comm, int* device, void** stream) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    *comm = &c->comm;
+    *device = c->device;
+    *stream = (void*)c->stream;
+    return MUSE_OK;
+}
+int muse_ctx_comm_buffer(muse_ctx* c, size_t doubles, double** buf) {
+    if (doubles > c->comm_buf_doubles) {
+        if (c->comm_buf) HIPCHK(hipFree(c->comm_buf));
+        c->comm_buf = nullptr;
+        c->comm_buf_doubles = 0;
+        if (hipMalloc(&c->comm_buf, doubles * sizeof(double)) != hipSuccess)
+            return fail(MUSE_ERR_ALLOC, "hipMalloc(comm buffer) failed");
+        c->comm_buf_doubles = doubles;
+    }
+    *buf = c->comm_buf;
+    return MUSE_OK;
+}
+
+int muse_ctx_destroy(muse_ctx* c) {
+    if (!c) return MUSE_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    muse_comm_destroy(c);
+    hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
+    hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
+    if (c->comm_buf) hipFree(c->comm_buf);
+    for (int r = 0; r < kResultAreas; ++r) {
+        hipFree(c->scores_dev[r]); hipFree(c->info_dev[r]);
+        hipHostFree(c->scores_pin[r]); hipHostFree(c->info_pin[r]);
+    }
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return MUSE_OK;
+}
+
+static int check_ctx(muse_ctx* c) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    return MUSE_OK;
+}
+static hipMemcpyKind in_kind(int mem) { return mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; }
+static hipMemcpyKind out_kind(int mem) { return mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost; }
+
+int muse_set_data(muse_ctx* c, const double* x, int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!x) return fail(MUSE_ERR_INVALID, "x is NULL");
+    HIPCHK(hipMemcpyAsync(c->x_data, x, (size_t)c->N * sizeof(double), in_kind(mem), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->has_data = true;
+    return MUSE_OK;
+}
+int muse_set_stream(muse_ctx* c, void* s) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MUSE_OK;
+}
+int muse_set_placement(muse_ctx* c, int placement) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    if (placement < -1 || placement > 1) return fail(MUSE_ERR_INVALID, "placement must be -1, 0 or 1");
+    if (placement == 1 && (c->N > kMaxResidentN || c->model == MUSE_MODEL_SMOOTH))
+        return fail(MUSE_ERR_INVALID, "resident placement not available for this problem");
+    c->placement = placement;
+    return MUSE_OK;
+}
+int muse_synchronize(muse_ctx* c) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MUSE_OK;
+}
+int muse_last_kernel_ms(muse_ctx* c, float* ms) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!ms) return fail(MUSE_ERR_INVALID, "ms is NULL");
+    if (!c->ev_valid) return fail(MUSE_ERR_INVALID, "no solver launch recorded yet");
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MUSE_OK;
+}
+
+static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
+    memset(&a, 0, sizeof(a));
+    a.N = c->N;
+    a.ld = c->ld;
+    a.ntheta = c->ntheta;
+    for (int k = 0; k <= kMaxTheta; ++k) a.bnd[k] = c->bnd[k];
+    make_thetaset(c, theta, a.tmap);
+    a.f_const = theta_const(c, theta);
+    a.fid_slot = -1;
+}
+
+int muse_sample_x_z(muse_ctx* c, uint64_t seed, int64_t sim, const double* theta, double* x_out, double* z_out,
+                    int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta || (!x_out && !z_out)) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (sim < 0) return fail(MUSE_ERR_INVALID, "sim must be >= 0");
+    BatchArgs a;
+    base_args(c, a, theta);
+    a.seed = seed;
+    double *dx = c->tmp, *dz = c->tmp + c->ld, *dn = c->tmp + 2 * c->ld;
+    const int grid = (int)((c->N + 255) / 256 < 4096 ? (c->N + 255) / 256 : 4096);
+    if (c->model == MUSE_MODEL_NOISE) hipLaunchKernelGGL(sample_kernel<MUSE_MODEL_NOISE>, dim3(grid), dim3(256), 0, c->stream, a, (uint64_t)sim, dx, dz);
+    else if (c->model == MUSE_MODEL_FUNNEL) hipLaunchKernelGGL(sample_kernel<MUSE_MODEL_FUNNEL>, dim3(grid), dim3(256), 0, c->stream, a, (uint64_t)sim, dx, dz);
+    else {
+        hipLaunchKernelGGL(sample_kernel<MUSE_MODEL_SMOOTH>, dim3(grid), dim3(256), 0, c->stream, a, (uint64_t)sim, dn, dz);
+        hipLaunchKernelGGL(smooth_finish_kernel, dim3(grid), dim3(256), 0, c->stream, c->N, dz, dn, dx);
+    }
+    HIPCHK(hipGetLastError());
+    if (x_out) HIPCHK(hipMemcpyAsync(x_out, dx, (size_t)c->N * sizeof(double), out_kind(mem), c->stream));
+    if (z_out) HIPCHK(hipMemcpyAsync(z_out, dz, (size_t)c->N * sizeof(double), out_kind(mem), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MUSE_OK;
+}
+
+static int run_loglike(muse_ctx* c, const double* x, const double* z, const double* theta, double* gdev, int mem) {
+    BatchArgs a;
+    base_args(c, a, theta);
+    double *dx = c->tmp, *dz = c->tmp + c->ld;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)c->N * sizeof(double), in_kind(mem), c->stream));
+    HIPCHK(hipMemcpyAsync(dz, z, (size_t)c->N * sizeof(double), in_kind(mem), c->stream));
+    if (c->model == MUSE_MODEL_NOISE) hipLaunchKernelGGL(loglike_kernel<NoiseModel>, dim3(1), dim3(1024), 0, c->stream, a, dx, dz, gdev, c->small_dev);
+    else if (c->model == MUSE_MODEL_FUNNEL) hipLaunchKernelGGL(loglike_kernel<FunnelModel<kMaxTheta>>, dim3(1), dim3(1024), 0, c->stream, a, dx, dz, gdev, c->small_dev);
+    else hipLaunchKernelGGL(loglike_kernel<SmoothModel<kMaxTheta>>, dim3(1), dim3(1024), 0, c->stream, a, dx, dz, gdev, c->small_dev);
+    HIPCHK(hipGetLastError());
+    return MUSE_OK;
+}
+
+int muse_logLike_and_grad_z(muse_ctx* c, const double* x, const double* z, const double* theta, double* logLike_out,
+                            double* grad_out, int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!x || !z || !theta) return fail(MUSE_ERR_INVALID, "NULL argument");
+    double* gdev = c->tmp + 2 * c->ld;
+    rc = run_loglike(c, x, z, theta, grad_out ? gdev : nullptr, mem);
+    if (rc) return rc;
+    double small[1 + kMaxTheta];
+    HIPCHK(hipMemcpyAsync(small, c->small_dev, sizeof(small), hipMemcpyDeviceToHost, c->stream));
+    if (grad_out) HIPCHK(hipMemcpyAsync(grad_out, gdev, (size_t)c->N * sizeof(double), out_kind(mem), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (logLike_out) *logLike_out = small[0];
+    return MUSE_OK;
+}
+
+int muse_grad_theta(muse_ctx* c, const double* x, const double* z, const double* theta, double* g_out, int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!x || !z || !theta || !g_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    rc = run_loglike(c, x, z, theta, nullptr, mem);
+    if (rc) return rc;
+    double small[1 + kMaxTheta];
+    HIPCHK(hipMemcpyAsync(small, c->small_dev, sizeof(small), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < c->ntheta; ++k) g_out[k] = small[1 + k];
+    return MUSE_OK;
+}
+
+static int enqueue_results_copy(muse_ctx* c, int area, int64_t n) {
+    HIPCHK(hipMemcpyAsync(c->scores_pin[area], c->scores_dev[area], (size_t)n * c->ntheta * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_pin[area], c->info_dev[area], (size_t)n * sizeof(muse_info), hipMemcpyDeviceToHost,
+                          c->stream));
+    c->res_n[area] = n;
+    return MUSE_OK;
+}
+
+int muse_zhat_at_theta(muse_ctx* c, const double* x, const double* z0, const double* theta, double atol, double* z_out,
+                       muse_info* info, int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!x || !z0 || !theta || !z_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    // the single-element solve uses a private zhat slot after the batch slots
+    rc = ensure_zhat(c, c->zhat_slots > 0 ? c->zhat_slots : 1);
+    if (rc) return rc;
+    rc = ensure_results(c, kResultAreas - 1, 1);
+    if (rc) return rc;
+    // stage z0 into a scratch slot: reuse tmp[1] as the z vector via a one-slot zhat view
+    BatchArgs a;
+    base_args(c, a, theta);
+    a.kind = BATCH_SINGLE;
+    a.atol = atol;
+    a.nproblems = 1;
+    a.store_zhat = 1;
+    a.slot0 = 0;
+    double* dx = c->tmp;
+    double* dz = c->tmp + c->ld;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)c->N * sizeof(double), in_kind(mem), c->stream));
+    HIPCHK(hipMemcpyAsync(dz, z0, (size_t)c->N * sizeof(double), in_kind(mem), c->stream));
+    a.x_given = dx;
+    a.scores = c->scores_dev[kResultAreas - 1];
+    a.info = c->info_dev[kResultAreas - 1];
+    // run with zhat pointing at the tmp z vector (slot 0 of a 1-slot view)
+    double* saved = c->zhat;
+    c->zhat = dz;
+    rc = launch_batch(c, a);
+    c->zhat = saved;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(z_out, dz, (size_t)c->N * sizeof(double), out_kind(mem), c->stream));
+    rc = enqueue_results_copy(c, kResultAreas - 1, 1);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (info) *info = c->info_pin[kResultAreas - 1][0];
+    return MUSE_OK;
+}
+
+int muse_map_and_score_batch_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                                   const double* theta, double atol, int z0_mode, int area) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta) return fail(MUSE_ERR_INVALID, "theta is NULL");
+    if (sim_end < sim_begin || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad sim range");
+    if (z0_mode < MUSE_Z0_ZERO || z0_mode > MUSE_Z0_WARM) return fail(MUSE_ERR_INVALID, "bad z0_mode");
+    if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
+    if (include_data && !c->has_data) return fail(MUSE_ERR_NODATA, "include_data set but muse_set_data was not called");
+    const int64_t n = (sim_end - sim_begin) + (include_data ? 1 : 0);
+    if (n == 0) { c->res_n[area] = 0; return MUSE_OK; }
+    if (n > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
+    rc = ensure_zhat(c, n);
+    if (rc) return rc;
+    rc = ensure_results(c, area, n);
+    if (rc) return rc;
+    BatchArgs a;
+    base_args(c, a, theta);
+    a.kind = BATCH_STD;
+    a.seed = seed;
+    a.atol = atol;
+    a.nproblems = (int)n;
+    a.include_data = include_data ? 1 : 0;
+    a.z0_mode = z0_mode;
+    a.store_zhat = 1;
+    a.sim_begin = sim_begin;
+    a.slot0 = 0;
+    a.scores = c->scores_dev[area];
+    a.info = c->info_dev[area];
+    rc = launch_batch(c, a);
+    if (rc) return rc;
+    return enqueue_results_copy(c, area, n);
+}
+
+int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int64_t n = c->res_n[area];
+    if (g_out && n) memcpy(g_out, c->scores_pin[area], (size_t)n * c->ntheta * sizeof(double));
+    if (info_out && n) memcpy(info_out, c->info_pin[area], (size_t)n * sizeof(muse_info));
+    return MUSE_OK;
+}
+
+int muse_map_and_score_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                             const double* theta, double atol, int z0_mode, double* g_out, muse_info* info_out) {
+    int rc = muse_map_and_score_batch_async(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, 0);
+    if (rc) return rc;
+    return muse_batch_wait(c, 0, g_out, info_out);
+}
+
+int muse_get_zhat(muse_ctx* c, int64_t b, int64_t e, double* out, int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!out || b < 0 || e < b || e > c->zhat_slots) return fail(MUSE_ERR_INVALID, "bad slot range");
+    if (e == b) return MUSE_OK;
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)c->N * sizeof(double), c->zhat + b * c->ld, (size_t)c->ld * sizeof(double),
+                            (size_t)c->N * sizeof(double), (size_t)(e - b), out_kind(mem), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MUSE_OK;
+}
+int muse_set_zhat(muse_ctx* c, int64_t b, int64_t e, const double* in, int mem) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!in || b < 0 || e < b) return fail(MUSE_ERR_INVALID, "bad slot range");
+    if (e == b) return MUSE_OK;
+    rc = ensure_zhat(c, e);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(c->zhat + b * c->ld, (size_t)c->ld * sizeof(double), in, (size_t)c->N * sizeof(double),
+                            (size_t)c->N * sizeof(double), (size_t)(e - b), in_kind(mem), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MUSE_OK;
+}
+
+int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0,
+                           const double* step, double atol, int fid_mode, int64_t fid_sim, double* Hs_out,
+                           muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !step || !Hs_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (sim_end < sim_begin || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad sim range");
+    if (fid_mode != 0 && fid_mode != 1) return fail(MUSE_ERR_INVALID, "fid_mode must be 0 or 1");
+    const int64_t nsims = sim_end - sim_begin;
+    if (nsims == 0) return MUSE_OK;
+    const int nt = c->ntheta;
+    const int64_t n = nsims * 2 * nt;
+    if (n > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
+    for (int j = 0; j < nt; ++j)
+        if (!(step[j] != 0.0) || !isfinite(step[j])) return fail(MUSE_ERR_INVALID, "step must be finite and non-zero");
+    // 1. fiducial MAPs at theta0 from zero(z) (src/muse.jl:417-423)
+    const int64_t nfid = fid_mode == 0 ? 1 : nsims;
+    rc = ensure_zhat(c, nfid);
+    if (rc) return rc;
+    rc = ensure_results(c, 1, n > nfid ? n : nfid);
+    if (rc) return rc;
+    {
+        BatchArgs a;
+        base_args(c, a, theta0);
+        a.kind = BATCH_STD;
+        a.seed = seed;
+        a.atol = atol;
+        a.nproblems = (int)nfid;
+        a.include_data = 0;
+        a.z0_mode = MUSE_Z0_ZERO;
+        a.store_zhat = 1;
+        a.sim_begin = fid_mode == 0 ? fid_sim : sim_begin;
+        a.slot0 = 0;
+        a.scores = c->scores_dev[1];
+        a.info = c->info_dev[1];
+        rc = launch_batch(c, a);
+        if (rc) return rc;
+    }
+    // 2. the 2*ntheta perturbed simulations per sim, MAP and score at theta0
+    std::vector<double> th(nt);
+    for (int j = 0; j < nt; ++j) {
+        for (int s = 0; s < 2; ++s) {
+            for (int k = 0; k < nt; ++k) th[k] = theta0[k];
+            th[j] = theta0[j] + (s == 0 ? step[j] : -step[j]);
+            make_thetaset(c, th.data(), c->tsample_pin[2 * j + s]);
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)2 * nt * sizeof(ThetaSet), hipMemcpyHostToDevice,
+                          c->stream));
+    {
+        BatchArgs a;
+        base_args(c, a, theta0);
+        a.kind = BATCH_FD;
+        a.seed = seed;
+        a.atol = atol;
+        a.nproblems = (int)n;
+        a.sim_begin = sim_begin;
+        a.fid_slot = fid_mode == 0 ? 0 : -1;
+        a.slot0 = 0;
+        a.tsample = c->tsample_dev;
+        a.scores = c->scores_dev[1];
+        a.info = c->info_dev[1];
+        rc = launch_batch(c, a);
+        if (rc) return rc;
+    }
+    rc = enqueue_results_copy(c, 1, n);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double* g = c->scores_pin[1];
+    for (int64_t s = 0; s < nsims; ++s)
+        for (int j = 0; j < nt; ++j) {
+            const double* gp = g + ((s * nt + j) * 2 + 0) * nt;
+            const double* gm = g + ((s * nt + j) * 2 + 1) * nt;
+            for (int i = 0; i < nt; ++i) Hs_out[(s * nt + i) * nt + j] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
+        }
+    if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
+    return MUSE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// rng.hpp -- counter-based normal stream for the HIP engine (gfx950).
+//
+// Stream definition (build-defined; Julia's RNG streams are not reproducible without Julia,
+// SURVEY.md §7 "RNG parity"): Philox4x32-10 (Salmon et al., SC'11) with
+//   key = (seed lo32, seed hi32), counter = (i lo32, i hi32, sim lo32, sim hi32)
+// one call per element i of simulation `sim`; the four output words give two uniforms on
+// (0,1) with 52 random bits each, mapped to two standard normals by Box-Muller.  log and
+// sin/cos(pi t) are fixed polynomial sequences in IEEE +,-,*,/,sqrt only (this translation
+// unit is compiled with -ffp-contract=off), so a stream depends on (seed, sim, i) alone:
+// the same on every GPU, for every launch geometry, and bit-equal to a host evaluation of
+// the same sequence.  This replaces split_rng (reference src/util.jl:87-92): "stream =
+// f(master rng, sim index), never advanced by the drivers".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace muse {
+
+struct NormalPair {
+    double n1, n2;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// log(x) for x in (0,1): fdlibm-style reduction x = 2^k (1+f), log(1+f) by the degree-14
+// odd series in s = f/(2+f).  Inputs here are never subnormal (x >= 2^-53).
+__device__ __forceinline__ double log_unit(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t bits = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    bits = ((uint64_t)hx << 32) | (bits & 0xffffffffull);
+    const double m = __longlong_as_double((long long)bits);
+    const double f = m - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+// sin(pi t), cos(pi t), t in [0,2): exact reduction to |r| <= 1/4, minimax kernels on pi r.
+__device__ __forceinline__ void sincospi_02(double t, double& sn, double& cs) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
+                 C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11,
+                 PI = 3.14159265358979311600e+00;
+    const int n = (int)(2.0 * t + 0.5);
+    const double r = t - 0.5 * (double)n;
+    const double y = r * PI;
+    const double z = y * y;
+    const double w = z * z;
+    const double rs = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double v = z * y;
+    const double ks = y + v * (S1 + z * rs);
+    const double rc = z * (C1 + z * (C2 + z * C3)) + w * w * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z;
+    const double ww = 1.0 - hz;
+    const double kc = ww + (((1.0 - ww) - hz) + z * rc);
+    const bool swap = (n & 1) != 0;
+    const double a = swap ? kc : ks;  // |sin|
+    const double b = swap ? ks : kc;  // |cos|
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
+
+__device__ __forceinline__ NormalPair normal_pair(uint64_t seed, uint64_t sim, uint64_t i) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)sim, (uint32_t)(sim >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), w);
+    const uint64_t k1 = ((uint64_t)w[0] << 20) | (uint64_t)(w[1] >> 12);
+    const uint64_t k2 = ((uint64_t)w[2] << 20) | (uint64_t)(w[3] >> 12);
+    const double u1 = ((double)k1 + 0.5) * 2.220446049250313080847e-16;
+    const double u2 = ((double)k2 + 0.5) * 2.220446049250313080847e-16;
+    const double r = __builtin_sqrt(-2.0 * log_unit(u1));
+    double sn, cs;
+    sincospi_02(2.0 * u2, sn, cs);
+    return NormalPair{r * cs, r * sn};
+}
+
+}  // namespace muse

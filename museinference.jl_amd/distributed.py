@@ -1,0 +1,113 @@
+"""Sharding of the sims of one map over the GPUs of a node, one process per GPU.
+
+The reference parallelises the same map with Distributed.pmap over a worker pool (src/util.jl:74-83,
+src/muse.jl:169,417,426,508).  Here rank r owns a contiguous block of the sim indices (its ẑ warm-start
+state stays resident on its GPU), the data element lives on rank 0, and the only exchange is ONE
+all-gather of the per-rank score blocks per map (<= 64 KB; latency-bound, never xGMI-bandwidth-bound),
+after which every rank holds all scores in the reference's sim order and does the same host algebra --
+so a result is bitwise independent of the number of GPUs.  Collectives go through torch.distributed
+(backend "nccl" = RCCL over xGMI on GPUs; "gloo" on CPU for the multi-process tests).
+"""
+import numpy as np
+
+from . import _capi
+
+
+def block_partition(begin, end, world, rank):
+    """Contiguous static partition of [begin, end): the first (n mod world) ranks get one extra."""
+    n = end - begin
+    base, extra = divmod(n, world)
+    lo = begin + rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedMuseProblem:
+    """Wraps a local problem (with batched seams) so that muse_/get_J_/get_H_ run sharded.
+
+    All attribute access other than the batched seams is forwarded to the local problem."""
+
+    def __init__(self, local, group=None, device=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.local = local
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._device = device
+
+    def __getattr__(self, name):
+        return getattr(self.local, name)
+
+    def _tensor_device(self):
+        import torch
+        if self._device is not None:
+            return self._device
+        return torch.device("cuda", torch.cuda.current_device()) if self._dist.get_backend(self.group) == "nccl" \
+            else torch.device("cpu")
+
+    def _allgather_rows(self, rows, counts):
+        """rows: [count_r, width] float64 on this rank -> concatenation over ranks in rank order."""
+        import torch
+        dev = self._tensor_device()
+        width = rows.shape[1] if rows.ndim == 2 else 0
+        cmax = max(counts)
+        send = np.zeros((cmax, width))
+        send[: rows.shape[0]] = rows
+        t = torch.from_numpy(send).to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(out, t, group=self.group)
+        return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0)
+
+    @staticmethod
+    def _info_to_rows(info):
+        flat = np.asarray(info).reshape(-1)
+        return np.stack([flat[n].astype(np.float64) for n in _capi.INFO_DTYPE.names], axis=1)
+
+    @staticmethod
+    def _rows_to_info(rows):
+        info = np.zeros(rows.shape[0], dtype=_capi.INFO_DTYPE)
+        for k, n in enumerate(_capi.INFO_DTYPE.names):
+            info[n] = rows[:, k]
+        return info
+
+    def map_and_score_batch(self, rng, sim_begin, sim_end, theta, *, include_data=False, atol=1e-2,
+                            z0_mode=_capi.Z0_ZERO):
+        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
+        data_here = include_data and self.rank == 0
+        g, info = self.local.map_and_score_batch(rng, lo, hi, theta, include_data=data_here, atol=atol,
+                                                 z0_mode=z0_mode)
+        counts = []
+        for r in range(self.world):
+            l, h = block_partition(sim_begin, sim_end, self.world, r)
+            counts.append((h - l) + (1 if include_data and r == 0 else 0))
+        nth = g.shape[1]
+        rows = np.concatenate([g, self._info_to_rows(info)], axis=1)
+        allrows = self._allgather_rows(rows, counts)
+        return np.ascontiguousarray(allrows[:, :nth]), self._rows_to_info(allrows[:, nth:])
+
+    def fd_jacobian_batch(self, rng, sim_begin, sim_end, theta0, step, *, atol=1e-2, fid_mode=0, fid_sim=None):
+        from .problem import MASTER_SIM
+        fid_sim = MASTER_SIM if fid_sim is None else fid_sim
+        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
+        nth = np.atleast_1d(theta0).size
+        if hi > lo:
+            Hs, info = self.local.fd_jacobian_batch(rng, lo, hi, theta0, step, atol=atol, fid_mode=fid_mode,
+                                                    fid_sim=fid_sim)
+        else:
+            Hs, info = np.zeros((0, nth, nth)), np.zeros((0, nth, 2), dtype=_capi.INFO_DTYPE)
+        counts = [block_partition(sim_begin, sim_end, self.world, r) for r in range(self.world)]
+        counts = [h - l for l, h in counts]
+        ninfo = len(_capi.INFO_DTYPE.names)
+        rows = np.concatenate([Hs.reshape(hi - lo, nth * nth),
+                               self._info_to_rows(info).reshape(hi - lo, nth * 2 * ninfo)], axis=1)
+        allrows = self._allgather_rows(rows, counts)
+        n = allrows.shape[0]
+        Hall = allrows[:, : nth * nth].reshape(n, nth, nth)
+        iall = self._rows_to_info(allrows[:, nth * nth:].reshape(n * nth * 2, ninfo)).reshape(n, nth, 2)
+        return np.ascontiguousarray(Hall), iall
+
+    def get_zhat(self, slot_begin, slot_end):
+        raise NotImplementedError("resident MAPs are sharded; read them from the owning rank's local problem")
+
+    def set_zhat(self, slot_begin, zs):
+        raise NotImplementedError("resident MAPs are sharded; set them on the owning rank's local problem")

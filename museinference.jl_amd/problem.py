@@ -1,0 +1,302 @@
+"""The problem interface (plugin/operator API) of the reference, src/interface.jl:4-186, and the
+MI355X-backed implementation of it.
+
+Name map (Julia identifiers that are not valid Python are transliterated; valid ones are aliased):
+    sample_x_z              -> sample_x_z
+    logLike_and_∇z_logLike  -> logLike_and_grad_z_logLike
+    ∇θ_logLike              -> grad_theta_logLike
+    ẑ_at_θ                  -> zhat_at_theta      (alias ẑ_at_θ)
+    logPriorθ               -> logPrior_theta     (alias logPriorθ)
+    transform_θ / inv_transform_θ / standardizeθ / ẑ_guess_from_truth
+                            -> transform_theta / inv_transform_theta / standardize_theta /
+                               zhat_guess_from_truth (aliases with θ/ẑ)
+An `rng` is a SimRng(seed, sim): the stream of simulation `sim` under master seed `seed`
+(split_rng, src/util.jl:87-92: a stream depends only on the master rng and the sim index).
+"""
+import ctypes as C
+import warnings
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from .priors import as_prior
+
+UnTransformedθ = "untransformed"  # src/interface.jl:8-11
+Transformedθ = "transformed"
+
+MASTER_SIM = (1 << 62) - 1  # stream index standing for the un-split master rng (src/muse.jl:418)
+DATA_SIM = (1 << 32) - 1    # stream used to draw synthetic "observed" data
+
+
+@dataclass(frozen=True)
+class SimRng:
+    seed: int
+    sim: int
+
+
+def split_rng(rng, N):
+    """split_rng(rng, N): N child streams, parent not advanced (src/util.jl:87-92)."""
+    seed = rng.seed if isinstance(rng, SimRng) else int(rng)
+    return [SimRng(seed, i) for i in range(N)]
+
+
+def _seed_of(rng):
+    return rng.seed if isinstance(rng, SimRng) else int(rng)
+
+
+class AbstractMuseProblem:
+    """abstract type AbstractMuseProblem (src/interface.jl:4) with the interface defaults."""
+
+    x = None  # observed data, prob.x (src/muse.jl:170)
+
+    # -- theta space transforms: identity defaults (src/interface.jl:20,28,134)
+    def transform_theta(self, theta):
+        return theta
+
+    def inv_transform_theta(self, theta):
+        return theta
+
+    def standardize_theta(self, theta):
+        return np.atleast_1d(np.asarray(theta, dtype=np.float64)).copy()
+
+    # -- prior: zero default (src/interface.jl:120-121)
+    def logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        return 0.0
+
+    def grad_logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        return np.zeros_like(np.asarray(theta, dtype=np.float64))
+
+    def hess_logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        n = np.asarray(theta).size
+        return np.zeros((n, n))
+
+    # -- per-simulation operators, to be implemented (src/interface.jl:41-99)
+    def sample_x_z(self, rng, theta):
+        raise NotImplementedError
+
+    def logLike_and_grad_z_logLike(self, x, z, theta):
+        raise NotImplementedError
+
+    def grad_theta_logLike(self, x, z, theta, theta_space=UnTransformedθ):
+        raise NotImplementedError
+
+    def zhat_at_theta(self, x, z0, theta, grad_z_logLike_atol=1e-2):
+        raise NotImplementedError
+
+    def zhat_guess_from_truth(self, x, z, theta):
+        """zero(z) (src/interface.jl:184-186)."""
+        return np.zeros_like(z)
+
+    # aliases with the reference's spelling where Python allows it
+    ẑ_at_θ = property(lambda self: self.zhat_at_theta)
+    logPriorθ = property(lambda self: self.logPrior_theta)
+    transform_θ = property(lambda self: self.transform_theta)
+    inv_transform_θ = property(lambda self: self.inv_transform_theta)
+    standardizeθ = property(lambda self: self.standardize_theta)
+    ẑ_guess_from_truth = property(lambda self: self.zhat_guess_from_truth)
+
+
+def check_optim_soln(info, where="MAP"):
+    """_check_optim_soln (src/interface.jl:168-171): warn if not converged, log an error (no throw)
+    if the minimum is not finite."""
+    info = np.atleast_1d(info)
+    bad = info["status"] >= _capi.STATUS_MAXITER
+    if np.any(bad):
+        warnings.warn(f"{where}: MAP solution did not converge within tolerance for {int(bad.sum())} "
+                      "element(s), result could be erroneous. Try tweaking θ₀ or ∇z_logLike_atol "
+                      "arguments to muse or fixing model.", RuntimeWarning, stacklevel=3)
+    nf = ~np.isfinite(info["f_min"]) | (info["status"] == _capi.STATUS_NONFINITE)
+    if np.any(nf):
+        import logging
+        logging.getLogger("museinference").error("%s: MAP solution failed with logjoint(MAP) non-finite "
+                                                 "for %d element(s).", where, int(nf.sum()))
+
+
+class HipMuseProblem(AbstractMuseProblem):
+    """An AbstractMuseProblem whose operators run on one MI355X through libmuse_hip.so.
+
+    Plays the role of SimpleMuseProblem (src/simple.jl:79-95) for the compiled-in models; on top of
+    the per-simulation interface it exposes the two batched seams that replace the reference's
+    pmap bodies: map_and_score_batch (src/muse.jl:169-176, :508-525) and fd_jacobian_batch
+    (src/muse.jl:426-442).
+    """
+
+    def __init__(self, x, model="funnel", ntheta=1, prior=None, device=0, N=None):
+        self._lib = _capi.load_library()
+        if model not in _capi.MODELS:
+            raise ValueError(f"unknown model {model!r}; choose from {sorted(_capi.MODELS)}")
+        if x is None and N is None:
+            raise ValueError("give the observed data x (or N for a data-less problem)")
+        self.x = None if x is None else _capi.f8(x)
+        self.N = int(N) if x is None else int(self.x.size)
+        self.model = model
+        self.ntheta = int(ntheta)
+        self.prior = as_prior(prior)
+        self.device = int(device)
+        ctx = C.c_void_p()
+        _capi.check(self._lib.muse_ctx_create(_capi.MODELS[model], self.N, self.ntheta, self.device,
+                                              C.byref(ctx)))
+        self._ctx = ctx
+        if self.x is not None:
+            _capi.check(self._lib.muse_set_data(self._ctx, _capi.ptr(self.x), _capi.MEM_HOST))
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.muse_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers
+    def _theta(self, theta):
+        return _capi.f8(theta, self.ntheta)
+
+    def set_placement(self, placement):
+        """-1 auto, 0 streaming, 1 resident (bitwise-identical results; for tests/benchmarks)."""
+        _capi.check(self._lib.muse_set_placement(self._ctx, int(placement)))
+
+    def set_stream(self, hip_stream):
+        _capi.check(self._lib.muse_set_stream(self._ctx, _capi.ptr(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        _capi.check(self._lib.muse_synchronize(self._ctx))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _capi.check(self._lib.muse_last_kernel_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
+    # -- prior (SimpleMuseProblem forwards to the user's function, src/simple.jl:93)
+    def logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        return self.prior.logpdf(np.asarray(theta, dtype=np.float64))
+
+    def grad_logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        return np.atleast_1d(self.prior.grad(np.asarray(theta, dtype=np.float64)))
+
+    def hess_logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        return np.atleast_2d(self.prior.hess(np.asarray(theta, dtype=np.float64)))
+
+    # -- per-simulation operators
+    def sample_x_z(self, rng, theta):
+        """sample_x_z(prob, rng, θ) -> (x, z)   [src/interface.jl:92-99]"""
+        x = np.empty(self.N)
+        z = np.empty(self.N)
+        th = self._theta(theta)
+        _capi.check(self._lib.muse_sample_x_z(self._ctx, rng.seed, rng.sim, _capi.ptr(th), _capi.ptr(x),
+                                              _capi.ptr(z), _capi.MEM_HOST))
+        return x, z
+
+    def logLike_and_grad_z_logLike(self, x, z, theta):
+        """logLike_and_∇z_logLike(prob, x, z, θ) -> (logLike, ∇z logLike)   [src/interface.jl:68-83]"""
+        x = _capi.f8(x, self.N)
+        z = _capi.f8(z, self.N)
+        th = self._theta(theta)
+        g = np.empty(self.N)
+        f = C.c_double()
+        _capi.check(self._lib.muse_logLike_and_grad_z(self._ctx, _capi.ptr(x), _capi.ptr(z), _capi.ptr(th),
+                                                      C.byref(f), _capi.ptr(g), _capi.MEM_HOST))
+        return f.value, g
+
+    def grad_theta_logLike(self, x, z, theta, theta_space=UnTransformedθ):
+        """∇θ_logLike(prob, x, z, θ[, θ_space])   [src/interface.jl:41-58]"""
+        x = _capi.f8(x, self.N)
+        z = _capi.f8(z, self.N)
+        th = self._theta(theta)
+        g = np.empty(self.ntheta)
+        _capi.check(self._lib.muse_grad_theta(self._ctx, _capi.ptr(x), _capi.ptr(z), _capi.ptr(th), _capi.ptr(g),
+                                              _capi.MEM_HOST))
+        return g
+
+    def zhat_at_theta(self, x, z0, theta, grad_z_logLike_atol=1e-2):
+        """ẑ_at_θ(prob, x, z₀, θ; ∇z_logLike_atol) -> (ẑ, info)   [src/interface.jl:141-171]"""
+        x = _capi.f8(x, self.N)
+        z0 = _capi.f8(z0, self.N)
+        th = self._theta(theta)
+        z = np.empty(self.N)
+        info = np.zeros(1, dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_zhat_at_theta(self._ctx, _capi.ptr(x), _capi.ptr(z0), _capi.ptr(th),
+                                                 float(grad_z_logLike_atol), _capi.ptr(z), _capi.ptr(info),
+                                                 _capi.MEM_HOST))
+        check_optim_soln(info, "ẑ_at_θ")
+        return z, info[0]
+
+    # -- batched seams
+    def map_and_score_batch(self, rng, sim_begin, sim_end, theta, *, include_data=False, atol=1e-2,
+                            z0_mode=_capi.Z0_ZERO):
+        """All elements of one muse!/get_J! map in one launch.  Returns (g [n, nθ], info [n]);
+        element order: [data], sim_begin .. sim_end-1.  ẑ of element e stays resident at slot e."""
+        th = self._theta(theta)
+        n = (sim_end - sim_begin) + (1 if include_data else 0)
+        g = np.empty((n, self.ntheta))
+        info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_map_and_score_batch(self._ctx, _seed_of(rng), sim_begin, sim_end,
+                                                       int(bool(include_data)), _capi.ptr(th), float(atol),
+                                                       int(z0_mode), _capi.ptr(g), _capi.ptr(info)))
+        return g, info
+
+    def map_and_score_batch_async(self, rng, sim_begin, sim_end, theta, *, include_data=False, atol=1e-2,
+                                  z0_mode=_capi.Z0_ZERO, result_area=0):
+        th = self._theta(theta)
+        _capi.check(self._lib.muse_map_and_score_batch_async(self._ctx, _seed_of(rng), sim_begin, sim_end,
+                                                             int(bool(include_data)), _capi.ptr(th), float(atol),
+                                                             int(z0_mode), int(result_area)))
+        return (sim_end - sim_begin) + (1 if include_data else 0)
+
+    def batch_wait(self, n, result_area=0):
+        g = np.empty((n, self.ntheta))
+        info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_batch_wait(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
+        return g, info
+
+    def get_zhat(self, slot_begin, slot_end):
+        out = np.empty((slot_end - slot_begin, self.N))
+        _capi.check(self._lib.muse_get_zhat(self._ctx, slot_begin, slot_end, _capi.ptr(out), _capi.MEM_HOST))
+        return out
+
+    def set_zhat(self, slot_begin, zs):
+        zs = np.ascontiguousarray(np.atleast_2d(np.asarray(zs, dtype=np.float64)))
+        if zs.shape[1] != self.N:
+            raise ValueError("zhat rows must have N columns")
+        _capi.check(self._lib.muse_set_zhat(self._ctx, slot_begin, slot_begin + zs.shape[0], _capi.ptr(zs),
+                                            _capi.MEM_HOST))
+
+    def fd_jacobian_batch(self, rng, sim_begin, sim_end, theta0, step, *, atol=1e-2, fid_mode=0,
+                          fid_sim=MASTER_SIM):
+        """get_H! finite-difference Jacobians for sims [sim_begin, sim_end): returns
+        (Hs [nsims, nθ, nθ], info [nsims, nθ, 2])."""
+        th = self._theta(theta0)
+        st = _capi.f8(step, self.ntheta)
+        ns = sim_end - sim_begin
+        Hs = np.empty((ns, self.ntheta, self.ntheta))
+        info = np.zeros((ns, self.ntheta, 2), dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_fd_jacobian_batch(self._ctx, _seed_of(rng), sim_begin, sim_end, _capi.ptr(th),
+                                                     _capi.ptr(st), float(atol), int(fid_mode), int(fid_sim),
+                                                     _capi.ptr(Hs), _capi.ptr(info)))
+        return Hs, info
+
+    # -- RCCL exchange (C1-C3 of SURVEY.md §2) through the C ABI, for hosts without torch.distributed
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * _capi.UNIQUE_ID_BYTES)()
+        _capi.check(_capi.load_library().muse_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        _capi.check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), C.c_char_p(unique_id)))
+        self._nranks = int(nranks)
+
+    def allgather_scores(self, send):
+        send = _capi.f8(send)
+        recv = np.empty((self._nranks, send.size))
+        _capi.check(self._lib.muse_allgather_scores(self._ctx, _capi.ptr(send), send.size, _capi.ptr(recv)))
+        return recv
+
+    def allreduce_sum(self, buf):
+        buf = _capi.f8(buf).copy()
+        _capi.check(self._lib.muse_allreduce_sum(self._ctx, _capi.ptr(buf), buf.size))
+        return buf

@@ -1,0 +1,756 @@
+/*
+ * muse_oracle.c -- CPU restatement of the MUSE inner loop.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product path (museinference.jl_amd/) never links, imports or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" against reference *outputs*: the reference
+ * (marius311/MuseInference.jl, Julia) cannot run in this image (no julia binary) and holds
+ * no golden vectors or known-answer tests for this path (test/runtests.jl:31,56,81 only
+ * assert |mu|/sigma < 2).  The oracle is instead pinned against
+ *   (i)  closed-form known answers of every model (tests/test_oracle.py):
+ *        funnel MAP  zhat = x/(1+e^-theta), score = 1/2 [e^-theta sum zhat^2 - N], ...
+ *   (ii) scipy.optimize L-BFGS-B minimisers of the same objective,
+ *   (iii) the Philox4x32-10 known-answer vectors of Salmon et al. (Random123 kat_vectors),
+ *   (iv) the reference's own statistical criterion mu/sigma < 2 on its 512-dim funnel test.
+ *
+ * What each function follows (paths relative to /root/reference):
+ *   mo_sample_x_z           src/simple.jl:61-65, docs/src/index.md:156-160  (funnel closure)
+ *   mo_logLike_and_grad_z   src/interface.jl:68-83, src/simple.jl:66-68,85
+ *   mo_grad_theta           src/interface.jl:41-58, src/simple.jl:84
+ *   mo_zhat_at_theta        src/interface.jl:162-171  (Optim.optimize(only_fg, z0, LBFGS(),
+ *                           Options(g_tol=atol)) -- minimise -logLike)
+ *   mo_map_and_score        src/muse.jl:169-176 (muse! map body), :508-525 (get_J! body)
+ *   mo_fd_jacobian          src/muse.jl:426-442 + src/util.jl:9-27 (pjacobian, central_fdm(3,1))
+ *
+ * Third-party arithmetic that is NOT vendored in the reference (Project.toml compat only,
+ * no Manifest.toml) and is restated here from the published algorithms:
+ *   Optim.jl ("1.5" compat, Project.toml:45)  LBFGS(m=10, alphaguess=InitialStatic(alpha=1),
+ *       linesearch=HagerZhang(), scaleinvH0=true); Options(x_abstol=x_reltol=f_abstol=
+ *       f_reltol=0, g_abstol=atol, successive_f_tol=1, iterations=1000,
+ *       allow_f_increases=true).
+ *   LineSearches.jl HagerZhang (delta=.1, sigma=.9, alphamax=Inf, rho=5, epsilon=1e-6,
+ *       gamma=.66, linesearchmax=50, psi3=.1): Hager & Zhang, "Algorithm 851: CG_DESCENT",
+ *       ACM TOMS 32 (2006), stages B0-B3 (bracket), U0-U3 (update), S1-S4 (secant2).
+ *   FiniteDifferences.jl central_fdm(3,1) (Project.toml:40): grid (-1,0,1), coefficients
+ *       (-1/2,0,1/2), explicit step => no adaptation.
+ * Random numbers: Julia's RNG streams cannot be reproduced without Julia; "same seeds"
+ * means the build-defined counter-based stream below, shared (as an algorithm, not as
+ * code) by this oracle and the HIP kernels:
+ *   Philox4x32-10, key = (seed lo32, seed hi32), counter = (i lo32, i hi32, sim lo32,
+ *   sim hi32); u1 = ((w0<<20 | w1>>12) + 0.5) 2^-52, u2 likewise from (w2,w3);
+ *   Box-Muller r = sqrt(-2 log u1), n1 = r cos(2 pi u2), n2 = r sin(2 pi u2), with log and
+ *   sin/cos(pi t) evaluated by the fixed fdlibm-style polynomial sequences written out
+ *   below using only IEEE +,-,*,/,sqrt (no contraction), so that both sides are bit-equal.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MO_MODEL_FUNNEL 0 /* z_i ~ N(0, e^theta_k(i)), x_i ~ N(z_i, 1)          */
+#define MO_MODEL_NOISE 1  /* z_i ~ N(0, 1),            x_i ~ N(z_i, e^theta)     */
+#define MO_MODEL_SMOOTH 2 /* z as funnel, x = A z + n, A = periodic (1/4,1/2,1/4) */
+
+#define MO_STATUS_G_CONVERGED 0
+#define MO_STATUS_X_CONVERGED 1
+#define MO_STATUS_F_CONVERGED 2
+#define MO_STATUS_MAXITER 3
+#define MO_STATUS_LINESEARCH_FAILED 4
+#define MO_STATUS_NONFINITE 5
+
+typedef struct {
+    int32_t iterations; /* L-BFGS iterations K                                  */
+    int32_t f_calls;    /* objective/gradient evaluations E                     */
+    int32_t status;     /* MO_STATUS_*                                          */
+    int32_t hist_words; /* sum_k min(k-1,m) over iterations (two-loop pairs)    */
+    double f_min;       /* minimum of -logLike                                  */
+    double gnorm;       /* ||grad||_inf at the returned point                   */
+} mo_info;
+
+/* ---------------------------------------------------------------- Philox4x32-10 */
+/* Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11. */
+void mo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* log(x) for finite x > 0: the classic fdlibm/musl argument reduction + degree-14 series. */
+static double mo_log(double x) {
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                        Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                        Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                        Lg7 = 1.479819860511658591e-01;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    int k = 0;
+    if (hx < 0x00100000u) { /* subnormal: scale up by 2^54 */
+        k -= 54;
+        x *= 18014398509481984.0;
+        memcpy(&bits, &x, 8);
+        hx = (uint32_t)(bits >> 32);
+    }
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    bits = ((uint64_t)hx << 32) | (bits & 0xffffffffu);
+    memcpy(&x, &bits, 8);
+    double f = x - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+/* sin(pi t), cos(pi t) for t in [0,2): exact octant reduction, fdlibm kernels on |y|<=pi/4. */
+static void mo_sincospi(double t, double* sn, double* cs) {
+    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
+                        C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11,
+                        PI = 3.14159265358979311600e+00;
+    int n = (int)(2.0 * t + 0.5); /* nearest half-integer index, 0..4 */
+    double r = t - 0.5 * (double)n; /* exact, |r| <= 1/4 */
+    double y = r * PI;
+    double z = y * y;
+    double w = z * z;
+    double rs = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    double v = z * y;
+    double ks = y + v * (S1 + z * rs);
+    double rc = z * (C1 + z * (C2 + z * C3)) + w * w * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    double ww = 1.0 - hz;
+    double kc = ww + (((1.0 - ww) - hz) + z * rc);
+    switch (n & 3) {
+        case 0: *sn = ks; *cs = kc; break;
+        case 1: *sn = kc; *cs = -ks; break;
+        case 2: *sn = -ks; *cs = -kc; break;
+        default: *sn = -kc; *cs = ks; break;
+    }
+}
+
+/* Two independent standard normals for (seed, sim, element i). */
+void mo_normal_pair(uint64_t seed, uint64_t sim, uint64_t i, double* n1, double* n2) {
+    uint32_t ctr[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)sim, (uint32_t)(sim >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    mo_philox4x32_10(ctr, key, w);
+    uint64_t k1 = ((uint64_t)w[0] << 20) | (w[1] >> 12);
+    uint64_t k2 = ((uint64_t)w[2] << 20) | (w[3] >> 12);
+    double u1 = ((double)k1 + 0.5) * 2.220446049250313080847e-16; /* 2^-52, in (0,1) */
+    double u2 = ((double)k2 + 0.5) * 2.220446049250313080847e-16;
+    double r = sqrt(-2.0 * mo_log(u1));
+    double sn, cs;
+    mo_sincospi(2.0 * u2, &sn, &cs);
+    *n1 = r * cs;
+    *n2 = r * sn;
+}
+
+void mo_normals(uint64_t seed, uint64_t sim, int64_t N, double* n1, double* n2) {
+    for (int64_t i = 0; i < N; ++i) mo_normal_pair(seed, sim, (uint64_t)i, &n1[i], &n2[i]);
+}
+
+/* ---------------------------------------------------------------- models */
+static inline int mo_block(int64_t i, int64_t N, int B) { return (int)((i * (int64_t)B) / N); }
+
+static inline double mo_Az(const double* z, int64_t i, int64_t N) { /* periodic (1/4,1/2,1/4) */
+    int64_t im = (i == 0) ? N - 1 : i - 1, ip = (i == N - 1) ? 0 : i + 1;
+    return 0.5 * z[i] + 0.25 * (z[im] + z[ip]);
+}
+
+
+/* sum_i theta_k(i) = sum_k N_k theta_k, N_k = size of block k */
+static double mo_theta_const(int64_t N, int ntheta, const double* theta) {
+    double cst = 0.0;
+    for (int k = 0; k < ntheta; ++k) {
+        int64_t lo = ((int64_t)k * N + ntheta - 1) / ntheta, hi = ((int64_t)(k + 1) * N + ntheta - 1) / ntheta;
+        cst += (double)(hi - lo) * theta[k];
+    }
+    return cst;
+}
+
+/* sample_x_z(prob, rng, theta) -> (x, z)   [src/interface.jl:92-99, src/simple.jl:61-65] */
+void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim, const double* theta,
+                   double* x, double* z) {
+    double sd[64];
+    for (int k = 0; k < ntheta; ++k) sd[k] = exp(0.5 * theta[k]);
+    if (model == MO_MODEL_NOISE) {
+        for (int64_t i = 0; i < N; ++i) {
+            double n1, n2;
+            mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
+            z[i] = n1;
+            x[i] = n1 + sd[0] * n2;
+        }
+    } else if (model == MO_MODEL_FUNNEL) {
+        for (int64_t i = 0; i < N; ++i) {
+            double n1, n2;
+            mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
+            z[i] = sd[mo_block(i, N, ntheta)] * n1;
+            x[i] = z[i] + n2;
+        }
+    } else { /* SMOOTH: x = A z + n2 */
+        for (int64_t i = 0; i < N; ++i) {
+            double n1, n2;
+            mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
+            z[i] = sd[mo_block(i, N, ntheta)] * n1;
+            x[i] = n2;
+        }
+        for (int64_t i = 0; i < N; ++i) x[i] = mo_Az(z, i, N) + x[i];
+    }
+}
+
+/* F(z) = -logLike(x,z,theta) and G = dF/dz.  This is what Optim minimises
+ * (src/interface.jl:163: only_fg(z -> .-logLike_and_grad_z)). */
+double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, const double* z,
+                          const double* theta, double* G) {
+    double iv[64];
+    for (int k = 0; k < ntheta; ++k) iv[k] = exp(-theta[k]);
+    double acc = 0.0, cst = 0.0;
+    if (model == MO_MODEL_NOISE) {
+        for (int64_t i = 0; i < N; ++i) {
+            double r = x[i] - z[i];
+            acc += iv[0] * (r * r) + z[i] * z[i];
+            if (G) G[i] = z[i] - iv[0] * r;
+        }
+        cst = (double)N * theta[0];
+    } else if (model == MO_MODEL_FUNNEL) {
+        for (int64_t i = 0; i < N; ++i) {
+            int k = mo_block(i, N, ntheta);
+            double r = x[i] - z[i];
+            acc += r * r + iv[k] * (z[i] * z[i]);
+            if (G) G[i] = iv[k] * z[i] - r;
+        }
+        cst = mo_theta_const(N, ntheta, theta);
+    } else {
+        /* F = 1/2 |x - A z|^2 + 1/2 sum iv z^2 + const ; G = iv z - A^T (x - A z), A symmetric */
+        double* r = (double*)malloc((size_t)N * sizeof(double));
+        for (int64_t i = 0; i < N; ++i) r[i] = x[i] - mo_Az(z, i, N);
+        for (int64_t i = 0; i < N; ++i) {
+            int k = mo_block(i, N, ntheta);
+            acc += r[i] * r[i] + iv[k] * (z[i] * z[i]);
+            if (G) G[i] = iv[k] * z[i] - mo_Az(r, i, N);
+        }
+        free(r);
+        cst = mo_theta_const(N, ntheta, theta);
+    }
+    return 0.5 * (acc + cst);
+}
+
+/* logLike_and_grad_z(prob,x,z,theta) -> (logLike, grad_z logLike)  [src/interface.jl:68-83] */
+double mo_logLike_and_grad_z(int model, int64_t N, int ntheta, const double* x, const double* z,
+                             const double* theta, double* g) {
+    double F = mo_negloglike_grad(model, N, ntheta, x, z, theta, g);
+    if (g)
+        for (int64_t i = 0; i < N; ++i) g[i] = -g[i];
+    return -F;
+}
+
+/* grad_theta logLike(x,z,theta)  [src/interface.jl:41-58, src/simple.jl:84] */
+void mo_grad_theta(int model, int64_t N, int ntheta, const double* x, const double* z, const double* theta,
+                   double* out) {
+    if (model == MO_MODEL_NOISE) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+            double r = x[i] - z[i];
+            acc += r * r;
+        }
+        out[0] = 0.5 * (exp(-theta[0]) * acc - (double)N);
+        return;
+    }
+    double acc[64];
+    int64_t cnt[64];
+    for (int k = 0; k < ntheta; ++k) { acc[k] = 0.0; cnt[k] = 0; }
+    for (int64_t i = 0; i < N; ++i) {
+        int k = mo_block(i, N, ntheta);
+        acc[k] += z[i] * z[i];
+        cnt[k] += 1;
+    }
+    for (int k = 0; k < ntheta; ++k) out[k] = 0.5 * (exp(-theta[k]) * acc[k] - (double)cnt[k]);
+}
+
+/* ---------------------------------------------------------------- objective wrapper with
+ * the NLSolversBase value_gradient! cache (evaluation is skipped when the point is the one
+ * last evaluated), which decides f_calls. */
+typedef struct {
+    int model, ntheta;
+    int64_t N;
+    const double *x, *theta;
+    double* x_last; /* point of the last evaluation */
+    double* g;      /* gradient(d): gradient at x_last */
+    double f;       /* value(d) */
+    int have;
+    int f_calls;
+} mo_obj;
+
+static void mo_value_gradient(mo_obj* d, const double* xp) {
+    if (d->have && memcmp(d->x_last, xp, (size_t)d->N * sizeof(double)) == 0) return;
+    d->f = mo_negloglike_grad(d->model, d->N, d->ntheta, d->x, xp, d->theta, d->g);
+    memcpy(d->x_last, xp, (size_t)d->N * sizeof(double));
+    d->have = 1;
+    d->f_calls += 1;
+}
+
+static double mo_dot(const double* a, const double* b, int64_t N) {
+    double s = 0.0;
+    for (int64_t i = 0; i < N; ++i) s += a[i] * b[i];
+    return s;
+}
+static double mo_maxabs(const double* a, int64_t N) {
+    double m = 0.0;
+    for (int64_t i = 0; i < N; ++i) {
+        double v = fabs(a[i]);
+        if (!(v <= m)) m = v; /* propagates NaN like Julia's maximum(abs, .) */
+    }
+    return m;
+}
+static int mo_allfinite(const double* a, int64_t N) {
+    for (int64_t i = 0; i < N; ++i)
+        if (!isfinite(a[i])) return 0;
+    return 1;
+}
+
+/* ---------------------------------------------------------------- HagerZhang line search */
+typedef struct {
+    double *alphas, *values, *slopes;
+    int n, cap;
+} hz_trace;
+static void hz_push(hz_trace* t, double a, double v, double s) {
+    if (t->n == t->cap) {
+        t->cap *= 2;
+        t->alphas = (double*)realloc(t->alphas, (size_t)t->cap * sizeof(double));
+        t->values = (double*)realloc(t->values, (size_t)t->cap * sizeof(double));
+        t->slopes = (double*)realloc(t->slopes, (size_t)t->cap * sizeof(double));
+    }
+    t->alphas[t->n] = a; t->values[t->n] = v; t->slopes[t->n] = s;
+    t->n += 1;
+}
+
+typedef struct {
+    mo_obj* d;
+    const double *x, *s;
+    double* x_new;
+} hz_line;
+
+/* phi(alpha), dphi(alpha): x_new = x + alpha s; value_gradient!(d, x_new). */
+static void hz_phidphi(hz_line* L, double alpha, double* phi, double* dphi) {
+    int64_t N = L->d->N;
+    for (int64_t i = 0; i < N; ++i) L->x_new[i] = L->x[i] + alpha * L->s[i];
+    mo_value_gradient(L->d, L->x_new);
+    *phi = L->d->f;
+    *dphi = mo_dot(L->d->g, L->s, N);
+}
+
+#define HZ_DELTA 0.1
+#define HZ_SIGMA 0.9
+#define HZ_RHO 5.0
+#define HZ_EPSILON 1e-6
+#define HZ_GAMMA 0.66
+#define HZ_LINESEARCHMAX 50
+#define HZ_PSI3 0.1
+#define MO_EPS 2.220446049250313e-16
+
+static double hz_eps_of(double b) { return nextafter(fabs(b), INFINITY) - fabs(b); } /* eps(b) */
+
+static int hz_satisfies_wolfe(double c, double phi_c, double dphi_c, double phi_0, double dphi_0,
+                              double phi_lim) {
+    int wolfe1 = (HZ_DELTA * dphi_0 >= (phi_c - phi_0) / c) && (dphi_c >= HZ_SIGMA * dphi_0);
+    int wolfe2 = ((2.0 * HZ_DELTA - 1.0) * dphi_0 >= dphi_c) && (dphi_c >= HZ_SIGMA * dphi_0) &&
+                 (phi_c <= phi_lim);
+    return wolfe1 || wolfe2;
+}
+
+/* HZ stage U3 (theta = 1/2).  Returns 0 ok, -1 on a failed internal assertion. */
+static int hz_bisect(hz_line* L, hz_trace* t, int ia, int ib, double phi_lim, int* oa, int* ob) {
+    double a = t->alphas[ia], b = t->alphas[ib];
+    if (!(t->slopes[ia] < 0.0 && t->values[ia] <= phi_lim && t->slopes[ib] < 0.0 &&
+          t->values[ib] > phi_lim && b > a))
+        return -1;
+    while (b - a > hz_eps_of(b)) {
+        double d = (a + b) / 2.0, phi_d, gphi;
+        hz_phidphi(L, d, &phi_d, &gphi);
+        if (!(isfinite(phi_d) && isfinite(gphi))) return -1;
+        hz_push(t, d, phi_d, gphi);
+        int id = t->n - 1;
+        if (gphi >= 0.0) { *oa = ia; *ob = id; return 0; }
+        if (phi_d <= phi_lim) { a = d; ia = id; }
+        else { b = d; ib = id; }
+    }
+    *oa = ia; *ob = ib;
+    return 0;
+}
+
+/* HZ stages U0-U3. */
+static int hz_update(hz_line* L, hz_trace* t, int ia, int ib, int ic, double phi_lim, int* oa, int* ob) {
+    double a = t->alphas[ia], b = t->alphas[ib];
+    if (!(t->slopes[ia] < 0.0 && t->values[ia] <= phi_lim && t->slopes[ib] >= 0.0 && b > a)) return -1;
+    double c = t->alphas[ic], phi_c = t->values[ic], dphi_c = t->slopes[ic];
+    if (c < a || c > b) { *oa = ia; *ob = ib; return 0; }
+    if (dphi_c >= 0.0) { *oa = ia; *ob = ic; return 0; }
+    if (phi_c <= phi_lim) { *oa = ic; *ob = ib; return 0; }
+    return hz_bisect(L, t, ia, ic, phi_lim, oa, ob);
+}
+
+static double hz_secant(double a, double b, double dphi_a, double dphi_b) {
+    return (a * dphi_b - b * dphi_a) / (dphi_b - dphi_a);
+}
+
+/* HZ stages S1-S4.  Returns 1 wolfe, 0 not, -1 failure. */
+static int hz_secant2(hz_line* L, hz_trace* t, int ia, int ib, double phi_lim, int* oA, int* oB) {
+    double phi_0 = t->values[0], dphi_0 = t->slopes[0];
+    double a = t->alphas[ia], b = t->alphas[ib];
+    double dphi_a = t->slopes[ia], dphi_b = t->slopes[ib];
+    if (!(dphi_a < 0.0 && dphi_b >= 0.0)) return -1;
+    double c = hz_secant(a, b, dphi_a, dphi_b);
+    if (!isfinite(c)) return -1;
+    double phi_c, dphi_c;
+    hz_phidphi(L, c, &phi_c, &dphi_c);
+    if (!(isfinite(phi_c) && isfinite(dphi_c))) return -1;
+    hz_push(t, c, phi_c, dphi_c);
+    int ic = t->n - 1;
+    if (hz_satisfies_wolfe(c, phi_c, dphi_c, phi_0, dphi_0, phi_lim)) { *oA = ic; *oB = ic; return 1; }
+    int iA, iB;
+    if (hz_update(L, t, ia, ib, ic, phi_lim, &iA, &iB) < 0) return -1;
+    a = t->alphas[iA];
+    b = t->alphas[iB];
+    if (iB == ic) c = hz_secant(t->alphas[ib], t->alphas[iB], t->slopes[ib], t->slopes[iB]);
+    else if (iA == ic) c = hz_secant(t->alphas[ia], t->alphas[iA], t->slopes[ia], t->slopes[iA]);
+    if ((iA == ic || iB == ic) && a <= c && c <= b) {
+        hz_phidphi(L, c, &phi_c, &dphi_c);
+        if (!(isfinite(phi_c) && isfinite(dphi_c))) return -1;
+        hz_push(t, c, phi_c, dphi_c);
+        ic = t->n - 1;
+        if (hz_satisfies_wolfe(c, phi_c, dphi_c, phi_0, dphi_0, phi_lim)) { *oA = ic; *oB = ic; return 1; }
+        int jA, jB;
+        if (hz_update(L, t, iA, iB, ic, phi_lim, &jA, &jB) < 0) return -1;
+        iA = jA; iB = jB;
+    }
+    *oA = iA; *oB = iB;
+    return 0;
+}
+
+/* The line search proper.  Returns 0 and *alpha on success; -1 (LineSearchException or a
+ * failed assertion) with *alpha = the step Optim would fall back to. */
+static int hz_linesearch(hz_line* L, double c, double phi_0, double dphi_0, double* alpha) {
+    double alphamax = INFINITY;
+    *alpha = 0.0;
+    if (!(isfinite(phi_0) && isfinite(dphi_0))) return -1;
+    if (dphi_0 >= MO_EPS * fabs(phi_0)) return -1; /* not a descent direction */
+    if (dphi_0 >= 0.0) return 0;                    /* alpha = 0 */
+    const int iterfinitemax = 52;                   /* ceil(-log2(eps)) */
+    hz_trace t;
+    t.cap = 16; t.n = 0;
+    t.alphas = (double*)malloc(16 * sizeof(double));
+    t.values = (double*)malloc(16 * sizeof(double));
+    t.slopes = (double*)malloc(16 * sizeof(double));
+    hz_push(&t, 0.0, phi_0, dphi_0);
+    int rc = -1;
+    double phi_lim = phi_0 + HZ_EPSILON * fabs(phi_0);
+    if (c <= MO_EPS) { rc = 0; goto done; }
+    double phi_c, dphi_c;
+    hz_phidphi(L, c, &phi_c, &dphi_c);
+    int iterfinite = 1;
+    while (!(isfinite(phi_c) && isfinite(dphi_c)) && iterfinite < iterfinitemax) {
+        iterfinite += 1;
+        c *= HZ_PSI3;
+        hz_phidphi(L, c, &phi_c, &dphi_c);
+    }
+    if (!(isfinite(phi_c) && isfinite(dphi_c))) { rc = 0; goto done; } /* alpha = 0 */
+    hz_push(&t, c, phi_c, dphi_c);
+    /* mayterminate is false under InitialStatic: no Wolfe test on the initial point. */
+    int isbracketed = 0, ia = 0, ib = 1, iter = 1;
+    double cold = -1.0;
+    while (!isbracketed && iter < HZ_LINESEARCHMAX) {
+        if (dphi_c >= 0.0) {
+            ib = t.n - 1;
+            for (int i = ib - 1; i >= 0; --i)
+                if (t.values[i] <= phi_lim) { ia = i; break; }
+            isbracketed = 1;
+        } else if (t.values[t.n - 1] > phi_lim) {
+            ib = t.n - 1;
+            ia = 0;
+            if (hz_bisect(L, &t, ia, ib, phi_lim, &ia, &ib) < 0) { *alpha = t.alphas[ia]; goto done; }
+            isbracketed = 1;
+        } else {
+            cold = c;
+            if (nextafter(cold, INFINITY) >= alphamax) { *alpha = cold; rc = 0; goto done; }
+            c *= HZ_RHO;
+            if (c > alphamax) c = alphamax;
+            hz_phidphi(L, c, &phi_c, &dphi_c);
+            iterfinite = 1;
+            while (!(isfinite(phi_c) && isfinite(dphi_c)) && c > nextafter(cold, INFINITY) &&
+                   iterfinite < iterfinitemax) {
+                alphamax = c;
+                iterfinite += 1;
+                c = (cold + c) / 2.0;
+                hz_phidphi(L, c, &phi_c, &dphi_c);
+            }
+            if (!(isfinite(phi_c) && isfinite(dphi_c))) { *alpha = cold; rc = 0; goto done; }
+            hz_push(&t, c, phi_c, dphi_c);
+        }
+        iter += 1;
+    }
+    while (iter < HZ_LINESEARCHMAX) {
+        double a = t.alphas[ia], b = t.alphas[ib];
+        if (!(b > a)) { *alpha = a; goto done; }
+        if (b - a <= hz_eps_of(b)) { *alpha = a; rc = 0; goto done; }
+        int iA, iB;
+        int w = hz_secant2(L, &t, ia, ib, phi_lim, &iA, &iB);
+        if (w < 0) { *alpha = a; goto done; }
+        if (w == 1) { *alpha = t.alphas[iA]; rc = 0; goto done; }
+        double A = t.alphas[iA], B = t.alphas[iB];
+        if (!(B > A)) { *alpha = A; goto done; }
+        if (B - A < HZ_GAMMA * (b - a)) {
+            if (nextafter(t.values[ia], INFINITY) >= t.values[ib] &&
+                nextafter(t.values[iA], INFINITY) >= t.values[iB]) {
+                *alpha = A; rc = 0; goto done; /* flat: secant did nothing useful */
+            }
+            ia = iA; ib = iB;
+        } else {
+            c = (A + B) / 2.0;
+            hz_phidphi(L, c, &phi_c, &dphi_c);
+            if (!(isfinite(phi_c) && isfinite(dphi_c))) { *alpha = A; goto done; }
+            hz_push(&t, c, phi_c, dphi_c);
+            if (hz_update(L, &t, iA, iB, t.n - 1, phi_lim, &ia, &ib) < 0) { *alpha = A; goto done; }
+        }
+        iter += 1;
+    }
+    *alpha = t.alphas[ia]; /* LineSearchException: reached linesearchmax */
+done:
+    free(t.alphas); free(t.values); free(t.slopes);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- Optim LBFGS */
+#define LBFGS_M 10
+#define LBFGS_MAXITER 1000
+static inline int mod1(int i, int m) { int r = i % m; return r == 0 ? m : r; }
+
+/* zhat_at_theta(prob, x, z0, theta; atol) -> (zhat, info)   [src/interface.jl:162-171] */
+int mo_zhat_at_theta(int model, int64_t N, int ntheta, const double* x, const double* z0,
+                     const double* theta, double atol, double* zout, mo_info* info) {
+    size_t nb = (size_t)N * sizeof(double);
+    mo_obj d;
+    d.model = model; d.ntheta = ntheta; d.N = N; d.x = x; d.theta = theta;
+    d.x_last = (double*)malloc(nb); d.g = (double*)malloc(nb);
+    d.have = 0; d.f_calls = 0; d.f = 0.0;
+    double* X = (double*)malloc(nb);
+    double* Xprev = (double*)malloc(nb);
+    double* gprev = (double*)malloc(nb);
+    double* s = (double*)malloc(nb);
+    double* q = (double*)malloc(nb);
+    double* dx = (double*)malloc(nb);
+    double* dg = (double*)malloc(nb);
+    double* x_ls = (double*)malloc(nb);
+    double* dxh = (double*)malloc(nb * LBFGS_M);
+    double* dgh = (double*)malloc(nb * LBFGS_M);
+    double rho[LBFGS_M + 1], tl_alpha[LBFGS_M + 1];
+    memcpy(X, z0, nb);
+
+    /* initial_state: value_gradient!!(d, x0); initial_convergence */
+    mo_value_gradient(&d, X);
+    int iterations = 0, pseudo = 0, status = MO_STATUS_MAXITER, hist_words = 0;
+    int counter_f_tol = 0;
+    double f_prev = NAN;
+    int converged = 0;
+    if (!isfinite(d.f) || !mo_allfinite(d.g, N)) {
+        status = MO_STATUS_NONFINITE;
+        converged = 1; /* "stopped": loop not entered */
+    } else if (mo_maxabs(d.g, N) <= atol) {
+        status = MO_STATUS_G_CONVERGED;
+        converged = 1;
+    }
+    while (!converged && iterations < LBFGS_MAXITER) {
+        iterations += 1;
+        /* ---- update_state! ---- */
+        pseudo += 1;
+        {   /* twoloop! */
+            int lower = pseudo - LBFGS_M, upper = pseudo - 1;
+            memcpy(q, d.g, nb);
+            for (int index = upper; index >= lower; --index) {
+                if (index < 1) continue;
+                int i = mod1(index, LBFGS_M);
+                const double *dgi = dgh + (size_t)(i - 1) * N, *dxi = dxh + (size_t)(i - 1) * N;
+                tl_alpha[i] = rho[i] * mo_dot(dxi, q, N);
+                for (int64_t e = 0; e < N; ++e) q[e] -= tl_alpha[i] * dgi[e];
+                hist_words += 1;
+            }
+            if (pseudo > 1) { /* scaleinvH0: Nocedal & Wright eq. (7.20) */
+                int i = mod1(upper, LBFGS_M);
+                const double *dgi = dgh + (size_t)(i - 1) * N, *dxi = dxh + (size_t)(i - 1) * N;
+                double scaling = mo_dot(dxi, dgi, N) / mo_dot(dgi, dgi, N);
+                for (int64_t e = 0; e < N; ++e) s[e] = scaling * q[e];
+            } else {
+                memcpy(s, q, nb);
+            }
+            for (int index = lower; index <= upper; ++index) {
+                if (index < 1) continue;
+                int i = mod1(index, LBFGS_M);
+                const double *dgi = dgh + (size_t)(i - 1) * N, *dxi = dxh + (size_t)(i - 1) * N;
+                double beta = rho[i] * mo_dot(dgi, s, N);
+                for (int64_t e = 0; e < N; ++e) s[e] += dxi[e] * (tl_alpha[i] - beta);
+            }
+            for (int64_t e = 0; e < N; ++e) s[e] *= -1.0;
+        }
+        memcpy(gprev, d.g, nb);
+        /* perform_linesearch! */
+        double dphi_0 = mo_dot(d.g, s, N);
+        if (dphi_0 >= 0.0) { /* reset_search_direction! */
+            pseudo = 1;
+            for (int64_t e = 0; e < N; ++e) s[e] = -d.g[e];
+            dphi_0 = mo_dot(d.g, s, N);
+        }
+        double phi_0 = d.f;
+        f_prev = phi_0;
+        memcpy(Xprev, X, nb);
+        hz_line L;
+        L.d = &d; L.x = X; L.s = s; L.x_new = x_ls;
+        double alpha;
+        int lsrc = hz_linesearch(&L, 1.0 /* InitialStatic */, phi_0, dphi_0, &alpha);
+        for (int64_t e = 0; e < N; ++e) dx[e] = alpha * s[e];
+        for (int64_t e = 0; e < N; ++e) X[e] = X[e] + dx[e];
+        if (lsrc < 0) { status = MO_STATUS_LINESEARCH_FAILED; break; }
+        /* ---- update_g! ---- */
+        mo_value_gradient(&d, X);
+        /* ---- assess_convergence ---- */
+        double xchange = 0.0;
+        for (int64_t e = 0; e < N; ++e) {
+            double v = fabs(X[e] - Xprev[e]);
+            if (!(v <= xchange)) xchange = v;
+        }
+        int x_conv = (xchange <= 0.0);
+        int f_conv = (fabs(d.f - f_prev) <= 0.0);
+        int g_conv = (mo_maxabs(d.g, N) <= atol);
+        counter_f_tol = f_conv ? counter_f_tol + 1 : 0;
+        converged = x_conv || g_conv || (counter_f_tol > 1);
+        if (g_conv) status = MO_STATUS_G_CONVERGED;
+        else if (x_conv) status = MO_STATUS_X_CONVERGED;
+        else if (counter_f_tol > 1) status = MO_STATUS_F_CONVERGED;
+        /* ---- update_h! ---- */
+        for (int64_t e = 0; e < N; ++e) dg[e] = d.g[e] - gprev[e];
+        double rho_it = 1.0 / mo_dot(dx, dg, N);
+        if (isinf(rho_it)) {
+            pseudo = 0;
+        } else {
+            int idx = mod1(pseudo, LBFGS_M);
+            memcpy(dxh + (size_t)(idx - 1) * N, dx, nb);
+            memcpy(dgh + (size_t)(idx - 1) * N, dg, nb);
+            rho[idx] = rho_it;
+        }
+        if (!mo_allfinite(d.g, N)) { status = MO_STATUS_NONFINITE; break; }
+    }
+    memcpy(zout, X, nb);
+    if (info) {
+        info->iterations = iterations;
+        info->f_calls = d.f_calls;
+        info->status = status;
+        info->hist_words = hist_words;
+        /* Optim reports value(d) at the last evaluated point; after update_g! that is X. */
+        info->f_min = d.f;
+        info->gnorm = mo_maxabs(d.g, N);
+        if (status <= MO_STATUS_F_CONVERGED && !isfinite(d.f)) info->status = MO_STATUS_NONFINITE;
+    }
+    free(d.x_last); free(d.g); free(X); free(Xprev); free(gprev); free(s); free(q);
+    free(dx); free(dg); free(x_ls); free(dxh); free(dgh);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- batched map bodies */
+/* One element of the muse!/get_J! map (src/muse.jl:169-176, :508-525):
+ *   x = data | sample_x_z(rng_sim, theta_sample).x ; zhat = zhat_at_theta(x, z0, theta) ;
+ *   g = grad_theta(x, zhat, theta).
+ * z0_mode: 0 zeros, 1 the simulation's true z (get_J!, src/muse.jl:511), 2 z_inout as given. */
+int mo_map_and_score(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, const double* x_data,
+                     const double* theta_sample, const double* theta, double atol, int z0_mode,
+                     double* z_inout, double* g_out, mo_info* info) {
+    size_t nb = (size_t)N * sizeof(double);
+    double* x = (double*)malloc(nb);
+    double* z0 = (double*)malloc(nb);
+    if (sim < 0) {
+        memcpy(x, x_data, nb);
+        if (z0_mode == 2) memcpy(z0, z_inout, nb);
+        else memset(z0, 0, nb);
+    } else {
+        mo_sample_x_z(model, N, ntheta, seed, (uint64_t)sim, theta_sample, x, z0);
+        if (z0_mode == 0) memset(z0, 0, nb);
+        else if (z0_mode == 2) memcpy(z0, z_inout, nb);
+    }
+    mo_zhat_at_theta(model, N, ntheta, x, z0, theta, atol, z_inout, info);
+    mo_grad_theta(model, N, ntheta, x, z_inout, theta, g_out);
+    free(x); free(z0);
+    return 0;
+}
+
+/* Batch over sims [sim_begin, sim_end) (+ the data element first when include_data).
+ * zhat: [(n)][N] in/out (used as start when z0_mode==2), g_out: [(n)][ntheta]. */
+int mo_map_and_score_batch(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim_begin,
+                           int64_t sim_end, int include_data, const double* x_data, const double* theta,
+                           double atol, int z0_mode, double* zhat, double* g_out, mo_info* info,
+                           int nthreads) {
+    int64_t n = (sim_end - sim_begin) + (include_data ? 1 : 0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t p = 0; p < n; ++p) {
+        int64_t sim = include_data ? (p == 0 ? -1 : sim_begin + p - 1) : sim_begin + p;
+        mo_map_and_score(model, N, ntheta, seed, sim, x_data, theta, theta, atol, z0_mode,
+                         zhat + (size_t)p * N, g_out + (size_t)p * ntheta, info ? &info[p] : NULL);
+    }
+    (void)nthreads;
+    return 0;
+}
+
+/* get_H! finite-difference branch for one sim (src/muse.jl:426-433, src/util.jl:9-27):
+ * column j = (-1/2 f(theta0 - h_j e_j) + 0 f(theta0) + 1/2 f(theta0 + h_j e_j)) / h_j with
+ * f(theta) = grad_theta(x(theta; same randoms), zhat(x; theta0, start zfid), theta0).
+ * The centre evaluation has coefficient 0 and is skipped.  H_out is [ntheta][ntheta]
+ * row-major with H_out[i][j] = d score_i / d theta_j (hcat of columns, src/util.jl:25). */
+int mo_fd_jacobian(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, const double* theta0,
+                   const double* step, double atol, const double* zfid, double* H_out) {
+    size_t nb = (size_t)N * sizeof(double);
+    double* z = (double*)malloc(nb);
+    double th[64], gp[64], gm[64];
+    for (int j = 0; j < ntheta; ++j) {
+        for (int k = 0; k < ntheta; ++k) th[k] = theta0[k];
+        th[j] = theta0[j] + step[j];
+        memcpy(z, zfid, nb);
+        mo_map_and_score(model, N, ntheta, seed, sim, NULL, th, theta0, atol, 2, z, gp, NULL);
+        th[j] = theta0[j] + (-step[j]);
+        memcpy(z, zfid, nb);
+        mo_map_and_score(model, N, ntheta, seed, sim, NULL, th, theta0, atol, 2, z, gm, NULL);
+        for (int i = 0; i < ntheta; ++i) H_out[i * ntheta + j] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
+    }
+    free(z);
+    return 0;
+}
+
+int mo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

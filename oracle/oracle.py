@@ -1,0 +1,160 @@
+"""ctypes binding of the CPU oracle (oracle/muse_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (museinference.jl_amd/) never does.  See muse_oracle.c for the reference
+file:line each entry follows and for the parity status ("parity unpinned" vs reference outputs,
+pinned against closed forms / scipy / Philox known-answer vectors).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmuse_oracle.so")
+
+MODEL_FUNNEL, MODEL_NOISE, MODEL_SMOOTH = 0, 1, 2
+MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH}
+STATUS = ["g_converged", "x_converged", "f_converged", "maxiter", "linesearch_failed", "nonfinite"]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("f_calls", C.c_int32),
+        ("status", C.c_int32),
+        ("hist_words", C.c_int32),
+        ("f_min", C.c_double),
+        ("gnorm", C.c_double),
+    ]
+
+
+INFO_DTYPE = np.dtype(
+    [("iterations", "<i4"), ("f_calls", "<i4"), ("status", "<i4"), ("hist_words", "<i4"),
+     ("f_min", "<f8"), ("gnorm", "<f8")]
+)
+
+
+def build(force=False):
+    """Compile libmuse_oracle.so with the committed Makefile (gcc)."""
+    src = os.path.join(_HERE, "muse_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.mo_negloglike_grad.restype = C.c_double
+        _lib.mo_logLike_and_grad_z.restype = C.c_double
+        _lib.mo_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f8(a):
+    return np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64)))
+
+
+def philox4x32_10(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().mo_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+def normals(seed, sim, N):
+    n1 = np.empty(N)
+    n2 = np.empty(N)
+    lib().mo_normals(C.c_uint64(seed), C.c_uint64(sim), C.c_int64(N), _p(n1), _p(n2))
+    return n1, n2
+
+
+def sample_x_z(model, N, seed, sim, theta):
+    """sample_x_z(prob, rng, theta) -> (x, z)   [reference src/interface.jl:92-99]"""
+    th = _f8(theta)
+    x = np.empty(N)
+    z = np.empty(N)
+    lib().mo_sample_x_z(C.c_int(MODELS[model]), C.c_int64(N), C.c_int(th.size), C.c_uint64(seed),
+                        C.c_uint64(sim), _p(th), _p(x), _p(z))
+    return x, z
+
+
+def logLike_and_grad_z(model, x, z, theta):
+    """logLike_and_grad_z(prob,x,z,theta) -> (logLike, grad_z)   [src/interface.jl:68-83]"""
+    th = _f8(theta)
+    x = _f8(x)
+    z = _f8(z)
+    g = np.empty_like(z)
+    f = lib().mo_logLike_and_grad_z(C.c_int(MODELS[model]), C.c_int64(x.size), C.c_int(th.size), _p(x),
+                                    _p(z), _p(th), _p(g))
+    return f, g
+
+
+def grad_theta(model, x, z, theta):
+    """grad_theta logLike(prob,x,z,theta)   [src/interface.jl:41-58]"""
+    th = _f8(theta)
+    x = _f8(x)
+    z = _f8(z)
+    out = np.empty(th.size)
+    lib().mo_grad_theta(C.c_int(MODELS[model]), C.c_int64(x.size), C.c_int(th.size), _p(x), _p(z), _p(th),
+                        _p(out))
+    return out
+
+
+def zhat_at_theta(model, x, z0, theta, atol=1e-2):
+    """zhat_at_theta(prob,x,z0,theta; atol) -> (zhat, info)   [src/interface.jl:162-171]"""
+    th = _f8(theta)
+    x = _f8(x)
+    z0 = _f8(z0)
+    z = np.empty_like(x)
+    info = Info()
+    lib().mo_zhat_at_theta(C.c_int(MODELS[model]), C.c_int64(x.size), C.c_int(th.size), _p(x), _p(z0),
+                           _p(th), C.c_double(atol), _p(z), C.byref(info))
+    return z, {f: getattr(info, f) for f, _ in Info._fields_}
+
+
+def map_and_score_batch(model, N, seed, sim_begin, sim_end, theta, atol=1e-2, x_data=None, z0_mode=0,
+                        zhat=None, nthreads=1):
+    """muse!/get_J! map body over a batch   [src/muse.jl:169-176, :508-525]"""
+    th = _f8(theta)
+    include_data = x_data is not None
+    n = (sim_end - sim_begin) + (1 if include_data else 0)
+    if zhat is None:
+        zhat = np.zeros((n, N))
+    assert zhat.shape == (n, N) and zhat.flags.c_contiguous
+    g = np.empty((n, th.size))
+    info = np.zeros(n, dtype=INFO_DTYPE)
+    xd = _f8(x_data) if include_data else None
+    lib().mo_map_and_score_batch(C.c_int(MODELS[model]), C.c_int64(N), C.c_int(th.size), C.c_uint64(seed),
+                                 C.c_int64(sim_begin), C.c_int64(sim_end), C.c_int(int(include_data)),
+                                 _p(xd), _p(th), C.c_double(atol), C.c_int(z0_mode), _p(zhat), _p(g),
+                                 _p(info), C.c_int(nthreads))
+    return g, zhat, info
+
+
+def fd_jacobian(model, N, seed, sim, theta0, step, zfid, atol=1e-2):
+    """get_H! finite-difference Jacobian for one sim   [src/muse.jl:426-433, src/util.jl:9-27]"""
+    th = _f8(theta0)
+    st = _f8(step)
+    zf = _f8(zfid)
+    H = np.empty((th.size, th.size))
+    lib().mo_fd_jacobian(C.c_int(MODELS[model]), C.c_int64(N), C.c_int(th.size), C.c_uint64(seed),
+                         C.c_int64(sim), _p(th), _p(st), C.c_double(atol), _p(zf), _p(H))
+    return H
+
+
+def num_threads():
+    return lib().mo_num_threads()

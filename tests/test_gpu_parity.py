@@ -1,0 +1,122 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeds.
+
+Tolerances (fp64, stated per north_star): the sampler is bit-exact; scores/logLike rtol 1e-10;
+MAPs agree to 1e-9 absolute when both sides follow the same L-BFGS path (same iteration and
+evaluation counts are asserted).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (model, N, ntheta, theta)
+    ("funnel", 512, 1, [1.0]),
+    ("funnel", 8, 1, [0.3]),
+    ("funnel", 777, 1, [-0.5]),
+    ("funnel", 4096, 1, [0.0]),
+    ("funnel", 5000, 1, [0.7]),
+    ("funnel", 10000, 1, [1.0]),
+    ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0]),
+    ("funnel", 1000, 8, [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]),
+    ("noise", 512, 1, [0.4]),
+    ("noise", 10000, 1, [-0.3]),
+    ("noise", 30011, 1, [0.2]),
+    ("smooth", 600, 4, [1.0, 2.0, 3.0, 0.5]),
+    ("smooth", 20000, 8, [1.0, 2.0, 3.0, 0.5, 0.0, -1.0, 1.5, 2.5]),
+    ("funnel", 50001, 2, [1.0, -1.0]),
+]
+
+
+@pytest.mark.parametrize("model,N,nth,theta", CASES)
+def test_sampler_bit_exact(gpu, M, O, model, N, nth, theta):
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    for sim in (0, 3, 2**40 + 7):
+        x, z = prob.sample_x_z(M.SimRng(1234, sim), theta)
+        xo, zo = O.sample_x_z(model, N, 1234, sim, theta)
+        assert np.array_equal(z, zo), f"z differs, max {np.abs(z - zo).max()}"
+        assert np.array_equal(x, xo), f"x differs, max {np.abs(x - xo).max()}"
+    prob.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta", CASES)
+def test_loglike_grad_score(gpu, M, O, model, N, nth, theta):
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    x, z = O.sample_x_z(model, N, 5, 1, theta)
+    zz = 0.7 * z + 0.1
+    f, g = prob.logLike_and_grad_z_logLike(x, zz, theta)
+    fo, go = O.logLike_and_grad_z(model, x, zz, theta)
+    np.testing.assert_allclose(f, fo, rtol=1e-12)
+    np.testing.assert_allclose(g, go, rtol=1e-13, atol=1e-13)
+    s = prob.grad_theta_logLike(x, zz, theta)
+    so = O.grad_theta(model, x, zz, theta)
+    np.testing.assert_allclose(s, so, rtol=1e-12)
+    prob.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta", CASES)
+@pytest.mark.parametrize("atol", [1e-2, 1e-6])
+def test_zhat_at_theta(gpu, M, O, model, N, nth, theta, atol):
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    x, z = O.sample_x_z(model, N, 9, 2, theta)
+    z0 = np.zeros(N)
+    zh, info = prob.zhat_at_theta(x, z0, theta, atol)
+    zo, io = O.zhat_at_theta(model, x, z0, theta, atol)
+    assert info["status"] == io["status"]
+    assert (info["iterations"], info["f_calls"]) == (io["iterations"], io["f_calls"])
+    assert info["hist_words"] == io["hist_words"]
+    np.testing.assert_allclose(zh, zo, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(info["f_min"], io["f_min"], rtol=1e-11)
+    prob.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta", CASES)
+@pytest.mark.parametrize("z0_mode", [0, 1])
+def test_map_and_score_batch(gpu, M, O, model, N, nth, theta, z0_mode):
+    xdata, _ = O.sample_x_z(model, N, 77, M.DATA_SIM, np.zeros(nth))
+    prob = M.HipMuseProblem(xdata, model=model, ntheta=nth)
+    nsims = 6 if N > 20000 else 19
+    g, info = prob.map_and_score_batch(42, 3, 3 + nsims, theta, include_data=True, atol=1e-2, z0_mode=z0_mode)
+    go, zo, io = O.map_and_score_batch(model, N, 42, 3, 3 + nsims, theta, atol=1e-2, x_data=xdata, z0_mode=z0_mode)
+    assert np.array_equal(info["iterations"], io["iterations"])
+    assert np.array_equal(info["f_calls"], io["f_calls"])
+    assert np.array_equal(info["status"], io["status"])
+    np.testing.assert_allclose(g, go, rtol=1e-10)
+    zh = prob.get_zhat(0, nsims + 1)
+    np.testing.assert_allclose(zh, zo, rtol=0, atol=1e-9)
+    # warm restart from the resident MAPs at a nearby theta
+    th2 = np.asarray(theta) + 0.05
+    g2, info2 = prob.map_and_score_batch(42, 3, 3 + nsims, th2, include_data=True, atol=1e-2, z0_mode=M.Z0_WARM)
+    go2, zo2, io2 = O.map_and_score_batch(model, N, 42, 3, 3 + nsims, th2, atol=1e-2, x_data=xdata, z0_mode=2, zhat=zo.copy())
+    assert np.array_equal(info2["f_calls"], io2["f_calls"])
+    np.testing.assert_allclose(g2, go2, rtol=1e-10)
+    prob.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta", [c for c in CASES if c[1] <= 10000 and c[0] != "smooth"])
+def test_resident_equals_streaming_bitwise(gpu, M, model, N, nth, theta):
+    """The storage policy must not change a single bit of the result."""
+    out = []
+    for placement in (0, 1):
+        prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+        prob.set_placement(placement)
+        g, info = prob.map_and_score_batch(7, 0, 12, theta, atol=1e-3, z0_mode=0)
+        out.append((g, info, prob.get_zhat(0, 12)))
+        prob.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("model,N,nth,theta", [CASES[0], CASES[6], CASES[7], CASES[11]])
+@pytest.mark.parametrize("fid_mode", [0, 1])
+def test_fd_jacobian(gpu, M, O, model, N, nth, theta, fid_mode):
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    step = np.full(nth, 0.05)
+    nsims = 3
+    Hs, info = prob.fd_jacobian_batch(11, 0, nsims, theta, step, atol=1e-2, fid_mode=fid_mode)
+    for s in range(nsims):
+        fid = M.MASTER_SIM if fid_mode == 0 else s
+        _, zfid, _ = O.map_and_score_batch(model, N, 11, fid, fid + 1, theta, atol=1e-2, z0_mode=0)
+        Ho = O.fd_jacobian(model, N, 11, s, theta, step, zfid[0], atol=1e-2)
+        np.testing.assert_allclose(Hs[s], Ho, rtol=1e-8, atol=1e-8 * np.abs(Ho).max())
+    prob.close()
