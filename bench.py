@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- MC sims/sec (MAP+score) of the MUSE inner loop on MI355X.
+
+One "step" = one pass of the hot path over one batch: for every one of the 512 simulations of the
+batch, sample (x, z) ~ P(x, z | θ), find the latent MAP ẑ by L-BFGS/HagerZhang from a cold start
+ẑ₀ = 0 to ||∇z||∞ <= 1e-2, and evaluate the score ∇θ logP(x, ẑ | θ) -- the get_J!/muse! map body of
+the reference (src/muse.jl:169-176, :508-525), one launch per batch.  Workload at N=1 GPU:
+BASELINE.json configs[1], Neal's funnel, 10^4-dim z, 1-dim θ (θ = 1), nsims = 512, fp64, synthetic
+(Philox) data.  With --gpus N every rank runs its own 512-sim block of a 512*N-sim map (weak scaling;
+sims are independent) and the per-rank score blocks are exchanged with one all-gather per step (RCCL).
+
+Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
+  roofline      algorithmic HBM bytes of the solver kernel per launch / its mean launch duration
+                (HIP events on the launch stream), against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: "port") timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+WORKLOADS = {
+    # name: (model, N, ntheta, theta, nsims)
+    "funnel_1e4": ("funnel", 10000, 1, [1.0], 512),        # BASELINE.json configs[1] (headline)
+    "funnel_512": ("funnel", 512, 1, [1.0], 32),           # configs[0]
+    "noise_1e6": ("noise", 1000000, 1, [0.5], 128),        # configs[2]
+    "funnel4_1e4": ("funnel", 10000, 4, [1.0] * 4, 512),   # configs[3] (s/J pass)
+    "smooth_1e5": ("smooth", 100000, 8, [1.0] * 8, 128),   # configs[4], per-GPU share
+}
+
+
+def algorithmic_bytes(info, N):
+    """SURVEY.md §8(d3) / BASELINE.md §3: words = 1 + 5E + Σ_k(4 h_k + 4) + 2 per sim, 8 B words."""
+    E = info["f_calls"].astype(np.int64)
+    K = info["iterations"].astype(np.int64)
+    H = info["hist_words"].astype(np.int64)
+    words = 1 + 5 * E + 4 * H + 4 * K + 2
+    return int(8 * N * words.sum())
+
+
+def cpu_baseline(model, N, theta, seed, budget_s=12.0):
+    """Time the oracle on the host cores over a bounded number of sims of the same workload."""
+    from oracle import oracle as O
+    O.build()
+    cores = O.num_threads() if hasattr(os, "sched_getaffinity") is False else min(O.num_threads(), len(os.sched_getaffinity(0)))
+    cores = max(1, cores)
+    t0 = time.perf_counter()
+    n1 = 16
+    O.map_and_score_batch(model, N, seed, 0, n1, theta, atol=1e-2, z0_mode=0, nthreads=1)
+    t1 = (time.perf_counter() - t0) / n1  # seconds per sim, one thread
+    nall = int(max(cores * 4, min(16384, budget_s * cores / max(t1, 1e-9))))
+    t0 = time.perf_counter()
+    O.map_and_score_batch(model, N, seed, 0, nall, theta, atol=1e-2, z0_mode=0, nthreads=cores)
+    tall = time.perf_counter() - t0
+    return {
+        "value": nall / tall, "unit": "sims/s", "cores": cores, "kind": "port",
+        "sample": f"{nall} sims of the same workload (oracle/muse_oracle.c, gcc -O3, OpenMP over sims, "
+                  f"{cores} threads); 1 thread: {1.0 / t1:.1f} sims/s on {n1} sims",
+        "value_1thread": 1.0 / t1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="funnel_1e4", choices=sorted(WORKLOADS))
+    ap.add_argument("--placement", type=int, default=-1, help="-1 auto, 0 streaming, 1 resident")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import museinference_jl_amd as M
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    model, N, nth, theta, nsims = WORKLOADS[args.workload]
+    seed = 0
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=local_rank)
+    if args.placement >= 0:
+        prob.set_placement(args.placement)
+    sim0 = rank * nsims  # this rank's block of the global map
+    gather_buf = None
+    if world > 1:
+        gather_buf = [torch.empty(nsims * nth, dtype=torch.float64, device="cuda") for _ in range(world)]
+
+    AREAS = 4
+
+    def run_steps(K, collect=None):
+        """K steps, software-pipelined: batch k is enqueued before batch k-1's results are awaited,
+        so the GPU never idles on the host; with >1 GPU the all-gather of step k-1 overlaps batch k."""
+        pending = []
+        for k in range(K):
+            n = prob.map_and_score_batch_async(seed, sim0, sim0 + nsims, theta, atol=1e-2, z0_mode=M.Z0_ZERO,
+                                               result_area=k % AREAS)
+            pending.append((k % AREAS, n))
+            if len(pending) > AREAS - 1:
+                finish(pending.pop(0), collect)
+        while pending:
+            finish(pending.pop(0), collect)
+
+    def finish(item, collect):
+        area, n = item
+        g, info = prob.batch_wait(n, area)
+        if world > 1:
+            t = torch.from_numpy(np.ascontiguousarray(g.reshape(-1))).cuda()
+            dist.all_gather(gather_buf, t)
+        if collect is not None:
+            collect.append((g, info))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        prob.synchronize()
+
+    run_steps(args.warmup)
+    barrier()
+    prob.profile_begin(args.steps + 8)
+    results = []
+    t0 = time.perf_counter()
+    run_steps(args.steps, results)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = prob.profile_end()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    g, info = results[-1]
+    assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
+    alg_bytes = algorithmic_bytes(info, N)
+    mean_kernel_s = float(kernel_ms.mean()) * 1e-3
+    achieved = alg_bytes / mean_kernel_s / 1e9
+
+    out = {
+        "metric": "MC sims/sec (MAP+score)",
+        "value": world * nsims * args.steps / dt,
+        "unit": "sims/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: Neal's funnel family model={model}, N={N}-dim z, {nth}-dim theta, "
+                               f"nsims={nsims} per GPU per step, cold start z0=0, atol=1e-2",
+                   "theta": theta, "sims_per_step_total": world * nsims,
+                   "parallelism": f"sims sharded over {world} GPU(s), one all-gather of scores per step"},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "map_score_kernel", "kernel_ms_mean": 1e3 * mean_kernel_s,
+            "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
+                        "hist_pairs_mean": float(info["hist_words"].mean())},
+        },
+        "kernel_sims_per_s": nsims / mean_kernel_s,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, N, theta, seed)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

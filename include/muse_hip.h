@@ -102,6 +102,11 @@ int64_t muse_max_resident_n(void);
 int muse_synchronize(muse_ctx* ctx);
 /* Device time in ms of the most recent solver launch (HIP events on the context's stream). */
 int muse_last_kernel_ms(muse_ctx* ctx, float* ms);
+/* Live timing of every solver launch between begin and end: HIP event pairs recorded on the
+ * context's stream around each launch (up to max_launches); end() synchronises and returns the
+ * per-launch durations in ms.  The reference only keeps wall-clock deltas (src/muse.jl:161,210,232). */
+int muse_profile_begin(muse_ctx* ctx, int max_launches);
+int muse_profile_end(muse_ctx* ctx, float* ms_out, int cap, int* count);
 
 /* ---- per-simulation operators (the AbstractMuseProblem interface, src/interface.jl:4-186) ----- */
 /* sample_x_z(prob, rng, theta) -> (;x, z)                       src/interface.jl:92-99, src/simple.jl:95 */

@@ -45,6 +45,8 @@ SIGNATURES = {
     "muse_max_resident_n": (_i64, []),
     "muse_synchronize": (_i, [_vp]),
     "muse_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "muse_profile_begin": (_i, [_vp, _i]),
+    "muse_profile_end": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "muse_sample_x_z": (_i, [_vp, _u64, _i64, _vp, _vp, _vp, _i]),
     "muse_logLike_and_grad_z": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_d), _vp, _i]),
     "muse_grad_theta": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),

@@ -1053,8 +1053,13 @@ struct muse_ctx {
     int64_t res_cap[kResultAreas] = {0};
     int64_t res_n[kResultAreas] = {0};
     double* small_dev = nullptr;  // 16 doubles
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, last0 = nullptr, last1 = nullptr;
     bool ev_valid = false;
+    hipEvent_t area_done[kResultAreas] = {nullptr};  // recorded after an area's device->host copies
+    // live kernel timing: a ring of event pairs, one per solver launch (muse_profile_*)
+    std::vector<hipEvent_t> prof_ev;
+    int prof_count = 0;
+    bool prof_on = false;
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
     double* comm_buf = nullptr;
     size_t comm_buf_doubles = 0;
@@ -1180,14 +1185,22 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.scratch = c->scratch;
     const size_t lds = place_lds(c, pl);
     HIPCHK(hipMemsetAsync(c->counter, 0, 16, c->stream));
-    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipEvent_t e0 = c->ev0, e1 = c->ev1;
+    if (c->prof_on && (size_t)(2 * c->prof_count + 1) < c->prof_ev.size()) {
+        e0 = c->prof_ev[2 * c->prof_count];
+        e1 = c->prof_ev[2 * c->prof_count + 1];
+        c->prof_count += 1;
+    }
+    HIPCHK(hipEventRecord(e0, c->stream));
     if (c->model == MUSE_MODEL_NOISE) rc = launch_place<NoiseModel>(c, a, pl, grid, lds);
     else if (c->model == MUSE_MODEL_FUNNEL)
         rc = c->ntheta == 1 ? launch_place<FunnelModel<1>>(c, a, pl, grid, lds)
                             : launch_place<FunnelModel<kMaxTheta>>(c, a, pl, grid, lds);
     else rc = launch_place<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    c->last0 = e0;
+    c->last1 = e1;
     c->ev_valid = true;
     return MUSE_OK;
 }
@@ -1234,6 +1247,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     HIPCHK(hipHostMalloc(&c->tsample_pin, 2 * kMaxTheta * sizeof(ThetaSet), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
+    for (int r = 0; r < kResultAreas; ++r) HIPCHK(hipEventCreateWithFlags(&c->area_done[r], hipEventDisableTiming));
     HIPCHK(hipMemsetAsync(c->x_data, 0, (size_t)c->ld * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->tmp, 0, (size_t)3 * c->ld * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1278,6 +1292,8 @@ int muse_ctx_destroy(muse_ctx* c) {
         hipHostFree(c->scores_pin[r]); hipHostFree(c->info_pin[r]);
     }
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    for (int r = 0; r < kResultAreas; ++r) hipEventDestroy(c->area_done[r]);
+    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     hipStreamDestroy(c->own_stream);
     delete c;
     return MUSE_OK;
@@ -1326,8 +1342,34 @@ int muse_last_kernel_ms(muse_ctx* c, float* ms) {
     if (rc) return rc;
     if (!ms) return fail(MUSE_ERR_INVALID, "ms is NULL");
     if (!c->ev_valid) return fail(MUSE_ERR_INVALID, "no solver launch recorded yet");
-    HIPCHK(hipEventSynchronize(c->ev1));
-    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    HIPCHK(hipEventSynchronize(c->last1));
+    HIPCHK(hipEventElapsedTime(ms, c->last0, c->last1));
+    return MUSE_OK;
+}
+
+int muse_profile_begin(muse_ctx* c, int max_launches) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (max_launches < 1 || max_launches > 65536) return fail(MUSE_ERR_INVALID, "max_launches out of range");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    while (c->prof_ev.size() < (size_t)(2 * max_launches + 2)) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_count = 0;
+    c->prof_on = true;
+    return MUSE_OK;
+}
+int muse_profile_end(muse_ctx* c, float* ms_out, int cap, int* count) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!count) return fail(MUSE_ERR_INVALID, "count is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->prof_on = false;
+    *count = c->prof_count;
+    for (int k = 0; k < c->prof_count && k < cap && ms_out; ++k)
+        HIPCHK(hipEventElapsedTime(&ms_out[k], c->prof_ev[2 * k], c->prof_ev[2 * k + 1]));
     return MUSE_OK;
 }
 
@@ -1414,6 +1456,7 @@ static int enqueue_results_copy(muse_ctx* c, int area, int64_t n) {
     HIPCHK(hipMemcpyAsync(c->info_pin[area], c->info_dev[area], (size_t)n * sizeof(muse_info), hipMemcpyDeviceToHost,
                           c->stream));
     c->res_n[area] = n;
+    HIPCHK(hipEventRecord(c->area_done[area], c->stream));
     return MUSE_OK;
 }
 
@@ -1494,7 +1537,7 @@ int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventSynchronize(c->area_done[area]));  // this area only: later launches keep running
     const int64_t n = c->res_n[area];
     if (g_out && n) memcpy(g_out, c->scores_pin[area], (size_t)n * c->ntheta * sizeof(double));
     if (info_out && n) memcpy(info_out, c->info_pin[area], (size_t)n * sizeof(muse_info));

@@ -171,6 +171,17 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_last_kernel_ms(self._ctx, C.byref(ms)))
         return ms.value
 
+    def profile_begin(self, max_launches=1024):
+        _capi.check(self._lib.muse_profile_begin(self._ctx, int(max_launches)))
+        self._prof_cap = int(max_launches)
+
+    def profile_end(self):
+        """Per-launch solver kernel durations (ms) since profile_begin (HIP events on the launch stream)."""
+        buf = (C.c_float * self._prof_cap)()
+        n = C.c_int()
+        _capi.check(self._lib.muse_profile_end(self._ctx, buf, self._prof_cap, C.byref(n)))
+        return np.array(buf[: min(n.value, self._prof_cap)], dtype=np.float64)
+
     # -- prior (SimpleMuseProblem forwards to the user's function, src/simple.jl:93)
     def logPrior_theta(self, theta, theta_space=UnTransformedθ):
         return self.prior.logpdf(np.asarray(theta, dtype=np.float64))
