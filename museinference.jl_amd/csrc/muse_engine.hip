@@ -64,6 +64,7 @@ struct BatchArgs {
     uint64_t seed;
     double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
     int nproblems, include_data, z0_mode, store_zhat;
+    int debug, pad_;  // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
     int64_t sim_begin, fid_slot, slot0;
     ThetaSet tmap;                 // theta of the MAP problem and of the score
     const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
@@ -75,6 +76,7 @@ struct BatchArgs {
     double* scratch;               // per workgroup
     int64_t scratch_stride;        // doubles per workgroup
     int* work_counter;
+    unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
 };
 
 struct ProblemDesc {
@@ -88,7 +90,7 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     if (a.kind == BATCH_STD) {
         const bool data = a.include_data && p == 0;
         d.sim = data ? -1 : a.sim_begin + p - (a.include_data ? 1 : 0);
-        d.x_mode = data ? X_DATA : X_SAMPLE;
+        d.x_mode = (data || (a.debug & 2)) ? X_DATA : X_SAMPLE;
         d.z0_mode = (data && a.z0_mode == Z0_TRUE) ? Z0_ZERO : a.z0_mode;
         d.tsample = -1;
         d.zslot = a.store_zhat ? a.slot0 + p : -1;
@@ -115,32 +117,90 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
 // ------------------------------------------------------------------------------------------------
 // Vec accessors: (jj, i) = (register slot, element index).  Register vectors ignore i, memory
 // vectors ignore jj; the solver source is written once against this interface.
+//
+// Every access is UNCONDITIONAL (no `if (i < N)` around it), so the compiler can issue all of a
+// thread's loads of a pass back to back and expose the memory latency once, not once per element:
+//   * a thread's slots beyond the vector are "phantom zeros": register slots are cleared, HBM vectors
+//     sit behind range-checked buffer descriptors (out-of-range loads return 0, stores are dropped),
+//     LDS vectors redirect out-of-range indices to a dummy slot that holds 0;
+//   * vectors are padded to an even length ld >= N and the pad element is kept at 0;
+//   * every model maps (x, z) = (0, 0) to a zero gradient / zero objective and score terms, so the
+//     phantoms contribute exact zeros to every reduction and write zeros back.
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) rsrc_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) double lds_double;
+
+// Buffer descriptor over `bytes` bytes at `base` (both workgroup-uniform; the readfirstlanes make
+// that provable so that no waterfall loop is generated around the buffer instructions).
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0,
+                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 template <int NR>
 struct RegVec {
     double r[NR > 0 ? NR : 1];
-    __device__ __forceinline__ double get(int jj, int64_t) const { return r[jj]; }
-    __device__ __forceinline__ void set(int jj, int64_t, double v) { r[jj] = v; }
+    __device__ __forceinline__ double get(int jj, int) const { return r[jj]; }
+    __device__ __forceinline__ void set(int jj, int, double v) { r[jj] = v; }
+    // Unconditional definition of every slot at the point where a problem first defines the vector:
+    // otherwise the previous problem's values stay live across the persistent loop.
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < (NR > 0 ? NR : 1); ++j) r[j] = 0.0;
+    }
 };
-struct MemVec {
-    double* __restrict__ p;
-    __device__ __forceinline__ double get(int, int64_t i) const { return p[i]; }
-    __device__ __forceinline__ void set(int, int64_t i, double v) { p[i] = v; }
+struct BufVec {  // a vector in HBM: buffer_load/store_dwordx2 with hardware range check
+    rsrc_t rsrc;
+    __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
+    __device__ __forceinline__ double get(int, int i) const {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, i * 8, 0, 0);
+        return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+    }
+    __device__ __forceinline__ void set(int, int i, double d) {
+        const long long b = __double_as_longlong(d);
+        u32x2 v;
+        v.x = (unsigned)(b & 0xffffffffll);
+        v.y = (unsigned)(b >> 32);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, i * 8, 0, 0);
+    }
+    __device__ __forceinline__ void clear() {}
+};
+struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
+    lds_double* p;
+    int ld;
+    __device__ __forceinline__ void bind(double* base, int64_t ld_) {
+        p = (lds_double*)base;
+        ld = (int)ld_;
+    }
+    __device__ __forceinline__ double get(int, int i) const { return p[i < ld ? i : ld]; }
+    __device__ __forceinline__ void set(int, int i, double v) { p[i < ld ? i : ld] = v; }
+    __device__ __forceinline__ void clear() {}
 };
 
-// Element loop of one thread: pairs q = tid + j*T, elements 2q and 2q+1, in increasing j.
+// Element loop of one thread: pairs q = tid + j*T, elements 2q and 2q+1, in increasing j; no bounds
+// checks (see above).  EPT > 0: compile-time trip count, fully unrolled (register slots are static).
+// Element indices are 32-bit (N < 2^28), and tid is laundered through an empty asm so that the
+// per-slot offsets are recomputed in each pass (two integer ops) instead of being hoisted out of
+// the persistent loop and held -- or spilled -- for the kernel's lifetime.
 template <int T, int EPT, class F>
-__device__ __forceinline__ void for_elems(int64_t N, int tid, F&& f) {
+__device__ __forceinline__ void for_elems(int64_t ld, int tid, F&& f) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
     if constexpr (EPT > 0) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int64_t i0 = 2 * ((int64_t)tid + (int64_t)j * T);
-            if (i0 < N) f(2 * j, i0);
-            if (i0 + 1 < N) f(2 * j + 1, i0 + 1);
+            const int i0 = 2 * (t + j * T);
+            f(2 * j, i0);
+            f(2 * j + 1, i0 + 1);
         }
     } else {
-        for (int64_t i0 = 2 * (int64_t)tid; i0 < N; i0 += 2 * (int64_t)T) {
+        const int n = (int)ld;
+        for (int i0 = 2 * t; i0 < n; i0 += 2 * T) {
             f(0, i0);
-            if (i0 + 1 < N) f(1, i0 + 1);
+            f(1, i0 + 1);
         }
     }
 }
@@ -156,18 +216,64 @@ __device__ __forceinline__ double uniform(double v) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Fixed-shape all-reduce over the workgroup: KS sums and KM NaN-propagating maxima.
+// ---- fixed-shape all-reduce over the workgroup: KS sums and KM NaN-propagating maxima ------------
+// Within a wave: four DPP exchange steps (xor 1, xor 2, half-row mirror, row mirror -- full-rate VALU
+// moves, no LDS crossbar) leave each 16-lane row's total in all of its lanes; the four row totals are
+// read with v_readlane into SGPRs and combined in a fixed order, so the wave total is a scalar.
+// Across waves: lane 0 of each wave stores its total to LDS, ONE barrier, then lane l of every wave
+// reads wave (l mod NW)'s total and a DPP butterfly over NW lanes + v_readfirstlane leaves the
+// workgroup total in SGPRs of every wave.  The tree is the same for every thread, launch and GPU.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7-i within 8
+constexpr int kDppMirror = 0x140;      // row_mirror:      lane i <-> 15-i within 16
+
+template <bool IS_MAX>
+__device__ __forceinline__ double combine(double a, double b) {
+    if constexpr (IS_MAX) return nanmax(a, b);
+    else return a + b;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ double wave_total(double v) {
+    v = combine<IS_MAX>(v, dpp_move<kDppXor1>(v));
+    v = combine<IS_MAX>(v, dpp_move<kDppXor2>(v));
+    v = combine<IS_MAX>(v, dpp_move<kDppHalfMirror>(v));
+    v = combine<IS_MAX>(v, dpp_move<kDppMirror>(v));
+    const double r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
+    return combine<IS_MAX>(combine<IS_MAX>(r0, r1), combine<IS_MAX>(r2, r3));
+}
+template <bool IS_MAX, int NW>
+__device__ __forceinline__ double lanes_total(double v) {  // butterfly over the first NW (<= 16) lanes of a row
+    if constexpr (NW >= 2) v = combine<IS_MAX>(v, dpp_move<kDppXor1>(v));
+    if constexpr (NW >= 4) v = combine<IS_MAX>(v, dpp_move<kDppXor2>(v));
+    if constexpr (NW >= 8) v = combine<IS_MAX>(v, dpp_move<kDppHalfMirror>(v));
+    if constexpr (NW >= 16) v = combine<IS_MAX>(v, dpp_move<kDppMirror>(v));
+    return uniform(v);
+}
+
 template <int T, int KS, int KM>
 __device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], double (&m)[KM > 0 ? KM : 1],
                                                 double* red, int& parity, int tid) {
     constexpr int NW = T / 64, K = KS + KM;
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "workgroup must be 2^k waves");
+    static_assert(K <= 8, "reduction scratch holds 8 values per wave");
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int k = 0; k < KS; ++k) s[k] = wave_total<false>(s[k]);
 #pragma unroll
-        for (int k = 0; k < KS; ++k) s[k] += __shfl_xor(s[k], off);
-#pragma unroll
-        for (int k = 0; k < KM; ++k) m[k] = nanmax(m[k], __shfl_xor(m[k], off));
-    }
+    for (int k = 0; k < KM; ++k) m[k] = wave_total<true>(m[k]);
     double* buf = red + parity * (NW * 8);
     const int wave = tid >> 6;
     if ((tid & 63) == 0) {
@@ -177,31 +283,18 @@ __device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], do
         for (int k = 0; k < KM; ++k) buf[wave * K + KS + k] = m[k];
     }
     __syncthreads();
-    // cross-wave combine without a second barrier: lane l reads wave (l mod NW)'s partial, then an
-    // xor butterfly over NW lanes leaves the total in every lane (same fixed tree for every thread)
     const int src = (tid & (NW - 1)) * K;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) s[k] = buf[src + k];
+    for (int k = 0; k < KS; ++k) s[k] = lanes_total<false, NW>(buf[src + k]);
 #pragma unroll
-    for (int k = 0; k < KM; ++k) m[k] = buf[src + KS + k];
-#pragma unroll
-    for (int off = NW / 2; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) s[k] += __shfl_xor(s[k], off);
-#pragma unroll
-        for (int k = 0; k < KM; ++k) m[k] = nanmax(m[k], __shfl_xor(m[k], off));
-    }
-#pragma unroll
-    for (int k = 0; k < KS; ++k) s[k] = uniform(s[k]);
-#pragma unroll
-    for (int k = 0; k < KM; ++k) m[k] = uniform(m[k]);
+    for (int k = 0; k < KM; ++k) m[k] = lanes_total<true, NW>(buf[src + KS + k]);
     parity ^= 1;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Models.  grad() returns d(-logLike)/dz_i and adds the element's share of -2 logLike (without the
 // constant) to facc; the score is assembled from per-block sums of score_term().
-__device__ __forceinline__ int block_of(const BatchArgs& a, int64_t i) {
+__device__ __forceinline__ int block_of(const BatchArgs& a, int i) {
     int k = 0;
 #pragma unroll
     for (int b = 1; b < kMaxTheta; ++b) k += (b < a.ntheta && i >= a.bnd[b]) ? 1 : 0;
@@ -256,13 +349,13 @@ template <int T_>
 struct PlaceStreaming {
     static constexpr int T = T_, EPT = 0;
     static constexpr bool kResident = false, kXgLds = false;
-    using VX = MemVec; using VG = MemVec; using VZ = MemVec; using VS = MemVec;
+    using VX = BufVec; using VG = BufVec; using VZ = BufVec; using VS = BufVec;
 };
 template <int T_, int EPT_, bool XG_LDS>
 struct PlaceResident {
     static constexpr int T = T_, EPT = EPT_;
     static constexpr bool kResident = true, kXgLds = XG_LDS;
-    using VX = typename std::conditional<XG_LDS, MemVec, RegVec<2 * EPT_>>::type;
+    using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
     using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;
 };
@@ -299,17 +392,38 @@ struct Solver {
         sh_alpha = shs + 2 * kM;
         sh_sd = shs + 3 * kM;
     }
-    __device__ __forceinline__ double* hdx(int slot) const { return hist + (int64_t)(2 * slot) * a.ld; }
-    __device__ __forceinline__ double* hdg(int slot) const { return hist + (int64_t)(2 * slot + 1) * a.ld; }
-    __device__ __forceinline__ double ivk(int64_t i) const {
+    // In-kernel stamps (cdna_hip_programming.md §7): diagnostic build only; values leave through a
+    // buffer of their own and no output is computed from them.
+    __device__ __forceinline__ void stamp(int p, int k) const {
+#ifdef MUSE_STAMPS
+        if (tid == 0 && a.stamps) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            a.stamps[(size_t)p * 16 + k] = t;
+        }
+#else
+        (void)p; (void)k;
+#endif
+    }
+    __device__ __forceinline__ BufVec hdx(int slot) const {
+        BufVec v;
+        v.bind(hist + (int64_t)(2 * slot) * a.ld, a.ld);
+        return v;
+    }
+    __device__ __forceinline__ BufVec hdg(int slot) const {
+        BufVec v;
+        v.bind(hist + (int64_t)(2 * slot + 1) * a.ld, a.ld);
+        return v;
+    }
+    __device__ __forceinline__ double ivk(int i) const {
         if constexpr (MAXB == 1) return iv0;
         else return a.tmap.iv[block_of(a, i)];
     }
-    __device__ __forceinline__ double sdk(int64_t i) const {
+    __device__ __forceinline__ double sdk(int i) const {
         if constexpr (MAXB == 1) return sd0;
         else return sh_sd[block_of(a, i)];
     }
-    __device__ __forceinline__ int blk(int64_t i) const {
+    __device__ __forceinline__ int blk(int i) const {
         if constexpr (MAXB == 1) return 0;
         else return block_of(a, i);
     }
@@ -317,10 +431,10 @@ struct Solver {
     // d(-logLike)/dz_i at the point whose components are given by zt(.), for the stencil model
     // (streaming only: neighbours come from HBM/L1).  Adds the element's share of -2 logLike to facc.
     template <class ZT>
-    __device__ __forceinline__ double stencil_grad(ZT&& zt, int64_t i, double& facc) const {
-        const int64_t N = a.N;
-        auto wrap = [&](int64_t k) { return k < 0 ? k + N : (k >= N ? k - N : k); };
-        const int64_t im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
+    __device__ __forceinline__ double stencil_grad(ZT&& zt, int i, double& facc) const {
+        const int N = (int)a.N;
+        auto wrap = [&](int k) { return k < 0 ? k + N : (k >= N ? k - N : k); };
+        const int im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
         const double zm2 = zt(im2), zm1 = zt(im1), z0 = zt(i), zp1 = zt(ip1), zp2 = zt(ip2);
         const double rm = x.get(0, im1) - (0.5 * zm1 + 0.25 * (zm2 + z0));
         const double r0 = x.get(0, i) - (0.5 * z0 + 0.25 * (zm1 + zp1));
@@ -337,7 +451,7 @@ struct Solver {
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
-            for_elems<T, EPT>(a.N, tid, [&](int jj, int64_t i) {
+            for_elems<T, EPT>(a.ld, tid, [&](int jj, int i) {
                 double zi = z.get(jj, i);
                 double si = 0.0;
                 if constexpr (USE_S) {
@@ -350,13 +464,18 @@ struct Solver {
                 mx[0] = nanmax(mx[0], fabs(gi));
             });
         } else {
-            auto zt = [&](int64_t k) {
+            auto zt = [&](int k) {
                 double v = z.get(0, k);
                 if constexpr (USE_S) v = v + c * s.get(0, k);
                 return v;
             };
-            for_elems<T, EPT>(a.N, tid, [&](int jj, int64_t i) {
-                const double gi = stencil_grad(zt, i, sum[0]);
+            const int N = (int)a.N;
+            for_elems<T, EPT>(a.ld, tid, [&](int jj, int i) {
+                double fi = 0.0;
+                double gi = stencil_grad(zt, i < N ? i : 0, fi);
+                const bool valid = i < N;  // the pad element has no neighbours: keep it a phantom zero
+                gi = valid ? gi : 0.0;
+                sum[0] += valid ? fi : 0.0;
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] += gi * s.get(0, i);
                 mx[0] = nanmax(mx[0], fabs(gi));
@@ -570,6 +689,7 @@ struct Solver {
     __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         const ProblemDesc d = describe(a, p);
         const int64_t N = a.N, ld = a.ld;
+        stamp(p, 0);
         iv0 = a.tmap.iv[0];
         sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.tmap.sd[0];
         if constexpr (MAXB > 1) {
@@ -578,23 +698,25 @@ struct Solver {
             __syncthreads();
         }
         // bind storage
-        double* zmem = nullptr;
+        const double* zmem = nullptr;
         if constexpr (Place::kResident) {
             hist = wg_scratch;
             if constexpr (Place::kXgLds) {
-                x.p = lds_x;
-                g.p = lds_g;
+                x.bind(lds_x, ld);
+                g.bind(lds_g, ld);
             }
         } else {
-            x.p = wg_scratch;
-            g.p = wg_scratch + ld;
-            s.p = wg_scratch + 2 * ld;
+            x.bind(wg_scratch, ld);
+            g.bind(wg_scratch + ld, ld);
+            s.bind(wg_scratch + 2 * ld, ld);
             zmem = d.zslot >= 0 ? a.zhat + d.zslot * ld : wg_scratch + 3 * ld;
-            z.p = zmem;
+            z.bind(zmem, ld);
             hist = wg_scratch + 4 * ld;
         }
-        const double* z0src = a.zhat + d.z0slot * ld;
-        const bool z_in_place = (!Place::kResident) && (d.z0_mode == Z0_WARM || d.z0_mode == Z0_COPY) && (z0src == zmem);
+        const double* z0ptr = a.zhat + d.z0slot * ld;
+        BufVec z0src;
+        z0src.bind(z0ptr, ld);
+        const bool z_in_place = (!Place::kResident) && (d.z0_mode == Z0_WARM || d.z0_mode == Z0_COPY) && (z0ptr == zmem);
 
         // ---- x and the starting point ---------------------------------------------------------
         if (d.x_mode == X_SAMPLE) {
@@ -604,10 +726,10 @@ struct Solver {
                 // chains in flight, not 2*EPT): x goes straight to LDS, the true z is staged in the
                 // (still unused) g area and picked up into registers below.
 #pragma unroll 1
-                for (int64_t i0 = 2 * (int64_t)tid; i0 < N; i0 += 2 * (int64_t)T) {
+                for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
-                        const int64_t i = i0 + v;
+                        const int i = i0 + v;
                         if (i < N) {
                             const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
                             double zt, xt;
@@ -617,56 +739,70 @@ struct Solver {
                         }
                     }
                 }
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                z.clear();
+                s.clear();
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
-                    else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.p[i]);
-                    else z.set(jj, i, z0src[i]);
+                    else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.get(jj, i));
+                    else z.set(jj, i, z0src.get(jj, i));
                 });
             } else {
-            for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
-                double zt, xt;
-                if constexpr (Model::kStencil) {
-                    zt = sdk(i) * np.n1;
-                    xt = np.n2;        // noise now, + A z after the barrier
-                    s.set(jj, i, zt);   // true z staged in the direction buffer
-                } else {
-                    Model::sample(sdk(i), np.n1, np.n2, zt, xt);
-                }
-                x.set(jj, i, xt);
-                if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
-                else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
-                else if (!z_in_place) z.set(jj, i, z0src[i]);
-            });
+                x.clear(); g.clear(); z.clear(); s.clear();
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                    const bool valid = i < N;  // phantom slots run the generator but keep zeros
+                    const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+                    double zt, xt;
+                    if constexpr (Model::kStencil) {
+                        zt = sdk(i) * np.n1;
+                        xt = np.n2;                           // noise now, + A z after the barrier
+                        s.set(jj, i, valid ? zt : 0.0);       // true z staged in the direction buffer
+                    } else {
+                        Model::sample(sdk(i), np.n1, np.n2, zt, xt);
+                    }
+                    zt = valid ? zt : 0.0;
+                    xt = valid ? xt : 0.0;
+                    x.set(jj, i, xt);
+                    if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
+                    else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
+                    else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
+                });
             }
             if constexpr (Model::kStencil) {
                 __syncthreads();
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                    const int64_t im = i == 0 ? N - 1 : i - 1, ip = i == N - 1 ? 0 : i + 1;
-                    const double az = 0.5 * s.get(0, i) + 0.25 * (s.get(0, im) + s.get(0, ip));
-                    x.set(jj, i, az + x.get(jj, i));
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                    const bool valid = i < N;
+                    const int ic = valid ? i : 0;
+                    const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
+                    const double az = 0.5 * s.get(0, ic) + 0.25 * (s.get(0, im) + s.get(0, ip));
+                    const double xv = az + x.get(jj, i);
+                    x.set(jj, i, valid ? xv : 0.0);
                 });
             }
         } else {
-            const double* xs = d.x_mode == X_DATA ? a.x_data : a.x_given;
-            for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                x.set(jj, i, xs[i]);
+            BufVec xs;
+            xs.bind(d.x_mode == X_DATA ? a.x_data : a.x_given, ld);
+            x.clear(); g.clear(); z.clear(); s.clear();
+            for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                x.set(jj, i, xs.get(jj, i));
                 if (d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE) z.set(jj, i, 0.0);
-                else if (!z_in_place) z.set(jj, i, z0src[i]);
+                else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
             });
         }
         __syncthreads();
 
+        stamp(p, 1);
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
         f_calls = 0;
         last_c = NAN;
         double f, dphi_unused, gmax;
         eval<false, true>(0.0, f, dphi_unused, gmax);
+        stamp(p, 2);
         int iterations = 0, pseudo = 0, hist_words = 0, counter_f_tol = 0;
         int status = MUSE_STATUS_MAXITER;
         bool done = false;
         if (!isfinite(f) || !isfinite(gmax)) { status = MUSE_STATUS_NONFINITE; done = true; }
         else if (gmax <= a.atol) { status = MUSE_STATUS_G_CONVERGED; done = true; }
+        if (a.debug & 1) done = true;
 
         double dot0 = 0.0;      // dot(dx_newest, g) prepared by the update pass
         bool have_pair = false;  // the update pass of the previous iteration stored a usable pair
@@ -679,7 +815,7 @@ struct Solver {
             double dphi_0;
             if (h == 0 || !have_pair) {
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] += gi * si;
@@ -694,22 +830,22 @@ struct Solver {
                     const int slot = (index - 1) % kM;
                     const double al = sh_rho[slot] * dot;
                     if (tid == 0) sh_alpha[slot] = al;
-                    const double* __restrict__ dgp = hdg(slot);
+                    const BufVec dgp = hdg(slot);
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index > lower) {
-                        const double* __restrict__ dxn = hdx((index - 2) % kM);
-                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                            const double qi = s.get(jj, i) - al * dgp[i];
+                        const BufVec dxn = hdx((index - 2) % kM);
+                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                            const double qi = s.get(jj, i) - al * dgp.get(jj, i);
                             s.set(jj, i, qi);
-                            sum[0] += dxn[i] * qi;
+                            sum[0] += dxn.get(jj, i) * qi;
                         });
                     } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
                         const double gam = sh_gam[(upper - 1) % kM];
-                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                            const double qi = s.get(jj, i) - al * dgp[i];
+                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                            const double qi = s.get(jj, i) - al * dgp.get(jj, i);
                             const double si = gam * qi;
                             s.set(jj, i, si);
-                            sum[0] += dgp[i] * si;
+                            sum[0] += dgp.get(jj, i) * si;
                         });
                     }
                     block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
@@ -720,18 +856,18 @@ struct Solver {
                     const int slot = (index - 1) % kM;
                     const double beta = sh_rho[slot] * dot;
                     const double coef = sh_alpha[slot] - beta;
-                    const double* __restrict__ dxp = hdx(slot);
+                    const BufVec dxp = hdx(slot);
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index < upper) {
-                        const double* __restrict__ dgn = hdg(index % kM);
-                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                            const double si = s.get(jj, i) + dxp[i] * coef;
+                        const BufVec dgn = hdg(index % kM);
+                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                            const double si = s.get(jj, i) + dxp.get(jj, i) * coef;
                             s.set(jj, i, si);
-                            sum[0] += dgn[i] * si;
+                            sum[0] += dgn.get(jj, i) * si;
                         });
                     } else {
-                        for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
-                            const double si = (s.get(jj, i) + dxp[i] * coef) * -1.0;
+                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                            const double si = (s.get(jj, i) + dxp.get(jj, i) * coef) * -1.0;
                             s.set(jj, i, si);
                             sum[0] += g.get(jj, i) * si;
                         });
@@ -745,7 +881,7 @@ struct Solver {
             if (dphi_0 >= 0.0) {
                 pseudo = 1;
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] += gi * si;
@@ -753,12 +889,14 @@ struct Solver {
                 block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
                 dphi_0 = sum[0];
             }
+            if (iterations == 1) stamp(p, 3);
             const double phi_0 = f, f_prev = f;
             last_c = NAN;  // no trial evaluated yet in this line search
             last_phi = f;
             last_gmax = gmax;
             double alpha;
             const bool ls_ok = linesearch(1.0, phi_0, dphi_0, alpha);
+            if (iterations == 1) stamp(p, 4);
             // ---- update_g! / assess_convergence: the scalars at z + alpha s are those of the last
             //      evaluation (or of the current point when the step is a no-op) ---------------------
             const double f_new = last_phi, gmax_new = last_gmax;
@@ -769,12 +907,12 @@ struct Solver {
             // ---- fused update pass: z += alpha s; gradient at the new point recomputed (bit-equal
             //      to the trial evaluation); (dx, dg) stored; g <- new gradient; q <- g -----------------
             const int slot_new = (pseudo - 1) % kM;
-            double* __restrict__ dxs = hdx(slot_new);
-            double* __restrict__ dgs = hdg(slot_new);
+            BufVec dxs = hdx(slot_new);
+            BufVec dgs = hdg(slot_new);
             const bool keep = !stop_hint;
             double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
             if constexpr (!Model::kStencil) {
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     const double zo = z.get(jj, i);
                     const double dxi = alpha * s.get(jj, i);
                     const double zn = zo + dxi;
@@ -787,39 +925,41 @@ struct Solver {
                         sum[0] += dxi * dgi;
                         sum[1] += dgi * dgi;
                         sum[2] += dxi * gn;
-                        dxs[i] = dxi;
-                        dgs[i] = dgi;
+                        dxs.set(jj, i, dxi);
+                        dgs.set(jj, i, dgi);
                         g.set(jj, i, gn);
                         s.set(jj, i, gn);
                     }
                 });
             } else {
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     const double zo = z.get(jj, i);
                     const double dxi = alpha * s.get(jj, i);
                     const double zn = zo + dxi;
                     z.set(jj, i, zn);
                     mx[0] = nanmax(mx[0], fabs(zn - zo));
-                    if (keep) dxs[i] = dxi;
+                    if (keep) dxs.set(jj, i, dxi);
                 });
                 if (keep) {
                     __syncthreads();  // neighbours' z must be complete before the stencil reads them
-                    auto zt = [&](int64_t k) { return z.get(0, k); };
-                    for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+                    auto zt = [&](int k) { return z.get(0, k); };
+                    for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                         double unused = 0.0;
-                        const double gn = stencil_grad(zt, i, unused);
-                        const double dxi = dxs[i];
+                        double gn = stencil_grad(zt, i < N ? i : 0, unused);
+                        gn = i < N ? gn : 0.0;
+                        const double dxi = dxs.get(jj, i);
                         const double dgi = gn - g.get(jj, i);
                         sum[0] += dxi * dgi;
                         sum[1] += dgi * dgi;
                         sum[2] += dxi * gn;
-                        dgs[i] = dgi;
+                        dgs.set(jj, i, dgi);
                         g.set(jj, i, gn);
                         s.set(jj, i, gn);
                     });
                 }
             }
             block_allreduce<T, 3, 1>(sum, mx, red, parity, tid);
+            if (iterations == 1) stamp(p, 5);
             if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
                 status = MUSE_STATUS_LINESEARCH_FAILED;
                 f = last_phi;
@@ -852,18 +992,20 @@ struct Solver {
             }
         }
 
+        stamp(p, 6);
         // ---- zhat out, score -------------------------------------------------------------------
         if constexpr (Place::kResident) {
             if (d.zslot >= 0) {
-                double* __restrict__ zo = a.zhat + d.zslot * ld;
-                for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) { zo[i] = z.get(jj, i); });
+                BufVec zo;
+                zo.bind(a.zhat + d.zslot * ld, ld);
+                for_elems<T, EPT>(ld, tid, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
             }
         }
         {
             double acc[MAXB], mx[1] = {0.0};
 #pragma unroll
             for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-            for_elems<T, EPT>(N, tid, [&](int jj, int64_t i) {
+            for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                 const double t = Model::score_term(x.get(jj, i), z.get(jj, i));
                 if constexpr (MAXB == 1) {
                     acc[0] += t;
@@ -892,6 +1034,7 @@ struct Solver {
                 a.info[p] = inf;
             }
         }
+        stamp(p, 7);
     }
     double last_phi;
 };
@@ -920,8 +1063,18 @@ __global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*r
     }
     __syncthreads();
     const BatchArgs& a = *reinterpret_cast<const BatchArgs*>(args_lds);
-    double* lds_x = args_lds + kArgsDoubles;
-    double* lds_g = lds_x + a.ld;
+    double* lds_x = args_lds + kArgsDoubles;  // [ld + 2]: elements, dummy slot (index ld), pad
+    double* lds_g = lds_x + a.ld + 2;         // [ld + 2]
+    if constexpr (Place::kXgLds) {
+        if (tid == 0) {  // the dummy slot and the pad element (N odd) hold 0 for the kernel's lifetime
+            lds_x[a.ld] = 0.0;
+            lds_g[a.ld] = 0.0;
+            if (a.N < a.ld) {
+                lds_x[a.N] = 0.0;
+                lds_g[a.N] = 0.0;
+            }
+        }
+    }
     double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
     for (;;) {
         __syncthreads();
@@ -981,19 +1134,23 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     double acc[MAXB];
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-    auto wrap = [&](int64_t i) { return i < 0 ? i + N : (i >= N ? i - N : i); };
-    for_elems<T, 0>(N, tid, [&](int, int64_t i) {
+    const int Ni = (int)N;
+    auto wrap = [&](int i) { return i < 0 ? i + Ni : (i >= Ni ? i - Ni : i); };
+    // vectors are padded to the even length ld with a zero pad element (phantom zero, see for_elems)
+    for_elems<T, 0>(a.ld, tid, [&](int, int i) {
         const int k = MAXB > 1 ? block_of(a, i) : 0;
         const double ivk = a.tmap.iv[k];
         double gi;
         if constexpr (Model::kStencil) {
-            const int64_t im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
-            const double zm2 = zin[im2], zm1 = zin[im1], z0 = zin[i], zp1 = zin[ip1], zp2 = zin[ip2];
+            const bool valid = i < Ni;
+            const int ic = valid ? i : 0;
+            const int im2 = wrap(ic - 2), im1 = wrap(ic - 1), ip1 = wrap(ic + 1), ip2 = wrap(ic + 2);
+            const double zm2 = zin[im2], zm1 = zin[im1], z0 = zin[ic], zp1 = zin[ip1], zp2 = zin[ip2];
             const double rm = xin[im1] - (0.5 * zm1 + 0.25 * (zm2 + z0));
-            const double r0 = xin[i] - (0.5 * z0 + 0.25 * (zm1 + zp1));
+            const double r0 = xin[ic] - (0.5 * z0 + 0.25 * (zm1 + zp1));
             const double rp = xin[ip1] - (0.5 * zp1 + 0.25 * (z0 + zp2));
-            sum[0] += r0 * r0 + ivk * (z0 * z0);
-            gi = ivk * z0 - (0.5 * r0 + 0.25 * (rm + rp));
+            sum[0] += valid ? r0 * r0 + ivk * (z0 * z0) : 0.0;
+            gi = valid ? ivk * z0 - (0.5 * r0 + 0.25 * (rm + rp)) : 0.0;
         } else {
             gi = Model::grad(ivk, xin[i], zin[i], sum[0]);
         }
@@ -1060,6 +1217,9 @@ struct muse_ctx {
     std::vector<hipEvent_t> prof_ev;
     int prof_count = 0;
     bool prof_on = false;
+    int debug = 0;
+    unsigned long long* stamps = nullptr;
+    int64_t stamps_cap = 0;
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
     double* comm_buf = nullptr;
     size_t comm_buf_doubles = 0;
@@ -1094,7 +1254,7 @@ static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 256
 static int place_wgs_per_cu(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 4 : (pl == P_R512x10 ? 1 : 2); }
 static size_t place_lds(const muse_ctx* c, int pl) {
     size_t fixed = (size_t)(2 * (place_threads(pl) / 64) * 8 + 42 + kArgsDoubles) * sizeof(double);
-    if (pl == P_R512x10) fixed += (size_t)2 * c->ld * sizeof(double);
+    if (pl == P_R512x10) fixed += (size_t)2 * (c->ld + 2) * sizeof(double);
     return fixed;
 }
 static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512) ? 4 + 2 * kM : 2 * kM; }
@@ -1175,6 +1335,8 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.x_data = c->x_data;
     a.zhat = c->zhat;
     a.work_counter = c->counter;
+    a.debug = c->debug;
+    a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     const int pl = choose_place(c);
     int grid = c->num_cus * place_wgs_per_cu(pl);
     if (grid > a.nproblems) grid = a.nproblems;
@@ -1347,6 +1509,25 @@ int muse_last_kernel_ms(muse_ctx* c, float* ms) {
     return MUSE_OK;
 }
 
+int muse_debug_stamps(muse_ctx* c, int64_t nproblems, unsigned long long* out) {  // diagnostic aid
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!out) {  // arm
+        if (c->stamps) HIPCHK(hipFree(c->stamps));
+        HIPCHK(hipMalloc(&c->stamps, (size_t)nproblems * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->stamps, 0, (size_t)nproblems * 16 * sizeof(unsigned long long)));
+        c->stamps_cap = nproblems;
+        return MUSE_OK;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->stamps, (size_t)nproblems * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MUSE_OK;
+}
+int muse_debug_flags(muse_ctx* c, int flags) {  // not part of the public header: profiling aid
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    c->debug = flags;
+    return MUSE_OK;
+}
 int muse_profile_begin(muse_ctx* c, int max_launches) {
     int rc = check_ctx(c);
     if (rc) return rc;

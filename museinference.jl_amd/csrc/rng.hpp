@@ -5,8 +5,8 @@
 //   key = (seed lo32, seed hi32), counter = (i lo32, i hi32, sim lo32, sim hi32)
 // one call per element i of simulation `sim`; the four output words give two uniforms on
 // (0,1) with 52 random bits each, mapped to two standard normals by Box-Muller.  log and
-// sin/cos(pi t) are fixed polynomial sequences in IEEE +,-,*,/,sqrt only (this translation
-// unit is compiled with -ffp-contract=off), so a stream depends on (seed, sim, i) alone:
+// sin/cos(pi t) are fixed polynomial sequences in IEEE +,-,*,/,sqrt and explicit fma only (this
+// translation unit is compiled with -ffp-contract=off: no implicit contraction), so a stream depends on (seed, sim, i) alone:
 // the same on every GPU, for every launch geometry, and bit-equal to a host evaluation of
 // the same sequence.  This replaces split_rng (reference src/util.jl:87-92): "stream =
 // f(master rng, sim index), never advanced by the drivers".
@@ -24,10 +24,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;  // one v_mad_u64_u32 each (hi and lo together)
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -53,11 +56,11 @@ __device__ __forceinline__ double log_unit(double x) {
     const double s = f / (2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double dk = (double)k;
-    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+    return fma(dk, ln2_hi, (fma(s, hfsq + R, dk * ln2_lo) - hfsq) + f);
 }
 
 // sin(pi t), cos(pi t), t in [0,2): exact reduction to |r| <= 1/4, minimax kernels on pi r.
@@ -74,13 +77,13 @@ __device__ __forceinline__ void sincospi_02(double t, double& sn, double& cs) {
     const double y = r * PI;
     const double z = y * y;
     const double w = z * z;
-    const double rs = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double rs = fma(z * w, fma(z, S6, S5), fma(z, fma(z, S4, S3), S2));
     const double v = z * y;
-    const double ks = y + v * (S1 + z * rs);
-    const double rc = z * (C1 + z * (C2 + z * C3)) + w * w * (C4 + z * (C5 + z * C6));
+    const double ks = fma(v, fma(z, rs, S1), y);
+    const double rc = fma(w * w, fma(z, fma(z, C6, C5), C4), z * fma(z, fma(z, C3, C2), C1));
     const double hz = 0.5 * z;
     const double ww = 1.0 - hz;
-    const double kc = ww + (((1.0 - ww) - hz) + z * rc);
+    const double kc = ww + fma(z, rc, (1.0 - ww) - hz);
     const bool swap = (n & 1) != 0;
     const double a = swap ? kc : ks;  // |sin|
     const double b = swap ? ks : kc;  // |cos|

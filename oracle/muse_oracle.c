@@ -41,7 +41,8 @@
  *   sim hi32); u1 = ((w0<<20 | w1>>12) + 0.5) 2^-52, u2 likewise from (w2,w3);
  *   Box-Muller r = sqrt(-2 log u1), n1 = r cos(2 pi u2), n2 = r sin(2 pi u2), with log and
  *   sin/cos(pi t) evaluated by the fixed fdlibm-style polynomial sequences written out
- *   below using only IEEE +,-,*,/,sqrt (no contraction), so that both sides are bit-equal.
+ *   below using only IEEE +,-,*,/,sqrt and explicit fma (no implicit contraction), so that both
+ *   sides are bit-equal.
  */
 #include <math.h>
 #include <stdint.h>
@@ -117,11 +118,11 @@ static double mo_log(double x) {
     double s = f / (2.0 + f);
     double z = s * s;
     double w = z * z;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
     double R = t2 + t1;
     double dk = (double)k;
-    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+    return fma(dk, ln2_hi, (fma(s, hfsq + R, dk * ln2_lo) - hfsq) + f);
 }
 
 /* sin(pi t), cos(pi t) for t in [0,2): exact octant reduction, fdlibm kernels on |y|<=pi/4. */
@@ -138,13 +139,13 @@ static void mo_sincospi(double t, double* sn, double* cs) {
     double y = r * PI;
     double z = y * y;
     double w = z * z;
-    double rs = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    double rs = fma(z * w, fma(z, S6, S5), fma(z, fma(z, S4, S3), S2));
     double v = z * y;
-    double ks = y + v * (S1 + z * rs);
-    double rc = z * (C1 + z * (C2 + z * C3)) + w * w * (C4 + z * (C5 + z * C6));
+    double ks = fma(v, fma(z, rs, S1), y);
+    double rc = fma(w * w, fma(z, fma(z, C6, C5), C4), z * fma(z, fma(z, C3, C2), C1));
     double hz = 0.5 * z;
     double ww = 1.0 - hz;
-    double kc = ww + (((1.0 - ww) - hz) + z * rc);
+    double kc = ww + fma(z, rc, (1.0 - ww) - hz);
     switch (n & 3) {
         case 0: *sn = ks; *cs = kc; break;
         case 1: *sn = kc; *cs = -ks; break;

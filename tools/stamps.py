@@ -1,0 +1,23 @@
+"""Diagnostic: per-phase shader-clock shares of one batch from the -DMUSE_STAMPS build (never timed)."""
+import sys, numpy as np, ctypes as C
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import museinference_jl_amd as M
+from museinference_jl_amd import build as B, _capi
+B.LIB_PATH = B.LIB_PATH.replace("libmuse_hip.so", "libmuse_hip_stamps.so")
+lib = M.load_library()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+n = 512
+prob = M.HipMuseProblem(None, model="funnel", ntheta=1, N=N)
+for _ in range(3): prob.map_and_score_batch(0,0,n,[1.0])
+lib.muse_debug_stamps(prob._ctx, C.c_int64(n), None)
+prob.map_and_score_batch(0,0,n,[1.0])
+out = np.zeros((n,16), dtype=np.uint64)
+lib.muse_debug_stamps(prob._ctx, C.c_int64(n), out.ctypes.data_as(C.c_void_p))
+st = out[:, :8].astype(np.int64)
+d = np.diff(st, axis=1)
+names = ["sample/load", "eval0", "twoloop(s=-g)", "linesearch", "update", "(loop exit)", "score+zhat"]
+print("median shader cycles per phase (wave 0):")
+for k, nm in enumerate(names): print(f"  {nm:16s} {np.median(d[:,k]):10.0f}   ({np.median(d[:,k])/np.median(st[:,7]-st[:,0])*100:5.1f} %)")
+print("total per problem", np.median(st[:,7]-st[:,0]), "cycles; first start -> last end:", (st[:,7].max()-st[:,0].min()), "cycles")
+order = np.argsort(st[:,0]); 
+print("start offsets of problems (cycles, sorted) sample:", (st[order,0]-st[:,0].min())[[0,1,100,255,256,300,511]])
