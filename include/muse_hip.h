@@ -100,8 +100,10 @@ int muse_set_stream(muse_ctx* ctx, void* hip_stream);
 int muse_set_placement(muse_ctx* ctx, int placement);
 int64_t muse_max_resident_n(void);
 int muse_synchronize(muse_ctx* ctx);
-/* Device time in ms of the most recent solver launch (HIP events on the context's stream). */
+/* Device time in ms of the most recent solver launch (HIP events on the context's stream);
+ * muse_set_timing(ctx, 0) stops recording the per-launch event pair (default: enabled). */
 int muse_last_kernel_ms(muse_ctx* ctx, float* ms);
+int muse_set_timing(muse_ctx* ctx, int enabled);
 /* Live timing of every solver launch between begin and end: HIP event pairs recorded on the
  * context's stream around each launch (up to max_launches); end() synchronises and returns the
  * per-launch durations in ms.  The reference only keeps wall-clock deltas (src/muse.jl:161,210,232). */

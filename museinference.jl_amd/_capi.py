@@ -45,6 +45,7 @@ SIGNATURES = {
     "muse_max_resident_n": (_i64, []),
     "muse_synchronize": (_i, [_vp]),
     "muse_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "muse_set_timing": (_i, [_vp, _i]),
     "muse_profile_begin": (_i, [_vp, _i]),
     "muse_profile_end": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "muse_sample_x_z": (_i, [_vp, _u64, _i64, _vp, _vp, _vp, _i]),

@@ -75,7 +75,8 @@ struct BatchArgs {
     muse_info* info;               // [nproblems]
     double* scratch;               // per workgroup
     int64_t scratch_stride;        // doubles per workgroup
-    int* work_counter;
+    int* work_counter;             // monotonically increasing ticket counter (never reset)
+    int ticket_base, pad2_;        // this launch's tickets are work_counter values base .. base+nproblems-1
     unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
 };
 
@@ -725,7 +726,7 @@ struct Solver {
                 // Sampler as a ROLLED loop over this thread's pairs (one or two Philox/Box-Muller
                 // chains in flight, not 2*EPT): x goes straight to LDS, the true z is staged in the
                 // (still unused) g area and picked up into registers below.
-#pragma unroll 1
+#pragma unroll 2
                 for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
@@ -1080,7 +1081,7 @@ __global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*r
         __syncthreads();
         if (tid == 0) ticket[0] = atomicAdd(a.work_counter, 1);
         __syncthreads();
-        const int p = __builtin_amdgcn_readfirstlane(ticket[0]);
+        const int p = __builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base;
         if (p >= a.nproblems) break;
         Solver<Model, Place> sv(a, tid, red, shs);
         sv.run(p, wg_scratch, lds_x, lds_g);
@@ -1218,6 +1219,8 @@ struct muse_ctx {
     int prof_count = 0;
     bool prof_on = false;
     int debug = 0;
+    unsigned int ticket_base = 0;  // value of the device ticket counter when the next launch starts
+    bool timing = true;            // record an event pair around every solver launch
     unsigned long long* stamps = nullptr;
     int64_t stamps_cap = 0;
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
@@ -1286,18 +1289,21 @@ static int ensure_scratch(muse_ctx* c, size_t doubles) {
     c->scratch_doubles = doubles;
     return MUSE_OK;
 }
+// One pinned, device-mapped host block per result area: [cap*ntheta] scores then [cap] infos.  The
+// solver kernel writes an element's score and info straight into it (a few hundred posted PCIe
+// writes per batch), so no device->host copy sits between consecutive launches.
+static size_t result_bytes(const muse_ctx* c, int64_t cap) {
+    return (size_t)cap * (size_t)c->ntheta * sizeof(double) + (size_t)cap * sizeof(muse_info);
+}
 static int ensure_results(muse_ctx* c, int area, int64_t n) {
     if (n <= c->res_cap[area]) return MUSE_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->scores_dev[area]) HIPCHK(hipFree(c->scores_dev[area]));
-    if (c->info_dev[area]) HIPCHK(hipFree(c->info_dev[area]));
     if (c->scores_pin[area]) HIPCHK(hipHostFree(c->scores_pin[area]));
-    if (c->info_pin[area]) HIPCHK(hipHostFree(c->info_pin[area]));
     const int64_t cap = n + n / 2 + 16;
-    HIPCHK(hipMalloc(&c->scores_dev[area], (size_t)cap * kMaxTheta * sizeof(double)));
-    HIPCHK(hipMalloc(&c->info_dev[area], (size_t)cap * sizeof(muse_info)));
-    HIPCHK(hipHostMalloc(&c->scores_pin[area], (size_t)cap * kMaxTheta * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(&c->info_pin[area], (size_t)cap * sizeof(muse_info), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->scores_pin[area], result_bytes(c, cap), hipHostMallocDefault));
+    c->info_pin[area] = reinterpret_cast<muse_info*>(c->scores_pin[area] + cap * c->ntheta);
+    c->scores_dev[area] = c->scores_pin[area];  // unified addressing: the kernel stores through the same pointers
+    c->info_dev[area] = c->info_pin[area];
     c->res_cap[area] = cap;
     return MUSE_OK;
 }
@@ -1346,24 +1352,34 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     if (rc) return rc;
     a.scratch = c->scratch;
     const size_t lds = place_lds(c, pl);
-    HIPCHK(hipMemsetAsync(c->counter, 0, 16, c->stream));
+    // Tickets: every workgroup draws tickets until it draws one past the batch, so a launch advances
+    // the counter by exactly nproblems + grid -- no per-launch memset.  Wrap-around: reset explicitly.
+    if (c->ticket_base > 0x70000000u) {
+        HIPCHK(hipMemsetAsync(c->counter, 0, 16, c->stream));
+        c->ticket_base = 0;
+    }
+    a.ticket_base = (int)c->ticket_base;
+    c->ticket_base += (unsigned)a.nproblems + (unsigned)grid;
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->prof_on && (size_t)(2 * c->prof_count + 1) < c->prof_ev.size()) {
         e0 = c->prof_ev[2 * c->prof_count];
         e1 = c->prof_ev[2 * c->prof_count + 1];
         c->prof_count += 1;
     }
-    HIPCHK(hipEventRecord(e0, c->stream));
+    const bool timed = c->timing || c->prof_on;
+    if (timed) HIPCHK(hipEventRecord(e0, c->stream));
     if (c->model == MUSE_MODEL_NOISE) rc = launch_place<NoiseModel>(c, a, pl, grid, lds);
     else if (c->model == MUSE_MODEL_FUNNEL)
         rc = c->ntheta == 1 ? launch_place<FunnelModel<1>>(c, a, pl, grid, lds)
                             : launch_place<FunnelModel<kMaxTheta>>(c, a, pl, grid, lds);
     else rc = launch_place<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(e1, c->stream));
-    c->last0 = e0;
-    c->last1 = e1;
-    c->ev_valid = true;
+    if (timed) {
+        HIPCHK(hipEventRecord(e1, c->stream));
+        c->last0 = e0;
+        c->last1 = e1;
+        c->ev_valid = true;
+    }
     return MUSE_OK;
 }
 
@@ -1403,6 +1419,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->x_data, (size_t)c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->counter, 16));
+    HIPCHK(hipMemset(c->counter, 0, 16));
     HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&c->tsample_dev, 2 * kMaxTheta * sizeof(ThetaSet)));
@@ -1450,8 +1467,7 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
     for (int r = 0; r < kResultAreas; ++r) {
-        hipFree(c->scores_dev[r]); hipFree(c->info_dev[r]);
-        hipHostFree(c->scores_pin[r]); hipHostFree(c->info_pin[r]);
+        hipHostFree(c->scores_pin[r]);
     }
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     for (int r = 0; r < kResultAreas; ++r) hipEventDestroy(c->area_done[r]);
@@ -1521,6 +1537,11 @@ int muse_debug_stamps(muse_ctx* c, int64_t nproblems, unsigned long long* out) {
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->stamps, (size_t)nproblems * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MUSE_OK;
+}
+int muse_set_timing(muse_ctx* c, int enabled) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    c->timing = enabled != 0;
     return MUSE_OK;
 }
 int muse_debug_flags(muse_ctx* c, int flags) {  // not part of the public header: profiling aid
@@ -1632,10 +1653,7 @@ int muse_grad_theta(muse_ctx* c, const double* x, const double* z, const double*
 }
 
 static int enqueue_results_copy(muse_ctx* c, int area, int64_t n) {
-    HIPCHK(hipMemcpyAsync(c->scores_pin[area], c->scores_dev[area], (size_t)n * c->ntheta * sizeof(double),
-                          hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->info_pin[area], c->info_dev[area], (size_t)n * sizeof(muse_info), hipMemcpyDeviceToHost,
-                          c->stream));
+    // results are already on their way to pinned host memory; mark the point at which they are complete
     c->res_n[area] = n;
     HIPCHK(hipEventRecord(c->area_done[area], c->stream));
     return MUSE_OK;

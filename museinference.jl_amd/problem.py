@@ -171,6 +171,9 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_last_kernel_ms(self._ctx, C.byref(ms)))
         return ms.value
 
+    def set_timing(self, enabled):
+        _capi.check(self._lib.muse_set_timing(self._ctx, int(bool(enabled))))
+
     def profile_begin(self, max_launches=1024):
         _capi.check(self._lib.muse_profile_begin(self._ctx, int(max_launches)))
         self._prof_cap = int(max_launches)
