@@ -1,0 +1,83 @@
+"""An AbstractMuseProblem whose operators are the CPU oracle -- TEST INFRASTRUCTURE.
+
+Lets the host drivers (muse_, get_J_, get_H_) and the multi-process sharding be exercised without a
+GPU, and serves as the checker the HIP-backed problem is compared with.  Never shipped: the product
+package does not import it.
+"""
+import numpy as np
+
+import museinference_jl_amd as M
+from oracle import oracle as O
+
+
+class OracleMuseProblem(M.AbstractMuseProblem):
+    def __init__(self, x, model="funnel", ntheta=1, prior=None, N=None, batched=True, nthreads=4):
+        from museinference_jl_amd.priors import as_prior
+        self.x = None if x is None else np.asarray(x, dtype=np.float64)
+        self.N = int(N) if x is None else self.x.size
+        self.model, self.ntheta, self.prior = model, ntheta, as_prior(prior)
+        self.nthreads = nthreads
+        self._zhat = {}
+        if not batched:  # hide the batched seams: drives the element-by-element path of the host drivers
+            self.map_and_score_batch = None
+            del self.map_and_score_batch
+
+    def logPrior_theta(self, theta, theta_space=None):
+        return self.prior.logpdf(np.asarray(theta, dtype=np.float64))
+
+    def grad_logPrior_theta(self, theta, theta_space=None):
+        return np.atleast_1d(self.prior.grad(np.asarray(theta, dtype=np.float64)))
+
+    def hess_logPrior_theta(self, theta, theta_space=None):
+        return np.atleast_2d(self.prior.hess(np.asarray(theta, dtype=np.float64)))
+
+    def sample_x_z(self, rng, theta):
+        return O.sample_x_z(self.model, self.N, rng.seed, rng.sim, theta)
+
+    def logLike_and_grad_z_logLike(self, x, z, theta):
+        return O.logLike_and_grad_z(self.model, x, z, theta)
+
+    def grad_theta_logLike(self, x, z, theta, theta_space=None):
+        return O.grad_theta(self.model, x, z, theta)
+
+    def zhat_at_theta(self, x, z0, theta, grad_z_logLike_atol=1e-2):
+        z, info = O.zhat_at_theta(self.model, x, z0, theta, grad_z_logLike_atol)
+        rec = np.zeros(1, dtype=M._capi.INFO_DTYPE)
+        for k in info:
+            rec[k] = info[k]
+        return z, rec[0]
+
+
+class OracleBatchedProblem(OracleMuseProblem):
+    """Adds the batched seams (same signatures as HipMuseProblem) on top of the oracle."""
+
+    def map_and_score_batch(self, rng, sim_begin, sim_end, theta, *, include_data=False, atol=1e-2, z0_mode=0):
+        seed = rng.seed if isinstance(rng, M.SimRng) else int(rng)
+        n = (sim_end - sim_begin) + (1 if include_data else 0)
+        zhat = None
+        if z0_mode == M.Z0_WARM:
+            zhat = np.stack([self._zhat.get(e, np.zeros(self.N)) for e in range(n)])
+        g, zh, info = O.map_and_score_batch(self.model, self.N, seed, sim_begin, sim_end, theta, atol=atol,
+                                            x_data=self.x if include_data else None, z0_mode=z0_mode, zhat=zhat,
+                                            nthreads=self.nthreads)
+        for e in range(n):
+            self._zhat[e] = zh[e]
+        return g, info.astype(M._capi.INFO_DTYPE)
+
+    def get_zhat(self, b, e):
+        return np.stack([self._zhat[k] for k in range(b, e)])
+
+    def set_zhat(self, b, zs):
+        for k, z in enumerate(np.atleast_2d(zs)):
+            self._zhat[b + k] = np.array(z, dtype=np.float64)
+
+    def fd_jacobian_batch(self, rng, sim_begin, sim_end, theta0, step, *, atol=1e-2, fid_mode=0, fid_sim=M.MASTER_SIM):
+        seed = rng.seed if isinstance(rng, M.SimRng) else int(rng)
+        th = np.atleast_1d(np.asarray(theta0, dtype=np.float64))
+        Hs = []
+        for s in range(sim_begin, sim_end):
+            fid = fid_sim if fid_mode == 0 else s
+            _, zfid, _ = O.map_and_score_batch(self.model, self.N, seed, fid, fid + 1, th, atol=atol, z0_mode=0)
+            Hs.append(O.fd_jacobian(self.model, self.N, seed, s, th, step, zfid[0], atol=atol))
+        info = np.zeros((sim_end - sim_begin, th.size, 2), dtype=M._capi.INFO_DTYPE)
+        return np.array(Hs).reshape(sim_end - sim_begin, th.size, th.size), info

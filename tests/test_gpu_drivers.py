@@ -1,0 +1,165 @@
+"""-m gpu: the drivers end to end on the HIP path, golden fixtures, full-size properties at
+BASELINE.json's sizes, error behaviour of the C ABI, and the RCCL exchange with one rank."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_problem import OracleBatchedProblem
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_golden_fixtures(gpu, M):
+    d = np.load(os.path.join(HERE, "golden", "per_sim.npz"))
+    keys = sorted({k.rsplit("_", 1)[0] for k in d.files})
+    for key in keys:
+        model = "funnel" if key.startswith("funnel") else ("noise" if key.startswith("noise") else "smooth")
+        N, seed = int(key.split("_N")[1].split("_")[0]), int(key.split("_s")[1])
+        th = d[key + "_theta"]
+        if model == "smooth" and N < 5:
+            continue
+        prob = M.HipMuseProblem(None, model=model, ntheta=th.size, N=N)
+        x, z = prob.sample_x_z(M.SimRng(seed, 5), th)
+        assert np.array_equal(x, d[key + "_x"]) and np.array_equal(z, d[key + "_z"])   # bit-exact sampler
+        zh, info = prob.zhat_at_theta(x, np.zeros(N), th, 1e-2)
+        assert (info["iterations"], info["f_calls"]) == tuple(d[key + "_iters"][:2])
+        np.testing.assert_allclose(zh, d[key + "_zhat"], rtol=0, atol=1e-9)
+        zh6, info6 = prob.zhat_at_theta(x, np.zeros(N), th, 1e-6)
+        assert (info6["iterations"], info6["f_calls"]) == tuple(d[key + "_iters"][2:])
+        np.testing.assert_allclose(zh6, d[key + "_zhat6"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(prob.grad_theta_logLike(x, d[key + "_zhat"], th), d[key + "_score"], rtol=1e-12)
+        f, g = prob.logLike_and_grad_z_logLike(x, 0.5 * z, th)
+        np.testing.assert_allclose(f, d[key + "_logLike"][0], rtol=1e-12)
+        np.testing.assert_allclose(g, d[key + "_gradz"], rtol=1e-13, atol=1e-13)
+        _, zf = None, None
+        Hs, _ = prob.fd_jacobian_batch(seed, 5, 6, th, np.full(th.size, 0.05), atol=1e-2, fid_mode=0, fid_sim=7)
+        np.testing.assert_allclose(Hs[0], d[key + "_H"], rtol=1e-8, atol=1e-8 * np.abs(d[key + "_H"]).max())
+        prob.close()
+
+
+def test_muse_end_to_end_matches_oracle_driven_run(gpu, M, O):
+    """muse! + get_J! + get_H! on the GPU against the same drivers on the oracle (rtol 1e-8 on theta-hat,
+    J, H, Sigma): identical random streams, identical L-BFGS paths."""
+    d = np.load(os.path.join(HERE, "golden", "muse_trajectory.npz"))
+    prob = M.HipMuseProblem(d["x"], model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    res = M.muse(prob, [1.0], rng=42, nsims=32, get_covariance=True)
+    np.testing.assert_allclose(np.array([h["θ"] for h in res.history]), d["thetas"], rtol=1e-9)
+    np.testing.assert_allclose(res.theta, d["theta"], rtol=1e-8)
+    np.testing.assert_allclose(np.array(res.gs), d["gs"], rtol=1e-10)
+    np.testing.assert_allclose(res.J, d["J"], rtol=1e-9)
+    np.testing.assert_allclose(res.H, d["H"], rtol=1e-7)
+    np.testing.assert_allclose(res.Sigma, d["Sigma"], rtol=1e-7)
+    assert abs(res.dist.μ) / res.dist.σ < 2      # the reference's acceptance criterion (test/runtests.jl:31)
+    prob.close()
+
+
+def test_multi_theta_muse_matches_oracle(gpu, M, O):
+    x, _ = O.sample_x_z("funnel", 2000, 9, M.DATA_SIM, [0.0] * 4)
+    kw = dict(rng=1, nsims=20, maxsteps=4, get_covariance=True)
+    a = M.muse(M.HipMuseProblem(x, model="funnel", ntheta=4, prior=M.GaussianPrior(0.0, 3.0)), [1.0] * 4, **kw)
+    b = M.muse(OracleBatchedProblem(x, "funnel", 4, prior=M.GaussianPrior(0.0, 3.0)), [1.0] * 4, **kw)
+    np.testing.assert_allclose(a.theta, b.theta, rtol=1e-8)
+    np.testing.assert_allclose(a.J, b.J, rtol=1e-8)
+    np.testing.assert_allclose(a.H, b.H, rtol=1e-6, atol=1e-6 * np.abs(b.H).max())
+    np.testing.assert_allclose(a.Sigma, b.Sigma, rtol=1e-6, atol=1e-9)
+
+
+def test_smooth_model_many_iterations_and_warm_history(gpu, M, O):
+    N, th = 3000, [2.0, 3.0, 1.0, 2.5]
+    prob = M.HipMuseProblem(None, model="smooth", ntheta=4, N=N)
+    g, info = prob.map_and_score_batch(5, 0, 10, th, atol=1e-5, z0_mode=0)
+    go, zo, io = O.map_and_score_batch("smooth", N, 5, 0, 10, th, atol=1e-5, z0_mode=0, nthreads=4)
+    assert info["iterations"].min() > 10           # the L-BFGS ring buffer (m = 10) wraps
+    assert np.array_equal(info["iterations"], io["iterations"]) and np.array_equal(info["f_calls"], io["f_calls"])
+    assert np.array_equal(info["hist_words"], io["hist_words"])
+    np.testing.assert_allclose(g, go, rtol=1e-10)
+    np.testing.assert_allclose(prob.get_zhat(0, 10), zo, rtol=0, atol=1e-9)
+    prob.close()
+
+
+def test_full_size_config2_properties(gpu, M):
+    """BASELINE.json configs[1] at full size (N = 10^4, nsims = 512): closed-form MAP and score for every sim,
+    and the score moments E[s] = -N/(2(1+e^θ)), Var[s] = N e^{2θ}/(2(1+e^θ)²)."""
+    N, S, theta = 10000, 512, 1.0
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=1, N=N)
+    g, info = prob.map_and_score_batch(0, 0, S, [theta], atol=1e-2, z0_mode=0)
+    assert np.all(info["status"] == 0) and np.all(info["iterations"] == 1) and np.all(info["f_calls"] == 3)
+    e = np.exp(theta)
+    mean, var = -N / (2 * (1 + e)), N * e**2 / (2 * (1 + e) ** 2)
+    assert abs(g.mean() - mean) < 4 * np.sqrt(var / S)
+    assert abs(g.var(ddof=1) / var - 1) < 4 * np.sqrt(2.0 / S)
+    for k in (0, 17, 511):
+        x, _ = prob.sample_x_z(M.SimRng(0, k), [theta])
+        zh = prob.get_zhat(k, k + 1)[0]
+        np.testing.assert_allclose(zh, x / (1 + np.exp(-theta)), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(g[k, 0], 0.5 * (np.exp(-theta) * np.sum(zh**2) - N), rtol=1e-12)
+    # idempotence: a warm restart at the MAP needs no iteration and returns the same scores
+    g2, info2 = prob.map_and_score_batch(0, 0, S, [theta], atol=1e-2, z0_mode=M.Z0_WARM)
+    assert np.all(info2["iterations"] == 0) and np.all(info2["f_calls"] == 1)
+    assert np.array_equal(g, g2)
+    prob.close()
+
+
+def test_full_size_config3_noise_1e6(gpu, M):
+    """configs[2]: noise-level model, N = 10^6 (streaming policy): closed-form MAP and score."""
+    N, theta = 1000000, 0.5
+    prob = M.HipMuseProblem(None, model="noise", ntheta=1, N=N)
+    g, info = prob.map_and_score_batch(3, 0, 4, [theta], atol=1e-2, z0_mode=0)
+    assert np.all(info["status"] == 0)
+    x, _ = prob.sample_x_z(M.SimRng(3, 2), [theta])
+    zh = prob.get_zhat(2, 3)[0]
+    np.testing.assert_allclose(zh, x / (1 + np.exp(theta)), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(g[2, 0], 0.5 * (np.exp(-theta) * np.sum((x - zh) ** 2) - N), rtol=1e-11)
+    prob.close()
+
+
+def test_results_do_not_depend_on_batch_geometry(gpu, M):
+    """A sim's result depends on (seed, sim, theta) only: not on where it sits in a batch or how many
+    workgroups share the launch (what makes a multi-GPU run equal the single-GPU run)."""
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=2, N=3001)
+    th = [0.4, -0.3]
+    g_all, _ = prob.map_and_score_batch(9, 0, 600, th)
+    g_part, _ = prob.map_and_score_batch(9, 250, 260, th)
+    assert np.array_equal(g_all[250:260], g_part)
+    prob.close()
+
+
+def test_c_abi_errors(gpu, M):
+    with pytest.raises(ValueError):
+        M.HipMuseProblem(None, model="nope", N=8)
+    with pytest.raises(M.MuseError):
+        M.HipMuseProblem(None, model="noise", ntheta=2, N=8)       # noise has one theta
+    with pytest.raises(M.MuseError):
+        M.HipMuseProblem(None, model="funnel", ntheta=9, N=80)     # > MUSE_MAX_THETA
+    p = M.HipMuseProblem(None, model="funnel", N=64)
+    with pytest.raises(M.MuseError) as e:
+        p.map_and_score_batch(0, 0, 4, [0.0], include_data=True)   # no data set
+    assert e.value.code == -3
+    with pytest.raises(M.MuseError):
+        p.map_and_score_batch_async(0, 5, 2, [0.0])                # bad range
+    g, info = p.map_and_score_batch(0, 0, 0, [0.0])                # empty batch is fine
+    assert g.shape == (0, 1)
+    p.close()
+
+
+def test_nonfinite_and_skip_errors(gpu, M):
+    x = np.ones(64)
+    x[3] = np.nan
+    p = M.HipMuseProblem(x, model="funnel", N=None)
+    with pytest.warns(RuntimeWarning):
+        g, info = p.map_and_score_batch(0, 0, 2, [0.0], include_data=True)
+        M.check_optim_soln(info)
+    assert info["status"][0] == 5 and np.all(info["status"][1:] == 0)   # only the data element is poisoned
+    p.close()
+
+
+def test_rccl_single_rank(gpu, M):
+    p = M.HipMuseProblem(None, model="funnel", N=64)
+    uid = M.HipMuseProblem.comm_unique_id()
+    p.comm_init(1, 0, uid)
+    v = np.arange(12.0)
+    assert np.array_equal(p.allgather_scores(v), v[None, :])
+    assert np.array_equal(p.allreduce_sum(v), v)
+    p.close()

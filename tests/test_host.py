@@ -1,0 +1,136 @@
+"""Host drivers (muse_, get_J_, get_H_, finalize_result_) on CPU, driven through the oracle-backed
+problem: reference semantics of src/muse.jl restated in SURVEY.md Appendix A."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_problem import OracleBatchedProblem, OracleMuseProblem
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def funnel512(M, O):
+    x, _ = O.sample_x_z("funnel", 512, 123, M.DATA_SIM, [0.0])
+    return x
+
+
+def test_muse_trajectory_matches_golden(M, O, funnel512):
+    d = np.load(os.path.join(HERE, "golden", "muse_trajectory.npz"))
+    assert np.array_equal(funnel512, d["x"])
+    prob = OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0))
+    res = M.muse(prob, [1.0], rng=42, nsims=32, get_covariance=True)
+    np.testing.assert_allclose(np.array([h["θ"] for h in res.history]), d["thetas"], rtol=1e-13)
+    np.testing.assert_allclose(res.theta, d["theta"], rtol=1e-12)
+    np.testing.assert_allclose(res.J, d["J"], rtol=1e-12)
+    np.testing.assert_allclose(res.H, d["H"], rtol=1e-10)
+    np.testing.assert_allclose(res.Sigma, d["Sigma"], rtol=1e-10)
+
+
+def test_reference_acceptance_criterion(M, O, funnel512):
+    """The reference's only numerical assertion (test/runtests.jl:31,56,81): |mu|/sigma < 2 at theta_true = 0,
+    512-dim funnel, start theta0 = 1, prior N(0,3), nsims = 100, get_covariance."""
+    prob = OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0))
+    res = M.muse(prob, 1.0, rng=0, nsims=100, get_covariance=True)
+    assert abs(res.dist.μ) / res.dist.σ < 2
+    # closed form posterior width: (H J^-1 H + 1/9)^-1/2 with H = J = N/8 at theta = 0
+    assert abs(res.dist.σ - 0.1249) < 0.02
+    assert len(res.gs) == 100 and len(res.Hs) == 10  # get_H! runs nsims ÷ 10 sims (src/muse.jl:246)
+    assert "MuseResult(" in repr(res) and "±" in repr(res)
+
+
+def test_serial_path_equals_batched_path(M, O, funnel512):
+    a = M.muse(OracleBatchedProblem(funnel512, prior=M.GaussianPrior()), [1.0], rng=7, nsims=8, maxsteps=3)
+    b = M.muse(OracleMuseProblem(funnel512, prior=M.GaussianPrior(), batched=False), [1.0], rng=7, nsims=8, maxsteps=3)
+    assert len(a.history) == len(b.history)
+    for ha, hb in zip(a.history, b.history):
+        np.testing.assert_allclose(ha["g_like′"], hb["g_like′"], rtol=1e-12)
+    np.testing.assert_allclose(a.theta, b.theta, rtol=1e-12)
+
+
+def test_get_J_reuses_gs_and_continues_streams(M, O, funnel512):
+    prob = OracleBatchedProblem(funnel512, prior=M.GaussianPrior())
+    res = M.muse(prob, [1.0], rng=5, nsims=16, maxsteps=2)
+    gs0 = np.array(res.gs)
+    M.get_J_(res, prob, nsims=16)                     # no new sims (src/muse.jl:499-502)
+    assert np.array_equal(np.array(res.gs), gs0)
+    np.testing.assert_allclose(res.J, np.atleast_2d(np.var(gs0, axis=0, ddof=1)), rtol=1e-13)
+    M.get_J_(res, prob, nsims=24)                     # sims 16..23 are appended, evaluated at result.theta
+    assert len(res.gs) == 24
+    extra, _, _ = O.map_and_score_batch("funnel", 512, 5, 16, 24, res.theta, atol=1e-2, z0_mode=1)
+    np.testing.assert_allclose(np.array(res.gs)[16:], extra, rtol=1e-13)
+
+
+def test_get_H_step_default_and_mean(M, O, funnel512):
+    prob = OracleBatchedProblem(funnel512, prior=M.GaussianPrior())
+    res = M.MuseResult(theta=np.array([0.2]), rng=3)
+    M.get_J_(res, prob, nsims=20)
+    M.get_H_(res, prob, nsims=4)
+    step = 0.1 / np.std(np.array(res.gs), axis=0, ddof=1)           # src/muse.jl:411-413
+    _, zfid, _ = O.map_and_score_batch("funnel", 512, 3, M.MASTER_SIM, M.MASTER_SIM + 1, [0.2], atol=1e-2, z0_mode=0)
+    want = [O.fd_jacobian("funnel", 512, 3, s, [0.2], step, zfid[0], atol=1e-2) for s in range(4)]
+    np.testing.assert_allclose(np.array(res.Hs), np.array(want), rtol=1e-12)
+    np.testing.assert_allclose(res.H, np.mean(want, axis=0), rtol=1e-12)
+    H, J = res.H, res.J
+    np.testing.assert_allclose(res.Sigma_inv, H.T @ np.linalg.inv(J) @ H + 1 / 9.0, rtol=1e-12)  # src/muse.jl:540
+    assert res.time > 0
+
+
+def test_multi_theta_and_update_modes(M, O):
+    x, _ = O.sample_x_z("funnel", 400, 9, M.DATA_SIM, [0.0] * 4)
+    prob = OracleBatchedProblem(x, "funnel", 4, prior=M.GaussianPrior(0.0, 3.0))
+    base = M.muse(prob, [1.0] * 4, rng=1, nsims=24, maxsteps=6, get_covariance=True)
+    assert base.Sigma.shape == (4, 4) and np.all(np.linalg.eigvalsh(base.Sigma) > 0)
+    assert np.all(np.abs(base.theta) < 1.0)
+    for mode in ("broyden", "diagonal_broyden"):
+        r = M.muse(prob, [1.0] * 4, rng=1, nsims=24, maxsteps=6, Hinv_update=mode)
+        assert np.all(np.isfinite(r.theta)) and np.all(np.abs(r.theta) < 1.5)
+    r = M.muse(prob, [1.0] * 4, rng=1, nsims=24, maxsteps=4, alpha=lambda i: 0.5, regularize=lambda t: np.clip(t, -0.5, 2))
+    assert np.all(r.history[-1]["θ"] >= -0.5)
+
+
+def test_checkpoint_and_resume(M, O, funnel512, tmp_path):
+    prob = OracleBatchedProblem(funnel512, prior=M.GaussianPrior())
+    ck = str(tmp_path / "ck.pkl")
+    kw = dict(rng=11, nsims=16, theta_rtol=0, grad_z_logLike_atol=1e-9)
+    full = M.muse(OracleBatchedProblem(funnel512, prior=M.GaussianPrior()), [1.0], maxsteps=4, **kw)
+    M.muse(prob, [1.0], maxsteps=2, checkpoint_filename=ck, **kw)
+    res = M.load_result(ck)
+    assert len(res.history) == 2 and res.rng == 11
+    # resumes at len(history)+1 from result.theta/rng (src/muse.jl:134-135,159)
+    M.muse_(res, prob, maxsteps=4, nsims=16, theta_rtol=0, grad_z_logLike_atol=1e-9)
+    assert len(res.history) == 4
+    # the resumed run restarts its MAPs from zero (src/muse.jl:151): same iterates up to the MAP tolerance
+    np.testing.assert_allclose(res.theta, full.theta, atol=1e-6)
+
+
+def test_save_maps_and_history_fields(M, O, funnel512):
+    prob = OracleBatchedProblem(funnel512, prior=M.GaussianPrior())
+    res = M.muse(prob, [1.0], rng=2, nsims=4, maxsteps=1, save_MAPs=True)
+    h = res.history[0]
+    for k in ("θ", "θunreg", "θ′", "θunreg′", "g_like_sims", "g_like_dat′", "g_like_sims′", "g_like′", "g_prior′",
+              "g_post′", "H⁻¹_post′", "H_prior′", "H⁻¹_like′", "H⁻¹_like_sims′", "ẑ_history_dat", "ẑ_history_sims",
+              "t", "ẑ_dat", "ẑ_sims"):
+        assert k in h
+    assert h["ẑ_dat"].shape == (512,) and len(h["ẑ_sims"]) == 4
+    np.testing.assert_allclose(h["ẑ_dat"], funnel512 / (1 + np.exp(-1.0)), atol=1e-2)
+
+
+def test_block_partition(M):
+    for n in (0, 1, 7, 512, 513):
+        for w in (1, 2, 3, 8):
+            parts = [M.block_partition(10, 10 + n, w, r) for r in range(w)]
+            assert parts[0][0] == 10 and parts[-1][1] == 10 + n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_priors(M):
+    g = M.GaussianPrior(0.0, 3.0)
+    c = M.CallablePrior(lambda t: -np.sum(t**2) / 18.0)
+    th = np.array([0.7, -1.2])
+    np.testing.assert_allclose(c.logpdf(th), g.logpdf(th), rtol=1e-12)
+    np.testing.assert_allclose(c.grad(th), g.grad(th), rtol=1e-6)
+    np.testing.assert_allclose(c.hess(th), g.hess(th), atol=1e-5)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/: kernel trace + stats, then HBM counters in separate --pmc passes
+# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no --pmc together with traces).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+W=${1:-funnel_1e4}
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --workload $W > $OUT/bench_trace_$W.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$W -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --workload $W > $OUT/bench_fetch_$W.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$W -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --workload $W > $OUT/bench_write_$W.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_$W -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --workload $W > $OUT/bench_sq_$W.log 2>&1
+find $OUT -name "*.csv" | head -30
