@@ -1,0 +1,163 @@
+# HipMuseInference.jl -- the reference-side binding a MuseInference.jl maintainer would add to put
+# the MI355X engine (libmuse_hip.so, include/muse_hip.h) behind the package's own problem interface.
+#
+# NOT exercised in this repository's CI: the build image has no julia.  It is the `ccall` counterpart
+# of museinference.jl_amd/problem.py + muse.py (which ARE exercised), kept next to them so that the
+# two bindings of the C ABI can be reviewed side by side.  Citations are to the reference sources.
+module HipMuseInference
+
+using MuseInference
+using MuseInference: AbstractMuseProblem, MuseResult, UnTransformedθ, Transformedθ
+import MuseInference: sample_x_z, logLike_and_∇z_logLike, ∇θ_logLike, ẑ_at_θ, logPriorθ, standardizeθ,
+                      muse!, get_J!, get_H!, finalize_result!
+using Random, Statistics, LinearAlgebra
+
+const libmuse_hip = get(ENV, "LIBMUSE_HIP", "libmuse_hip.so")
+const MODELS = Dict(:funnel => 0, :noise => 1, :smooth => 2)
+const MEM_HOST = Cint(0)
+
+struct MuseInfo            # muse_info of include/muse_hip.h
+    iterations::Int32
+    f_calls::Int32
+    status::Int32
+    hist_words::Int32
+    f_min::Float64
+    gnorm::Float64
+end
+
+function check(rc::Cint)
+    rc == 0 && return
+    error("libmuse_hip error $rc: " * unsafe_string(ccall((:muse_last_error, libmuse_hip), Cstring, ())))
+end
+
+# A problem whose operators run on the GPU; plays the role of SimpleMuseProblem (src/simple.jl:4-12).
+mutable struct HipMuseProblem <: AbstractMuseProblem
+    ctx::Ptr{Cvoid}
+    x::Vector{Float64}
+    N::Int
+    nθ::Int
+    logPriorθ
+    function HipMuseProblem(x::Vector{Float64}; model=:funnel, nθ=1, logPriorθ=(θ->0), device=0)
+        ctx = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:muse_ctx_create, libmuse_hip), Cint, (Cint, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
+                    MODELS[model], length(x), nθ, device, ctx))
+        check(ccall((:muse_set_data, libmuse_hip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), ctx[], x, MEM_HOST))
+        prob = new(ctx[], x, length(x), nθ, logPriorθ)
+        finalizer(p -> ccall((:muse_ctx_destroy, libmuse_hip), Cint, (Ptr{Cvoid},), p.ctx), prob)
+    end
+end
+
+standardizeθ(prob::HipMuseProblem, θ) = collect(Float64, θ isa Number ? [θ] : θ)
+logPriorθ(prob::HipMuseProblem, θ) = prob.logPriorθ(θ)
+
+# An rng for this engine is (master seed, sim index): split_rng's contract (src/util.jl:87-92).
+struct SimRng <: AbstractRNG
+    seed::UInt64
+    sim::Int64
+end
+
+# ---- per-simulation interface (src/interface.jl:41-99,141-166)
+function sample_x_z(prob::HipMuseProblem, rng::SimRng, θ)
+    x = Vector{Float64}(undef, prob.N); z = similar(x)
+    check(ccall((:muse_sample_x_z, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint),
+                prob.ctx, rng.seed, rng.sim, standardizeθ(prob, θ), x, z, MEM_HOST))
+    (;x, z)
+end
+function logLike_and_∇z_logLike(prob::HipMuseProblem, x, z, θ)
+    g = similar(z); f = Ref{Float64}(0)
+    check(ccall((:muse_logLike_and_grad_z, libmuse_hip), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Cint),
+                prob.ctx, x, z, standardizeθ(prob, θ), f, g, MEM_HOST))
+    (f[], g)
+end
+function ∇θ_logLike(prob::HipMuseProblem, x, z, θ)
+    g = Vector{Float64}(undef, prob.nθ)
+    check(ccall((:muse_grad_theta, libmuse_hip), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint),
+                prob.ctx, x, z, standardizeθ(prob, θ), g, MEM_HOST))
+    g
+end
+function ẑ_at_θ(prob::HipMuseProblem, x, z₀, θ; ∇z_logLike_atol)
+    ẑ = similar(z₀); info = Ref{MuseInfo}()
+    check(ccall((:muse_zhat_at_theta, libmuse_hip), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ref{MuseInfo}, Cint),
+                prob.ctx, x, z₀, standardizeθ(prob, θ), ∇z_logLike_atol, ẑ, info, MEM_HOST))
+    info[].status >= 3 && @warn("MAP solution did not converge within tolerance, result could be erroneous.")
+    isfinite(info[].f_min) || @error("MAP solution failed with logjoint(MAP)=$(-info[].f_min).")
+    ẑ, info[]
+end
+
+# ---- batched seams: one launch for all elements of the reference's pmap (src/muse.jl:169-176,508-525)
+function map_and_score_batch(prob::HipMuseProblem, seed::Integer, sims::UnitRange, θ;
+                             include_data=false, atol=1e-2, z0_mode=0)
+    n = length(sims) + include_data
+    g = Matrix{Float64}(undef, prob.nθ, n); info = Vector{MuseInfo}(undef, n)
+    check(ccall((:muse_map_and_score_batch, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{MuseInfo}),
+                prob.ctx, seed, first(sims), last(sims) + 1, include_data, standardizeθ(prob, θ), atol, z0_mode, g, info))
+    [g[:, i] for i in 1:n], info
+end
+
+# muse! for this problem type: the reference's own loop (src/muse.jl:159-236) with the pmap replaced by
+# one batched launch; dispatch on the problem type as src/turing.jl:248-256 does for PPL models.
+function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=nothing, maxsteps=50, θ_rtol=1e-1,
+               ∇z_logLike_atol=1e-2, nsims=100, α=0.7, get_covariance=false, kwargs...)
+    seed = UInt64(something(rng, result.rng, rand(UInt32)))
+    result.rng = seed
+    θ = standardizeθ(prob, something(result.θ, θ₀))
+    history = result.history
+    for i = (length(history)+1):maxsteps
+        if i > 2
+            Δθ = history[end].θ′ - history[end-1].θ′
+            sqrt(-(Δθ' * history[end].H⁻¹_post′ * Δθ)) < θ_rtol && break
+        end
+        z0_mode = i == length(history) + 1 ? 0 : 2     # zero(z) first, then warm starts (src/muse.jl:151,181)
+        gs, _ = map_and_score_batch(prob, seed, 0:nsims-1, θ; include_data=true, atol=∇z_logLike_atol, z0_mode)
+        g_like_dat, g_like_sims = gs[1], gs[2:end]
+        g_like′ = g_like_dat .- mean(g_like_sims)
+        g_prior′ = MuseInference.AD.gradient(MuseInference.AD.ForwardDiffBackend(), θ -> logPriorθ(prob, θ), θ)[1]
+        g_post′ = g_like′ .+ g_prior′
+        H⁻¹_like′ = Diagonal(-1 ./ var(g_like_sims))
+        H_prior′ = MuseInference.AD.hessian(MuseInference.AD.ForwardDiffBackend(), θ -> logPriorθ(prob, θ), θ)[1]
+        H⁻¹_post′ = inv(inv(H⁻¹_like′) + H_prior′)
+        push!(history, (;θ, θ′=θ, g_like_sims, g_like′, g_prior′, g_post′, H⁻¹_post′, H_prior′, H⁻¹_like′))
+        θ = θ .- α .* (H⁻¹_post′ * g_post′)
+        result.θ = θ
+        result.gs = g_like_sims
+    end
+    if get_covariance
+        get_J!(result, prob; rng=seed, nsims, ∇z_logLike_atol)
+        get_H!(result, prob; rng=seed, nsims=max(1, nsims ÷ 10), ∇z_logLike_atol)
+    end
+    result
+end
+
+function get_J!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=result.rng, nsims=100, ∇z_logLike_atol=1e-2, kwargs...)
+    θ₀ = standardizeθ(prob, something(θ₀, result.θ))
+    existing = length(result.gs)
+    if nsims > existing                                   # src/muse.jl:499-506
+        gs, _ = map_and_score_batch(prob, UInt64(rng), existing:nsims-1, θ₀; atol=∇z_logLike_atol, z0_mode=1)
+        append!(result.gs, gs)
+    end
+    result.J = cov(reduce(hcat, result.gs)'; corrected=true)
+    finalize_result!(result, prob)
+end
+
+function get_H!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=result.rng, nsims=10, step=nothing,
+                ∇z_logLike_atol=1e-2, kwargs...)
+    θ₀ = standardizeθ(prob, something(θ₀, result.θ))
+    remaining = nsims - length(result.Hs)
+    remaining <= 0 && return
+    step = something(step, 0.1 ./ std(result.gs))         # src/muse.jl:411-413
+    Hs = Array{Float64}(undef, prob.nθ, prob.nθ, remaining)
+    check(ccall((:muse_fd_jacobian_batch, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Int64, Ptr{Float64}, Ptr{Cvoid}),
+                prob.ctx, UInt64(rng), 0, remaining, θ₀, collect(Float64, step), ∇z_logLike_atol, 0, (1 << 62) - 1, Hs, C_NULL))
+    # the C ABI returns row-major [sim][i][j]; Julia reads it column-major as [j][i][sim]
+    append!(result.Hs, [permutedims(Hs[:, :, s]) for s in 1:remaining])
+    result.H = mean(result.Hs)
+    finalize_result!(result, prob)
+end
+
+end # module
