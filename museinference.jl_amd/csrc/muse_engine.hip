@@ -313,9 +313,9 @@ struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
         x = z + n2;
     }
     __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
-        const double r = x - z;
-        facc += r * r + iv * (z * z);
-        return iv * z - r;
+        const double r = x - z, t = iv * z;
+        facc = fma(t, z, fma(r, r, facc));
+        return t - r;
     }
     __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
 };
@@ -328,9 +328,9 @@ struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
         x = n1 + sd * n2;
     }
     __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
-        const double r = x - z;
-        facc += iv * (r * r) + z * z;
-        return z - iv * r;
+        const double r = x - z, t = iv * r;
+        facc = fma(z, z, fma(t, r, facc));
+        return z - t;
     }
     __device__ static __forceinline__ double score_term(double x, double z) {
         const double r = x - z;
@@ -438,12 +438,12 @@ struct Solver {
         auto wrap = [&](int k) { return k < 0 ? k + N : (k >= N ? k - N : k); };
         const int im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
         const double zm2 = zt(im2), zm1 = zt(im1), z0 = zt(i), zp1 = zt(ip1), zp2 = zt(ip2);
-        const double rm = x.get(0, im1) - (0.5 * zm1 + 0.25 * (zm2 + z0));
-        const double r0 = x.get(0, i) - (0.5 * z0 + 0.25 * (zm1 + zp1));
-        const double rp = x.get(0, ip1) - (0.5 * zp1 + 0.25 * (z0 + zp2));
-        const double ivk = this->ivk(i);
-        facc += r0 * r0 + ivk * (z0 * z0);
-        return ivk * z0 - (0.5 * r0 + 0.25 * (rm + rp));
+        const double rm = x.get(0, im1) - fma(0.25, zm2 + z0, 0.5 * zm1);
+        const double r0 = x.get(0, i) - fma(0.25, zm1 + zp1, 0.5 * z0);
+        const double rp = x.get(0, ip1) - fma(0.25, z0 + zp2, 0.5 * zp1);
+        const double t = this->ivk(i) * z0;
+        facc = fma(t, z0, fma(r0, r0, facc));
+        return t - fma(0.25, rm + rp, 0.5 * r0);
     }
 
     // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
@@ -458,28 +458,28 @@ struct Solver {
                 double si = 0.0;
                 if constexpr (USE_S) {
                     si = s.get(jj, i);
-                    zi = zi + c * si;
+                    zi = fma(c, si, zi);
                 }
                 const double gi = Model::grad(ivk(i), x.get(jj, i), zi, sum[0]);
                 if constexpr (STORE_G) g.set(jj, i, gi);
-                if constexpr (USE_S) sum[1] += gi * si;
+                if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
                 mx[0] = nanmax(mx[0], fabs(gi));
             });
         } else {
             auto zt = [&](int k) {
                 double v = z.get(0, k);
-                if constexpr (USE_S) v = v + c * s.get(0, k);
+                if constexpr (USE_S) v = fma(c, s.get(0, k), v);
                 return v;
             };
             const int N = (int)a.N;
             for_elems<T, EPT>(a.ld, tid, [&](int jj, int i) {
-                double fi = 0.0;
+                double fi = sum[0];
                 double gi = stencil_grad(zt, i < N ? i : 0, fi);
                 const bool valid = i < N;  // the pad element has no neighbours: keep it a phantom zero
                 gi = valid ? gi : 0.0;
-                sum[0] += valid ? fi : 0.0;
+                sum[0] = valid ? fi : sum[0];
                 if constexpr (STORE_G) g.set(jj, i, gi);
-                if constexpr (USE_S) sum[1] += gi * s.get(0, i);
+                if constexpr (USE_S) sum[1] = fma(gi, s.get(0, i), sum[1]);
                 mx[0] = nanmax(mx[0], fabs(gi));
             });
         }
@@ -775,7 +775,7 @@ struct Solver {
                     const bool valid = i < N;
                     const int ic = valid ? i : 0;
                     const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
-                    const double az = 0.5 * s.get(0, ic) + 0.25 * (s.get(0, im) + s.get(0, ip));
+                    const double az = fma(0.25, s.get(0, im) + s.get(0, ip), 0.5 * s.get(0, ic));
                     const double xv = az + x.get(jj, i);
                     x.set(jj, i, valid ? xv : 0.0);
                 });
@@ -820,7 +820,7 @@ struct Solver {
                 for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
-                    sum[0] += gi * si;
+                    sum[0] = fma(gi, si, sum[0]);
                 });
                 block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
                 dphi_0 = sum[0];
@@ -837,17 +837,17 @@ struct Solver {
                     if (index > lower) {
                         const BufVec dxn = hdx((index - 2) % kM);
                         for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
-                            const double qi = s.get(jj, i) - al * dgp.get(jj, i);
+                            const double qi = fma(-al, dgp.get(jj, i), s.get(jj, i));
                             s.set(jj, i, qi);
-                            sum[0] += dxn.get(jj, i) * qi;
+                            sum[0] = fma(dxn.get(jj, i), qi, sum[0]);
                         });
                     } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
                         const double gam = sh_gam[(upper - 1) % kM];
                         for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
-                            const double qi = s.get(jj, i) - al * dgp.get(jj, i);
-                            const double si = gam * qi;
+                            const double dgi = dgp.get(jj, i);
+                            const double si = gam * fma(-al, dgi, s.get(jj, i));
                             s.set(jj, i, si);
-                            sum[0] += dgp.get(jj, i) * si;
+                            sum[0] = fma(dgi, si, sum[0]);
                         });
                     }
                     block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
@@ -863,15 +863,15 @@ struct Solver {
                     if (index < upper) {
                         const BufVec dgn = hdg(index % kM);
                         for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
-                            const double si = s.get(jj, i) + dxp.get(jj, i) * coef;
+                            const double si = fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
-                            sum[0] += dgn.get(jj, i) * si;
+                            sum[0] = fma(dgn.get(jj, i), si, sum[0]);
                         });
                     } else {
                         for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
-                            const double si = (s.get(jj, i) + dxp.get(jj, i) * coef) * -1.0;
+                            const double si = -fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
-                            sum[0] += g.get(jj, i) * si;
+                            sum[0] = fma(g.get(jj, i), si, sum[0]);
                         });
                     }
                     block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
@@ -886,7 +886,7 @@ struct Solver {
                 for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
-                    sum[0] += gi * si;
+                    sum[0] = fma(gi, si, sum[0]);
                 });
                 block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
                 dphi_0 = sum[0];
@@ -915,18 +915,18 @@ struct Solver {
             double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
             if constexpr (!Model::kStencil) {
                 for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
-                    const double zo = z.get(jj, i);
-                    const double dxi = alpha * s.get(jj, i);
-                    const double zn = zo + dxi;
+                    const double zo = z.get(jj, i), si = s.get(jj, i);
+                    const double dxi = alpha * si;
+                    const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
                     z.set(jj, i, zn);
                     mx[0] = nanmax(mx[0], fabs(zn - zo));
                     if (keep) {
                         double unused = 0.0;
                         const double gn = Model::grad(ivk(i), x.get(jj, i), zn, unused);
                         const double dgi = gn - g.get(jj, i);
-                        sum[0] += dxi * dgi;
-                        sum[1] += dgi * dgi;
-                        sum[2] += dxi * gn;
+                        sum[0] = fma(dxi, dgi, sum[0]);
+                        sum[1] = fma(dgi, dgi, sum[1]);
+                        sum[2] = fma(dxi, gn, sum[2]);
                         dxs.set(jj, i, dxi);
                         dgs.set(jj, i, dgi);
                         g.set(jj, i, gn);
@@ -935,9 +935,9 @@ struct Solver {
                 });
             } else {
                 for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
-                    const double zo = z.get(jj, i);
-                    const double dxi = alpha * s.get(jj, i);
-                    const double zn = zo + dxi;
+                    const double zo = z.get(jj, i), si = s.get(jj, i);
+                    const double dxi = alpha * si;
+                    const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);
                     mx[0] = nanmax(mx[0], fabs(zn - zo));
                     if (keep) dxs.set(jj, i, dxi);
@@ -951,9 +951,9 @@ struct Solver {
                         gn = i < N ? gn : 0.0;
                         const double dxi = dxs.get(jj, i);
                         const double dgi = gn - g.get(jj, i);
-                        sum[0] += dxi * dgi;
-                        sum[1] += dgi * dgi;
-                        sum[2] += dxi * gn;
+                        sum[0] = fma(dxi, dgi, sum[0]);
+                        sum[1] = fma(dgi, dgi, sum[1]);
+                        sum[2] = fma(dxi, gn, sum[2]);
                         dgs.set(jj, i, dgi);
                         g.set(jj, i, gn);
                         s.set(jj, i, gn);
@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(256) smooth_finish_kernel(int64_t N, const dou
                                                             const double* __restrict__ noise, double* __restrict__ x) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t im = i == 0 ? N - 1 : i - 1, ip = i == N - 1 ? 0 : i + 1;
-        x[i] = (0.5 * z[i] + 0.25 * (z[im] + z[ip])) + noise[i];
+        x[i] = fma(0.25, z[im] + z[ip], 0.5 * z[i]) + noise[i];
     }
 }
 
@@ -1148,11 +1148,12 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
             const int ic = valid ? i : 0;
             const int im2 = wrap(ic - 2), im1 = wrap(ic - 1), ip1 = wrap(ic + 1), ip2 = wrap(ic + 2);
             const double zm2 = zin[im2], zm1 = zin[im1], z0 = zin[ic], zp1 = zin[ip1], zp2 = zin[ip2];
-            const double rm = xin[im1] - (0.5 * zm1 + 0.25 * (zm2 + z0));
-            const double r0 = xin[ic] - (0.5 * z0 + 0.25 * (zm1 + zp1));
-            const double rp = xin[ip1] - (0.5 * zp1 + 0.25 * (z0 + zp2));
-            sum[0] += valid ? r0 * r0 + ivk * (z0 * z0) : 0.0;
-            gi = valid ? ivk * z0 - (0.5 * r0 + 0.25 * (rm + rp)) : 0.0;
+            const double rm = xin[im1] - fma(0.25, zm2 + z0, 0.5 * zm1);
+            const double r0 = xin[ic] - fma(0.25, zm1 + zp1, 0.5 * z0);
+            const double rp = xin[ip1] - fma(0.25, z0 + zp2, 0.5 * zp1);
+            const double t = ivk * z0;
+            sum[0] = valid ? fma(t, z0, fma(r0, r0, sum[0])) : sum[0];
+            gi = valid ? t - fma(0.25, rm + rp, 0.5 * r0) : 0.0;
         } else {
             gi = Model::grad(ivk, xin[i], zin[i], sum[0]);
         }

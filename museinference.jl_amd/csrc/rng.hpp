@@ -95,10 +95,13 @@ __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, uint64_t sim, u
     uint32_t w[4];
     philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)sim, (uint32_t)(sim >> 32), (uint32_t)seed,
                   (uint32_t)(seed >> 32), w);
+    // u = (k + 1/2) 2^-52 with k the 52 random bits: put k in the mantissa of a double in [1,2),
+    // subtract 1 (exact) and add 2^-53 (exact: (2k+1) 2^-53 has 53 significant bits).  No int->fp
+    // conversion instructions; the value is identical to ((double)k + 0.5) * 2^-52.
     const uint64_t k1 = ((uint64_t)w[0] << 20) | (uint64_t)(w[1] >> 12);
     const uint64_t k2 = ((uint64_t)w[2] << 20) | (uint64_t)(w[3] >> 12);
-    const double u1 = ((double)k1 + 0.5) * 2.220446049250313080847e-16;
-    const double u2 = ((double)k2 + 0.5) * 2.220446049250313080847e-16;
+    const double u1 = (__longlong_as_double((long long)(0x3FF0000000000000ull | k1)) - 1.0) + 1.1102230246251565404e-16;
+    const double u2 = (__longlong_as_double((long long)(0x3FF0000000000000ull | k2)) - 1.0) + 1.1102230246251565404e-16;
     const double r = __builtin_sqrt(-2.0 * log_unit(u1));
     double sn, cs;
     sincospi_02(2.0 * u2, sn, cs);

@@ -43,6 +43,10 @@
  *   sin/cos(pi t) evaluated by the fixed fdlibm-style polynomial sequences written out
  *   below using only IEEE +,-,*,/,sqrt and explicit fma (no implicit contraction), so that both
  *   sides are bit-equal.
+ * Model arithmetic: the reference's closures are plain Julia broadcasts; here the elementwise
+ * objective/gradient and the L-BFGS vector updates are written with explicit fma in the places the
+ * HIP kernels use it (x + alpha s, q - alpha dg, s + coef dx, sums of products), so that the two
+ * sides differ only in reduction order.
  */
 #include <math.h>
 #include <stdint.h>
@@ -180,7 +184,7 @@ static inline int mo_block(int64_t i, int64_t N, int B) { return (int)((i * (int
 
 static inline double mo_Az(const double* z, int64_t i, int64_t N) { /* periodic (1/4,1/2,1/4) */
     int64_t im = (i == 0) ? N - 1 : i - 1, ip = (i == N - 1) ? 0 : i + 1;
-    return 0.5 * z[i] + 0.25 * (z[im] + z[ip]);
+    return fma(0.25, z[im] + z[ip], 0.5 * z[i]);
 }
 
 
@@ -233,17 +237,17 @@ double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, con
     double acc = 0.0, cst = 0.0;
     if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) {
-            double r = x[i] - z[i];
-            acc += iv[0] * (r * r) + z[i] * z[i];
-            if (G) G[i] = z[i] - iv[0] * r;
+            double r = x[i] - z[i], t = iv[0] * r;
+            acc = fma(z[i], z[i], fma(t, r, acc));
+            if (G) G[i] = z[i] - t;
         }
         cst = (double)N * theta[0];
     } else if (model == MO_MODEL_FUNNEL) {
         for (int64_t i = 0; i < N; ++i) {
             int k = mo_block(i, N, ntheta);
-            double r = x[i] - z[i];
-            acc += r * r + iv[k] * (z[i] * z[i]);
-            if (G) G[i] = iv[k] * z[i] - r;
+            double r = x[i] - z[i], t = iv[k] * z[i];
+            acc = fma(t, z[i], fma(r, r, acc));
+            if (G) G[i] = t - r;
         }
         cst = mo_theta_const(N, ntheta, theta);
     } else {
@@ -252,8 +256,9 @@ double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, con
         for (int64_t i = 0; i < N; ++i) r[i] = x[i] - mo_Az(z, i, N);
         for (int64_t i = 0; i < N; ++i) {
             int k = mo_block(i, N, ntheta);
-            acc += r[i] * r[i] + iv[k] * (z[i] * z[i]);
-            if (G) G[i] = iv[k] * z[i] - mo_Az(r, i, N);
+            double t = iv[k] * z[i];
+            acc = fma(t, z[i], fma(r[i], r[i], acc));
+            if (G) G[i] = t - mo_Az(r, i, N);
         }
         free(r);
         cst = mo_theta_const(N, ntheta, theta);
@@ -317,7 +322,7 @@ static void mo_value_gradient(mo_obj* d, const double* xp) {
 
 static double mo_dot(const double* a, const double* b, int64_t N) {
     double s = 0.0;
-    for (int64_t i = 0; i < N; ++i) s += a[i] * b[i];
+    for (int64_t i = 0; i < N; ++i) s = fma(a[i], b[i], s);
     return s;
 }
 static double mo_maxabs(const double* a, int64_t N) {
@@ -359,7 +364,7 @@ typedef struct {
 /* phi(alpha), dphi(alpha): x_new = x + alpha s; value_gradient!(d, x_new). */
 static void hz_phidphi(hz_line* L, double alpha, double* phi, double* dphi) {
     int64_t N = L->d->N;
-    for (int64_t i = 0; i < N; ++i) L->x_new[i] = L->x[i] + alpha * L->s[i];
+    for (int64_t i = 0; i < N; ++i) L->x_new[i] = fma(alpha, L->s[i], L->x[i]);
     mo_value_gradient(L->d, L->x_new);
     *phi = L->d->f;
     *dphi = mo_dot(L->d->g, L->s, N);
@@ -596,7 +601,7 @@ int mo_zhat_at_theta(int model, int64_t N, int ntheta, const double* x, const do
                 int i = mod1(index, LBFGS_M);
                 const double *dgi = dgh + (size_t)(i - 1) * N, *dxi = dxh + (size_t)(i - 1) * N;
                 tl_alpha[i] = rho[i] * mo_dot(dxi, q, N);
-                for (int64_t e = 0; e < N; ++e) q[e] -= tl_alpha[i] * dgi[e];
+                for (int64_t e = 0; e < N; ++e) q[e] = fma(-tl_alpha[i], dgi[e], q[e]);
                 hist_words += 1;
             }
             if (pseudo > 1) { /* scaleinvH0: Nocedal & Wright eq. (7.20) */
@@ -612,7 +617,7 @@ int mo_zhat_at_theta(int model, int64_t N, int ntheta, const double* x, const do
                 int i = mod1(index, LBFGS_M);
                 const double *dgi = dgh + (size_t)(i - 1) * N, *dxi = dxh + (size_t)(i - 1) * N;
                 double beta = rho[i] * mo_dot(dgi, s, N);
-                for (int64_t e = 0; e < N; ++e) s[e] += dxi[e] * (tl_alpha[i] - beta);
+                { const double coef = tl_alpha[i] - beta; for (int64_t e = 0; e < N; ++e) s[e] = fma(dxi[e], coef, s[e]); }
             }
             for (int64_t e = 0; e < N; ++e) s[e] *= -1.0;
         }
@@ -632,7 +637,7 @@ int mo_zhat_at_theta(int model, int64_t N, int ntheta, const double* x, const do
         double alpha;
         int lsrc = hz_linesearch(&L, 1.0 /* InitialStatic */, phi_0, dphi_0, &alpha);
         for (int64_t e = 0; e < N; ++e) dx[e] = alpha * s[e];
-        for (int64_t e = 0; e < N; ++e) X[e] = X[e] + dx[e];
+        for (int64_t e = 0; e < N; ++e) X[e] = fma(alpha, s[e], X[e]); /* = the point the line search evaluated */
         if (lsrc < 0) { status = MO_STATUS_LINESEARCH_FAILED; break; }
         /* ---- update_g! ---- */
         mo_value_gradient(&d, X);

@@ -3,7 +3,7 @@ import sys, numpy as np, ctypes as C
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import museinference_jl_amd as M
 from museinference_jl_amd import build as B, _capi
-B.LIB_PATH = B.LIB_PATH.replace("libmuse_hip.so", "libmuse_hip_stamps.so")
+B.LIB_PATH = B.LIB_PATH.replace("libmuse_hip.so", __import__("os").environ.get("MUSE_STAMPS_LIB", "libmuse_hip_stamps.so"))
 lib = M.load_library()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 n = 512
