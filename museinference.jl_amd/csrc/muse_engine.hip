@@ -62,6 +62,8 @@ struct BatchArgs {
     int64_t N, ld;
     int ntheta, kind;
     int64_t bnd[kMaxTheta + 1];  // block k = elements [bnd[k], bnd[k+1])
+    int bnd32[kMaxTheta + 1];    // the same, 32-bit (N < 2^28), for the per-element block lookup
+    int pad0_;
     uint64_t seed;
     double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
     int nproblems, include_data, z0_mode, store_zhat;
@@ -170,6 +172,39 @@ struct BufVec {  // a vector in HBM: buffer_load/store_dwordx2 with hardware ran
     }
     __device__ __forceinline__ void clear() {}
 };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Streaming policy, elementwise models: the element loop visits a thread's two adjacent elements
+// (jj even then jj odd) back to back, so the pair moves with ONE 16-byte buffer instruction: the load
+// is issued at jj = 0 and its second half served at jj = 1; a store is staged at jj = 0 and issued at
+// jj = 1 (buffer_load/store_dwordx4, 1 KiB per wave-instruction).
+struct BufVec2 {
+    rsrc_t rsrc;
+    mutable double c0, c1;
+    __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
+    __device__ __forceinline__ double get(int jj, int i) const {
+        if ((jj & 1) == 0) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i * 8, 0, 0);
+            c0 = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+            c1 = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+            return c0;
+        }
+        return c1;
+    }
+    __device__ __forceinline__ void set(int jj, int i, double d) {
+        if ((jj & 1) == 0) {
+            c0 = d;
+        } else {
+            const long long b0 = __double_as_longlong(c0), b1 = __double_as_longlong(d);
+            u32x4 v;
+            v.x = (unsigned)(b0 & 0xffffffffll);
+            v.y = (unsigned)(b0 >> 32);
+            v.z = (unsigned)(b1 & 0xffffffffll);
+            v.w = (unsigned)(b1 >> 32);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (i - 1) * 8, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void clear() {}
+};
 struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
     lds_double* p;
     int ld;
@@ -200,6 +235,7 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tid, F&& f) {
         }
     } else {
         const int n = (int)ld;
+#pragma unroll 2
         for (int i0 = 2 * t; i0 < n; i0 += 2 * T) {
             f(0, i0);
             f(1, i0 + 1);
@@ -296,10 +332,11 @@ __device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], do
 // ------------------------------------------------------------------------------------------------
 // Models.  grad() returns d(-logLike)/dz_i and adds the element's share of -2 logLike (without the
 // constant) to facc; the score is assembled from per-block sums of score_term().
+template <int MAXB = kMaxTheta>
 __device__ __forceinline__ int block_of(const BatchArgs& a, int i) {
     int k = 0;
 #pragma unroll
-    for (int b = 1; b < kMaxTheta; ++b) k += (b < a.ntheta && i >= a.bnd[b]) ? 1 : 0;
+    for (int b = 1; b < MAXB; ++b) k += (i >= a.bnd32[b]) ? 1 : 0;  // bnd32[b] = INT_MAX for b >= ntheta
     return k;
 }
 
@@ -347,11 +384,15 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
 
 // ------------------------------------------------------------------------------------------------
 // Storage policies.
-template <int T_>
+template <int T_, bool PAIRS = true>
 struct PlaceStreaming {
     static constexpr int T = T_, EPT = 0;
     static constexpr bool kResident = false, kXgLds = false;
-    using VX = BufVec; using VG = BufVec; using VZ = BufVec; using VS = BufVec;
+    // a get and a set of the same vector in one pass use separate accessor objects (VH), so the
+    // staged half of a store never aliases the cached half of a load
+    using VX = typename std::conditional<PAIRS, BufVec2, BufVec>::type;
+    using VG = VX; using VZ = VX; using VS = VX;
+    using VH = VX;
 };
 template <int T_, int EPT_, bool XG_LDS>
 struct PlaceResident {
@@ -360,6 +401,7 @@ struct PlaceResident {
     using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
     using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;
+    using VH = BufVec2;  // history vectors and zhat in HBM: 16-byte accesses
 };
 
 struct HzPoint {
@@ -407,27 +449,28 @@ struct Solver {
         (void)p; (void)k;
 #endif
     }
-    __device__ __forceinline__ BufVec hdx(int slot) const {
-        BufVec v;
+    using VH = typename Place::VH;
+    __device__ __forceinline__ VH hdx(int slot) const {
+        VH v;
         v.bind(hist + (int64_t)(2 * slot) * a.ld, a.ld);
         return v;
     }
-    __device__ __forceinline__ BufVec hdg(int slot) const {
-        BufVec v;
+    __device__ __forceinline__ VH hdg(int slot) const {
+        VH v;
         v.bind(hist + (int64_t)(2 * slot + 1) * a.ld, a.ld);
         return v;
     }
     __device__ __forceinline__ double ivk(int i) const {
         if constexpr (MAXB == 1) return iv0;
-        else return a.tmap.iv[block_of(a, i)];
+        else return a.tmap.iv[block_of<MAXB>(a, i)];
     }
     __device__ __forceinline__ double sdk(int i) const {
         if constexpr (MAXB == 1) return sd0;
-        else return sh_sd[block_of(a, i)];
+        else return sh_sd[block_of<MAXB>(a, i)];
     }
     __device__ __forceinline__ int blk(int i) const {
         if constexpr (MAXB == 1) return 0;
-        else return block_of(a, i);
+        else return block_of<MAXB>(a, i);
     }
 
     // d(-logLike)/dz_i at the point whose components are given by zt(.), for the stencil model
@@ -716,7 +759,7 @@ struct Solver {
             hist = wg_scratch + 4 * ld;
         }
         const double* z0ptr = a.zhat + d.z0slot * ld;
-        BufVec z0src;
+        VH z0src;
         z0src.bind(z0ptr, ld);
         const bool z_in_place = (!Place::kResident) && (d.z0_mode == Z0_WARM || d.z0_mode == Z0_COPY) && (z0ptr == zmem);
 
@@ -727,7 +770,7 @@ struct Solver {
                 // Sampler as a ROLLED loop over this thread's pairs (one or two Philox/Box-Muller
                 // chains in flight, not 2*EPT): x goes straight to LDS, the true z is staged in the
                 // (still unused) g area and picked up into registers below.
-#pragma unroll 2
+#pragma unroll 1
                 for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
@@ -741,6 +784,7 @@ struct Solver {
                         }
                     }
                 }
+                stamp(p, 8);
                 z.clear();
                 s.clear();
                 for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
@@ -781,7 +825,7 @@ struct Solver {
                 });
             }
         } else {
-            BufVec xs;
+            VH xs;
             xs.bind(d.x_mode == X_DATA ? a.x_data : a.x_given, ld);
             x.clear(); g.clear(); z.clear(); s.clear();
             for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
@@ -790,6 +834,7 @@ struct Solver {
                 else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
             });
         }
+        stamp(p, 9);
         __syncthreads();
 
         stamp(p, 1);
@@ -832,10 +877,10 @@ struct Solver {
                     const int slot = (index - 1) % kM;
                     const double al = sh_rho[slot] * dot;
                     if (tid == 0) sh_alpha[slot] = al;
-                    const BufVec dgp = hdg(slot);
+                    const VH dgp = hdg(slot);
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index > lower) {
-                        const BufVec dxn = hdx((index - 2) % kM);
+                        const VH dxn = hdx((index - 2) % kM);
                         for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                             const double qi = fma(-al, dgp.get(jj, i), s.get(jj, i));
                             s.set(jj, i, qi);
@@ -858,10 +903,10 @@ struct Solver {
                     const int slot = (index - 1) % kM;
                     const double beta = sh_rho[slot] * dot;
                     const double coef = sh_alpha[slot] - beta;
-                    const BufVec dxp = hdx(slot);
+                    const VH dxp = hdx(slot);
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index < upper) {
-                        const BufVec dgn = hdg(index % kM);
+                        const VH dgn = hdg(index % kM);
                         for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
                             const double si = fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
@@ -909,8 +954,8 @@ struct Solver {
             // ---- fused update pass: z += alpha s; gradient at the new point recomputed (bit-equal
             //      to the trial evaluation); (dx, dg) stored; g <- new gradient; q <- g -----------------
             const int slot_new = (pseudo - 1) % kM;
-            BufVec dxs = hdx(slot_new);
-            BufVec dgs = hdg(slot_new);
+            VH dxs = hdx(slot_new);
+            VH dgs = hdg(slot_new);
             const bool keep = !stop_hint;
             double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
             if constexpr (!Model::kStencil) {
@@ -998,7 +1043,7 @@ struct Solver {
         // ---- zhat out, score -------------------------------------------------------------------
         if constexpr (Place::kResident) {
             if (d.zslot >= 0) {
-                BufVec zo;
+                VH zo;
                 zo.bind(a.zhat + d.zslot * ld, ld);
                 for_elems<T, EPT>(ld, tid, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
             }
@@ -1321,8 +1366,8 @@ static int launch_one(muse_ctx* c, const BatchArgs& a, int grid, size_t lds) {
 template <class Model>
 static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_t lds) {
     if constexpr (Model::kStencil) {
-        if (pl == P_S256) return launch_one<Model, PlaceStreaming<256>>(c, a, grid, lds);
-        return launch_one<Model, PlaceStreaming<512>>(c, a, grid, lds);
+        if (pl == P_S256) return launch_one<Model, PlaceStreaming<256, false>>(c, a, grid, lds);
+        return launch_one<Model, PlaceStreaming<512, false>>(c, a, grid, lds);
     } else {
         switch (pl) {
             case P_R256x1: return launch_one<Model, PlaceResident<256, 1, false>>(c, a, grid, lds);
@@ -1339,7 +1384,10 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.N = c->N;
     a.ld = c->ld;
     a.ntheta = c->ntheta;
-    for (int k = 0; k <= kMaxTheta; ++k) a.bnd[k] = c->bnd[k];
+    for (int k = 0; k <= kMaxTheta; ++k) {
+        a.bnd[k] = c->bnd[k];
+        a.bnd32[k] = k < c->ntheta ? (int)c->bnd[k] : 0x7fffffff;
+    }
     a.x_data = c->x_data;
     a.zhat = c->zhat;
     a.work_counter = c->counter;
@@ -1372,9 +1420,14 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     if (timed) HIPCHK(hipEventRecord(e0, c->stream));
     if (c->model == MUSE_MODEL_NOISE) rc = launch_place<NoiseModel>(c, a, pl, grid, lds);
     else if (c->model == MUSE_MODEL_FUNNEL)
-        rc = c->ntheta == 1 ? launch_place<FunnelModel<1>>(c, a, pl, grid, lds)
-                            : launch_place<FunnelModel<kMaxTheta>>(c, a, pl, grid, lds);
-    else rc = launch_place<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
+        rc = c->ntheta == 1   ? launch_place<FunnelModel<1>>(c, a, pl, grid, lds)
+             : c->ntheta == 2 ? launch_place<FunnelModel<2>>(c, a, pl, grid, lds)
+             : c->ntheta <= 4 ? launch_place<FunnelModel<4>>(c, a, pl, grid, lds)
+                              : launch_place<FunnelModel<kMaxTheta>>(c, a, pl, grid, lds);
+    else
+        rc = c->ntheta <= 2   ? launch_place<SmoothModel<2>>(c, a, pl, grid, lds)
+             : c->ntheta <= 4 ? launch_place<SmoothModel<4>>(c, a, pl, grid, lds)
+                              : launch_place<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
     if (rc) return rc;
     if (timed) {
         HIPCHK(hipEventRecord(e1, c->stream));
@@ -1582,7 +1635,10 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     a.N = c->N;
     a.ld = c->ld;
     a.ntheta = c->ntheta;
-    for (int k = 0; k <= kMaxTheta; ++k) a.bnd[k] = c->bnd[k];
+    for (int k = 0; k <= kMaxTheta; ++k) {
+        a.bnd[k] = c->bnd[k];
+        a.bnd32[k] = k < c->ntheta ? (int)c->bnd[k] : 0x7fffffff;
+    }
     make_thetaset(c, theta, a.tmap);
     a.f_const = theta_const(c, theta);
     a.fid_slot = -1;
