@@ -41,6 +41,8 @@ constexpr int kM = 10;         // L-BFGS memory (Optim.LBFGS default m)
 constexpr int kMaxIter = 1000;  // Optim.Options default iterations
 constexpr int kMaxTheta = MUSE_MAX_THETA;
 constexpr int kResultAreas = 4;
+constexpr int kMaxCluster = 16;
+constexpr int64_t kClusterMinN = 65536;  // N >= this: several workgroups cooperate on one problem
 constexpr int64_t kMaxResidentN = 10000;
 
 // HagerZhang() defaults of LineSearches.jl
@@ -80,6 +82,11 @@ struct BatchArgs {
     int64_t scratch_stride;        // doubles per workgroup
     int* work_counter;             // monotonically increasing ticket counter (never reset)
     int ticket_base, pad2_;        // this launch's tickets are work_counter values base .. base+nproblems-1
+    // cluster mode (several workgroups per problem): csize workgroups 0..csize-1 of cluster blockIdx/csize
+    int csize, nclusters;
+    unsigned int* cl_counter;      // [nclusters] arrival counters (zeroed per launch)
+    double* cl_part;               // [nclusters][2][csize][8] partial sums / maxima
+    int* error_flag;               // set when a bounded cluster wait expires
     unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
 };
 
@@ -223,10 +230,11 @@ struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
 // per-slot offsets are recomputed in each pass (two integer ops) instead of being hoisted out of
 // the persistent loop and held -- or spilled -- for the kernel's lifetime.
 template <int T, int EPT, class F>
-__device__ __forceinline__ void for_elems(int64_t ld, int tid, F&& f) {
-    int t = tid;
+__device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F&& f) {
+    int t = tfirst;
     asm volatile("" : "+v"(t));
     if constexpr (EPT > 0) {
+        (void)pstride;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int i0 = 2 * (t + j * T);
@@ -234,9 +242,10 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tid, F&& f) {
             f(2 * j + 1, i0 + 1);
         }
     } else {
+        // streaming: pairs tfirst, tfirst + pstride, ... (pstride = T, or csize*T in cluster mode)
         const int n = (int)ld;
 #pragma unroll 2
-        for (int i0 = 2 * t; i0 < n; i0 += 2 * T) {
+        for (int i0 = 2 * t; i0 < n; i0 += 2 * pstride) {
             f(0, i0);
             f(1, i0 + 1);
         }
@@ -384,10 +393,10 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
 
 // ------------------------------------------------------------------------------------------------
 // Storage policies.
-template <int T_, bool PAIRS = true>
+template <int T_, bool PAIRS = true, bool CLUSTER = false>
 struct PlaceStreaming {
     static constexpr int T = T_, EPT = 0;
-    static constexpr bool kResident = false, kXgLds = false;
+    static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
     // a get and a set of the same vector in one pass use separate accessor objects (VH), so the
     // staged half of a store never aliases the cached half of a load
     using VX = typename std::conditional<PAIRS, BufVec2, BufVec>::type;
@@ -397,7 +406,7 @@ struct PlaceStreaming {
 template <int T_, int EPT_, bool XG_LDS>
 struct PlaceResident {
     static constexpr int T = T_, EPT = EPT_;
-    static constexpr bool kResident = true, kXgLds = XG_LDS;
+    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = false;
     using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
     using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;
@@ -429,12 +438,92 @@ struct Solver {
     double* sh_sd;     // MAXB > 1: sampling sd[k] in LDS (the MAP iv[k] is read from the LDS argument block)
     int f_calls;
     double last_c, last_gmax;
+    // element ownership: thread pairs tfirst + k*pstride (cluster mode: the cluster acts as one csize*T block)
+    int tfirst, pstride;
+    int crank, csize;          // this workgroup's rank in its cluster, cluster size
+    unsigned int cl_epoch;     // cluster reductions done so far in this launch
+    bool cl_aborted;           // a bounded wait expired: stop waiting
+    unsigned int* cl_counter;  // this cluster's arrival counter
+    double* cl_part;           // this cluster's partial slots [2][csize][8]
 
     __device__ Solver(const BatchArgs& a_, int tid_, double* red_, double* shs) : a(a_), tid(tid_), red(red_), parity(0) {
         sh_rho = shs;
         sh_gam = shs + kM;
         sh_alpha = shs + 2 * kM;
         sh_sd = shs + 3 * kM;
+        tfirst = tid_;
+        pstride = T;
+        crank = 0;
+        csize = 1;
+        cl_epoch = 0;
+        cl_aborted = false;
+        cl_counter = nullptr;
+        cl_part = nullptr;
+    }
+
+    // Cluster all-reduce (Guideline 16 of the CDNA guide: placement-independent release/acquire).
+    // Each workgroup has reduced to workgroup-uniform values; lane 0 publishes them with write-through
+    // stores, releases at agent scope (which also makes the pass's vector stores visible to the other
+    // workgroups of the cluster -- the stencil model reads neighbours across workgroups), arrives on
+    // the cluster's monotonic counter and polls it (bounded) for this epoch; one agent-scope acquire,
+    // then every thread reads the csize partials with L1-bypassing loads and combines them in rank
+    // order.  Partial slots alternate between two buffers by epoch parity (WAR safe).
+    template <int KS, int KM>
+    __device__ __forceinline__ void cluster_allreduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
+        constexpr int K = KS + KM;
+        cl_epoch += 1;
+        double* slots = cl_part + (size_t)(cl_epoch & 1u) * csize * 8;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+        __syncthreads();
+        if (tid == 0) {
+            double* mine = slots + crank * 8;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) __hip_atomic_store(mine + k, sv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < KM; ++k) __hip_atomic_store(mine + KS + k, mv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(cl_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = cl_epoch * (unsigned)csize;
+            unsigned spins = 0;
+            // bounded (about a second): a cluster whose members are not all resident must not hang the
+            // GPU; after one expiry this workgroup never waits again and the host reports the error
+            while (!cl_aborted && __hip_atomic_load(cl_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) {
+                    __hip_atomic_store(a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    cl_aborted = true;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double acc = __hip_atomic_load(slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 1; c < csize; ++c) {
+                const double v = __hip_atomic_load(slots + c * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc = k < KS ? acc + v : nanmax(acc, v);
+            }
+            if (k < KS) sv[k] = uniform(acc);
+            else mv[k - KS] = uniform(acc);
+        }
+    }
+    // Workgroup reduction, then (cluster mode) the cluster reduction.
+    template <int KS, int KM>
+    __device__ __forceinline__ void reduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
+        block_allreduce<T, KS, KM>(sv, mv, red, parity, tid);
+        if constexpr (Place::kCluster) cluster_allreduce<KS, KM>(sv, mv);
+    }
+    // Orders this pass's vector stores before the next pass's neighbour reads (stencil model).
+    __device__ __forceinline__ void pass_barrier() {
+        if constexpr (Place::kCluster) {
+            double z1[1] = {0.0}, z2[1] = {0.0};
+            cluster_allreduce<1, 0>(z1, z2);
+        } else {
+            __syncthreads();
+        }
     }
     // In-kernel stamps (cdna_hip_programming.md §7): diagnostic build only; values leave through a
     // buffer of their own and no output is computed from them.
@@ -496,7 +585,7 @@ struct Solver {
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
-            for_elems<T, EPT>(a.ld, tid, [&](int jj, int i) {
+            for_elems<T, EPT>(a.ld, tfirst, pstride, [&](int jj, int i) {
                 double zi = z.get(jj, i);
                 double si = 0.0;
                 if constexpr (USE_S) {
@@ -515,7 +604,7 @@ struct Solver {
                 return v;
             };
             const int N = (int)a.N;
-            for_elems<T, EPT>(a.ld, tid, [&](int jj, int i) {
+            for_elems<T, EPT>(a.ld, tfirst, pstride, [&](int jj, int i) {
                 double fi = sum[0];
                 double gi = stencil_grad(zt, i < N ? i : 0, fi);
                 const bool valid = i < N;  // the pad element has no neighbours: keep it a phantom zero
@@ -526,7 +615,7 @@ struct Solver {
                 mx[0] = nanmax(mx[0], fabs(gi));
             });
         }
-        block_allreduce<T, 2, 1>(sum, mx, red, parity, tid);
+        reduce<2, 1>(sum, mx);
         f = 0.5 * (sum[0] + a.f_const);
         dphi = sum[1];
         gmax = mx[0];
@@ -787,14 +876,14 @@ struct Solver {
                 stamp(p, 8);
                 z.clear();
                 s.clear();
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.get(jj, i));
                     else z.set(jj, i, z0src.get(jj, i));
                 });
             } else {
                 x.clear(); g.clear(); z.clear(); s.clear();
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const bool valid = i < N;  // phantom slots run the generator but keep zeros
                     const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
                     double zt, xt;
@@ -814,8 +903,8 @@ struct Solver {
                 });
             }
             if constexpr (Model::kStencil) {
-                __syncthreads();
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                pass_barrier();
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const bool valid = i < N;
                     const int ic = valid ? i : 0;
                     const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
@@ -828,14 +917,15 @@ struct Solver {
             VH xs;
             xs.bind(d.x_mode == X_DATA ? a.x_data : a.x_given, ld);
             x.clear(); g.clear(); z.clear(); s.clear();
-            for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+            for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                 x.set(jj, i, xs.get(jj, i));
                 if (d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE) z.set(jj, i, 0.0);
                 else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
             });
         }
         stamp(p, 9);
-        __syncthreads();
+        if constexpr (Model::kStencil) pass_barrier();  // x (and the start z) complete before neighbours read them
+        else __syncthreads();
 
         stamp(p, 1);
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
@@ -862,12 +952,12 @@ struct Solver {
             double dphi_0;
             if (h == 0 || !have_pair) {
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] = fma(gi, si, sum[0]);
                 });
-                block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                reduce<1, 0>(sum, mx);
                 dphi_0 = sum[0];
             } else {
                 hist_words += h;
@@ -881,21 +971,21 @@ struct Solver {
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index > lower) {
                         const VH dxn = hdx((index - 2) % kM);
-                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double qi = fma(-al, dgp.get(jj, i), s.get(jj, i));
                             s.set(jj, i, qi);
                             sum[0] = fma(dxn.get(jj, i), qi, sum[0]);
                         });
                     } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
                         const double gam = sh_gam[(upper - 1) % kM];
-                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double dgi = dgp.get(jj, i);
                             const double si = gam * fma(-al, dgi, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(dgi, si, sum[0]);
                         });
                     }
-                    block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                    reduce<1, 0>(sum, mx);
                     dot = sum[0];
                 }
                 // forward pass
@@ -907,19 +997,19 @@ struct Solver {
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index < upper) {
                         const VH dgn = hdg(index % kM);
-                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double si = fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(dgn.get(jj, i), si, sum[0]);
                         });
                     } else {
-                        for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double si = -fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(g.get(jj, i), si, sum[0]);
                         });
                     }
-                    block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                    reduce<1, 0>(sum, mx);
                     dot = sum[0];
                 }
                 dphi_0 = dot;
@@ -928,12 +1018,12 @@ struct Solver {
             if (dphi_0 >= 0.0) {
                 pseudo = 1;
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] = fma(gi, si, sum[0]);
                 });
-                block_allreduce<T, 1, 0>(sum, mx, red, parity, tid);
+                reduce<1, 0>(sum, mx);
                 dphi_0 = sum[0];
             }
             if (iterations == 1) stamp(p, 3);
@@ -959,7 +1049,7 @@ struct Solver {
             const bool keep = !stop_hint;
             double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
             if constexpr (!Model::kStencil) {
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
@@ -979,7 +1069,7 @@ struct Solver {
                     }
                 });
             } else {
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);
@@ -988,9 +1078,9 @@ struct Solver {
                     if (keep) dxs.set(jj, i, dxi);
                 });
                 if (keep) {
-                    __syncthreads();  // neighbours' z must be complete before the stencil reads them
+                    pass_barrier();  // neighbours' z must be complete before the stencil reads them
                     auto zt = [&](int k) { return z.get(0, k); };
-                    for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                         double unused = 0.0;
                         double gn = stencil_grad(zt, i < N ? i : 0, unused);
                         gn = i < N ? gn : 0.0;
@@ -1005,7 +1095,7 @@ struct Solver {
                     });
                 }
             }
-            block_allreduce<T, 3, 1>(sum, mx, red, parity, tid);
+            reduce<3, 1>(sum, mx);
             if (iterations == 1) stamp(p, 5);
             if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
                 status = MUSE_STATUS_LINESEARCH_FAILED;
@@ -1045,14 +1135,14 @@ struct Solver {
             if (d.zslot >= 0) {
                 VH zo;
                 zo.bind(a.zhat + d.zslot * ld, ld);
-                for_elems<T, EPT>(ld, tid, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
             }
         }
         {
             double acc[MAXB], mx[1] = {0.0};
 #pragma unroll
             for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-            for_elems<T, EPT>(ld, tid, [&](int jj, int i) {
+            for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                 const double t = Model::score_term(x.get(jj, i), z.get(jj, i));
                 if constexpr (MAXB == 1) {
                     acc[0] += t;
@@ -1062,8 +1152,8 @@ struct Solver {
                     for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
                 }
             });
-            block_allreduce<T, MAXB, 0>(acc, mx, red, parity, tid);
-            if (tid == 0) {
+            reduce<MAXB, 0>(acc, mx);
+            if (tid == 0 && crank == 0) {
 #pragma unroll
                 for (int b = 0; b < MAXB; ++b) {
                     if (b < a.ntheta) {
@@ -1122,15 +1212,34 @@ __global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*r
             }
         }
     }
-    double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) ticket[0] = atomicAdd(a.work_counter, 1);
-        __syncthreads();
-        const int p = __builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base;
-        if (p >= a.nproblems) break;
+    if constexpr (Place::kCluster) {
+        // csize consecutive workgroups form a cluster that works on one problem at a time; problems are
+        // dealt to clusters round-robin (every member computes the same sequence: no communication).
+        const int csize = a.csize, cluster = blockIdx.x / csize, crank = blockIdx.x % csize;
+        double* cl_scratch = a.scratch + (int64_t)cluster * a.scratch_stride;
         Solver<Model, Place> sv(a, tid, red, shs);
-        sv.run(p, wg_scratch, lds_x, lds_g);
+        sv.crank = crank;
+        sv.csize = csize;
+        sv.tfirst = crank * T + tid;
+        sv.pstride = csize * T;
+        sv.cl_counter = a.cl_counter + cluster;
+        sv.cl_part = a.cl_part + (size_t)cluster * 2 * csize * 8;
+        for (int p = cluster; p < a.nproblems; p += a.nclusters) {
+            sv.parity = 0;
+            __syncthreads();
+            sv.run(p, cl_scratch, lds_x, lds_g);
+        }
+    } else {
+        double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) ticket[0] = atomicAdd(a.work_counter, 1);
+            __syncthreads();
+            const int p = __builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base;
+            if (p >= a.nproblems) break;
+            Solver<Model, Place> sv(a, tid, red, shs);
+            sv.run(p, wg_scratch, lds_x, lds_g);
+        }
     }
 }
 
@@ -1184,7 +1293,7 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     const int Ni = (int)N;
     auto wrap = [&](int i) { return i < 0 ? i + Ni : (i >= Ni ? i - Ni : i); };
     // vectors are padded to the even length ld with a zero pad element (phantom zero, see for_elems)
-    for_elems<T, 0>(a.ld, tid, [&](int, int i) {
+    for_elems<T, 0>(a.ld, tid, T, [&](int, int i) {
         const int k = MAXB > 1 ? block_of(a, i) : 0;
         const double ivk = a.tmap.iv[k];
         double gi;
@@ -1265,6 +1374,10 @@ struct muse_ctx {
     std::vector<hipEvent_t> prof_ev;
     int prof_count = 0;
     bool prof_on = false;
+    unsigned int* cl_counter = nullptr;  // cluster mode: [cl_cap] arrival counters
+    double* cl_part = nullptr;           // [cl_cap][2][kMaxCluster][8]
+    int cl_cap = 0;
+    int* error_flag = nullptr;           // pinned, device-mapped
     int debug = 0;
     unsigned int ticket_base = 0;  // value of the device ticket counter when the next launch starts
     bool timing = true;            // record an event pair around every solver launch
@@ -1289,25 +1402,32 @@ static double theta_const(const muse_ctx* c, const double* theta) {
     return cst;
 }
 
-enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4 };
+enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5 };
+
+// Cluster size: a function of N alone (results must not depend on how many problems share a launch).
+static int cluster_size(int64_t N) { return N >= 4194304 ? 16 : (N >= kClusterMinN ? 4 : 1); }
 
 // Workgroup size is a function of N alone (256 threads for N <= 512, else 512), so that the
 // streaming and the resident policy reduce in the same order and give bitwise equal results.
 static int choose_place(const muse_ctx* c) {
     const bool small = c->N <= 512;
+    // cluster mode: elementwise models only.  The stencil model reads neighbours owned by other
+    // workgroups, which needs a halo hand-off (plain loads after an agent acquire were observed to
+    // return stale neighbour values across XCDs); until that exists it stays single-workgroup.
+    if (c->N >= kClusterMinN && c->model != MUSE_MODEL_SMOOTH) return P_C256;
     if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN) return small ? P_S256 : P_S512;
     if (small) return P_R256x1;
     if (c->N <= 4096) return P_R512x4;
     return P_R512x10;
 }
-static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 256 : 512; }
-static int place_wgs_per_cu(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 4 : (pl == P_R512x10 ? 1 : 2); }
+static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1 || pl == P_C256) ? 256 : 512; }
+static int place_wgs_per_cu(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 4 : ((pl == P_R512x10) ? 1 : 2); }
 static size_t place_lds(const muse_ctx* c, int pl) {
     size_t fixed = (size_t)(2 * (place_threads(pl) / 64) * 8 + 42 + kArgsDoubles) * sizeof(double);
     if (pl == P_R512x10) fixed += (size_t)2 * (c->ld + 2) * sizeof(double);
     return fixed;
 }
-static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512) ? 4 + 2 * kM : 2 * kM; }
+static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512 || pl == P_C256) ? 4 + 2 * kM : 2 * kM; }
 
 static int ensure_zhat(muse_ctx* c, int64_t slots) {
     if (slots <= c->zhat_slots) return MUSE_OK;
@@ -1373,6 +1493,7 @@ static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_
             case P_R256x1: return launch_one<Model, PlaceResident<256, 1, false>>(c, a, grid, lds);
             case P_R512x4: return launch_one<Model, PlaceResident<512, 4, false>>(c, a, grid, lds);
             case P_R512x10: return launch_one<Model, PlaceResident<512, 10, true>>(c, a, grid, lds);
+            case P_C256: return launch_one<Model, PlaceStreaming<256, true, true>>(c, a, grid, lds);
             case P_S256: return launch_one<Model, PlaceStreaming<256>>(c, a, grid, lds);
             default: return launch_one<Model, PlaceStreaming<512>>(c, a, grid, lds);
         }
@@ -1395,10 +1516,35 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     const int pl = choose_place(c);
     int grid = c->num_cus * place_wgs_per_cu(pl);
-    if (grid > a.nproblems) grid = a.nproblems;
-    if (grid < 1) grid = 1;
+    a.csize = 1;
+    a.nclusters = 0;
+    if (pl == P_C256) {
+        // every workgroup of a cluster must be resident at once (they wait for each other): size the grid
+        // from 2 workgroups of 256 threads per CU, which the kernel's register budget always admits
+        a.csize = cluster_size(c->N);
+        int ncl = grid / a.csize;
+        if (ncl > a.nproblems) ncl = a.nproblems;
+        if (ncl < 1) ncl = 1;
+        a.nclusters = ncl;
+        grid = ncl * a.csize;
+        if (ncl > c->cl_cap) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->cl_counter) HIPCHK(hipFree(c->cl_counter));
+            if (c->cl_part) HIPCHK(hipFree(c->cl_part));
+            HIPCHK(hipMalloc(&c->cl_counter, (size_t)ncl * sizeof(unsigned int)));
+            HIPCHK(hipMalloc(&c->cl_part, (size_t)ncl * 2 * kMaxCluster * 8 * sizeof(double)));
+            c->cl_cap = ncl;
+        }
+        HIPCHK(hipMemsetAsync(c->cl_counter, 0, (size_t)ncl * sizeof(unsigned int), c->stream));
+        a.cl_counter = c->cl_counter;
+        a.cl_part = c->cl_part;
+    } else {
+        if (grid > a.nproblems) grid = a.nproblems;
+        if (grid < 1) grid = 1;
+    }
+    a.error_flag = c->error_flag;
     a.scratch_stride = place_scratch_vectors(pl) * c->ld;
-    int rc = ensure_scratch(c, (size_t)grid * a.scratch_stride);
+    int rc = ensure_scratch(c, (size_t)(pl == P_C256 ? a.nclusters : grid) * a.scratch_stride);
     if (rc) return rc;
     a.scratch = c->scratch;
     const size_t lds = place_lds(c, pl);
@@ -1475,6 +1621,8 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     HIPCHK(hipMalloc(&c->x_data, (size_t)c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->counter, 16));
     HIPCHK(hipMemset(c->counter, 0, 16));
+    HIPCHK(hipHostMalloc(&c->error_flag, 64, hipHostMallocDefault));
+    *c->error_flag = 0;
     HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&c->tsample_dev, 2 * kMaxTheta * sizeof(ThetaSet)));
@@ -1518,6 +1666,7 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     muse_comm_destroy(c);
+    hipFree(c->cl_counter); hipFree(c->cl_part); hipHostFree(c->error_flag);
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
     hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
@@ -1795,6 +1944,10 @@ int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {
     if (rc) return rc;
     if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
     HIPCHK(hipEventSynchronize(c->area_done[area]));  // this area only: later launches keep running
+    if (*c->error_flag) {
+        *c->error_flag = 0;
+        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident)");
+    }
     const int64_t n = c->res_n[area];
     if (g_out && n) memcpy(g_out, c->scores_pin[area], (size_t)n * c->ntheta * sizeof(double));
     if (info_out && n) memcpy(info_out, c->info_pin[area], (size_t)n * sizeof(muse_info));

@@ -24,6 +24,10 @@ CASES = [  # (model, N, ntheta, theta)
     ("smooth", 600, 4, [1.0, 2.0, 3.0, 0.5]),
     ("smooth", 20000, 8, [1.0, 2.0, 3.0, 0.5, 0.0, -1.0, 1.5, 2.5]),
     ("funnel", 50001, 2, [1.0, -1.0]),
+    # N >= 65536: several workgroups cooperate on one problem (cluster mode)
+    ("funnel", 70001, 1, [0.3]),
+    ("noise", 131072, 1, [-0.4]),
+    ("smooth", 66001, 2, [1.0, 2.5]),
 ]
 
 
@@ -119,4 +123,24 @@ def test_fd_jacobian(gpu, M, O, model, N, nth, theta, fid_mode):
         _, zfid, _ = O.map_and_score_batch(model, N, 11, fid, fid + 1, theta, atol=1e-2, z0_mode=0)
         Ho = O.fd_jacobian(model, N, 11, s, theta, step, zfid[0], atol=1e-2)
         np.testing.assert_allclose(Hs[s], Ho, rtol=1e-8, atol=1e-8 * np.abs(Ho).max())
+    prob.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta,placement", [
+    ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0], 0), ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0], 1),
+    ("funnel", 10000, 1, [1.0], -1), ("noise", 131072, 1, [-0.4], -1), ("funnel", 70001, 2, [0.3, 0.1], -1),
+    ("smooth", 20000, 8, [1.0, 2.0, 3.0, 0.5, 0.0, -1.0, 1.5, 2.5], -1), ("smooth", 66001, 2, [1.0, 2.5], -1)])
+def test_run_to_run_determinism(gpu, M, model, N, nth, theta, placement):
+    """Fixed-shape reductions and placement-independent hand-offs: repeated launches agree bit for bit
+    (this is the test that exposes a missing release/acquire between cooperating workgroups)."""
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    if placement >= 0:
+        prob.set_placement(placement)
+    ref = None
+    for _ in range(6):
+        g, info = prob.map_and_score_batch(7, 0, 9, theta, atol=1e-3, z0_mode=0)
+        cur = (g.copy(), info.copy(), prob.get_zhat(0, 9))
+        if ref is None:
+            ref = cur
+        assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1]) and np.array_equal(cur[2], ref[2])
     prob.close()
