@@ -140,6 +140,10 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
 typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) rsrc_t;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double lds_double;
+// words shared between workgroups inside a launch are accessed through GLOBAL (never flat) pointers
+typedef __attribute__((address_space(1))) double gf64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef __attribute__((address_space(1))) int gi32;
 
 // Buffer descriptor over `bytes` bytes at `base` (both workgroup-uniform; the readfirstlanes make
 // that provable so that no waterfall loop is generated around the buffer instructions).
@@ -472,26 +476,27 @@ struct Solver {
     __device__ __forceinline__ void cluster_allreduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
         constexpr int K = KS + KM;
         cl_epoch += 1;
-        double* slots = cl_part + (size_t)(cl_epoch & 1u) * csize * 8;
+        gf64* slots = (gf64*)(cl_part + (size_t)(cl_epoch & 1u) * csize * 8);
+        gu32* counter = (gu32*)cl_counter;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
         __syncthreads();
         if (tid == 0) {
-            double* mine = slots + crank * 8;
+            gf64* mine = slots + crank * 8;
 #pragma unroll
             for (int k = 0; k < KS; ++k) __hip_atomic_store(mine + k, sv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < KM; ++k) __hip_atomic_store(mine + KS + k, mv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(cl_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = cl_epoch * (unsigned)csize;
             unsigned spins = 0;
             // bounded (about a second): a cluster whose members are not all resident must not hang the
             // GPU; after one expiry this workgroup never waits again and the host reports the error
-            while (!cl_aborted && __hip_atomic_load(cl_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while (!cl_aborted && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1u << 22)) {
-                    __hip_atomic_store(a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     cl_aborted = true;
                 }
             }
@@ -966,7 +971,7 @@ struct Solver {
                 for (int index = upper; index >= lower; --index) {
                     const int slot = (index - 1) % kM;
                     const double al = sh_rho[slot] * dot;
-                    if (tid == 0) sh_alpha[slot] = al;
+                    if ((tid & 63) == 0) sh_alpha[slot] = al;  // lane 0 of EVERY wave: a wave reads back its own write (no barrier needed)
                     const VH dgp = hdg(slot);
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index > lower) {
@@ -1119,7 +1124,7 @@ struct Solver {
                 if (isinf(rho_it)) {
                     pseudo = 0;
                 } else {
-                    if (tid == 0) {
+                    if ((tid & 63) == 0) {  // every wave writes the identical value and later reads its own write
                         sh_rho[slot_new] = rho_it;
                         sh_gam[slot_new] = sum[0] / sum[1];
                     }
