@@ -1416,10 +1416,10 @@ static int cluster_size(int64_t N) { return N >= 4194304 ? 16 : (N >= kClusterMi
 // streaming and the resident policy reduce in the same order and give bitwise equal results.
 static int choose_place(const muse_ctx* c) {
     const bool small = c->N <= 512;
-    // cluster mode: elementwise models only.  The stencil model reads neighbours owned by other
-    // workgroups, which needs a halo hand-off (plain loads after an agent acquire were observed to
-    // return stale neighbour values across XCDs); until that exists it stays single-workgroup.
-    if (c->N >= kClusterMinN && c->model != MUSE_MODEL_SMOOTH) return P_C256;
+    // cluster mode: for the stencil model the neighbours owned by other workgroups become visible through
+    // the agent-scope release/acquire of the cluster reduction that ends every pass (pass_barrier where a
+    // pass has no reduction)
+    if (c->N >= kClusterMinN) return P_C256;
     if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN) return small ? P_S256 : P_S512;
     if (small) return P_R256x1;
     if (c->N <= 4096) return P_R512x4;
@@ -1491,6 +1491,7 @@ static int launch_one(muse_ctx* c, const BatchArgs& a, int grid, size_t lds) {
 template <class Model>
 static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_t lds) {
     if constexpr (Model::kStencil) {
+        if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, false, true>>(c, a, grid, lds);
         if (pl == P_S256) return launch_one<Model, PlaceStreaming<256, false>>(c, a, grid, lds);
         return launch_one<Model, PlaceStreaming<512, false>>(c, a, grid, lds);
     } else {

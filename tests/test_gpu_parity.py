@@ -146,3 +146,21 @@ def test_run_to_run_determinism(gpu, M, model, N, nth, theta, placement):
         assert np.array_equal(cur[0], ref[0]), np.argwhere(cur[0] != ref[0])
         assert np.array_equal(cur[2], ref[2]), np.argwhere(cur[2] != ref[2])[:10]
     prob.close()
+
+
+def test_cluster_stencil_many_clusters_under_load(gpu, M, O):
+    """Cluster mode with the stencil model: neighbours cross workgroup (and XCD) boundaries every pass.
+    Enough problems to occupy every CU with two workgroups; two runs bitwise equal, spot checks vs the oracle."""
+    N, th = 80001, [1.5, 2.5, 0.5, 3.0]
+    prob = M.HipMuseProblem(None, model="smooth", ntheta=4, N=N)
+    g1, i1 = prob.map_and_score_batch(11, 0, 150, th, atol=1e-3, z0_mode=0)
+    z1 = prob.get_zhat(0, 150)
+    g2, i2 = prob.map_and_score_batch(11, 0, 150, th, atol=1e-3, z0_mode=0)
+    assert np.array_equal(g1, g2) and np.array_equal(i1, i2) and np.array_equal(z1, prob.get_zhat(0, 150))
+    assert i1["iterations"].min() >= 5
+    for k in (0, 77, 149):
+        go, zo, io = O.map_and_score_batch("smooth", N, 11, k, k + 1, th, atol=1e-3, z0_mode=0)
+        assert (i1["iterations"][k], i1["f_calls"][k]) == (io["iterations"][0], io["f_calls"][0])
+        np.testing.assert_allclose(g1[k], go[0], rtol=1e-10)
+        np.testing.assert_allclose(z1[k], zo[0], rtol=0, atol=1e-9)
+    prob.close()
