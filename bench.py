@@ -46,6 +46,22 @@ def algorithmic_bytes(info, N):
     return int(8 * N * words.sum())
 
 
+def measured_traffic(workload):
+    """HBM bytes per solver launch from the committed rocprofv3 PMC passes (profiles/r01_summary.csv:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB,
+    the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM).  None if not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_summary.csv")
+    try:
+        import csv
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["workload"] == workload:
+                    return float(row["hbm_traffic_MB"]) * 1e6
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(model, N, theta, seed, budget_s=12.0):
     """Time the oracle on the host cores over a bounded number of sims of the same workload."""
     from oracle import oracle as O
@@ -179,7 +195,7 @@ def main():
                    "parallelism": f"sims sharded over {world} GPU(s), one all-gather of scores per step"},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
             "kernel": "map_score_kernel", "kernel_ms_mean": 1e3 * mean_kernel_s,
             "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
             "algorithmic_bytes_per_launch": alg_bytes,
