@@ -11,13 +11,13 @@ from .build import build_extension
 from .distributed import ShardedMuseProblem, block_partition
 from .muse import (MuseResult, Normal, finalize_result_, get_H_, get_J_, load_result, muse, muse_, save_result)
 from .priors import CallablePrior, FlatPrior, GaussianPrior
-from .problem import (DATA_SIM, MASTER_SIM, AbstractMuseProblem, HipMuseProblem, SimRng, Transformedθ,
-                      UnTransformedθ, check_optim_soln, split_rng)
+from .problem import (DATA_SIM, MASTER_SIM, AbstractMuseProblem, HipMuseProblem, PositiveThetaProblem, SimRng,
+                      Transformedθ, UnTransformedθ, check_optim_soln, check_self_consistency, split_rng)
 
 __all__ = [
     "AbstractMuseProblem", "HipMuseProblem", "ShardedMuseProblem", "MuseResult", "Normal", "SimRng",
     "muse", "muse_", "get_J_", "get_H_", "finalize_result_", "split_rng", "block_partition",
     "GaussianPrior", "FlatPrior", "CallablePrior", "build_extension", "load_library", "MuseError",
-    "save_result", "load_result", "check_optim_soln", "Transformedθ", "UnTransformedθ",
+    "save_result", "load_result", "check_optim_soln", "check_self_consistency", "PositiveThetaProblem", "Transformedθ", "UnTransformedθ",
     "Z0_ZERO", "Z0_TRUE", "Z0_WARM", "MASTER_SIM", "DATA_SIM", "STATUS_NAMES",
 ]

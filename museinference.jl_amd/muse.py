@@ -153,7 +153,8 @@ def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rt
         if batched:
             g, info = prob.map_and_score_batch(rng, 0, nsims, theta, include_data=True,
                                                atol=grad_z_logLike_atol, z0_mode=z0_mode)
-            g_t = g  # identity θ transform (src/interface.jl:57-58): g′ is the same evaluation
+            # g′ = ∇θ′ logLike in the transformed space (src/muse.jl:173); identity for untransformed problems
+            g, g_t = prob.scores_in_both_spaces(g, theta, theta_t) if hasattr(prob, "scores_in_both_spaces") else (g, g)
             from .problem import check_optim_soln
             check_optim_soln(info, "muse!")
             zhist = info
@@ -243,6 +244,8 @@ def get_J_(result, prob, theta0=None, *, z0=None, grad_z_logLike_atol=1e-2, rng=
         if _has_batch(prob) and z0 is None:
             g, info = prob.map_and_score_batch(rng, existing, nsims, theta0, include_data=False,
                                                atol=grad_z_logLike_atol, z0_mode=_capi.Z0_TRUE)
+            if hasattr(prob, "scores_in_both_spaces"):  # J is built from untransformed-space scores (src/muse.jl:513)
+                g, _ = prob.scores_in_both_spaces(g, theta0, prob.transform_theta(theta0))
             g, _ = _apply_skip_errors(g, info, skip_errors, "get_J!")
         else:
             zst = None if z0 is None else [np.asarray(z0, dtype=np.float64)] * (nsims - existing)
@@ -296,11 +299,15 @@ def get_H_(result, prob, theta0=None, *, fdm="central_fdm(3,1)", grad_z_logLike_
                                   "run get_J_ first or pass step")
     step = np.broadcast_to(np.atleast_1d(np.asarray(step, dtype=np.float64)), theta0.shape).copy()
     # split_rng(rng, nsims_remaining): streams 0 .. remaining-1 (src/muse.jl:323)
+    Hs = None
     if _has_batch(prob) and z0 is None:
-        Hs, info = prob.fd_jacobian_batch(rng, 0, remaining, theta0, step, atol=grad_z_logLike_atol,
-                                          fid_mode=fid_mode, fid_sim=MASTER_SIM)
-        Hs, _ = _apply_skip_errors(Hs, info, skip_errors, "get_H!")
-    else:
+        try:
+            Hs, info = prob.fd_jacobian_batch(rng, 0, remaining, theta0, step, atol=grad_z_logLike_atol,
+                                              fid_mode=fid_mode, fid_sim=MASTER_SIM)
+            Hs, _ = _apply_skip_errors(Hs, info, skip_errors, "get_H!")
+        except NotImplementedError:
+            Hs = None
+    if Hs is None:
         Hs = _fd_serial(prob, rng, remaining, theta0, step, grad_z_logLike_atol, z0, fid_mode)
     result.Hs = list(result.Hs) + list(Hs)
     result.H = np.mean(np.array(result.Hs), axis=0)

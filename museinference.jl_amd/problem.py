@@ -97,6 +97,48 @@ class AbstractMuseProblem:
     ẑ_guess_from_truth = property(lambda self: self.zhat_guess_from_truth)
 
 
+def check_self_consistency(prob, theta, *, atol=1e-2, rng=None, has_volume_factor=True, step=1e-5):
+    """check_self_consistency(prob, θ; fdm, atol, rng, has_volume_factor)   (src/interface.jl:209-230).
+
+    Checks, for a freshly sampled (x, z):  inv_transform∘transform = id;  the prior in both θ spaces
+    differs by the log-volume V(θ) = logdet J(θ), J = d transform/dθ;  and
+    ∇θ logLike (untransformed) = Jᵀ ∇θ′ logLike (transformed) + ∇θ V.  J and ∇V by central differences,
+    as the reference (it does not assume the transform is AD-able).  Returns a dict of the three
+    residuals and raises AssertionError if one exceeds atol."""
+    th = prob.standardize_theta(theta)
+    n = th.size
+    rng = SimRng(0, 0) if rng is None else rng
+    x, z = prob.sample_x_z(rng, th)
+
+    def jac(t):
+        J = np.zeros((n, n))
+        for j in range(n):
+            e = np.zeros(n)
+            e[j] = step
+            J[:, j] = (np.atleast_1d(prob.transform_theta(t + e)) - np.atleast_1d(prob.transform_theta(t - e))) / (2 * step)
+        return J
+
+    def V(t):
+        return np.linalg.slogdet(jac(t))[1] if has_volume_factor else 0.0
+
+    gradV = np.zeros(n)
+    if has_volume_factor:
+        for j in range(n):
+            e = np.zeros(n)
+            e[j] = step
+            gradV[j] = (V(th + e) - V(th - e)) / (2 * step)
+    th_t = np.atleast_1d(prob.transform_theta(th))
+    r1 = np.max(np.abs(np.atleast_1d(prob.inv_transform_theta(th_t)) - th))
+    r2 = abs(prob.logPrior_theta(th, UnTransformedθ) - (prob.logPrior_theta(th_t, Transformedθ) + V(th)))
+    g_u = np.atleast_1d(prob.grad_theta_logLike(x, z, th, UnTransformedθ))
+    g_t = np.atleast_1d(prob.grad_theta_logLike(x, z, th_t, Transformedθ))
+    r3 = np.max(np.abs(g_u - (jac(th).T @ g_t + gradV)))
+    res = {"inv_transform": float(r1), "prior_volume": float(r2), "grad_chain_rule": float(r3)}
+    for k, v in res.items():
+        assert v <= atol, f"self-consistency check {k} failed: residual {v} > atol {atol}"
+    return res
+
+
 def check_optim_soln(info, where="MAP"):
     """_check_optim_soln (src/interface.jl:168-171): warn if not converged, log an error (no throw)
     if the minimum is not finite."""
@@ -314,3 +356,86 @@ class HipMuseProblem(AbstractMuseProblem):
         buf = _capi.f8(buf).copy()
         _capi.check(self._lib.muse_allreduce_sum(self._ctx, _capi.ptr(buf), buf.size))
         return buf
+
+
+class PositiveThetaProblem(AbstractMuseProblem):
+    """A bounded-θ front-end: the user's parameters are the VARIANCES v_k = e^{θ_k} > 0 of the engine's
+    models; the transformed space (domain (-inf, inf)) is the engine's own θ = log v.  Exercises the
+    Transformedθ / UnTransformedθ machinery of the reference (src/interface.jl:8-28,41-58,107-121; the
+    Turing adapter is its precedent, src/turing.jl:171-186): muse! iterates in the transformed space, the
+    map bodies receive untransformed θ, the result is reported untransformed.
+
+    `prior` is the prior density over the variances v (an object with logpdf/grad/hess); in the transformed
+    space it picks up the log-volume factor: logPrior′(θ′) = logPrior(e^{θ′}) + Σ θ′.
+    """
+
+    def __init__(self, base, prior=None):
+        from .priors import as_prior
+        self.base = base
+        self.x = base.x
+        self.prior_v = as_prior(prior)
+
+    def __getattr__(self, name):  # N, ntheta, get_zhat, set_zhat, ...
+        return getattr(self.base, name)
+
+    def standardize_theta(self, v):
+        return np.atleast_1d(np.asarray(v, dtype=np.float64)).copy()
+
+    def transform_theta(self, v):
+        return np.log(np.asarray(v, dtype=np.float64))
+
+    def inv_transform_theta(self, t):
+        return np.exp(np.asarray(t, dtype=np.float64))
+
+    def logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        if theta_space == Transformedθ:
+            t = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+            return self.prior_v.logpdf(np.exp(t)) + float(np.sum(t))
+        return self.prior_v.logpdf(np.atleast_1d(np.asarray(theta, dtype=np.float64)))
+
+    def grad_logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        if theta_space == Transformedθ:
+            t = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+            v = np.exp(t)
+            return np.atleast_1d(self.prior_v.grad(v)) * v + 1.0
+        return np.atleast_1d(self.prior_v.grad(np.atleast_1d(np.asarray(theta, dtype=np.float64))))
+
+    def hess_logPrior_theta(self, theta, theta_space=UnTransformedθ):
+        if theta_space == Transformedθ:
+            t = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+            v = np.exp(t)
+            H = np.atleast_2d(self.prior_v.hess(v))
+            return np.outer(v, v) * H + np.diag(np.atleast_1d(self.prior_v.grad(v)) * v)
+        return np.atleast_2d(self.prior_v.hess(np.atleast_1d(np.asarray(theta, dtype=np.float64))))
+
+    # per-simulation operators: θ arrives untransformed (variances) except where θ_space says otherwise
+    def sample_x_z(self, rng, v):
+        return self.base.sample_x_z(rng, np.log(np.atleast_1d(v)))
+
+    def logLike_and_grad_z_logLike(self, x, z, v):
+        return self.base.logLike_and_grad_z_logLike(x, z, np.log(np.atleast_1d(v)))
+
+    def zhat_at_theta(self, x, z0, v, grad_z_logLike_atol=1e-2):
+        return self.base.zhat_at_theta(x, z0, np.log(np.atleast_1d(v)), grad_z_logLike_atol)
+
+    def grad_theta_logLike(self, x, z, theta, theta_space=UnTransformedθ):
+        th = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+        if theta_space == Transformedθ:
+            # d/dθ′ with θ′ = log v, plus the gradient of the log-volume term (+Σθ′) that the transformed
+            # density carries in the reference's convention (the logjoint of src/turing.jl:188-192); it is
+            # the same constant for the data and every simulation, so it cancels in the MUSE gradient
+            return self.base.grad_theta_logLike(x, z, th) + 1.0
+        return self.base.grad_theta_logLike(x, z, np.log(th)) / th       # d/dv = (d/dθ′) / v
+
+    # batched seams: the engine works in θ′ = log v
+    def map_and_score_batch(self, rng, sim_begin, sim_end, v, **kw):
+        return self.base.map_and_score_batch(rng, sim_begin, sim_end, np.log(np.atleast_1d(v)), **kw)
+
+    def scores_in_both_spaces(self, g_engine, v, theta_t):
+        """The engine's score is d logLike/dθ′; untransformed g = that / v, transformed g′ = that + 1."""
+        return g_engine / np.atleast_1d(v)[None, :], g_engine + 1.0
+
+    def fd_jacobian_batch(self, rng, sim_begin, sim_end, v0, step, **kw):
+        """Finite differences in the untransformed space through the engine's θ′-space FD is not the same
+        stencil; fall back to the element-by-element path of get_H_ (which calls the per-sim operators)."""
+        raise NotImplementedError

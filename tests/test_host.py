@@ -134,3 +134,25 @@ def test_priors(M):
     np.testing.assert_allclose(c.logpdf(th), g.logpdf(th), rtol=1e-12)
     np.testing.assert_allclose(c.grad(th), g.grad(th), rtol=1e-6)
     np.testing.assert_allclose(c.hess(th), g.hess(th), atol=1e-5)
+
+
+def test_theta_transforms_and_self_consistency(M, O, funnel512):
+    """Row f4: Transformedθ/UnTransformedθ (src/interface.jl:8-28) through a bounded-θ front-end whose
+    parameters are the variances v = e^θ > 0, and check_self_consistency (src/interface.jl:209-230)."""
+    base = OracleBatchedProblem(funnel512, "funnel", 1)
+    prior_v = M.CallablePrior(lambda v: float(np.sum(-np.log(v) ** 2 / 18.0 - np.log(v))))  # N(0,3²) on log v
+    prob = M.PositiveThetaProblem(base, prior=prior_v)
+    res = M.check_self_consistency(prob, [1.7], atol=1e-2)
+    assert max(res.values()) < 1e-4
+    assert M.check_self_consistency(base, [0.3], atol=1e-2)["grad_chain_rule"] < 1e-8   # identity transform
+    # muse in the transformed space lands where the untransformed-problem run does: v̂ = e^θ̂
+    r_t = M.muse(prob, [np.e], rng=4, nsims=40, get_covariance=True)
+    r_u = M.muse(OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0)), [1.0], rng=4, nsims=40)
+    np.testing.assert_allclose(np.log(r_t.theta), r_u.theta, atol=2e-3)
+    assert r_t.theta[0] > 0 and r_t.Sigma.shape == (1, 1)
+    # chain rule on the Jacobian: H_v = H_θ′ / v² (scores and FD both in the untransformed space).  J is not
+    # compared: result.gs are the scores at the θ *before* the last step (src/muse.jl:231,499-502), whose
+    # 1/v factor differs from the final v̂.
+    r_u = M.muse(OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0)), [1.0], rng=4, nsims=40,
+                 get_covariance=True)
+    np.testing.assert_allclose(r_t.H * r_t.theta[0] ** 2, r_u.H, rtol=1e-3)
