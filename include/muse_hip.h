@@ -158,6 +158,16 @@ int muse_fd_jacobian_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int6
                            const double* theta0, const double* step, double atol, int fid_mode,
                            int64_t fid_sim, double* Hs_out, muse_info* info_out);
 
+/* The get_H! implicit-differentiation branch (src/muse.jl:335-405) for sims sim_begin..sim_end-1:
+ *   H = H1 - dFdtheta^T A^{-1} dFdtheta1, A = Hessian_z logLike at (x, zhat, theta0), A^{-1} by conjugate
+ *   gradients (IterativeSolvers.cg defaults: x0 = 0, reltol sqrt(eps), maxiter = cg_maxiter, reference 100);
+ *   zhat from zero(z) to `atol` (the reference hard-codes 1e-1 here, src/muse.jl:344).  The reference takes the
+ *   derivative operands by nested AD; for the compiled-in models they are closed forms.
+ * Hs_out [nsims][ntheta][ntheta] host; cg_iters_out [nsims][ntheta] host (may be NULL; the
+ * metadata[:implicit_diff_cg_hists] of src/muse.jl:405). */
+int muse_implicit_H_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0,
+                          double atol, int cg_maxiter, double* Hs_out, int32_t* cg_iters_out);
+
 /* ---- multi-GPU exchange of the per-sim accumulators (RCCL over xGMI) --------------------------- */
 /* Collectives C1-C3 of SURVEY.md §2: gather of per-rank score blocks (so that every rank reduces
  * mean/var/cov in the reference's sim order, src/muse.jl:183,188,529) and sum of per-rank H

@@ -58,7 +58,7 @@ struct ThetaSet {
 
 enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
 enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
-enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2 };
+enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2, BATCH_IMPLICIT = 3 };
 
 struct BatchArgs {
     int64_t N, ld;
@@ -69,7 +69,8 @@ struct BatchArgs {
     uint64_t seed;
     double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
     int nproblems, include_data, z0_mode, store_zhat;
-    int debug, pad_;  // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
+    int cg_maxiter;   // BATCH_IMPLICIT: IterativeSolvers.cg maxiter (reference default 100)
+    int debug;        // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
     int64_t sim_begin, fid_slot, slot0;
     ThetaSet tmap;                 // theta of the MAP problem and of the score
     const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
@@ -114,6 +115,13 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.tsample = p % per;
         d.zslot = -1;
         d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + p / per;
+    } else if (a.kind == BATCH_IMPLICIT) {
+        d.sim = a.sim_begin + p;
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_ZERO;  // zhat_guess_from_truth = zero(z) (src/muse.jl:343, src/interface.jl:184-186)
+        d.tsample = -1;
+        d.zslot = -1;
+        d.z0slot = a.slot0;
     } else {
         d.sim = -1;
         d.x_mode = X_GIVEN;
@@ -825,8 +833,22 @@ struct Solver {
     }
 
     // -- one element: sample/load x, MAP by L-BFGS, score.
+    // state of the element being processed, shared by the phases begin -> solve -> finish
+    ProblemDesc d;
+    double f, gmax;
+    int iterations, hist_words, status;
+    double* extra;  // one more scratch vector (streaming): the simulation's true z for the implicit-diff H
+
     __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
-        const ProblemDesc d = describe(a, p);
+        begin<false>(p, wg_scratch, lds_x, lds_g);
+        solve(p);
+        finish(p);
+    }
+
+    // -- phase 1: bind storage, produce x and the starting point
+    template <bool KEEP_ZTRUE>
+    __device__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
+        d = describe(a, p);
         const int64_t N = a.N, ld = a.ld;
         stamp(p, 0);
         iv0 = a.tmap.iv[0];
@@ -851,6 +873,7 @@ struct Solver {
             zmem = d.zslot >= 0 ? a.zhat + d.zslot * ld : wg_scratch + 3 * ld;
             z.bind(zmem, ld);
             hist = wg_scratch + 4 * ld;
+            extra = hist + (int64_t)2 * kM * ld;
         }
         const double* z0ptr = a.zhat + d.z0slot * ld;
         VH z0src;
@@ -888,6 +911,8 @@ struct Solver {
                 });
             } else {
                 x.clear(); g.clear(); z.clear(); s.clear();
+                VH ztrue;
+                if constexpr (KEEP_ZTRUE) ztrue.bind(extra, ld);
                 for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                     const bool valid = i < N;  // phantom slots run the generator but keep zeros
                     const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
@@ -901,6 +926,7 @@ struct Solver {
                     }
                     zt = valid ? zt : 0.0;
                     xt = valid ? xt : 0.0;
+                    if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
                     x.set(jj, i, xt);
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
@@ -933,14 +959,22 @@ struct Solver {
         else __syncthreads();
 
         stamp(p, 1);
+    }
+
+    // -- phase 2: zhat_at_theta -- Optim LBFGS + HagerZhang on -logLike from the z prepared by begin()
+    __device__ void solve(int p) {
+        const int64_t ld = a.ld;
+        const int N = (int)a.N;
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
         f_calls = 0;
         last_c = NAN;
-        double f, dphi_unused, gmax;
+        double dphi_unused;
         eval<false, true>(0.0, f, dphi_unused, gmax);
         stamp(p, 2);
-        int iterations = 0, pseudo = 0, hist_words = 0, counter_f_tol = 0;
-        int status = MUSE_STATUS_MAXITER;
+        iterations = 0;
+        hist_words = 0;
+        int pseudo = 0, counter_f_tol = 0;
+        status = MUSE_STATUS_MAXITER;
         bool done = false;
         if (!isfinite(f) || !isfinite(gmax)) { status = MUSE_STATUS_NONFINITE; done = true; }
         else if (gmax <= a.atol) { status = MUSE_STATUS_G_CONVERGED; done = true; }
@@ -1087,7 +1121,7 @@ struct Solver {
                     auto zt = [&](int k) { return z.get(0, k); };
                     for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
                         double unused = 0.0;
-                        double gn = stencil_grad(zt, i < N ? i : 0, unused);
+                        double gn = stencil_grad(zt, i < N ? i : 0, unused);  // N: see top of solve()
                         gn = i < N ? gn : 0.0;
                         const double dxi = dxs.get(jj, i);
                         const double dgi = gn - g.get(jj, i);
@@ -1135,7 +1169,157 @@ struct Solver {
         }
 
         stamp(p, 6);
-        // ---- zhat out, score -------------------------------------------------------------------
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // get_H! implicit-differentiation branch for one simulation (src/muse.jl:335-405):
+    //   H = H1 - dFdtheta^T A^{-1} dFdtheta1,  A = Hessian_z logLike at (x, zhat, theta0),
+    // A^{-1} by conjugate gradients (IterativeSolvers.cg: x0 = 0, reltol sqrt(eps), abstol 0, maxiter).
+    // The reference gets the derivative operands by nested AD; for the compiled-in models they are
+    // closed forms (see oracle/muse_oracle.c, mo_implicit_H, for the list).  Streaming policy only:
+    // the CG vectors reuse the solver's g, s and history buffers; z_true sits in the extra vector.
+    // Writes H[p] (row-major ntheta x ntheta) and the CG iteration count of column j to info[p*ntheta+j].
+    __device__ void run_implicit(int p, double* wg_scratch, double* lds_x, double* lds_g) {
+        begin<true>(p, wg_scratch, lds_x, lds_g);
+        solve(p);
+        const int64_t ld = a.ld;
+        const int N = (int)a.N, nth = a.ntheta;
+        VH ztrue, v, r, pp, Ap, t1, t2;
+        ztrue.bind(extra, ld);
+        v.bind(wg_scratch + ld, ld);       // g buffer
+        r.bind(wg_scratch + 2 * ld, ld);   // s buffer
+        pp.bind(hist, ld);
+        Ap.bind(hist + ld, ld);
+        t1.bind(hist + 2 * ld, ld);
+        t2.bind(hist + 3 * ld, ld);
+        auto Aat = [&](const VH& w, int i) {  // (A w)_i, periodic (1/4, 1/2, 1/4); the pad element maps to 0
+            const bool valid = i < N;
+            const int ic = valid ? i : 0;
+            const int im = ic == 0 ? N - 1 : ic - 1, ip = ic == N - 1 ? 0 : ic + 1;
+            const double a0 = fma(0.25, w.get(0, im) + w.get(0, ip), 0.5 * w.get(0, ic));
+            return valid ? a0 : 0.0;
+        };
+        for (int j = 0; j < nth; ++j) {
+            // ---- right-hand side b = dFdtheta1[:, j]; v = 0, r = p = b --------------------------------
+            double sum[1] = {0.0}, mx[1] = {0.0};
+            if constexpr (Model::kStencil) {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    t1.set(jj, i, blk(i) == j ? 0.5 * ztrue.get(jj, i) : 0.0);
+                });
+                pass_barrier();
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); });
+                pass_barrier();
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    const double bi = Aat(t2, i);
+                    v.set(jj, i, 0.0);
+                    r.set(jj, i, bi);
+                    pp.set(jj, i, bi);
+                    sum[0] = fma(bi, bi, sum[0]);
+                });
+            } else {
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    double bi;
+                    if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - ztrue.get(jj, i)));
+                    else bi = blk(i) == j ? 0.5 * ztrue.get(jj, i) : 0.0;
+                    v.set(jj, i, 0.0);
+                    r.set(jj, i, bi);
+                    pp.set(jj, i, bi);
+                    sum[0] = fma(bi, bi, sum[0]);
+                });
+            }
+            reduce<1, 0>(sum, mx);
+            double rr = sum[0];
+            const double tol = __builtin_sqrt(kEps) * __builtin_sqrt(rr);
+            int it = 0;
+            while (it < a.cg_maxiter && !(__builtin_sqrt(rr) <= tol)) {
+                // ---- Ap = A_hess p, p.Ap -----------------------------------------------------------
+                double s1[1] = {0.0};
+                if constexpr (Model::kStencil) {
+                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) { t1.set(jj, i, Aat(pp, i)); });
+                    pass_barrier();
+                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                        const double pi = pp.get(jj, i);
+                        const double api = -(Aat(t1, i) + ivk(i) * pi);
+                        Ap.set(jj, i, api);
+                        s1[0] = fma(pi, api, s1[0]);
+                    });
+                } else {
+                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                        const double pi = pp.get(jj, i);
+                        double api;
+                        if constexpr (Model::kId == MUSE_MODEL_NOISE) api = -((iv0 + 1.0) * pi);
+                        else api = -(pi + ivk(i) * pi);
+                        Ap.set(jj, i, api);
+                        s1[0] = fma(pi, api, s1[0]);
+                    });
+                }
+                reduce<1, 0>(s1, mx);
+                const double alpha = rr / s1[0];
+                // ---- v += alpha p ; r -= alpha Ap ; r.r ---------------------------------------------
+                double s2[1] = {0.0};
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    v.set(jj, i, fma(alpha, pp.get(jj, i), v.get(jj, i)));
+                    const double ri = fma(-alpha, Ap.get(jj, i), r.get(jj, i));
+                    r.set(jj, i, ri);
+                    s2[0] = fma(ri, ri, s2[0]);
+                });
+                reduce<1, 0>(s2, mx);
+                const double beta = s2[0] / rr;
+                rr = s2[0];
+                // ---- p = r + beta p (its stores are ordered before the next stencil read by pass_barrier)
+                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    pp.set(jj, i, fma(beta, pp.get(jj, i), r.get(jj, i)));
+                });
+                if constexpr (Model::kStencil) pass_barrier();
+                it += 1;
+            }
+            // ---- H[:, j] = H1[:, j] - dFdtheta^T v ----------------------------------------------------
+            constexpr int KA = Model::kId == MUSE_MODEL_NOISE ? 2 : MAXB;  // noise: [dFdtheta^T v, H1 sum]
+            double acc[KA];
+#pragma unroll
+            for (int b = 0; b < KA; ++b) acc[b] = 0.0;
+            for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                const double zi = z.get(jj, i), vi = v.get(jj, i);
+                if constexpr (Model::kId == MUSE_MODEL_NOISE) {
+                    const double dd = x.get(jj, i) - zi;
+                    acc[0] = fma(-iv0 * dd, vi, acc[0]);
+                    acc[1] = fma(dd, 0.5 * (x.get(jj, i) - ztrue.get(jj, i)), acc[1]);
+                } else {
+                    const double t = ivk(i) * zi;
+                    if constexpr (MAXB == 1) {
+                        acc[0] = fma(t, vi, acc[0]);
+                    } else {
+                        const int k = blk(i);
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
+                    }
+                }
+            });
+            reduce<KA, 0>(acc, mx);
+            if (tid == 0 && crank == 0) {
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) {
+                    if (b < nth) {
+                        double h1 = 0.0;
+                        if constexpr (Model::kId == MUSE_MODEL_NOISE) h1 = iv0 * acc[1];
+                        a.scores[((int64_t)p * nth + b) * nth + j] = h1 - acc[b];
+                    }
+                }
+                muse_info inf;
+                inf.iterations = it;
+                inf.f_calls = f_calls;
+                inf.status = status;
+                inf.hist_words = hist_words;
+                inf.f_min = f;
+                inf.gnorm = gmax;
+                a.info[(int64_t)p * nth + j] = inf;
+            }
+        }
+    }
+
+    // -- phase 3: zhat out, score grad_theta logLike(x, zhat, theta), solver info
+    __device__ void finish(int p) {
+        const int64_t ld = a.ld;
         if constexpr (Place::kResident) {
             if (d.zslot >= 0) {
                 VH zo;
@@ -1187,7 +1371,7 @@ constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS c
 // parameter: hipcc materialises a by-value aggregate in scratch as soon as any select/phi of two
 // field addresses is formed, and every access then becomes a scratch access.  LDS loads at uniform
 // addresses are uniform values, so control flow on them stays scalar.
-template <class Model, class Place>
+template <class Model, class Place, bool IMPLICIT = false>
 __global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Place::T;
@@ -1232,7 +1416,8 @@ __global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*r
         for (int p = cluster; p < a.nproblems; p += a.nclusters) {
             sv.parity = 0;
             __syncthreads();
-            sv.run(p, cl_scratch, lds_x, lds_g);
+            if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);
+            else sv.run(p, cl_scratch, lds_x, lds_g);
         }
     } else {
         double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
@@ -1243,7 +1428,8 @@ __global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*r
             const int p = __builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base;
             if (p >= a.nproblems) break;
             Solver<Model, Place> sv(a, tid, red, shs);
-            sv.run(p, wg_scratch, lds_x, lds_g);
+            if constexpr (IMPLICIT) sv.run_implicit(p, wg_scratch, lds_x, lds_g);
+            else sv.run(p, wg_scratch, lds_x, lds_g);
         }
     }
 }
@@ -1432,7 +1618,7 @@ static size_t place_lds(const muse_ctx* c, int pl) {
     if (pl == P_R512x10) fixed += (size_t)2 * (c->ld + 2) * sizeof(double);
     return fixed;
 }
-static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512 || pl == P_C256) ? 4 + 2 * kM : 2 * kM; }
+static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512 || pl == P_C256) ? 4 + 2 * kM + 1 : 2 * kM; }
 
 static int ensure_zhat(muse_ctx* c, int64_t slots) {
     if (slots <= c->zhat_slots) return MUSE_OK;
@@ -1480,9 +1666,9 @@ static int ensure_results(muse_ctx* c, int area, int64_t n) {
     return MUSE_OK;
 }
 
-template <class Model, class Place>
+template <class Model, class Place, bool IMPLICIT = false>
 static int launch_one(muse_ctx* c, const BatchArgs& a, int grid, size_t lds) {
-    auto kern = map_score_kernel<Model, Place>;
+    auto kern = map_score_kernel<Model, Place, IMPLICIT>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Place::T), lds, c->stream, a);
     HIPCHK(hipGetLastError());
@@ -1506,6 +1692,14 @@ static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_
     }
 }
 
+// The implicit-differentiation H runs in the streaming policy only (single workgroup, or a cluster for large N).
+template <class Model>
+static int launch_place_implicit(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_t lds) {
+    constexpr bool pairs = !Model::kStencil;
+    if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, pairs, true>, true>(c, a, grid, lds);
+    return launch_one<Model, PlaceStreaming<512, pairs>, true>(c, a, grid, lds);
+}
+
 // Fill the common fields and launch the solver for `a.nproblems` elements.
 static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.N = c->N;
@@ -1520,7 +1714,8 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.work_counter = c->counter;
     a.debug = c->debug;
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
-    const int pl = choose_place(c);
+    const bool implicit = a.kind == BATCH_IMPLICIT;
+    const int pl = implicit ? (c->N >= kClusterMinN ? P_C256 : P_S512) : choose_place(c);
     int grid = c->num_cus * place_wgs_per_cu(pl);
     a.csize = 1;
     a.nclusters = 0;
@@ -1570,7 +1765,18 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     }
     const bool timed = c->timing || c->prof_on;
     if (timed) HIPCHK(hipEventRecord(e0, c->stream));
-    if (c->model == MUSE_MODEL_NOISE) rc = launch_place<NoiseModel>(c, a, pl, grid, lds);
+    if (implicit) {
+        if (c->model == MUSE_MODEL_NOISE) rc = launch_place_implicit<NoiseModel>(c, a, pl, grid, lds);
+        else if (c->model == MUSE_MODEL_FUNNEL)
+            rc = c->ntheta == 1   ? launch_place_implicit<FunnelModel<1>>(c, a, pl, grid, lds)
+                 : c->ntheta == 2 ? launch_place_implicit<FunnelModel<2>>(c, a, pl, grid, lds)
+                 : c->ntheta <= 4 ? launch_place_implicit<FunnelModel<4>>(c, a, pl, grid, lds)
+                                  : launch_place_implicit<FunnelModel<kMaxTheta>>(c, a, pl, grid, lds);
+        else
+            rc = c->ntheta <= 2   ? launch_place_implicit<SmoothModel<2>>(c, a, pl, grid, lds)
+                 : c->ntheta <= 4 ? launch_place_implicit<SmoothModel<4>>(c, a, pl, grid, lds)
+                                  : launch_place_implicit<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
+    } else if (c->model == MUSE_MODEL_NOISE) rc = launch_place<NoiseModel>(c, a, pl, grid, lds);
     else if (c->model == MUSE_MODEL_FUNNEL)
         rc = c->ntheta == 1   ? launch_place<FunnelModel<1>>(c, a, pl, grid, lds)
              : c->ntheta == 2 ? launch_place<FunnelModel<2>>(c, a, pl, grid, lds)
@@ -2066,6 +2272,47 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
             for (int i = 0; i < nt; ++i) Hs_out[(s * nt + i) * nt + j] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
         }
     if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
+    return MUSE_OK;
+}
+
+int muse_implicit_H_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0, double atol,
+                          int cg_maxiter, double* Hs_out, int32_t* cg_iters_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !Hs_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (sim_end < sim_begin || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad sim range");
+    if (cg_maxiter < 1) return fail(MUSE_ERR_INVALID, "cg_maxiter must be >= 1");
+    const int64_t nsims = sim_end - sim_begin;
+    if (nsims == 0) return MUSE_OK;
+    const int nt = c->ntheta;
+    if (nsims * nt > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
+    rc = ensure_zhat(c, 1);
+    if (rc) return rc;
+    rc = ensure_results(c, 2, nsims * nt);
+    if (rc) return rc;
+    BatchArgs a;
+    base_args(c, a, theta0);
+    a.kind = BATCH_IMPLICIT;
+    a.seed = seed;
+    a.atol = atol;
+    a.cg_maxiter = cg_maxiter;
+    a.nproblems = (int)nsims;
+    a.sim_begin = sim_begin;
+    a.slot0 = 0;
+    a.scores = c->scores_dev[2];
+    a.info = c->info_dev[2];
+    rc = launch_batch(c, a);
+    if (rc) return rc;
+    rc = enqueue_results_copy(c, 2, nsims * nt);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (*c->error_flag) {
+        *c->error_flag = 0;
+        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel");
+    }
+    memcpy(Hs_out, c->scores_pin[2], (size_t)nsims * nt * nt * sizeof(double));
+    if (cg_iters_out)
+        for (int64_t k = 0; k < nsims * nt; ++k) cg_iters_out[k] = c->info_pin[2][k].iterations;
     return MUSE_OK;
 }
 

@@ -274,7 +274,7 @@ def _apply_skip_errors(g, info, skip_errors, where):
 
 def get_H_(result, prob, theta0=None, *, fdm="central_fdm(3,1)", grad_z_logLike_atol=1e-2, rng=None, nsims=10,
            step=None, pool=None, pmap_over="auto", progress=False, skip_errors=False, z0=None,
-           implicit_diff=False, fid_mode=0):
+           implicit_diff=False, implicit_diff_H1_is_zero=False, implicit_diff_cg_kwargs=None, fid_mode=0):
     """get_H!(result, prob, θ₀; ...) finite-difference branch   (src/muse.jl:296-333, 407-450).
 
     step defaults to 0.1 ./ std(result.gs) (src/muse.jl:411-413).  fid_mode 0 reproduces the reference's
@@ -282,7 +282,7 @@ def get_H_(result, prob, theta0=None, *, fdm="central_fdm(3,1)", grad_z_logLike_
     master stream, src/muse.jl:417-423); fid_mode 1 uses each sim's own fiducial MAP.
     """
     if implicit_diff:
-        raise NotImplementedError("implicit_diff=true (src/muse.jl:335-405) is not built yet (SURVEY.md §8 f1)")
+        return _get_H_implicit(result, prob, theta0, rng, nsims, implicit_diff_cg_kwargs, skip_errors)
     if fdm != "central_fdm(3,1)":
         raise NotImplementedError("only central_fdm(3,1), the reference default (src/muse.jl:300), is built")
     rng = int(_something(rng, result.rng, _default_rng()))
@@ -310,6 +310,27 @@ def get_H_(result, prob, theta0=None, *, fdm="central_fdm(3,1)", grad_z_logLike_
     if Hs is None:
         Hs = _fd_serial(prob, rng, remaining, theta0, step, grad_z_logLike_atol, z0, fid_mode)
     result.Hs = list(result.Hs) + list(Hs)
+    result.H = np.mean(np.array(result.Hs), axis=0)
+    result.time += time.perf_counter() - t0
+    return finalize_result_(result, prob)
+
+
+def _get_H_implicit(result, prob, theta0, rng, nsims, cg_kwargs, skip_errors):
+    """get_H! with implicit_diff=true (src/muse.jl:335-405): H = H1 - dFdθᵀ A⁻¹ dFdθ1 per sim, A⁻¹ by CG
+    (implicit_diff_cg_kwargs default (maxiter=100, Pl=I)); the fiducial MAP is solved to 1e-1 as the
+    reference hard-codes (src/muse.jl:344).  CG iteration counts go to metadata["implicit_diff_cg_hists"]."""
+    rng = int(_something(rng, result.rng, _default_rng()))
+    theta0 = prob.standardize_theta(_something(theta0, result.theta))
+    remaining = nsims - len(result.Hs)
+    if remaining <= 0:
+        return result
+    if not hasattr(prob, "implicit_H_batch"):
+        raise NotImplementedError("implicit_diff needs a problem with the implicit_H_batch seam")
+    t0 = time.perf_counter()
+    maxiter = int((cg_kwargs or {}).get("maxiter", 100))
+    Hs, its = prob.implicit_H_batch(rng, 0, remaining, theta0, atol=1e-1, cg_maxiter=maxiter)
+    result.Hs = list(result.Hs) + list(Hs)
+    result.metadata.setdefault("implicit_diff_cg_hists", []).extend(list(its))
     result.H = np.mean(np.array(result.Hs), axis=0)
     result.time += time.perf_counter() - t0
     return finalize_result_(result, prob)

@@ -335,6 +335,17 @@ class HipMuseProblem(AbstractMuseProblem):
                                                      _capi.ptr(Hs), _capi.ptr(info)))
         return Hs, info
 
+    def implicit_H_batch(self, rng, sim_begin, sim_end, theta0, *, atol=1e-1, cg_maxiter=100):
+        """get_H! implicit-differentiation branch for sims [sim_begin, sim_end): (Hs [nsims, nθ, nθ],
+        cg iteration counts [nsims, nθ])   [src/muse.jl:335-405]"""
+        th = self._theta(theta0)
+        ns = sim_end - sim_begin
+        Hs = np.empty((ns, self.ntheta, self.ntheta))
+        its = np.zeros((ns, self.ntheta), dtype=np.int32)
+        _capi.check(self._lib.muse_implicit_H_batch(self._ctx, _seed_of(rng), sim_begin, sim_end, _capi.ptr(th),
+                                                    float(atol), int(cg_maxiter), _capi.ptr(Hs), _capi.ptr(its)))
+        return Hs, its
+
     # -- RCCL exchange (C1-C3 of SURVEY.md §2) through the C ABI, for hosts without torch.distributed
     @staticmethod
     def comm_unique_id():

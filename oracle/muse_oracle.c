@@ -22,6 +22,7 @@
  *                           Options(g_tol=atol)) -- minimise -logLike)
  *   mo_map_and_score        src/muse.jl:169-176 (muse! map body), :508-525 (get_J! body)
  *   mo_fd_jacobian          src/muse.jl:426-442 + src/util.jl:9-27 (pjacobian, central_fdm(3,1))
+ *   mo_implicit_H           src/muse.jl:335-405 (get_H! implicit-differentiation branch, CG solve)
  *
  * Third-party arithmetic that is NOT vendored in the reference (Project.toml compat only,
  * no Manifest.toml) and is restated here from the published algorithms:
@@ -750,6 +751,97 @@ int mo_fd_jacobian(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim,
         for (int i = 0; i < ntheta; ++i) H_out[i * ntheta + j] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
     }
     free(z);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- get_H! implicit-differentiation branch
+ * (src/muse.jl:335-405), per sim:
+ *   (x, z) = sample_x_z(rng, theta0); zhat = zhat_at_theta(x, zero(z), theta0; atol)   [the reference hard-codes
+ *   atol = 1e-1 here, src/muse.jl:344; the caller passes it]
+ *   H1     = d/dtheta [ grad_theta' logLike(x(theta), zhat, theta') ]_{theta'=theta0}          (:353-358)
+ *   dFdth  = d/dtheta [ grad_z logLike(x, zhat, theta) ]            (N x ntheta)                 (:361-365)
+ *   dFdth1 = d/dtheta [ grad_z logLike(x(theta), zhat, theta0) ]    (N x ntheta)                 (:366-371)
+ *   A w    = Hessian_z logLike(x, zhat, theta0) w                                                (:373-379)
+ *   H      = H1 - dFdth^T A^{-1} dFdth1, A^{-1} by conjugate gradients (IterativeSolvers.cg,
+ *            maxiter = 100, reltol = sqrt(eps), abstol = 0, x0 = 0)                              (:380-389)
+ * The reference obtains the derivatives by nested AD; for the compiled-in models they are closed forms:
+ *   funnel/smooth: grad_z = A^T(x - A z) - iv_k z;  score_k = 1/2 (iv_k sum_k z^2 - N_k)  (no x dependence => H1 = 0)
+ *                  dFdth[:,k] = iv_k zhat 1_k;  dx/dtheta_k = A (1/2 z_true 1_k);  dFdth1[:,k] = A^T A (1/2 z_true 1_k)
+ *                  A_hess w = -(A^T A w + iv w)
+ *   noise:         grad_z = iv (x - z) - z;  score = 1/2 (iv sum (x-z)^2 - N);  dx/dtheta = 1/2 (x - z_true)
+ *                  H1 = iv sum (x - zhat) 1/2 (x - z_true);  dFdth = -iv (x - zhat);  dFdth1 = iv 1/2 (x - z_true)
+ *                  A_hess w = -(iv + 1) w
+ * H_out[i][j] row-major; cg_iters_out[ntheta] (may be NULL). */
+static void mo_hess_apply(int model, int64_t N, int ntheta, const double* iv, const double* w, double* out, double* tmp) {
+    if (model == MO_MODEL_NOISE) {
+        for (int64_t i = 0; i < N; ++i) out[i] = -((iv[0] + 1.0) * w[i]);
+    } else if (model == MO_MODEL_FUNNEL) {
+        for (int64_t i = 0; i < N; ++i) out[i] = -(w[i] + iv[mo_block(i, N, ntheta)] * w[i]);
+    } else {
+        for (int64_t i = 0; i < N; ++i) tmp[i] = mo_Az(w, i, N);
+        for (int64_t i = 0; i < N; ++i) out[i] = -(mo_Az(tmp, i, N) + iv[mo_block(i, N, ntheta)] * w[i]);
+    }
+}
+
+int mo_implicit_H(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, const double* theta0, double atol,
+                  int cg_maxiter, double* H_out, int32_t* cg_iters_out) {
+    size_t nb = (size_t)N * sizeof(double);
+    double *x = (double*)malloc(nb), *zt = (double*)malloc(nb), *zh = (double*)malloc(nb), *z0 = (double*)calloc((size_t)N, sizeof(double));
+    double *b = (double*)malloc(nb), *v = (double*)malloc(nb), *r = (double*)malloc(nb), *pp = (double*)malloc(nb);
+    double *Ap = (double*)malloc(nb), *tmp = (double*)malloc(nb);
+    double iv[64];
+    for (int k = 0; k < ntheta; ++k) iv[k] = exp(-theta0[k]);
+    mo_sample_x_z(model, N, ntheta, seed, (uint64_t)sim, theta0, x, zt);
+    mo_zhat_at_theta(model, N, ntheta, x, z0, theta0, atol, zh, NULL);
+    for (int j = 0; j < ntheta; ++j) {
+        /* right-hand side dFdth1[:, j] */
+        if (model == MO_MODEL_NOISE) {
+            for (int64_t i = 0; i < N; ++i) b[i] = iv[0] * (0.5 * (x[i] - zt[i]));
+        } else {
+            for (int64_t i = 0; i < N; ++i) tmp[i] = mo_block(i, N, ntheta) == j ? 0.5 * zt[i] : 0.0;
+            if (model == MO_MODEL_FUNNEL) memcpy(b, tmp, nb);
+            else {
+                for (int64_t i = 0; i < N; ++i) r[i] = mo_Az(tmp, i, N);
+                for (int64_t i = 0; i < N; ++i) b[i] = mo_Az(r, i, N);
+            }
+        }
+        /* conjugate gradients on A v = b, x0 = 0 */
+        memset(v, 0, nb);
+        memcpy(r, b, nb);
+        memcpy(pp, b, nb);
+        double rr = mo_dot(r, r, N);
+        const double tol = sqrt(MO_EPS) * sqrt(rr);
+        int it = 0;
+        while (it < cg_maxiter && !(sqrt(rr) <= tol)) {
+            mo_hess_apply(model, N, ntheta, iv, pp, Ap, tmp);
+            const double alpha = rr / mo_dot(pp, Ap, N);
+            for (int64_t i = 0; i < N; ++i) v[i] = fma(alpha, pp[i], v[i]);
+            for (int64_t i = 0; i < N; ++i) r[i] = fma(-alpha, Ap[i], r[i]);
+            const double rr_new = mo_dot(r, r, N);
+            const double beta = rr_new / rr;
+            for (int64_t i = 0; i < N; ++i) pp[i] = fma(beta, pp[i], r[i]);
+            rr = rr_new;
+            it += 1;
+        }
+        if (cg_iters_out) cg_iters_out[j] = it;
+        /* H[:, j] = H1[:, j] - dFdth^T v */
+        for (int i2 = 0; i2 < ntheta; ++i2) {
+            double acc = 0.0, h1 = 0.0;
+            if (model == MO_MODEL_NOISE) {
+                for (int64_t i = 0; i < N; ++i) {
+                    const double d = x[i] - zh[i];
+                    acc = fma(-iv[0] * d, v[i], acc);
+                    h1 = fma(d, 0.5 * (x[i] - zt[i]), h1);
+                }
+                h1 *= iv[0];
+            } else {
+                for (int64_t i = 0; i < N; ++i)
+                    if (mo_block(i, N, ntheta) == i2) acc = fma(iv[i2] * zh[i], v[i], acc);
+            }
+            H_out[i2 * ntheta + j] = h1 - acc;
+        }
+    }
+    free(x); free(zt); free(zh); free(z0); free(b); free(v); free(r); free(pp); free(Ap); free(tmp);
     return 0;
 }
 

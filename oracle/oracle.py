@@ -156,5 +156,15 @@ def fd_jacobian(model, N, seed, sim, theta0, step, zfid, atol=1e-2):
     return H
 
 
+def implicit_H(model, N, seed, sim, theta0, atol=1e-1, cg_maxiter=100):
+    """get_H! implicit-differentiation branch for one sim   [src/muse.jl:335-405]"""
+    th = _f8(theta0)
+    H = np.empty((th.size, th.size))
+    its = np.zeros(th.size, dtype=np.int32)
+    lib().mo_implicit_H(C.c_int(MODELS[model]), C.c_int64(N), C.c_int(th.size), C.c_uint64(seed), C.c_int64(sim),
+                        _p(th), C.c_double(atol), C.c_int(cg_maxiter), _p(H), _p(its))
+    return H, its
+
+
 def num_threads():
     return lib().mo_num_threads()

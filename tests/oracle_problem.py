@@ -81,3 +81,8 @@ class OracleBatchedProblem(OracleMuseProblem):
             Hs.append(O.fd_jacobian(self.model, self.N, seed, s, th, step, zfid[0], atol=atol))
         info = np.zeros((sim_end - sim_begin, th.size, 2), dtype=M._capi.INFO_DTYPE)
         return np.array(Hs).reshape(sim_end - sim_begin, th.size, th.size), info
+
+    def implicit_H_batch(self, rng, sim_begin, sim_end, theta0, *, atol=1e-1, cg_maxiter=100):
+        seed = rng.seed if isinstance(rng, M.SimRng) else int(rng)
+        out = [O.implicit_H(self.model, self.N, seed, s, theta0, atol, cg_maxiter) for s in range(sim_begin, sim_end)]
+        return np.array([h for h, _ in out]), np.array([i for _, i in out])

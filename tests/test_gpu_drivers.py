@@ -163,3 +163,38 @@ def test_rccl_single_rank(gpu, M):
     assert np.array_equal(p.allgather_scores(v), v[None, :])
     assert np.array_equal(p.allreduce_sum(v), v)
     p.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta", [
+    ("funnel", 512, 1, [0.3]), ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0]), ("noise", 3001, 1, [0.4]),
+    ("smooth", 2000, 3, [1.0, 2.0, 0.5]), ("funnel", 70001, 2, [0.3, 0.1]), ("smooth", 66001, 2, [1.0, 2.5])])
+def test_implicit_diff_H(gpu, M, O, model, N, nth, theta):
+    """Row f1: get_H! implicit-differentiation branch (src/muse.jl:335-405) against the oracle, and the
+    oracle's own cross-check against the finite-difference Jacobian."""
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    Hs, its = prob.implicit_H_batch(5, 0, 4, theta, atol=1e-1, cg_maxiter=100)
+    for s in range(4):
+        Ho, io = O.implicit_H(model, N, 5, s, theta, atol=1e-1, cg_maxiter=100)
+        assert np.array_equal(its[s], io)
+        np.testing.assert_allclose(Hs[s], Ho, rtol=1e-9, atol=1e-9 * np.abs(Ho).max())
+    # tight MAP: implicit differentiation agrees with central differences of the same map
+    Hs2, _ = prob.implicit_H_batch(5, 0, 1, theta, atol=1e-10)
+    _, zfid, _ = O.map_and_score_batch(model, N, 5, 0, 1, theta, atol=1e-12, z0_mode=0)
+    Hfd = O.fd_jacobian(model, N, 5, 0, theta, [1e-5] * nth, zfid[0], atol=1e-12)
+    np.testing.assert_allclose(Hs2[0], Hfd, rtol=2e-6, atol=2e-6 * np.abs(Hfd).max())
+    prob.close()
+
+
+def test_get_H_implicit_diff_driver(gpu, M, O):
+    x, _ = O.sample_x_z("funnel", 2000, 9, M.DATA_SIM, [0.0, 0.0])
+    prob = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+    res = M.muse(prob, [0.5, 0.5], rng=2, nsims=30, maxsteps=4)
+    M.get_J_(res, prob, nsims=30)
+    M.get_H_(res, prob, nsims=5, implicit_diff=True)
+    a = res.H.copy()
+    assert len(res.metadata["implicit_diff_cg_hists"]) == 5
+    res.Hs, res.H = [], None
+    M.get_H_(res, prob, nsims=5)          # finite-difference branch on the same streams
+    np.testing.assert_allclose(a, res.H, rtol=0.05, atol=0.05 * np.abs(res.H).max())
+    assert res.Sigma.shape == (2, 2)
+    prob.close()

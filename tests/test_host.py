@@ -156,3 +156,15 @@ def test_theta_transforms_and_self_consistency(M, O, funnel512):
     r_u = M.muse(OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0)), [1.0], rng=4, nsims=40,
                  get_covariance=True)
     np.testing.assert_allclose(r_t.H * r_t.theta[0] ** 2, r_u.H, rtol=1e-3)
+
+
+def test_get_H_implicit_diff_host(M, O, funnel512):
+    prob = OracleBatchedProblem(funnel512, prior=M.GaussianPrior())
+    res = M.MuseResult(theta=np.array([0.2]), rng=3)
+    M.get_J_(res, prob, nsims=20)
+    M.get_H_(res, prob, nsims=6, implicit_diff=True, implicit_diff_cg_kwargs=dict(maxiter=50))
+    want = np.mean([O.implicit_H("funnel", 512, 3, s, [0.2], atol=1e-1, cg_maxiter=50)[0] for s in range(6)], axis=0)
+    np.testing.assert_allclose(res.H, want, rtol=1e-13)
+    assert len(res.metadata["implicit_diff_cg_hists"]) == 6 and res.Sigma is not None
+    M.get_H_(res, prob, nsims=6, implicit_diff=True)   # already have 6: no new sims (src/muse.jl:317-319)
+    assert len(res.Hs) == 6

@@ -164,3 +164,20 @@ def test_oracle_reproduces_golden_fixtures(O):
         assert np.array_equal(zh, d[key + "_zhat"])
         assert (info["iterations"], info["f_calls"]) == tuple(d[key + "_iters"][:2])
         assert np.array_equal(O.grad_theta(model, x, zh, th), d[key + "_score"])
+
+
+def test_implicit_diff_H_closed_form_and_fd(O):
+    """get_H! implicit-differentiation branch (src/muse.jl:335-405): funnel closed form
+    H_sim = 1/2 e^-θ σ(θ)² Σ x z_true, and agreement with the finite-difference branch for every model."""
+    N, th = 512, 0.3
+    x, z = O.sample_x_z("funnel", N, 3, 1, [th])
+    H, its = O.implicit_H("funnel", N, 3, 1, [th], atol=1e-12)
+    sig = 1 / (1 + np.exp(-th))
+    np.testing.assert_allclose(H[0, 0], 0.5 * np.exp(-th) * sig**2 * np.sum(x * z), rtol=1e-12)
+    assert its[0] == 1  # isotropic Hessian: CG converges in one step
+    for model, t in [("noise", [0.4]), ("funnel", [0.3, -0.2]), ("smooth", [1.0, 2.0, 0.5])]:
+        _, zfid, _ = O.map_and_score_batch(model, 600, 5, 2, 3, t, atol=1e-12, z0_mode=0)
+        Hfd = O.fd_jacobian(model, 600, 5, 2, t, [1e-5] * len(t), zfid[0], atol=1e-13)
+        Him, its = O.implicit_H(model, 600, 5, 2, t, atol=1e-12)
+        np.testing.assert_allclose(Him, Hfd, rtol=1e-6, atol=1e-6 * np.abs(Hfd).max())
+    assert its.max() > 5   # the smooth model needs real CG iterations
