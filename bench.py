@@ -62,24 +62,29 @@ def measured_traffic(workload):
     return None
 
 
-def cpu_baseline(model, N, theta, seed, budget_s=12.0):
-    """Time the oracle on the host cores over a bounded number of sims of the same workload."""
+def cpu_baseline(model, N, theta, seed, cpu_seconds=30.0):
+    """Time the oracle on the host cores over a bounded number of sims of the same workload
+    (about `cpu_seconds` of CPU work in total, OpenMP over sims on every core the process may use)."""
     from oracle import oracle as O
     O.build()
-    cores = O.num_threads() if hasattr(os, "sched_getaffinity") is False else min(O.num_threads(), len(os.sched_getaffinity(0)))
+    cores = O.num_threads()
+    if hasattr(os, "sched_getaffinity"):
+        cores = min(cores, len(os.sched_getaffinity(0)))
     cores = max(1, cores)
+    n1 = 32
+    O.map_and_score_batch(model, N, seed, 0, 4, theta, atol=1e-2, z0_mode=0, nthreads=1)       # warm the library
     t0 = time.perf_counter()
-    n1 = 16
     O.map_and_score_batch(model, N, seed, 0, n1, theta, atol=1e-2, z0_mode=0, nthreads=1)
     t1 = (time.perf_counter() - t0) / n1  # seconds per sim, one thread
-    nall = int(max(cores * 4, min(16384, budget_s * cores / max(t1, 1e-9))))
+    O.map_and_score_batch(model, N, seed, 0, 4 * cores, theta, atol=1e-2, z0_mode=0, nthreads=cores)  # spin the team up
+    nall = int(max(8 * cores, cpu_seconds / max(t1, 1e-9)))
     t0 = time.perf_counter()
     O.map_and_score_batch(model, N, seed, 0, nall, theta, atol=1e-2, z0_mode=0, nthreads=cores)
     tall = time.perf_counter() - t0
     return {
         "value": nall / tall, "unit": "sims/s", "cores": cores, "kind": "port",
         "sample": f"{nall} sims of the same workload (oracle/muse_oracle.c, gcc -O3, OpenMP over sims, "
-                  f"{cores} threads); 1 thread: {1.0 / t1:.1f} sims/s on {n1} sims",
+                  f"{cores} threads, {tall:.2f} s wall); 1 thread: {1.0 / t1:.1f} sims/s on {n1} sims",
         "value_1thread": 1.0 / t1,
     }
 

@@ -175,7 +175,10 @@ struct RegVec {
         for (int j = 0; j < (NR > 0 ? NR : 1); ++j) r[j] = 0.0;
     }
 };
-struct BufVec {  // a vector in HBM: buffer_load/store_dwordx2 with hardware range check
+// ST_AUX: cache policy of the stores (0 default; 16 = sc1, write-through: used in cluster mode so that the
+// XCD's L2 holds no dirty vector lines when a cluster reduction releases)
+template <int ST_AUX = 0>
+struct BufVecT {  // a vector in HBM: buffer_load/store_dwordx2 with hardware range check
     rsrc_t rsrc;
     __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
     __device__ __forceinline__ double get(int, int i) const {
@@ -187,7 +190,7 @@ struct BufVec {  // a vector in HBM: buffer_load/store_dwordx2 with hardware ran
         u32x2 v;
         v.x = (unsigned)(b & 0xffffffffll);
         v.y = (unsigned)(b >> 32);
-        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, i * 8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, i * 8, 0, ST_AUX);
     }
     __device__ __forceinline__ void clear() {}
 };
@@ -196,7 +199,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // (jj even then jj odd) back to back, so the pair moves with ONE 16-byte buffer instruction: the load
 // is issued at jj = 0 and its second half served at jj = 1; a store is staged at jj = 0 and issued at
 // jj = 1 (buffer_load/store_dwordx4, 1 KiB per wave-instruction).
-struct BufVec2 {
+template <int ST_AUX = 0>
+struct BufVec2T {
     rsrc_t rsrc;
     mutable double c0, c1;
     __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
@@ -219,11 +223,13 @@ struct BufVec2 {
             v.y = (unsigned)(b0 >> 32);
             v.z = (unsigned)(b1 & 0xffffffffll);
             v.w = (unsigned)(b1 >> 32);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (i - 1) * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (i - 1) * 8, 0, ST_AUX);
         }
     }
     __device__ __forceinline__ void clear() {}
 };
+using BufVec = BufVecT<0>;
+using BufVec2 = BufVec2T<0>;
 struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
     lds_double* p;
     int ld;
@@ -256,7 +262,7 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F
     } else {
         // streaming: pairs tfirst, tfirst + pstride, ... (pstride = T, or csize*T in cluster mode)
         const int n = (int)ld;
-#pragma unroll 2
+#pragma unroll 4
         for (int i0 = 2 * t; i0 < n; i0 += 2 * pstride) {
             f(0, i0);
             f(1, i0 + 1);
@@ -411,7 +417,8 @@ struct PlaceStreaming {
     static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
     // a get and a set of the same vector in one pass use separate accessor objects (VH), so the
     // staged half of a store never aliases the cached half of a load
-    using VX = typename std::conditional<PAIRS, BufVec2, BufVec>::type;
+    static constexpr int kStAux = 0;  // (sc1 write-through stores in cluster mode were measured slower)
+    using VX = typename std::conditional<PAIRS, BufVec2T<kStAux>, BufVecT<kStAux>>::type;
     using VG = VX; using VZ = VX; using VS = VX;
     using VH = VX;
 };
@@ -591,6 +598,87 @@ struct Solver {
         return t - fma(0.25, rm + rp, 0.5 * r0);
     }
 
+    // ---- stencil model, pair-wise --------------------------------------------------------------
+    // A lane loads its own element pair of z, s, x with one 16-byte buffer instruction each and gets the
+    // neighbouring pairs from the adjacent lanes with DPP wave shifts (lanes of a wave own consecutive
+    // pairs); only the two edge lanes of a wave fetch their outer neighbour pair from memory, and the few
+    // pairs that touch the periodic wrap or the pad element take the generic element-wise path.  The
+    // arithmetic (operand order included) is that of stencil_grad, so both paths give the same bits.
+    struct Pair {
+        double a, b;
+    };
+    __device__ __forceinline__ static Pair load_pair(const rsrc_t& rs, int i0) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 8, 0, 0);
+        return Pair{__longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x)),
+                    __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z))};
+    }
+    static constexpr int kDppWaveShr1 = 0x138;  // lane L reads lane L-1
+    static constexpr int kDppWaveShl1 = 0x130;  // lane L reads lane L+1
+
+    // Calls body(i0, g0, g1, s0, s1) for every pair this thread owns: g = d(-logLike)/dz at z + c s
+    // (at z when !USE_S), zero for the pad element; adds the pair's share of -2 logLike to facc.
+    template <bool USE_S, class F>
+    __device__ __forceinline__ void stencil_pairs(double c, double& facc, F&& body) {
+        const int N = (int)a.N, n = (int)a.ld, lane = tid & 63;
+        int t = tfirst;
+        asm volatile("" : "+v"(t));
+        auto ztf = [&](int k) {
+            double v = z.get(0, k);
+            if constexpr (USE_S) v = fma(c, s.get(0, k), v);
+            return v;
+        };
+        for (int i0 = 2 * t; i0 < n; i0 += 2 * pstride) {
+            const Pair zp = load_pair(z.rsrc, i0), xp = load_pair(x.rsrc, i0);
+            Pair sp{0.0, 0.0}, ztp = zp;
+            if constexpr (USE_S) {
+                sp = load_pair(s.rsrc, i0);
+                ztp = Pair{fma(c, sp.a, zp.a), fma(c, sp.b, zp.b)};
+            }
+            Pair ztL{dpp_move<kDppWaveShr1>(ztp.a), dpp_move<kDppWaveShr1>(ztp.b)};
+            Pair ztR{dpp_move<kDppWaveShl1>(ztp.a), dpp_move<kDppWaveShl1>(ztp.b)};
+            double xL = dpp_move<kDppWaveShr1>(xp.b), xR = dpp_move<kDppWaveShl1>(xp.a);
+            const bool interior = i0 >= 2 && i0 + 3 < N;  // the 6-element window has no wrap and no pad
+            if (lane == 0 && interior) {
+                ztL = load_pair(z.rsrc, i0 - 2);
+                if constexpr (USE_S) {
+                    const Pair sq = load_pair(s.rsrc, i0 - 2);
+                    ztL = Pair{fma(c, sq.a, ztL.a), fma(c, sq.b, ztL.b)};
+                }
+                xL = x.get(0, i0 - 1);
+            }
+            if (lane == 63 && interior) {
+                ztR = load_pair(z.rsrc, i0 + 2);
+                if constexpr (USE_S) {
+                    const Pair sq = load_pair(s.rsrc, i0 + 2);
+                    ztR = Pair{fma(c, sq.a, ztR.a), fma(c, sq.b, ztR.b)};
+                }
+                xR = x.get(0, i0 + 2);
+            }
+            double g0, g1;
+            if (interior) {
+                const double rm = xL - fma(0.25, ztL.a + ztp.a, 0.5 * ztL.b);    // r at i0-1
+                const double r0 = xp.a - fma(0.25, ztL.b + ztp.b, 0.5 * ztp.a);  // r at i0
+                const double r1 = xp.b - fma(0.25, ztp.a + ztR.a, 0.5 * ztp.b);  // r at i0+1
+                const double r2 = xR - fma(0.25, ztp.b + ztR.b, 0.5 * ztR.a);    // r at i0+2
+                const double t0 = ivk(i0) * ztp.a, t1 = ivk(i0 + 1) * ztp.b;
+                facc = fma(t0, ztp.a, fma(r0, r0, facc));
+                g0 = t0 - fma(0.25, rm + r1, 0.5 * r0);
+                facc = fma(t1, ztp.b, fma(r1, r1, facc));
+                g1 = t1 - fma(0.25, r0 + r2, 0.5 * r1);
+            } else {  // wrap-around or pad: element-wise with modular neighbour indices
+                double fi = facc;
+                g0 = stencil_grad(ztf, i0 < N ? i0 : 0, fi);
+                if (i0 < N) facc = fi;
+                else g0 = 0.0;
+                fi = facc;
+                g1 = stencil_grad(ztf, i0 + 1 < N ? i0 + 1 : 0, fi);
+                if (i0 + 1 < N) facc = fi;
+                else g1 = 0.0;
+            }
+            body(i0, g0, g1, sp.a, sp.b);
+        }
+    }
+
     // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
     //    dphi = grad . s and gmax = ||grad||_inf; the gradient itself is stored (into g) only when
     //    STORE_G -- a line-search trial needs just the three scalars.  One pass, one barrier.
@@ -611,21 +699,13 @@ struct Solver {
                 mx[0] = nanmax(mx[0], fabs(gi));
             });
         } else {
-            auto zt = [&](int k) {
-                double v = z.get(0, k);
-                if constexpr (USE_S) v = fma(c, s.get(0, k), v);
-                return v;
-            };
-            const int N = (int)a.N;
-            for_elems<T, EPT>(a.ld, tfirst, pstride, [&](int jj, int i) {
-                double fi = sum[0];
-                double gi = stencil_grad(zt, i < N ? i : 0, fi);
-                const bool valid = i < N;  // the pad element has no neighbours: keep it a phantom zero
-                gi = valid ? gi : 0.0;
-                sum[0] = valid ? fi : sum[0];
-                if constexpr (STORE_G) g.set(jj, i, gi);
-                if constexpr (USE_S) sum[1] = fma(gi, s.get(0, i), sum[1]);
-                mx[0] = nanmax(mx[0], fabs(gi));
+            stencil_pairs<USE_S>(c, sum[0], [&](int i0, double g0, double g1, double s0, double s1) {
+                if constexpr (STORE_G) {
+                    g.set(0, i0, g0);
+                    g.set(1, i0 + 1, g1);
+                }
+                if constexpr (USE_S) sum[1] = fma(g1, s1, fma(g0, s0, sum[1]));
+                mx[0] = nanmax(nanmax(mx[0], fabs(g0)), fabs(g1));
             });
         }
         reduce<2, 1>(sum, mx);
@@ -1118,19 +1198,22 @@ struct Solver {
                 });
                 if (keep) {
                     pass_barrier();  // neighbours' z must be complete before the stencil reads them
-                    auto zt = [&](int k) { return z.get(0, k); };
-                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
-                        double unused = 0.0;
-                        double gn = stencil_grad(zt, i < N ? i : 0, unused);  // N: see top of solve()
-                        gn = i < N ? gn : 0.0;
-                        const double dxi = dxs.get(jj, i);
-                        const double dgi = gn - g.get(jj, i);
-                        sum[0] = fma(dxi, dgi, sum[0]);
-                        sum[1] = fma(dgi, dgi, sum[1]);
-                        sum[2] = fma(dxi, gn, sum[2]);
-                        dgs.set(jj, i, dgi);
-                        g.set(jj, i, gn);
-                        s.set(jj, i, gn);
+                    double unused = 0.0;
+                    stencil_pairs<false>(0.0, unused, [&](int i0, double gn0, double gn1, double, double) {
+                        const double gnv[2] = {gn0, gn1};
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const int i = i0 + v;
+                            const double gn = gnv[v];
+                            const double dxi = dxs.get(v, i);
+                            const double dgi = gn - g.get(v, i);
+                            sum[0] = fma(dxi, dgi, sum[0]);
+                            sum[1] = fma(dgi, dgi, sum[1]);
+                            sum[2] = fma(dxi, gn, sum[2]);
+                            dgs.set(v, i, dgi);
+                            g.set(v, i, gn);
+                            s.set(v, i, gn);
+                        }
                     });
                 }
             }
@@ -1596,7 +1679,10 @@ static double theta_const(const muse_ctx* c, const double* theta) {
 enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5 };
 
 // Cluster size: a function of N alone (results must not depend on how many problems share a launch).
-static int cluster_size(int64_t N) { return N >= 4194304 ? 16 : (N >= kClusterMinN ? 4 : 1); }
+static int cluster_size(int64_t N) {
+    if (const char* e = getenv("MUSE_DEBUG_CLUSTER_SIZE")) return atoi(e);  // tuning aid
+    return N >= 4194304 ? 16 : (N >= kClusterMinN ? 4 : 1);
+}
 
 // Workgroup size is a function of N alone (256 threads for N <= 512, else 512), so that the
 // streaming and the resident policy reduce in the same order and give bitwise equal results.

@@ -57,6 +57,28 @@
 #include <omp.h>
 #endif
 
+/* Per-thread workspace: the work vectors of a solve are carved from a thread-local arena that is
+ * reserved once per thread and reused across sims (a malloc/mmap per vector per sim serialises in the
+ * kernel when many OpenMP threads run sims -- it only matters for the timed CPU baseline). */
+static __thread char* tl_arena = NULL;
+static __thread size_t tl_cap = 0, tl_off = 0;
+static void ws_reserve(int64_t N) {
+    const size_t need = ((size_t)(40 + 2 * 10) * (size_t)N + 1024) * sizeof(double);
+    if (need > tl_cap) {
+        free(tl_arena);
+        tl_arena = (char*)malloc(need);
+        tl_cap = need;
+        tl_off = 0;
+    }
+}
+static double* ws_alloc(size_t n) {
+    const size_t bytes = (n * sizeof(double) + 63) & ~(size_t)63;
+    if (tl_off + bytes > tl_cap) return (double*)malloc(bytes); /* falls back (never freed by ws_release) */
+    double* p = (double*)(tl_arena + tl_off);
+    tl_off += bytes;
+    return p;
+}
+
 #define MO_MODEL_FUNNEL 0 /* z_i ~ N(0, e^theta_k(i)), x_i ~ N(z_i, 1)          */
 #define MO_MODEL_NOISE 1  /* z_i ~ N(0, 1),            x_i ~ N(z_i, e^theta)     */
 #define MO_MODEL_SMOOTH 2 /* z as funnel, x = A z + n, A = periodic (1/4,1/2,1/4) */
@@ -560,20 +582,23 @@ static inline int mod1(int i, int m) { int r = i % m; return r == 0 ? m : r; }
 int mo_zhat_at_theta(int model, int64_t N, int ntheta, const double* x, const double* z0,
                      const double* theta, double atol, double* zout, mo_info* info) {
     size_t nb = (size_t)N * sizeof(double);
+    const int outermost = (tl_off == 0);
+    if (outermost) ws_reserve(N);
+    const size_t mark = tl_off;
     mo_obj d;
     d.model = model; d.ntheta = ntheta; d.N = N; d.x = x; d.theta = theta;
-    d.x_last = (double*)malloc(nb); d.g = (double*)malloc(nb);
+    d.x_last = ws_alloc(N); d.g = ws_alloc(N);
     d.have = 0; d.f_calls = 0; d.f = 0.0;
-    double* X = (double*)malloc(nb);
-    double* Xprev = (double*)malloc(nb);
-    double* gprev = (double*)malloc(nb);
-    double* s = (double*)malloc(nb);
-    double* q = (double*)malloc(nb);
-    double* dx = (double*)malloc(nb);
-    double* dg = (double*)malloc(nb);
-    double* x_ls = (double*)malloc(nb);
-    double* dxh = (double*)malloc(nb * LBFGS_M);
-    double* dgh = (double*)malloc(nb * LBFGS_M);
+    double* X = ws_alloc(N);
+    double* Xprev = ws_alloc(N);
+    double* gprev = ws_alloc(N);
+    double* s = ws_alloc(N);
+    double* q = ws_alloc(N);
+    double* dx = ws_alloc(N);
+    double* dg = ws_alloc(N);
+    double* x_ls = ws_alloc(N);
+    double* dxh = ws_alloc((size_t)N * LBFGS_M);
+    double* dgh = ws_alloc((size_t)N * LBFGS_M);
     double rho[LBFGS_M + 1], tl_alpha[LBFGS_M + 1];
     memcpy(X, z0, nb);
 
@@ -680,8 +705,7 @@ int mo_zhat_at_theta(int model, int64_t N, int ntheta, const double* x, const do
         info->gnorm = mo_maxabs(d.g, N);
         if (status <= MO_STATUS_F_CONVERGED && !isfinite(d.f)) info->status = MO_STATUS_NONFINITE;
     }
-    free(d.x_last); free(d.g); free(X); free(Xprev); free(gprev); free(s); free(q);
-    free(dx); free(dg); free(x_ls); free(dxh); free(dgh);
+    tl_off = mark;
     return 0;
 }
 
@@ -694,8 +718,11 @@ int mo_map_and_score(int model, int64_t N, int ntheta, uint64_t seed, int64_t si
                      const double* theta_sample, const double* theta, double atol, int z0_mode,
                      double* z_inout, double* g_out, mo_info* info) {
     size_t nb = (size_t)N * sizeof(double);
-    double* x = (double*)malloc(nb);
-    double* z0 = (double*)malloc(nb);
+    const int outermost = (tl_off == 0);
+    if (outermost) ws_reserve(N);
+    const size_t mark = tl_off;
+    double* x = ws_alloc(N);
+    double* z0 = ws_alloc(N);
     if (sim < 0) {
         memcpy(x, x_data, nb);
         if (z0_mode == 2) memcpy(z0, z_inout, nb);
@@ -707,7 +734,7 @@ int mo_map_and_score(int model, int64_t N, int ntheta, uint64_t seed, int64_t si
     }
     mo_zhat_at_theta(model, N, ntheta, x, z0, theta, atol, z_inout, info);
     mo_grad_theta(model, N, ntheta, x, z_inout, theta, g_out);
-    free(x); free(z0);
+    tl_off = mark;
     return 0;
 }
 
