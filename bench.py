@@ -62,15 +62,34 @@ def measured_traffic(workload):
     return None
 
 
+def usable_cores(limit):
+    """Threads the CPU baseline may really use: affinity mask and the cgroup CPU quota (cpu.max), whichever is smaller."""
+    n = limit
+    if hasattr(os, "sched_getaffinity"):
+        n = min(n, len(os.sched_getaffinity(0)))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(model, N, theta, seed, cpu_seconds=30.0):
     """Time the oracle on the host cores over a bounded number of sims of the same workload
     (about `cpu_seconds` of CPU work in total, OpenMP over sims on every core the process may use)."""
     from oracle import oracle as O
     O.build()
-    cores = O.num_threads()
-    if hasattr(os, "sched_getaffinity"):
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    cores = max(1, cores)
+    cores = usable_cores(O.num_threads())
     n1 = 32
     O.map_and_score_batch(model, N, seed, 0, 4, theta, atol=1e-2, z0_mode=0, nthreads=1)       # warm the library
     t0 = time.perf_counter()
