@@ -198,3 +198,46 @@ def test_get_H_implicit_diff_driver(gpu, M, O):
     np.testing.assert_allclose(a, res.H, rtol=0.05, atol=0.05 * np.abs(res.H).max())
     assert res.Sigma.shape == (2, 2)
     prob.close()
+
+
+_SHARD_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r})
+import numpy as np, torch.distributed as dist
+import museinference_jl_amd as M
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+x = np.load({xfile!r})
+local = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0), device=0)
+prob = M.ShardedMuseProblem(local)
+res = M.muse(prob, [1.0, 0.5], rng=3, nsims=21, maxsteps=4, get_covariance=True)
+with open({out!r} + str(rank), "wb") as f:
+    pickle.dump(dict(theta=res.theta, J=res.J, H=res.H, Sigma=res.Sigma, gs=np.array(res.gs)), f)
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_match_single_process(gpu, M, O, tmp_path):
+    """The sharded path on real kernels: two processes (gloo group, both on GPU 0) each solve their block of
+    the sims; every rank must reproduce the single-process result bit for bit."""
+    import pickle
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    x, _ = O.sample_x_z("funnel", 3000, 5, M.DATA_SIM, [0.0, 0.0])
+    xfile = str(tmp_path / "x.npy")
+    np.save(xfile, x)
+    out = str(tmp_path / "res")
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARD_WORKER.format(root=root, port=29700 + os.getpid() % 200, xfile=xfile, out=out))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2"))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    single = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+    ref = M.muse(single, [1.0, 0.5], rng=3, nsims=21, maxsteps=4, get_covariance=True)
+    for r in range(2):
+        got = pickle.load(open(out + str(r), "rb"))
+        for k, want in (("theta", ref.theta), ("J", ref.J), ("H", ref.H), ("Sigma", ref.Sigma), ("gs", np.array(ref.gs))):
+            assert np.array_equal(got[k], want), (r, k)
+    single.close()
