@@ -164,3 +164,31 @@ def test_cluster_stencil_many_clusters_under_load(gpu, M, O):
         np.testing.assert_allclose(g1[k], go[0], rtol=1e-10)
         np.testing.assert_allclose(z1[k], zo[0], rtol=0, atol=1e-9)
     prob.close()
+
+
+def test_fuzz_sizes_and_models(gpu, M, O):
+    """Edge sizes around every storage-policy boundary (256x1 | 512x4 | 512x10 resident, streaming, cluster),
+    odd and even N, every model and several theta dimensions, against the oracle."""
+    rng = np.random.default_rng(2024)
+    sizes = [1, 2, 3, 5, 6, 63, 64, 65, 511, 512, 513, 1023, 4095, 4096, 4097, 9999, 10000, 10001, 20001, 65535, 65536, 65537]
+    for N in sizes:
+        for model in ("funnel", "noise", "smooth"):
+            if model == "smooth" and N < 5:
+                continue
+            nth = 1 if model == "noise" else int(rng.choice([1, 2, 3, 4, 5, 8]))
+            nth = min(nth, N)
+            theta = rng.uniform(-1.0, 2.0, size=nth)
+            prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+            n = 3
+            seed, s0 = int(rng.integers(1, 2**40)), int(rng.integers(0, 1000))
+            g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=1e-4, z0_mode=0)
+            go, zo, io = O.map_and_score_batch(model, N, seed, s0, s0 + n, theta, atol=1e-4, z0_mode=0, nthreads=4)
+            ctx = f"{model} N={N} ntheta={nth}"
+            assert np.array_equal(info["iterations"], io["iterations"]) and np.array_equal(info["f_calls"], io["f_calls"]), ctx
+            assert np.array_equal(info["status"], io["status"]), ctx
+            np.testing.assert_allclose(g, go, rtol=1e-9, atol=1e-9, err_msg=ctx)
+            np.testing.assert_allclose(prob.get_zhat(0, n), zo, rtol=0, atol=1e-9, err_msg=ctx)
+            x, z = prob.sample_x_z(M.SimRng(seed, s0), theta)
+            xo, zz = O.sample_x_z(model, N, seed, s0, theta)
+            assert np.array_equal(x, xo) and np.array_equal(z, zz), ctx
+            prob.close()
