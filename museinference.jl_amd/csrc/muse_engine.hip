@@ -969,19 +969,19 @@ struct Solver {
                 // (still unused) g area and picked up into registers below.
 #pragma unroll 1
                 for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const int i = i0 + v;
-                        if (i < N) {
-                            const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
-                            double zt, xt;
-                            Model::sample(sdk(i), np.n1, np.n2, zt, xt);
-                            x.p[i] = xt;
-                            g.p[i] = zt;
-                        }
-                    }
+                    // both elements of the pair unconditionally (one basic block: their Philox/Box-Muller
+                    // chains interleave); for odd N the last pair's second element is the pad slot, kept at 0
+                    const NormalPair np0 = normal_pair(a.seed, sim, (uint64_t)i0);
+                    const NormalPair np1 = normal_pair(a.seed, sim, (uint64_t)(i0 + 1));
+                    double zt0, xt0, zt1, xt1;
+                    Model::sample(sdk(i0), np0.n1, np0.n2, zt0, xt0);
+                    Model::sample(sdk(i0 + 1), np1.n1, np1.n2, zt1, xt1);
+                    const bool valid1 = i0 + 1 < (int)N;
+                    x.p[i0] = xt0;
+                    g.p[i0] = zt0;
+                    x.p[i0 + 1] = valid1 ? xt1 : 0.0;
+                    g.p[i0 + 1] = valid1 ? zt1 : 0.0;
                 }
-                stamp(p, 8);
                 z.clear();
                 s.clear();
                 for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
