@@ -456,6 +456,7 @@ struct Solver {
     double iv0, sd0;   // MAXB == 1: coefficients in registers
     double* sh_sd;     // MAXB > 1: sampling sd[k] in LDS (the MAP iv[k] is read from the LDS argument block)
     int f_calls;
+    int iter_stamp, stamp_p;  // diagnostic build: which evaluation of the first line search
     double last_c, last_gmax;
     // element ownership: thread pairs tfirst + k*pstride (cluster mode: the cluster acts as one csize*T block)
     int tfirst, pstride;
@@ -771,7 +772,10 @@ struct Solver {
         bool ok = true;
         for (;;) {
             double phi, dphi;
+            if (iter_stamp < 3) stamp(stamp_p, 10 + 2 * iter_stamp);
             phidphi(c, phi, dphi);
+            if (iter_stamp < 3) stamp(stamp_p, 11 + 2 * iter_stamp);
+            iter_stamp += 1;
             const bool fin = finite2(phi, dphi);
             switch (state) {
                 case S_INIT:
@@ -1151,6 +1155,8 @@ struct Solver {
             last_phi = f;
             last_gmax = gmax;
             double alpha;
+            iter_stamp = iterations == 1 ? 0 : 99;
+            stamp_p = p;
             const bool ls_ok = linesearch(1.0, phi_0, dphi_0, alpha);
             if (iterations == 1) stamp(p, 4);
             // ---- update_g! / assess_convergence: the scalars at z + alpha s are those of the last

@@ -19,6 +19,8 @@ names = ["sample/load", "eval0", "twoloop(s=-g)", "linesearch", "update", "(loop
 print("median shader cycles per phase (wave 0):")
 for k, nm in enumerate(names): print(f"  {nm:16s} {np.median(d[:,k]):10.0f}   ({np.median(d[:,k])/np.median(st[:,7]-st[:,0])*100:5.1f} %)")
 print("  sample detail: start->sampler loop end", np.median(out[:,8].astype(np.int64)-st[:,0]), " ->z init end", np.median(out[:,9].astype(np.int64)-out[:,8].astype(np.int64)), " ->barrier end", np.median(st[:,1]-out[:,9].astype(np.int64)))
+o=out.astype(np.int64)
+print("  line search detail: pre-logic", np.median(o[:,10]-st[:,3]), " eval1", np.median(o[:,11]-o[:,10]), " logic1", np.median(o[:,12]-o[:,11]), " eval2", np.median(o[:,13]-o[:,12]), " post-logic", np.median(st[:,4]-o[:,13]))
 print("total per problem", np.median(st[:,7]-st[:,0]), "cycles; first start -> last end:", (st[:,7].max()-st[:,0].min()), "cycles")
 order = np.argsort(st[:,0]); 
 print("start offsets of problems (cycles, sorted) sample:", (st[order,0]-st[:,0].min())[[0,1,100,255,256,300,511]])
