@@ -128,10 +128,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    sharded = world > 1 or os.environ.get("MUSE_BENCH_FORCE_DIST") == "1"  # the env var exercises the N>1 path on one GPU
+    if sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     model, N, nth, theta, nsims = WORKLOADS[args.workload]
     seed = 0
@@ -140,35 +144,63 @@ def main():
         prob.set_placement(args.placement)
     sim0 = rank * nsims  # this rank's block of the global map
     gather_buf = None
-    if world > 1:
-        gather_buf = [torch.empty(nsims * nth, dtype=torch.float64, device="cuda") for _ in range(world)]
+    collective = None
+    if sharded:
+        # Preferred: the engine's own RCCL communicator (scores stay on the device, the all-gather runs on a
+        # second stream from C).  Fallback, agreed on by all ranks: torch.distributed's all_gather.
+        ok = 1
+        try:
+            uid = [M.HipMuseProblem.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            prob.comm_init(world, rank, uid[0])
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the fallback", on every rank
+            print(f"[bench rank {rank}] engine RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        collective = "rccl-capi" if int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch" else "torch"
+        if collective == "torch":
+            gather_buf = [torch.empty(nsims * nth, dtype=torch.float64, device="cuda") for _ in range(world)]
 
     AREAS = 4
+    host_t = [0.0, 0.0]  # host seconds spent enqueueing / waiting+collecting (reported under "host_us_per_step")
 
     def run_steps(K, collect=None):
         """K steps, software-pipelined: batch k is enqueued before batch k-1's results are awaited,
         so the GPU never idles on the host; with >1 GPU the all-gather of step k-1 overlaps batch k."""
         pending = []
         for k in range(K):
-            n = prob.map_and_score_batch_async(seed, sim0, sim0 + nsims, theta, atol=1e-2, z0_mode=M.Z0_ZERO,
-                                               result_area=k % AREAS)
+            t_enq0 = time.perf_counter()
+            if collective == "rccl-capi":
+                n = prob.map_and_score_batch_gather_async(seed, sim0, sim0 + nsims, theta, nsims, atol=1e-2,
+                                                          z0_mode=M.Z0_ZERO, result_area=k % AREAS)
+            else:
+                n = prob.map_and_score_batch_async(seed, sim0, sim0 + nsims, theta, atol=1e-2, z0_mode=M.Z0_ZERO,
+                                                   result_area=k % AREAS)
+            host_t[0] += time.perf_counter() - t_enq0
             pending.append((k % AREAS, n))
             if len(pending) > AREAS - 1:
+                t_w0 = time.perf_counter()
                 finish(pending.pop(0), collect)
+                host_t[1] += time.perf_counter() - t_w0
         while pending:
             finish(pending.pop(0), collect)
 
     def finish(item, collect):
         area, n = item
-        g, info = prob.batch_wait(n, area)
-        if world > 1:
-            t = torch.from_numpy(np.ascontiguousarray(g.reshape(-1))).cuda()
-            dist.all_gather(gather_buf, t)
+        if collective == "rccl-capi":
+            g_all, info = prob.batch_wait_gathered(n, nsims, area)  # [world, nsims, nth]: every rank holds all scores
+            g = g_all[rank]
+        else:
+            g, info = prob.batch_wait(n, area)
+            if collective == "torch":
+                t = torch.from_numpy(np.ascontiguousarray(g.reshape(-1))).cuda()
+                dist.all_gather(gather_buf, t)
         if collect is not None:
             collect.append((g, info))
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
         prob.synchronize()
@@ -178,11 +210,13 @@ def main():
     run_steps(args.warmup)
     barrier()
     results = []
+    host_t[0] = host_t[1] = 0.0
     t0 = time.perf_counter()
     run_steps(args.steps, results)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    host_us = {"enqueue": 1e6 * host_t[0] / args.steps, "wait_and_collect": 1e6 * host_t[1] / args.steps}
+    if sharded:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -216,7 +250,8 @@ def main():
         "config": {"workload": f"{args.workload}: Neal's funnel family model={model}, N={N}-dim z, {nth}-dim theta, "
                                f"nsims={nsims} per GPU per step, cold start z0=0, atol=1e-2",
                    "theta": theta, "sims_per_step_total": world * nsims,
-                   "parallelism": f"sims sharded over {world} GPU(s), one all-gather of scores per step"},
+                   "parallelism": f"sims sharded over {world} GPU(s), one all-gather of scores per step"
+                                  + (f" ({collective})" if collective else "")},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
@@ -227,13 +262,15 @@ def main():
                         "hist_pairs_mean": float(info["hist_words"].mean())},
         },
         "kernel_sims_per_s": nsims / mean_kernel_s,
+        "host_us_per_step": host_us,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, N, theta, seed)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
+        prob.close()
         dist.destroy_process_group()
 
 

@@ -180,6 +180,18 @@ int muse_comm_destroy(muse_ctx* ctx);
 int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, double* recv_out);
 /* in-place sum over ranks of count doubles (host) */
 int muse_allreduce_sum(muse_ctx* ctx, double* buf, int64_t count);
+/* The sharded map body (the pmap of src/muse.jl:169-176 / :508-525 over a pool of GPUs, src/util.jl:74-83):
+ * this rank's block [sim_begin, sim_end) (plus the data element where include_data) is solved exactly as
+ * by muse_map_and_score_batch_async, but the scores stay on the device and the per-rank blocks are
+ * all-gathered by RCCL on a stream of the communicator's own, so that the collective of batch k overlaps
+ * the solver launch of batch k+1 and no host copy sits between solver and collective.  Every rank passes
+ * the same rows_per_rank >= its own element count; shorter blocks are zero-padded.
+ * muse_batch_wait_gathered blocks until the area's gathered block has landed: g_all_out is
+ * [nranks][rows_per_rank][ntheta] host, info_out this rank's own [n] infos (may be NULL). */
+int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                                          int include_data, const double* theta, double atol, int z0_mode,
+                                          int64_t rows_per_rank, int result_area);
+int muse_batch_wait_gathered(muse_ctx* ctx, int result_area, double* g_all_out, muse_info* info_out);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,8 @@ SIGNATURES = {
     "muse_comm_destroy": (_i, [_vp]),
     "muse_allgather_scores": (_i, [_vp, _vp, _i64, _vp]),
     "muse_allreduce_sum": (_i, [_vp, _vp, _i64]),
+    "muse_map_and_score_batch_gather_async": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _i64, _i]),
+    "muse_batch_wait_gathered": (_i, [_vp, _i, _vp, _vp]),
 }
 
 _lib = None

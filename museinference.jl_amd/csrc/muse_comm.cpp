@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -35,7 +36,26 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
-thread_local std::string g_comm_err;
+
+constexpr int kAreas = 4;  // result areas of the engine (muse_hip.h: result_area in [0, 4))
+// One per context/rank: the communicator, a stream of its own for the collectives (so that the
+// all-gather of batch k overlaps the solver launch of batch k+1), and per result area the device
+// send/receive buffers plus a pinned host landing block.
+struct CommState {
+    ncclComm_t comm = nullptr;
+    int nranks = 1;
+    hipStream_t cstream = nullptr;
+    bool own_stream = true;
+    bool direct_host = false;
+    double* send_dev[kAreas] = {nullptr};
+    double* recv_dev[kAreas] = {nullptr};
+    double* recv_pin[kAreas] = {nullptr};
+    size_t cap[kAreas] = {0};      // doubles per rank
+    size_t count[kAreas] = {0};    // doubles per rank of the gather in flight
+    hipEvent_t kdone[kAreas] = {nullptr};  // solver launch of the area finished (recorded on the solver stream)
+    hipEvent_t gdone[kAreas] = {nullptr};  // gathered block landed in recv_pin (recorded on cstream)
+    bool pending[kAreas] = {false};
+};
 
 bool load_rccl() {
     if (g_rccl.h) return true;
@@ -60,7 +80,19 @@ bool load_rccl() {
 extern "C" {
 int muse_ctx_comm_slot(muse_ctx* ctx, void*** comm, int* device, void** stream);
 int muse_ctx_comm_buffer(muse_ctx* ctx, size_t doubles, double** buf);
+int muse_ctx_area_event(muse_ctx* ctx, int area, void** event, int* ntheta);
+int muse_internal_map_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                            const double* theta, double atol, int z0_mode, int area, double* scores_dev);
 int muse_set_error(int code, const char* msg);
+}
+
+static CommState* state_of(muse_ctx* ctx, void** stream_out = nullptr) {
+    void** slot;
+    int device;
+    void* stream;
+    if (muse_ctx_comm_slot(ctx, &slot, &device, &stream)) return nullptr;
+    if (stream_out) *stream_out = stream;
+    return (CommState*)*slot;
 }
 
 #define RCCLCHK(expr)                                                                                     \
@@ -103,7 +135,25 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     memcpy(&uid, id, MUSE_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
     RCCLCHK(g_rccl.CommInitRank(&comm, nranks, uid, rank));
-    *slot = comm;
+    CommState* st = new CommState();
+    st->comm = comm;
+    st->nranks = nranks;
+    if (getenv("MUSE_COMM_ONE_STREAM")) st->cstream = (hipStream_t)stream;  // tuning aid: collectives in line with the solver
+    else {
+        // Highest priority: the persistent solver kernel fills every CU (LDS- and VGPR-bound, nothing can
+        // co-reside), so a collective can only be dispatched in the gap between two solver launches -- with
+        // default priority it loses that race to the next solver launch (measured: 86 vs 73 us per step).
+        int lo = 0, hi = 0;
+        HIPCHK2(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK2(hipStreamCreateWithPriority(&st->cstream, hipStreamNonBlocking, hi));
+    }
+    st->direct_host = getenv("MUSE_COMM_DIRECT_HOST") != nullptr;
+    st->own_stream = st->cstream != (hipStream_t)stream;
+    for (int a = 0; a < kAreas; ++a) {
+        HIPCHK2(hipEventCreateWithFlags(&st->kdone[a], hipEventDisableTiming));
+        HIPCHK2(hipEventCreateWithFlags(&st->gdone[a], hipEventDisableTiming));
+    }
+    *slot = st;
     return MUSE_OK;
 }
 
@@ -113,7 +163,20 @@ int muse_comm_destroy(muse_ctx* ctx) {
     void* stream;
     int rc = muse_ctx_comm_slot(ctx, &slot, &device, &stream);
     if (rc) return rc;
-    if (*slot && g_rccl.h) g_rccl.CommDestroy((ncclComm_t)*slot);
+    if (CommState* st = (CommState*)*slot) {
+        hipSetDevice(device);
+        if (st->cstream) hipStreamSynchronize(st->cstream);
+        if (st->comm && g_rccl.h) g_rccl.CommDestroy(st->comm);
+        for (int a = 0; a < kAreas; ++a) {
+            hipFree(st->send_dev[a]);
+            hipFree(st->recv_dev[a]);
+            hipHostFree(st->recv_pin[a]);
+            if (st->kdone[a]) hipEventDestroy(st->kdone[a]);
+            if (st->gdone[a]) hipEventDestroy(st->gdone[a]);
+        }
+        if (st->cstream && st->own_stream) hipStreamDestroy(st->cstream);
+        delete st;
+    }
     *slot = nullptr;
     return MUSE_OK;
 }
@@ -127,16 +190,14 @@ int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, doub
     if (!*slot) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
     if (!send || !recv_out || count < 0) return muse_set_error(MUSE_ERR_INVALID, "bad arguments");
     if (count == 0) return MUSE_OK;
-    typedef ncclResult_t (*CountFn)(ncclComm_t, int*);
-    CountFn cnt = (CountFn)dlsym(g_rccl.h, "ncclCommCount");
-    if (!cnt) return muse_set_error(MUSE_ERR_RCCL, "ncclCommCount missing");
-    RCCLCHK(cnt((ncclComm_t)*slot, &nranks));
+    ncclComm_t comm = ((CommState*)*slot)->comm;
+    nranks = ((CommState*)*slot)->nranks;
     double* buf;
     rc = muse_ctx_comm_buffer(ctx, (size_t)count * (size_t)(nranks + 1), &buf);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK2(hipMemcpyAsync(buf, send, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
-    RCCLCHK(g_rccl.AllGather(buf, buf + count, (size_t)count, ncclFloat64, (ncclComm_t)*slot, st));
+    RCCLCHK(g_rccl.AllGather(buf, buf + count, (size_t)count, ncclFloat64, comm, st));
     HIPCHK2(hipMemcpyAsync(recv_out, buf + count, (size_t)count * nranks * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK2(hipStreamSynchronize(st));
     return MUSE_OK;
@@ -156,10 +217,79 @@ int muse_allreduce_sum(muse_ctx* ctx, double* hostbuf, int64_t count) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK2(hipMemcpyAsync(buf, hostbuf, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
-    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)*slot, st));
+    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat64, ncclSum, ((CommState*)*slot)->comm, st));
     HIPCHK2(hipMemcpyAsync(hostbuf, buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK2(hipStreamSynchronize(st));
     return MUSE_OK;
+}
+
+// ---- sharded map: solver launch + device-side all-gather, pipelined over the result areas ------------
+static int ensure_gather_buffers(CommState* st, int area, size_t doubles_per_rank) {
+    if (doubles_per_rank <= st->cap[area]) return MUSE_OK;
+    HIPCHK2(hipStreamSynchronize(st->cstream));
+    hipFree(st->send_dev[area]);
+    hipFree(st->recv_dev[area]);
+    hipHostFree(st->recv_pin[area]);
+    st->send_dev[area] = st->recv_dev[area] = st->recv_pin[area] = nullptr;
+    st->cap[area] = 0;
+    const size_t cap = doubles_per_rank + doubles_per_rank / 2 + 16;
+    if (hipMalloc(&st->send_dev[area], cap * sizeof(double)) != hipSuccess ||
+        hipMalloc(&st->recv_dev[area], cap * st->nranks * sizeof(double)) != hipSuccess)
+        return muse_set_error(MUSE_ERR_ALLOC, "hipMalloc(gather buffers) failed");
+    HIPCHK2(hipHostMalloc(&st->recv_pin[area], cap * st->nranks * sizeof(double), hipHostMallocDefault));
+    st->cap[area] = cap;
+    return MUSE_OK;
+}
+
+int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                                          int include_data, const double* theta, double atol, int z0_mode,
+                                          int64_t rows_per_rank, int area) {
+    void* stream = nullptr;
+    CommState* st = state_of(ctx, &stream);
+    if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
+    void* area_ev = nullptr;
+    int nt = 0;
+    int rc = muse_ctx_area_event(ctx, area, &area_ev, &nt);
+    if (rc) return rc;
+    const int64_t n = (sim_end - sim_begin) + (include_data ? 1 : 0);
+    if (sim_end < sim_begin || rows_per_rank < n || rows_per_rank < 1)
+        return muse_set_error(MUSE_ERR_INVALID, "rows_per_rank must be >= this rank's element count (and >= 1)");
+    const size_t cnt = (size_t)rows_per_rank * (size_t)nt;
+    rc = ensure_gather_buffers(st, area, cnt);
+    if (rc) return rc;
+    hipStream_t ks = (hipStream_t)stream;
+    // the area's previous gather must have drained its send buffer before the solver overwrites it
+    if (st->pending[area]) HIPCHK2(hipStreamWaitEvent(ks, st->gdone[area], 0));
+    if ((size_t)n * nt < cnt)  // padding rows of a short block are zeros
+        HIPCHK2(hipMemsetAsync(st->send_dev[area] + (size_t)n * nt, 0, (cnt - (size_t)n * nt) * sizeof(double), ks));
+    rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area,
+                                 st->send_dev[area]);
+    if (rc) return rc;
+    HIPCHK2(hipEventRecord(st->kdone[area], ks));
+    HIPCHK2(hipStreamWaitEvent(st->cstream, st->kdone[area], 0));
+    if (st->direct_host) {
+        // the collective's receive buffer IS the pinned host block (device-mapped): no copy operation follows
+        RCCLCHK(g_rccl.AllGather(st->send_dev[area], st->recv_pin[area], cnt, ncclFloat64, st->comm, st->cstream));
+    } else {
+        RCCLCHK(g_rccl.AllGather(st->send_dev[area], st->recv_dev[area], cnt, ncclFloat64, st->comm, st->cstream));
+        HIPCHK2(hipMemcpyAsync(st->recv_pin[area], st->recv_dev[area], cnt * st->nranks * sizeof(double),
+                               hipMemcpyDeviceToHost, st->cstream));
+    }
+    HIPCHK2(hipEventRecord(st->gdone[area], st->cstream));
+    st->count[area] = cnt;
+    st->pending[area] = true;
+    return MUSE_OK;
+}
+
+int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_info* info_out) {
+    CommState* st = state_of(ctx);
+    if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
+    if (area < 0 || area >= kAreas) return muse_set_error(MUSE_ERR_INVALID, "bad result_area");
+    if (!st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "no gather in flight on this result area");
+    HIPCHK2(hipEventSynchronize(st->gdone[area]));
+    st->pending[area] = false;
+    if (g_all_out) memcpy(g_all_out, st->recv_pin[area], st->count[area] * st->nranks * sizeof(double));
+    return muse_batch_wait(ctx, area, nullptr, info_out);  // the solver's own completion, error flag, local infos
 }
 
 }  // extern "C"

@@ -1952,6 +1952,12 @@ int muse_ctx_comm_slot(muse_ctx* c, void*** comm, int* device, void** stream) {
     *stream = (void*)c->stream;
     return MUSE_OK;
 }
+int muse_ctx_area_event(muse_ctx* c, int area, void** event, int* ntheta) {
+    if (!c || area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
+    *event = (void*)c->area_done[area];
+    *ntheta = c->ntheta;
+    return MUSE_OK;
+}
 int muse_ctx_comm_buffer(muse_ctx* c, size_t doubles, double** buf) {
     if (doubles > c->comm_buf_doubles) {
         if (c->comm_buf) HIPCHK(hipFree(c->comm_buf));
@@ -2209,8 +2215,11 @@ int muse_zhat_at_theta(muse_ctx* c, const double* x, const double* z0, const dou
     return MUSE_OK;
 }
 
-int muse_map_and_score_batch_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
-                                   const double* theta, double atol, int z0_mode, int area) {
+// The batched map with the scores directed at `scores_dev` (any device-accessible buffer of n*ntheta
+// doubles; NULL = the area's pinned host block).  muse_comm.cpp points it at the send buffer of the
+// RCCL all-gather so that the scores never visit the host between the solver and the collective.
+int muse_internal_map_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                            const double* theta, double atol, int z0_mode, int area, double* scores_dev) {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!theta) return fail(MUSE_ERR_INVALID, "theta is NULL");
@@ -2236,11 +2245,16 @@ int muse_map_and_score_batch_async(muse_ctx* c, uint64_t seed, int64_t sim_begin
     a.store_zhat = 1;
     a.sim_begin = sim_begin;
     a.slot0 = 0;
-    a.scores = c->scores_dev[area];
+    a.scores = scores_dev ? scores_dev : c->scores_dev[area];
     a.info = c->info_dev[area];
     rc = launch_batch(c, a);
     if (rc) return rc;
     return enqueue_results_copy(c, area, n);
+}
+
+int muse_map_and_score_batch_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                                   const double* theta, double atol, int z0_mode, int area) {
+    return muse_internal_map_async(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, nullptr);
 }
 
 int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {

@@ -363,6 +363,23 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_allgather_scores(self._ctx, _capi.ptr(send), send.size, _capi.ptr(recv)))
         return recv
 
+    def map_and_score_batch_gather_async(self, rng, sim_begin, sim_end, theta, rows_per_rank, *, include_data=False,
+                                         atol=1e-2, z0_mode=_capi.Z0_ZERO, result_area=0):
+        """This rank's block of a sharded map; the score blocks of all ranks are all-gathered on the device
+        (RCCL, on the communicator's own stream).  Returns this rank's element count."""
+        th = self._theta(theta)
+        _capi.check(self._lib.muse_map_and_score_batch_gather_async(
+            self._ctx, _seed_of(rng), sim_begin, sim_end, int(bool(include_data)), _capi.ptr(th), float(atol),
+            int(z0_mode), int(rows_per_rank), int(result_area)))
+        return (sim_end - sim_begin) + (1 if include_data else 0)
+
+    def batch_wait_gathered(self, n, rows_per_rank, result_area=0):
+        """(g_all [nranks, rows_per_rank, nθ], this rank's info [n]) of the gather enqueued on result_area."""
+        g = np.empty((self._nranks, int(rows_per_rank), self.ntheta))
+        info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_batch_wait_gathered(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
+        return g, info
+
     def allreduce_sum(self, buf):
         buf = _capi.f8(buf).copy()
         _capi.check(self._lib.muse_allreduce_sum(self._ctx, _capi.ptr(buf), buf.size))

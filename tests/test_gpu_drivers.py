@@ -165,6 +165,37 @@ def test_rccl_single_rank(gpu, M):
     p.close()
 
 
+def test_gathered_map_single_rank_matches_plain_map(gpu, M):
+    """The sharded map body (solver -> device-side RCCL all-gather on a second stream -> pinned host), one
+    rank: identical scores/infos to the plain batched map, padding rows zero, areas pipelined and reused."""
+    N, nth, theta = 10000, 4, [1.0, 0.5, -0.5, 2.0]
+    x = np.random.default_rng(3).normal(size=N)
+    p = M.HipMuseProblem(x, model="funnel", ntheta=nth)
+    p.comm_init(1, 0, M.HipMuseProblem.comm_unique_id())
+    ref = [p.map_and_score_batch(0, b, b + 24, theta, include_data=(b == 0)) for b in (0, 24, 48, 72, 96, 120)]
+    rows = 32
+    pend = []
+    out = []
+    for k, b in enumerate((0, 24, 48, 72, 96, 120)):
+        n = p.map_and_score_batch_gather_async(0, b, b + 24, theta, rows, include_data=(b == 0), result_area=k % 4)
+        pend.append((n, k % 4))
+        if len(pend) > 3:
+            out.append(p.batch_wait_gathered(pend[0][0], rows, pend[0][1]) + (pend[0][0],))
+            pend.pop(0)
+    for n, area in pend:
+        out.append(p.batch_wait_gathered(n, rows, area) + (n,))
+    for (g_all, info, n), (g, inf) in zip(out, ref):
+        assert g_all.shape == (1, rows, nth)
+        assert np.array_equal(g_all[0, :n], g)
+        assert np.all(g_all[0, n:] == 0.0)
+        assert np.array_equal(info, inf)
+    with pytest.raises(M.MuseError):
+        p.batch_wait_gathered(1, rows, 0)          # nothing in flight on that area any more
+    with pytest.raises(M.MuseError):
+        p.map_and_score_batch_gather_async(0, 0, 24, theta, 8)   # rows_per_rank below the element count
+    p.close()
+
+
 @pytest.mark.parametrize("model,N,nth,theta", [
     ("funnel", 512, 1, [0.3]), ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0]), ("noise", 3001, 1, [0.4]),
     ("smooth", 2000, 3, [1.0, 2.0, 0.5]), ("funnel", 70001, 2, [0.3, 0.1]), ("smooth", 66001, 2, [1.0, 2.5])])
