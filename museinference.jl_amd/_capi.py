@@ -72,7 +72,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    """The in-tree library; MUSE_HIP_LIB names an alternative build of the same sources (diagnostic builds)."""
+    return os.environ.get("MUSE_HIP_LIB") or _build.LIB_PATH
 
 
 def load_library():

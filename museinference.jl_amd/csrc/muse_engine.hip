@@ -174,62 +174,97 @@ struct RegVec {
 #pragma unroll
         for (int j = 0; j < (NR > 0 ? NR : 1); ++j) r[j] = 0.0;
     }
-};
-// ST_AUX: cache policy of the stores (0 default; 16 = sc1, write-through: used in cluster mode so that the
-// XCD's L2 holds no dirty vector lines when a cluster reduction releases)
-template <int ST_AUX = 0>
-struct BufVecT {  // a vector in HBM: buffer_load/store_dwordx2 with hardware range check
-    rsrc_t rsrc;
-    __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
-    __device__ __forceinline__ double get(int, int i) const {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, i * 8, 0, 0);
-        return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
-    }
-    __device__ __forceinline__ void set(int, int i, double d) {
-        const long long b = __double_as_longlong(d);
-        u32x2 v;
-        v.x = (unsigned)(b & 0xffffffffll);
-        v.y = (unsigned)(b >> 32);
-        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, i * 8, 0, ST_AUX);
-    }
-    __device__ __forceinline__ void clear() {}
+    template <int UU>
+    __device__ __forceinline__ void flush(int, int) {}
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// Streaming policy, elementwise models: the element loop visits a thread's two adjacent elements
-// (jj even then jj odd) back to back, so the pair moves with ONE 16-byte buffer instruction: the load
-// is issued at jj = 0 and its second half served at jj = 1; a store is staged at jj = 0 and issued at
-// jj = 1 (buffer_load/store_dwordx4, 1 KiB per wave-instruction).
-template <int ST_AUX = 0>
-struct BufVec2T {
+__device__ __forceinline__ int off8(int i) { return (int)((unsigned)i << 3); }  // byte offset of element i (may exceed 2^31: unsigned)
+__device__ __forceinline__ double load_f64(const rsrc_t& rs, int i) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off8(i), 0, 0);
+    return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+}
+__device__ __forceinline__ void load_f64x2(const rsrc_t& rs, int i, double& d0, double& d1) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off8(i), 0, 0);
+    d0 = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+    d1 = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+}
+__device__ __forceinline__ void store_f64x2(const rsrc_t& rs, int i, double d0, double d1) {
+    const long long b0 = __double_as_longlong(d0), b1 = __double_as_longlong(d1);
+    u32x4 v;
+    v.x = (unsigned)(b0 & 0xffffffffll);
+    v.y = (unsigned)(b0 >> 32);
+    v.z = (unsigned)(b1 & 0xffffffffll);
+    v.w = (unsigned)(b1 >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off8(i), 0, 0);
+}
+// A vector in HBM, resident policy (history pairs, zhat): the element loop visits a thread's two
+// adjacent elements (jj even then jj odd) back to back, so the pair moves with ONE 16-byte buffer
+// instruction: the load is issued at jj even and its second half served at jj odd; a store is staged at
+// jj even and issued at jj odd (buffer_load/store_dwordx4, 1 KiB per wave-instruction).
+struct BufVec2 {
     rsrc_t rsrc;
     mutable double c0, c1;
     __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
     __device__ __forceinline__ double get(int jj, int i) const {
         if ((jj & 1) == 0) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i * 8, 0, 0);
-            c0 = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
-            c1 = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+            load_f64x2(rsrc, i, c0, c1);
             return c0;
         }
         return c1;
     }
     __device__ __forceinline__ void set(int jj, int i, double d) {
-        if ((jj & 1) == 0) {
-            c0 = d;
-        } else {
-            const long long b0 = __double_as_longlong(c0), b1 = __double_as_longlong(d);
-            u32x4 v;
-            v.x = (unsigned)(b0 & 0xffffffffll);
-            v.y = (unsigned)(b0 >> 32);
-            v.z = (unsigned)(b1 & 0xffffffffll);
-            v.w = (unsigned)(b1 >> 32);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (i - 1) * 8, 0, ST_AUX);
-        }
+        if ((jj & 1) == 0) c0 = d;
+        else store_f64x2(rsrc, i - 1, c0, d);
     }
     __device__ __forceinline__ void clear() {}
+    template <int UU>
+    __device__ __forceinline__ void flush(int, int) {}
 };
-using BufVec = BufVecT<0>;
-using BufVec2 = BufVec2T<0>;
+// A vector in HBM, streaming policy.  A streaming pass handles U of a thread's pairs per trip
+// ("chunk", jj = 2u, 2u+1): gets are 16-byte loads issued where they appear, sets are STAGED in
+// registers and written by flush() after the chunk's U element bodies have run.  Inside a chunk no
+// store sits between the loads, so the compiler issues all of the chunk's loads back to back and a wave
+// has U x (vectors read) 1-KiB requests in flight per trip -- with the stores interleaved (hipcc cannot
+// prove the buffers distinct) every pair's loads waited for the previous pair's store to issue and a
+// pass paid one memory round trip per pair.  get1() is an 8-byte load at an arbitrary element (stencil
+// neighbours).
+template <int U>
+struct BufChunk {
+    rsrc_t rsrc;
+    mutable double c1[U];
+    double st[2 * U];
+    __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
+    __device__ __forceinline__ double get(int jj, int i) const {
+        if ((jj & 1) == 0) {
+            double d0;
+            load_f64x2(rsrc, i, d0, c1[jj >> 1]);
+            return d0;
+        }
+        return c1[jj >> 1];
+    }
+    __device__ __forceinline__ double get1(int i) const { return load_f64(rsrc, i); }
+    __device__ __forceinline__ void set(int jj, int, double d) { st[jj] = d; }
+    __device__ __forceinline__ void clear() {}
+    // the UU (<= U) pairs i0, i0 + 2*pstride, ... of the trip that started at element i0
+    template <int UU>
+    __device__ __forceinline__ void flush(int i0, int pstride) {
+        static_assert(UU <= U, "trip longer than the staging area");
+#pragma unroll
+        for (int u = 0; u < UU; ++u) store_f64x2(rsrc, i0 + 2 * u * pstride, st[2 * u], st[2 * u + 1]);
+    }
+};
+// flush-list entry for a vector that a pass writes only under a (workgroup-uniform) condition
+template <class V>
+struct FlushIf {
+    V& v;
+    bool on;
+    template <int UU>
+    __device__ __forceinline__ void flush(int i0, int pstride) {
+        if (on) v.template flush<UU>(i0, pstride);
+    }
+};
+template <class V>
+__device__ __forceinline__ FlushIf<V> when(bool on, V& v) { return FlushIf<V>{v, on}; }
 struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
     lds_double* p;
     int ld;
@@ -240,15 +275,20 @@ struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
     __device__ __forceinline__ double get(int, int i) const { return p[i < ld ? i : ld]; }
     __device__ __forceinline__ void set(int, int i, double v) { p[i < ld ? i : ld] = v; }
     __device__ __forceinline__ void clear() {}
+    template <int UU>
+    __device__ __forceinline__ void flush(int, int) {}
 };
 
 // Element loop of one thread: pairs q = tid + j*T, elements 2q and 2q+1, in increasing j; no bounds
 // checks (see above).  EPT > 0: compile-time trip count, fully unrolled (register slots are static).
+// EPT == 0 (streaming): U pairs per trip with jj = 2u, 2u+1; the vectors the pass writes are listed
+// after the body and flushed once per trip (BufChunk).  A trip may reach up to U-1 pairs past the end
+// of the vector: those are phantom zeros like every other out-of-range slot.
 // Element indices are 32-bit (N < 2^28), and tid is laundered through an empty asm so that the
 // per-slot offsets are recomputed in each pass (two integer ops) instead of being hoisted out of
 // the persistent loop and held -- or spilled -- for the kernel's lifetime.
-template <int T, int EPT, class F>
-__device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F&& f) {
+template <int T, int EPT, int U, class F, class... W>
+__device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F&& f, W&&... written) {
     int t = tfirst;
     asm volatile("" : "+v"(t));
     if constexpr (EPT > 0) {
@@ -262,10 +302,15 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F
     } else {
         // streaming: pairs tfirst, tfirst + pstride, ... (pstride = T, or csize*T in cluster mode)
         const int n = (int)ld;
-#pragma unroll 4
-        for (int i0 = 2 * t; i0 < n; i0 += 2 * pstride) {
-            f(0, i0);
-            f(1, i0 + 1);
+#pragma unroll 1
+        for (int i0 = 2 * t; i0 < n; i0 += 2 * U * pstride) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 2 * u * pstride;
+                f(2 * u, i);
+                f(2 * u + 1, i + 1);
+            }
+            (written.template flush<U>(i0, pstride), ...);
         }
     }
 }
@@ -411,20 +456,21 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
 
 // ------------------------------------------------------------------------------------------------
 // Storage policies.
-template <int T_, bool PAIRS = true, bool CLUSTER = false>
+template <int T_, bool CLUSTER = false, int U_ = 4>
 struct PlaceStreaming {
-    static constexpr int T = T_, EPT = 0;
+    static constexpr int T = T_, EPT = 0, U = U_;  // U pairs of a thread per trip of a streaming pass
+    // two waves per SIMD: 2 workgroups of 256 threads (cluster mode sizes its grid from that) or 1 of 512 per CU,
+    // i.e. a budget of 256 registers per lane
+    static constexpr int kWavesPerEu = 2;
     static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
-    // a get and a set of the same vector in one pass use separate accessor objects (VH), so the
-    // staged half of a store never aliases the cached half of a load
-    static constexpr int kStAux = 0;  // (sc1 write-through stores in cluster mode were measured slower)
-    using VX = typename std::conditional<PAIRS, BufVec2T<kStAux>, BufVecT<kStAux>>::type;
+    using VX = BufChunk<U_>;
     using VG = VX; using VZ = VX; using VS = VX;
     using VH = VX;
 };
 template <int T_, int EPT_, bool XG_LDS>
 struct PlaceResident {
-    static constexpr int T = T_, EPT = EPT_;
+    static constexpr int T = T_, EPT = EPT_, U = 1;
+    static constexpr int kWavesPerEu = 1;  // no lower bound beyond the launch bounds
     static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = false;
     using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
@@ -440,7 +486,7 @@ struct HzPoint {
 // ------------------------------------------------------------------------------------------------
 template <class Model, class Place>
 struct Solver {
-    static constexpr int T = Place::T, EPT = Place::EPT, MAXB = Model::MAXB;
+    static constexpr int T = Place::T, EPT = Place::EPT, U = Place::U, MAXB = Model::MAXB;
     const BatchArgs& a;
     const int tid;
     double* red;
@@ -584,99 +630,121 @@ struct Solver {
     }
 
     // d(-logLike)/dz_i at the point whose components are given by zt(.), for the stencil model
-    // (streaming only: neighbours come from HBM/L1).  Adds the element's share of -2 logLike to facc.
+    // (streaming only: neighbours come from HBM/L1).  The element's share of -2 logLike is
+    // fma(t, z0, fma(r0, r0, .)) with the returned (t, z0, r0).
     template <class ZT>
-    __device__ __forceinline__ double stencil_grad(ZT&& zt, int i, double& facc) const {
+    __device__ __forceinline__ double stencil_grad(ZT&& zt, int i, double& t_out, double& z_out, double& r_out) const {
         const int N = (int)a.N;
         auto wrap = [&](int k) { return k < 0 ? k + N : (k >= N ? k - N : k); };
         const int im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
         const double zm2 = zt(im2), zm1 = zt(im1), z0 = zt(i), zp1 = zt(ip1), zp2 = zt(ip2);
-        const double rm = x.get(0, im1) - fma(0.25, zm2 + z0, 0.5 * zm1);
-        const double r0 = x.get(0, i) - fma(0.25, zm1 + zp1, 0.5 * z0);
-        const double rp = x.get(0, ip1) - fma(0.25, z0 + zp2, 0.5 * zp1);
+        const double rm = x.get1(im1) - fma(0.25, zm2 + z0, 0.5 * zm1);
+        const double r0 = x.get1(i) - fma(0.25, zm1 + zp1, 0.5 * z0);
+        const double rp = x.get1(ip1) - fma(0.25, z0 + zp2, 0.5 * zp1);
         const double t = this->ivk(i) * z0;
-        facc = fma(t, z0, fma(r0, r0, facc));
+        t_out = t;
+        z_out = z0;
+        r_out = r0;
         return t - fma(0.25, rm + rp, 0.5 * r0);
     }
 
     // ---- stencil model, pair-wise --------------------------------------------------------------
     // A lane loads its own element pair of z, s, x with one 16-byte buffer instruction each and gets the
     // neighbouring pairs from the adjacent lanes with DPP wave shifts (lanes of a wave own consecutive
-    // pairs); only the two edge lanes of a wave fetch their outer neighbour pair from memory, and the few
-    // pairs that touch the periodic wrap or the pad element take the generic element-wise path.  The
-    // arithmetic (operand order included) is that of stencil_grad, so both paths give the same bits.
+    // pairs); the two edge lanes of a wave fetch their outer neighbour pair from memory with loads that
+    // every lane issues but whose offset is out of range (no memory access) for the 62 inner lanes, and
+    // the few pairs that touch the periodic wrap or the pad element are patched element-wise afterwards.
+    // U pairs per trip: all loads of the trip are issued before anything is stored (see BufChunk).  The
+    // arithmetic (operand order included) is that of stencil_grad, and a thread accumulates its elements'
+    // shares of the objective in element order, so every path gives the same bits.
     struct Pair {
         double a, b;
     };
     __device__ __forceinline__ static Pair load_pair(const rsrc_t& rs, int i0) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 8, 0, 0);
-        return Pair{__longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x)),
-                    __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z))};
+        Pair p;
+        load_f64x2(rs, i0, p.a, p.b);
+        return p;
     }
     static constexpr int kDppWaveShr1 = 0x138;  // lane L reads lane L-1
     static constexpr int kDppWaveShl1 = 0x130;  // lane L reads lane L+1
+    static constexpr int kOutOfRange = 0x10000000;  // element index beyond any vector (N < 2^28): loads give 0
 
-    // Calls body(i0, g0, g1, s0, s1) for every pair this thread owns: g = d(-logLike)/dz at z + c s
-    // (at z when !USE_S), zero for the pad element; adds the pair's share of -2 logLike to facc.
-    template <bool USE_S, class F>
-    __device__ __forceinline__ void stencil_pairs(double c, double& facc, F&& body) {
+    // For every pair this thread owns: pre(u, i0) first (the caller's own loads of the trip), then
+    // body(u, i0, g0, g1, s0, s1) with g = d(-logLike)/dz at z + c s (at z when !USE_S), zero for the pad
+    // element; adds the pairs' shares of -2 logLike to facc; flushes the `written` vectors once per trip.
+    template <bool USE_S, class P, class F, class... W>
+    __device__ __forceinline__ void stencil_pairs(double c, double& facc, P&& pre, F&& body, W&&... written) {
         const int N = (int)a.N, n = (int)a.ld, lane = tid & 63;
         int t = tfirst;
         asm volatile("" : "+v"(t));
         auto ztf = [&](int k) {
-            double v = z.get(0, k);
-            if constexpr (USE_S) v = fma(c, s.get(0, k), v);
+            double v = z.get1(k);
+            if constexpr (USE_S) v = fma(c, s.get1(k), v);
             return v;
         };
-        for (int i0 = 2 * t; i0 < n; i0 += 2 * pstride) {
-            const Pair zp = load_pair(z.rsrc, i0), xp = load_pair(x.rsrc, i0);
-            Pair sp{0.0, 0.0}, ztp = zp;
-            if constexpr (USE_S) {
-                sp = load_pair(s.rsrc, i0);
-                ztp = Pair{fma(c, sp.a, zp.a), fma(c, sp.b, zp.b)};
-            }
-            Pair ztL{dpp_move<kDppWaveShr1>(ztp.a), dpp_move<kDppWaveShr1>(ztp.b)};
-            Pair ztR{dpp_move<kDppWaveShl1>(ztp.a), dpp_move<kDppWaveShl1>(ztp.b)};
-            double xL = dpp_move<kDppWaveShr1>(xp.b), xR = dpp_move<kDppWaveShl1>(xp.a);
-            const bool interior = i0 >= 2 && i0 + 3 < N;  // the 6-element window has no wrap and no pad
-            if (lane == 0 && interior) {
-                ztL = load_pair(z.rsrc, i0 - 2);
+#pragma unroll 1
+        for (int ic = 2 * t; ic < n; ic += 2 * U * pstride) {
+            double g0[U], g1[U], tt[U][2], zz[U][2], rr[U][2];
+            Pair spv[U];
+            bool interior[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i0 = ic + 2 * u * pstride;
+                interior[u] = i0 >= 2 && i0 + 3 < N;  // the 6-element window has no wrap and no pad
+                const Pair zp = load_pair(z.rsrc, i0), xp = load_pair(x.rsrc, i0);
+                // the outer neighbour pair of an edge lane; every other lane aims out of range
+                const bool edge = interior[u] && (lane == 0 || lane == 63);
+                const int ie = edge ? (lane == 0 ? i0 - 2 : i0 + 2) : kOutOfRange;
+                const int ix = edge ? (lane == 0 ? i0 - 1 : i0 + 2) : kOutOfRange;
+                Pair ze = load_pair(z.rsrc, ie);
+                const double xe = x.get1(ix);
+                Pair sp{0.0, 0.0}, ztp = zp;
                 if constexpr (USE_S) {
-                    const Pair sq = load_pair(s.rsrc, i0 - 2);
-                    ztL = Pair{fma(c, sq.a, ztL.a), fma(c, sq.b, ztL.b)};
+                    sp = load_pair(s.rsrc, i0);
+                    const Pair se = load_pair(s.rsrc, ie);
+                    ztp = Pair{fma(c, sp.a, zp.a), fma(c, sp.b, zp.b)};
+                    ze = Pair{fma(c, se.a, ze.a), fma(c, se.b, ze.b)};
                 }
-                xL = x.get(0, i0 - 1);
-            }
-            if (lane == 63 && interior) {
-                ztR = load_pair(z.rsrc, i0 + 2);
-                if constexpr (USE_S) {
-                    const Pair sq = load_pair(s.rsrc, i0 + 2);
-                    ztR = Pair{fma(c, sq.a, ztR.a), fma(c, sq.b, ztR.b)};
-                }
-                xR = x.get(0, i0 + 2);
-            }
-            double g0, g1;
-            if (interior) {
+                pre(u, i0);
+                spv[u] = sp;
+                Pair ztL{dpp_move<kDppWaveShr1>(ztp.a), dpp_move<kDppWaveShr1>(ztp.b)};
+                Pair ztR{dpp_move<kDppWaveShl1>(ztp.a), dpp_move<kDppWaveShl1>(ztp.b)};
+                double xL = dpp_move<kDppWaveShr1>(xp.b), xR = dpp_move<kDppWaveShl1>(xp.a);
+                if (lane == 0) { ztL = ze; xL = xe; }
+                if (lane == 63) { ztR = ze; xR = xe; }
                 const double rm = xL - fma(0.25, ztL.a + ztp.a, 0.5 * ztL.b);    // r at i0-1
                 const double r0 = xp.a - fma(0.25, ztL.b + ztp.b, 0.5 * ztp.a);  // r at i0
                 const double r1 = xp.b - fma(0.25, ztp.a + ztR.a, 0.5 * ztp.b);  // r at i0+1
                 const double r2 = xR - fma(0.25, ztp.b + ztR.b, 0.5 * ztR.a);    // r at i0+2
                 const double t0 = ivk(i0) * ztp.a, t1 = ivk(i0 + 1) * ztp.b;
-                facc = fma(t0, ztp.a, fma(r0, r0, facc));
-                g0 = t0 - fma(0.25, rm + r1, 0.5 * r0);
-                facc = fma(t1, ztp.b, fma(r1, r1, facc));
-                g1 = t1 - fma(0.25, r0 + r2, 0.5 * r1);
-            } else {  // wrap-around or pad: element-wise with modular neighbour indices
-                double fi = facc;
-                g0 = stencil_grad(ztf, i0 < N ? i0 : 0, fi);
-                if (i0 < N) facc = fi;
-                else g0 = 0.0;
-                fi = facc;
-                g1 = stencil_grad(ztf, i0 + 1 < N ? i0 + 1 : 0, fi);
-                if (i0 + 1 < N) facc = fi;
-                else g1 = 0.0;
+                g0[u] = t0 - fma(0.25, rm + r1, 0.5 * r0);
+                g1[u] = t1 - fma(0.25, r0 + r2, 0.5 * r1);
+                tt[u][0] = t0; zz[u][0] = ztp.a; rr[u][0] = r0;
+                tt[u][1] = t1; zz[u][1] = ztp.b; rr[u][1] = r1;
             }
-            body(i0, g0, g1, sp.a, sp.b);
+            // wrap-around, pad and out-of-range pairs: element-wise with modular neighbour indices
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i0 = ic + 2 * u * pstride;
+                if (!interior[u]) {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int i = i0 + v;
+                        double gt = 0.0, t_ = 0.0, z_ = 0.0, r_ = 0.0;
+                        if (i < N) gt = stencil_grad(ztf, i, t_, z_, r_);
+                        (v == 0 ? g0[u] : g1[u]) = gt;
+                        tt[u][v] = t_; zz[u][v] = z_; rr[u][v] = r_;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i0 = ic + 2 * u * pstride;
+                facc = fma(tt[u][0], zz[u][0], fma(rr[u][0], rr[u][0], facc));
+                facc = fma(tt[u][1], zz[u][1], fma(rr[u][1], rr[u][1], facc));
+                body(u, i0, g0[u], g1[u], spv[u].a, spv[u].b);
+            }
+            (written.template flush<U>(ic, pstride), ...);
         }
     }
 
@@ -687,7 +755,7 @@ struct Solver {
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
-            for_elems<T, EPT>(a.ld, tfirst, pstride, [&](int jj, int i) {
+            for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
                 double zi = z.get(jj, i);
                 double si = 0.0;
                 if constexpr (USE_S) {
@@ -698,16 +766,16 @@ struct Solver {
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
                 mx[0] = nanmax(mx[0], fabs(gi));
-            });
+            }, when(STORE_G, g));
         } else {
-            stencil_pairs<USE_S>(c, sum[0], [&](int i0, double g0, double g1, double s0, double s1) {
+            stencil_pairs<USE_S>(c, sum[0], [](int, int) {}, [&](int u, int i0, double g0, double g1, double s0, double s1) {
                 if constexpr (STORE_G) {
-                    g.set(0, i0, g0);
-                    g.set(1, i0 + 1, g1);
+                    g.set(2 * u, i0, g0);
+                    g.set(2 * u + 1, i0 + 1, g1);
                 }
                 if constexpr (USE_S) sum[1] = fma(g1, s1, fma(g0, s0, sum[1]));
                 mx[0] = nanmax(nanmax(mx[0], fabs(g0)), fabs(g1));
-            });
+            }, when(STORE_G, g));
         }
         reduce<2, 1>(sum, mx);
         f = 0.5 * (sum[0] + a.f_const);
@@ -988,7 +1056,7 @@ struct Solver {
                 }
                 z.clear();
                 s.clear();
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.get(jj, i));
                     else z.set(jj, i, z0src.get(jj, i));
@@ -997,7 +1065,12 @@ struct Solver {
                 x.clear(); g.clear(); z.clear(); s.clear();
                 VH ztrue;
                 if constexpr (KEEP_ZTRUE) ztrue.bind(extra, ld);
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                // streaming: ONE pair per trip (two Philox/Box-Muller chains in flight, as in the rolled
+                // resident sampler) -- the pass is generator-bound and loads nothing; a warm start is
+                // copied by a pass of its own below
+                constexpr int US = Place::kResident ? U : 1;
+                const bool z_from_sample = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
+                for_elems<T, EPT, US>(ld, tfirst, pstride, [&](int jj, int i) {
                     const bool valid = i < N;  // phantom slots run the generator but keep zeros
                     const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
                     double zt, xt;
@@ -1014,29 +1087,34 @@ struct Solver {
                     x.set(jj, i, xt);
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
-                    else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
-                });
+                    else if constexpr (Place::kResident) z.set(jj, i, z0src.get(jj, i));
+                }, when(Model::kStencil, s), when(KEEP_ZTRUE, ztrue), x, when(z_from_sample, z));
+                if constexpr (!Place::kResident) {
+                    if (!z_from_sample && !z_in_place)
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); }, z);
+                }
             }
             if constexpr (Model::kStencil) {
                 pass_barrier();
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const bool valid = i < N;
                     const int ic = valid ? i : 0;
                     const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
-                    const double az = fma(0.25, s.get(0, im) + s.get(0, ip), 0.5 * s.get(0, ic));
+                    const double az = fma(0.25, s.get1(im) + s.get1(ip), 0.5 * s.get1(ic));
                     const double xv = az + x.get(jj, i);
                     x.set(jj, i, valid ? xv : 0.0);
-                });
+                }, x);
             }
         } else {
             VH xs;
             xs.bind(d.x_mode == X_DATA ? a.x_data : a.x_given, ld);
             x.clear(); g.clear(); z.clear(); s.clear();
-            for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+            const bool z_zero = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
+            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                 x.set(jj, i, xs.get(jj, i));
-                if (d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE) z.set(jj, i, 0.0);
+                if (z_zero) z.set(jj, i, 0.0);
                 else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
-            });
+            }, x, when(z_zero || !z_in_place, z));
         }
         stamp(p, 9);
         if constexpr (Model::kStencil) pass_barrier();  // x (and the start z) complete before neighbours read them
@@ -1075,11 +1153,11 @@ struct Solver {
             double dphi_0;
             if (h == 0 || !have_pair) {
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] = fma(gi, si, sum[0]);
-                });
+                }, s);
                 reduce<1, 0>(sum, mx);
                 dphi_0 = sum[0];
             } else {
@@ -1094,19 +1172,19 @@ struct Solver {
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index > lower) {
                         const VH dxn = hdx((index - 2) % kM);
-                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double qi = fma(-al, dgp.get(jj, i), s.get(jj, i));
                             s.set(jj, i, qi);
                             sum[0] = fma(dxn.get(jj, i), qi, sum[0]);
-                        });
+                        }, s);
                     } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
                         const double gam = sh_gam[(upper - 1) % kM];
-                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double dgi = dgp.get(jj, i);
                             const double si = gam * fma(-al, dgi, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(dgi, si, sum[0]);
-                        });
+                        }, s);
                     }
                     reduce<1, 0>(sum, mx);
                     dot = sum[0];
@@ -1120,17 +1198,17 @@ struct Solver {
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index < upper) {
                         const VH dgn = hdg(index % kM);
-                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double si = fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(dgn.get(jj, i), si, sum[0]);
-                        });
+                        }, s);
                     } else {
-                        for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                             const double si = -fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(g.get(jj, i), si, sum[0]);
-                        });
+                        }, s);
                     }
                     reduce<1, 0>(sum, mx);
                     dot = sum[0];
@@ -1141,11 +1219,11 @@ struct Solver {
             if (dphi_0 >= 0.0) {
                 pseudo = 1;
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] = fma(gi, si, sum[0]);
-                });
+                }, s);
                 reduce<1, 0>(sum, mx);
                 dphi_0 = sum[0];
             }
@@ -1174,7 +1252,7 @@ struct Solver {
             const bool keep = !stop_hint;
             double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
             if constexpr (!Model::kStencil) {
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
@@ -1192,35 +1270,43 @@ struct Solver {
                         g.set(jj, i, gn);
                         s.set(jj, i, gn);
                     }
-                });
+                }, z, when(keep, dxs), when(keep, dgs), when(keep, g), when(keep, s));
             } else {
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);
                     mx[0] = nanmax(mx[0], fabs(zn - zo));
                     if (keep) dxs.set(jj, i, dxi);
-                });
+                }, z, when(keep, dxs));
                 if (keep) {
                     pass_barrier();  // neighbours' z must be complete before the stencil reads them
                     double unused = 0.0;
-                    stencil_pairs<false>(0.0, unused, [&](int i0, double gn0, double gn1, double, double) {
-                        const double gnv[2] = {gn0, gn1};
+                    double dxv[U][2], gov[U][2];
+                    stencil_pairs<false>(0.0, unused,
+                        [&](int u, int i0) {  // this trip's own loads, issued with the stencil's
+                            dxv[u][0] = dxs.get(2 * u, i0);
+                            dxv[u][1] = dxs.get(2 * u + 1, i0 + 1);
+                            gov[u][0] = g.get(2 * u, i0);
+                            gov[u][1] = g.get(2 * u + 1, i0 + 1);
+                        },
+                        [&](int u, int i0, double gn0, double gn1, double, double) {
+                            const double gnv[2] = {gn0, gn1};
 #pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int i = i0 + v;
-                            const double gn = gnv[v];
-                            const double dxi = dxs.get(v, i);
-                            const double dgi = gn - g.get(v, i);
-                            sum[0] = fma(dxi, dgi, sum[0]);
-                            sum[1] = fma(dgi, dgi, sum[1]);
-                            sum[2] = fma(dxi, gn, sum[2]);
-                            dgs.set(v, i, dgi);
-                            g.set(v, i, gn);
-                            s.set(v, i, gn);
-                        }
-                    });
+                            for (int v = 0; v < 2; ++v) {
+                                const int i = i0 + v;
+                                const double gn = gnv[v];
+                                const double dxi = dxv[u][v];
+                                const double dgi = gn - gov[u][v];
+                                sum[0] = fma(dxi, dgi, sum[0]);
+                                sum[1] = fma(dgi, dgi, sum[1]);
+                                sum[2] = fma(dxi, gn, sum[2]);
+                                dgs.set(2 * u + v, i, dgi);
+                                g.set(2 * u + v, i, gn);
+                                s.set(2 * u + v, i, gn);
+                            }
+                        }, dgs, g, s);
                 }
             }
             reduce<3, 1>(sum, mx);
@@ -1285,36 +1371,38 @@ struct Solver {
             const bool valid = i < N;
             const int ic = valid ? i : 0;
             const int im = ic == 0 ? N - 1 : ic - 1, ip = ic == N - 1 ? 0 : ic + 1;
-            const double a0 = fma(0.25, w.get(0, im) + w.get(0, ip), 0.5 * w.get(0, ic));
+            const double a0 = fma(0.25, w.get1(im) + w.get1(ip), 0.5 * w.get1(ic));
             return valid ? a0 : 0.0;
         };
         for (int j = 0; j < nth; ++j) {
             // ---- right-hand side b = dFdtheta1[:, j]; v = 0, r = p = b --------------------------------
             double sum[1] = {0.0}, mx[1] = {0.0};
             if constexpr (Model::kStencil) {
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
-                    t1.set(jj, i, blk(i) == j ? 0.5 * ztrue.get(jj, i) : 0.0);
-                });
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                    const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
+                    t1.set(jj, i, blk(i) == j ? 0.5 * zt : 0.0);
+                }, t1);
                 pass_barrier();
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); });
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); }, t2);
                 pass_barrier();
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double bi = Aat(t2, i);
                     v.set(jj, i, 0.0);
                     r.set(jj, i, bi);
                     pp.set(jj, i, bi);
                     sum[0] = fma(bi, bi, sum[0]);
-                });
+                }, v, r, pp);
             } else {
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                    const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
                     double bi;
-                    if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - ztrue.get(jj, i)));
-                    else bi = blk(i) == j ? 0.5 * ztrue.get(jj, i) : 0.0;
+                    if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - zt));
+                    else bi = blk(i) == j ? 0.5 * zt : 0.0;
                     v.set(jj, i, 0.0);
                     r.set(jj, i, bi);
                     pp.set(jj, i, bi);
                     sum[0] = fma(bi, bi, sum[0]);
-                });
+                }, v, r, pp);
             }
             reduce<1, 0>(sum, mx);
             double rr = sum[0];
@@ -1324,41 +1412,41 @@ struct Solver {
                 // ---- Ap = A_hess p, p.Ap -----------------------------------------------------------
                 double s1[1] = {0.0};
                 if constexpr (Model::kStencil) {
-                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) { t1.set(jj, i, Aat(pp, i)); });
+                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t1.set(jj, i, Aat(pp, i)); }, t1);
                     pass_barrier();
-                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                         const double pi = pp.get(jj, i);
                         const double api = -(Aat(t1, i) + ivk(i) * pi);
                         Ap.set(jj, i, api);
                         s1[0] = fma(pi, api, s1[0]);
-                    });
+                    }, Ap);
                 } else {
-                    for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                         const double pi = pp.get(jj, i);
                         double api;
                         if constexpr (Model::kId == MUSE_MODEL_NOISE) api = -((iv0 + 1.0) * pi);
                         else api = -(pi + ivk(i) * pi);
                         Ap.set(jj, i, api);
                         s1[0] = fma(pi, api, s1[0]);
-                    });
+                    }, Ap);
                 }
                 reduce<1, 0>(s1, mx);
                 const double alpha = rr / s1[0];
                 // ---- v += alpha p ; r -= alpha Ap ; r.r ---------------------------------------------
                 double s2[1] = {0.0};
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     v.set(jj, i, fma(alpha, pp.get(jj, i), v.get(jj, i)));
                     const double ri = fma(-alpha, Ap.get(jj, i), r.get(jj, i));
                     r.set(jj, i, ri);
                     s2[0] = fma(ri, ri, s2[0]);
-                });
+                }, v, r);
                 reduce<1, 0>(s2, mx);
                 const double beta = s2[0] / rr;
                 rr = s2[0];
                 // ---- p = r + beta p (its stores are ordered before the next stencil read by pass_barrier)
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     pp.set(jj, i, fma(beta, pp.get(jj, i), r.get(jj, i)));
-                });
+                }, pp);
                 if constexpr (Model::kStencil) pass_barrier();
                 it += 1;
             }
@@ -1367,12 +1455,13 @@ struct Solver {
             double acc[KA];
 #pragma unroll
             for (int b = 0; b < KA; ++b) acc[b] = 0.0;
-            for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                 const double zi = z.get(jj, i), vi = v.get(jj, i);
                 if constexpr (Model::kId == MUSE_MODEL_NOISE) {
-                    const double dd = x.get(jj, i) - zi;
+                    const double xi = x.get(jj, i);
+                    const double dd = xi - zi;
                     acc[0] = fma(-iv0 * dd, vi, acc[0]);
-                    acc[1] = fma(dd, 0.5 * (x.get(jj, i) - ztrue.get(jj, i)), acc[1]);
+                    acc[1] = fma(dd, 0.5 * (xi - ztrue.get(jj, i)), acc[1]);
                 } else {
                     const double t = ivk(i) * zi;
                     if constexpr (MAXB == 1) {
@@ -1413,14 +1502,14 @@ struct Solver {
             if (d.zslot >= 0) {
                 VH zo;
                 zo.bind(a.zhat + d.zslot * ld, ld);
-                for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
             }
         }
         {
             double acc[MAXB], mx[1] = {0.0};
 #pragma unroll
             for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-            for_elems<T, EPT>(ld, tfirst, pstride, [&](int jj, int i) {
+            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                 const double t = Model::score_term(x.get(jj, i), z.get(jj, i));
                 if constexpr (MAXB == 1) {
                     acc[0] += t;
@@ -1461,7 +1550,8 @@ constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS c
 // field addresses is formed, and every access then becomes a scratch access.  LDS loads at uniform
 // addresses are uniform values, so control flow on them stays scalar.
 template <class Model, class Place, bool IMPLICIT = false>
-__global__ void __launch_bounds__(Place::T) map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
+__global__ void __launch_bounds__(Place::T) __attribute__((amdgpu_waves_per_eu(Place::kWavesPerEu)))
+map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Place::T;
     // LDS carve (all offsets multiples of 16 B): reduction scratch, L-BFGS scalars, ticket, args, x, g
@@ -1573,7 +1663,7 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     const int Ni = (int)N;
     auto wrap = [&](int i) { return i < 0 ? i + Ni : (i >= Ni ? i - Ni : i); };
     // vectors are padded to the even length ld with a zero pad element (phantom zero, see for_elems)
-    for_elems<T, 0>(a.ld, tid, T, [&](int, int i) {
+    for_elems<T, 0, 1>(a.ld, tid, T, [&](int, int i) {
         const int k = MAXB > 1 ? block_of(a, i) : 0;
         const double ivk = a.tmap.iv[k];
         double gi;
@@ -1682,6 +1772,11 @@ static double theta_const(const muse_ctx* c, const double* theta) {
     return cst;
 }
 
+#ifndef MUSE_STENCIL_U
+#define MUSE_STENCIL_U 4
+#endif
+constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil model (register budget: see tools/regs.py)
+
 enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5 };
 
 // Cluster size: a function of N alone (results must not depend on how many problems share a launch).
@@ -1769,15 +1864,15 @@ static int launch_one(muse_ctx* c, const BatchArgs& a, int grid, size_t lds) {
 template <class Model>
 static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_t lds) {
     if constexpr (Model::kStencil) {
-        if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, false, true>>(c, a, grid, lds);
-        if (pl == P_S256) return launch_one<Model, PlaceStreaming<256, false>>(c, a, grid, lds);
-        return launch_one<Model, PlaceStreaming<512, false>>(c, a, grid, lds);
+        if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, true, kStencilU>>(c, a, grid, lds);
+        if (pl == P_S256) return launch_one<Model, PlaceStreaming<256, false, kStencilU>>(c, a, grid, lds);
+        return launch_one<Model, PlaceStreaming<512, false, kStencilU>>(c, a, grid, lds);
     } else {
         switch (pl) {
             case P_R256x1: return launch_one<Model, PlaceResident<256, 1, false>>(c, a, grid, lds);
             case P_R512x4: return launch_one<Model, PlaceResident<512, 4, false>>(c, a, grid, lds);
             case P_R512x10: return launch_one<Model, PlaceResident<512, 10, true>>(c, a, grid, lds);
-            case P_C256: return launch_one<Model, PlaceStreaming<256, true, true>>(c, a, grid, lds);
+            case P_C256: return launch_one<Model, PlaceStreaming<256, true>>(c, a, grid, lds);
             case P_S256: return launch_one<Model, PlaceStreaming<256>>(c, a, grid, lds);
             default: return launch_one<Model, PlaceStreaming<512>>(c, a, grid, lds);
         }
@@ -1787,9 +1882,9 @@ static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_
 // The implicit-differentiation H runs in the streaming policy only (single workgroup, or a cluster for large N).
 template <class Model>
 static int launch_place_implicit(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_t lds) {
-    constexpr bool pairs = !Model::kStencil;
-    if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, pairs, true>, true>(c, a, grid, lds);
-    return launch_one<Model, PlaceStreaming<512, pairs>, true>(c, a, grid, lds);
+    constexpr int U = Model::kStencil ? kStencilU : 4;
+    if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, true, U>, true>(c, a, grid, lds);
+    return launch_one<Model, PlaceStreaming<512, false, U>, true>(c, a, grid, lds);
 }
 
 // Fill the common fields and launch the solver for `a.nproblems` elements.
