@@ -84,6 +84,7 @@ int muse_ctx_area_event(muse_ctx* ctx, int area, void** event, int* ntheta);
 int muse_internal_map_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
                             const double* theta, double atol, int z0_mode, int area, double* scores_dev);
 int muse_set_error(int code, const char* msg);
+int muse_wait_event(void* event);
 }
 
 static CommState* state_of(muse_ctx* ctx, void** stream_out = nullptr) {
@@ -286,7 +287,8 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_in
     if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
     if (area < 0 || area >= kAreas) return muse_set_error(MUSE_ERR_INVALID, "bad result_area");
     if (!st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "no gather in flight on this result area");
-    HIPCHK2(hipEventSynchronize(st->gdone[area]));
+    int rc = muse_wait_event(st->gdone[area]);
+    if (rc) return rc;
     st->pending[area] = false;
     if (g_all_out) memcpy(g_all_out, st->recv_pin[area], st->count[area] * st->nranks * sizeof(double));
     return muse_batch_wait(ctx, area, nullptr, info_out);  // the solver's own completion, error flag, local infos
