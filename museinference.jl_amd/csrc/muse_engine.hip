@@ -751,7 +751,9 @@ struct Solver {
     // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
     //    dphi = grad . s and gmax = ||grad||_inf; the gradient itself is stored (into g) only when
     //    STORE_G -- a line-search trial needs just the three scalars.  One pass, one barrier.
-    template <bool USE_S, bool STORE_G>
+    //    INIT_S (resident policy, where s lives in registers): the pass also sets the steepest-descent
+    //    direction s = -g and returns dphi = g . s, exactly as the separate pass would.
+    template <bool USE_S, bool STORE_G, bool INIT_S = false>
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
@@ -765,8 +767,13 @@ struct Solver {
                 const double gi = Model::grad(ivk(i), x.get(jj, i), zi, sum[0]);
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
+                if constexpr (INIT_S) {
+                    const double sd = -gi;
+                    s.set(jj, i, sd);
+                    sum[1] = fma(gi, sd, sum[1]);
+                }
                 mx[0] = nanmax(mx[0], fabs(gi));
-            }, when(STORE_G, g));
+            }, when(STORE_G, g), when(INIT_S, s));
         } else {
             stencil_pairs<USE_S>(c, sum[0], [](int, int) {}, [&](int u, int i0, double g0, double g1, double s0, double s1) {
                 if constexpr (STORE_G) {
@@ -1130,8 +1137,10 @@ struct Solver {
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
         f_calls = 0;
         last_c = NAN;
-        double dphi_unused;
-        eval<false, true>(0.0, f, dphi_unused, gmax);
+        constexpr bool kFuseInit = Place::kResident && !Model::kStencil;
+        double dphi_init;
+        eval<false, true, kFuseInit>(0.0, f, dphi_init, gmax);
+        score_ready = false;
         stamp(p, 2);
         iterations = 0;
         hist_words = 0;
@@ -1151,7 +1160,9 @@ struct Solver {
             const int upper = pseudo - 1, lower = (pseudo - kM) > 1 ? (pseudo - kM) : 1;
             const int h = upper >= lower ? upper - lower + 1 : 0;
             double dphi_0;
-            if (h == 0 || !have_pair) {
+            if (kFuseInit && iterations == 1) {
+                dphi_0 = dphi_init;  // s = -g and g . s came with the initial evaluation
+            } else if (h == 0 || !have_pair) {
                 double sum[1] = {0.0}, mx[1] = {0.0};
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
@@ -1251,26 +1262,61 @@ struct Solver {
             VH dgs = hdg(slot_new);
             const bool keep = !stop_hint;
             double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
-            if constexpr (!Model::kStencil) {
+            if (!keep) {
+                // ---- the solve ends with this step (whatever x_converged says): z += alpha s, and in the same
+                //      pass what finish() would compute from the final z -- the score terms and the zhat store
+                double acc[MAXB];
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
+                VH zout;
+                const bool store = Place::kResident && d.zslot >= 0;  // streaming: z already lives in its zhat slot
+                if (store) zout.bind(a.zhat + d.zslot * ld, ld);
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                    const double zo = z.get(jj, i), si = s.get(jj, i);
+                    const double zn = fma(alpha, si, zo);
+                    z.set(jj, i, zn);
+                    mx[0] = nanmax(mx[0], fabs(zn - zo));
+                    if constexpr (Place::kResident) {
+                        if (store) zout.set(jj, i, zn);
+                    }
+                    const double t = Model::score_term(x.get(jj, i), zn);
+                    if constexpr (MAXB == 1) {
+                        acc[0] += t;
+                    } else {
+                        const int k = blk(i);
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
+                    }
+                }, z);
+                if constexpr (MAXB + 1 <= 8) {
+                    reduce<MAXB, 1>(acc, mx);
+                } else {
+                    double none[1] = {0.0};
+                    reduce<0, 1>(none, mx);
+                    reduce<MAXB, 0>(acc, none);
+                }
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) score_acc[b] = acc[b];
+                score_ready = true;
+            } else if constexpr (!Model::kStencil) {
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
                     z.set(jj, i, zn);
                     mx[0] = nanmax(mx[0], fabs(zn - zo));
-                    if (keep) {
-                        double unused = 0.0;
-                        const double gn = Model::grad(ivk(i), x.get(jj, i), zn, unused);
-                        const double dgi = gn - g.get(jj, i);
-                        sum[0] = fma(dxi, dgi, sum[0]);
-                        sum[1] = fma(dgi, dgi, sum[1]);
-                        sum[2] = fma(dxi, gn, sum[2]);
-                        dxs.set(jj, i, dxi);
-                        dgs.set(jj, i, dgi);
-                        g.set(jj, i, gn);
-                        s.set(jj, i, gn);
-                    }
-                }, z, when(keep, dxs), when(keep, dgs), when(keep, g), when(keep, s));
+                    double unused = 0.0;
+                    const double gn = Model::grad(ivk(i), x.get(jj, i), zn, unused);
+                    const double dgi = gn - g.get(jj, i);
+                    sum[0] = fma(dxi, dgi, sum[0]);
+                    sum[1] = fma(dgi, dgi, sum[1]);
+                    sum[2] = fma(dxi, gn, sum[2]);
+                    dxs.set(jj, i, dxi);
+                    dgs.set(jj, i, dgi);
+                    g.set(jj, i, gn);
+                    s.set(jj, i, gn);
+                }, z, dxs, dgs, g, s);
+                reduce<3, 1>(sum, mx);
             } else {
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
@@ -1278,38 +1324,36 @@ struct Solver {
                     const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);
                     mx[0] = nanmax(mx[0], fabs(zn - zo));
-                    if (keep) dxs.set(jj, i, dxi);
-                }, z, when(keep, dxs));
-                if (keep) {
-                    pass_barrier();  // neighbours' z must be complete before the stencil reads them
-                    double unused = 0.0;
-                    double dxv[U][2], gov[U][2];
-                    stencil_pairs<false>(0.0, unused,
-                        [&](int u, int i0) {  // this trip's own loads, issued with the stencil's
-                            dxv[u][0] = dxs.get(2 * u, i0);
-                            dxv[u][1] = dxs.get(2 * u + 1, i0 + 1);
-                            gov[u][0] = g.get(2 * u, i0);
-                            gov[u][1] = g.get(2 * u + 1, i0 + 1);
-                        },
-                        [&](int u, int i0, double gn0, double gn1, double, double) {
-                            const double gnv[2] = {gn0, gn1};
+                    dxs.set(jj, i, dxi);
+                }, z, dxs);
+                pass_barrier();  // neighbours' z must be complete before the stencil reads them
+                double unused = 0.0;
+                double dxv[U][2], gov[U][2];
+                stencil_pairs<false>(0.0, unused,
+                    [&](int u, int i0) {  // this trip's own loads, issued with the stencil's
+                        dxv[u][0] = dxs.get(2 * u, i0);
+                        dxv[u][1] = dxs.get(2 * u + 1, i0 + 1);
+                        gov[u][0] = g.get(2 * u, i0);
+                        gov[u][1] = g.get(2 * u + 1, i0 + 1);
+                    },
+                    [&](int u, int i0, double gn0, double gn1, double, double) {
+                        const double gnv[2] = {gn0, gn1};
 #pragma unroll
-                            for (int v = 0; v < 2; ++v) {
-                                const int i = i0 + v;
-                                const double gn = gnv[v];
-                                const double dxi = dxv[u][v];
-                                const double dgi = gn - gov[u][v];
-                                sum[0] = fma(dxi, dgi, sum[0]);
-                                sum[1] = fma(dgi, dgi, sum[1]);
-                                sum[2] = fma(dxi, gn, sum[2]);
-                                dgs.set(2 * u + v, i, dgi);
-                                g.set(2 * u + v, i, gn);
-                                s.set(2 * u + v, i, gn);
-                            }
-                        }, dgs, g, s);
-                }
+                        for (int v = 0; v < 2; ++v) {
+                            const int i = i0 + v;
+                            const double gn = gnv[v];
+                            const double dxi = dxv[u][v];
+                            const double dgi = gn - gov[u][v];
+                            sum[0] = fma(dxi, dgi, sum[0]);
+                            sum[1] = fma(dgi, dgi, sum[1]);
+                            sum[2] = fma(dxi, gn, sum[2]);
+                            dgs.set(2 * u + v, i, dgi);
+                            g.set(2 * u + v, i, gn);
+                            s.set(2 * u + v, i, gn);
+                        }
+                    }, dgs, g, s);
+                reduce<3, 1>(sum, mx);
             }
-            reduce<3, 1>(sum, mx);
             if (iterations == 1) stamp(p, 5);
             if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
                 status = MUSE_STATUS_LINESEARCH_FAILED;
@@ -1498,28 +1542,33 @@ struct Solver {
     // -- phase 3: zhat out, score grad_theta logLike(x, zhat, theta), solver info
     __device__ void finish(int p) {
         const int64_t ld = a.ld;
-        if constexpr (Place::kResident) {
-            if (d.zslot >= 0) {
-                VH zo;
-                zo.bind(a.zhat + d.zslot * ld, ld);
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { zo.set(jj, i, z.get(jj, i)); });
-            }
-        }
         {
             double acc[MAXB], mx[1] = {0.0};
+            if (score_ready) {  // the solve's last pass already did both (see solve())
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                const double t = Model::score_term(x.get(jj, i), z.get(jj, i));
-                if constexpr (MAXB == 1) {
-                    acc[0] += t;
-                } else {
-                    const int k = blk(i);
+                for (int b = 0; b < MAXB; ++b) acc[b] = score_acc[b];
+            } else {
+                VH zout;
+                const bool store = Place::kResident && d.zslot >= 0;
+                if (store) zout.bind(a.zhat + d.zslot * ld, ld);
 #pragma unroll
-                    for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
-                }
-            });
-            reduce<MAXB, 0>(acc, mx);
+                for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                    const double zi = z.get(jj, i);
+                    if constexpr (Place::kResident) {
+                        if (store) zout.set(jj, i, zi);
+                    }
+                    const double t = Model::score_term(x.get(jj, i), zi);
+                    if constexpr (MAXB == 1) {
+                        acc[0] += t;
+                    } else {
+                        const int k = blk(i);
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
+                    }
+                });
+                reduce<MAXB, 0>(acc, mx);
+            }
             if (tid == 0 && crank == 0) {
 #pragma unroll
                 for (int b = 0; b < MAXB; ++b) {
@@ -1541,6 +1590,8 @@ struct Solver {
         stamp(p, 7);
     }
     double last_phi;
+    double score_acc[MAXB];  // per-block sums of the score terms when the solve's last pass computed them
+    bool score_ready;
 };
 
 constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS copy of the kernel arguments
