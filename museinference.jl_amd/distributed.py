@@ -26,7 +26,11 @@ class ShardedMuseProblem:
 
     All attribute access other than the batched seams is forwarded to the local problem."""
 
-    def __init__(self, local, group=None, device=None):
+    def __init__(self, local, group=None, device=None, engine_comm=None):
+        """engine_comm: exchange through the engine's own RCCL communicator (muse_comm_* of the C ABI: pinned
+        host -> device -> ncclAllGather -> pinned host, no torch tensors on the path).  Default: yes when the
+        process group's backend is nccl (= RCCL) and the local problem is a HipMuseProblem; torch.distributed
+        collectives otherwise (gloo on CPU).  The unique id travels over the process group once."""
         import torch.distributed as dist
         self._dist = dist
         self.local = local
@@ -34,6 +38,13 @@ class ShardedMuseProblem:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._device = device
+        if engine_comm is None:
+            engine_comm = dist.get_backend(group) == "nccl" and hasattr(local, "comm_init")
+        self.engine_comm = bool(engine_comm)
+        if self.engine_comm and getattr(local, "_nranks", None) is None:
+            uid = [type(local).comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            local.comm_init(self.world, self.rank, uid[0])
 
     def __getattr__(self, name):
         return getattr(self.local, name)
@@ -53,6 +64,9 @@ class ShardedMuseProblem:
         cmax = max(counts)
         send = np.zeros((cmax, width))
         send[: rows.shape[0]] = rows
+        if self.engine_comm:
+            recv = self.local.allgather_scores(send.reshape(-1)).reshape(self.world, cmax, width)
+            return np.concatenate([recv[r, :c] for r, c in enumerate(counts)], axis=0)
         t = torch.from_numpy(send).to(dev)
         out = [torch.empty_like(t) for _ in range(self.world)]
         self._dist.all_gather(out, t, group=self.group)

@@ -272,3 +272,45 @@ def test_two_ranks_on_one_gpu_match_single_process(gpu, M, O, tmp_path):
         for k, want in (("theta", ref.theta), ("J", ref.J), ("H", ref.H), ("Sigma", ref.Sigma), ("gs", np.array(ref.gs))):
             assert np.array_equal(got[k], want), (r, k)
     single.close()
+
+
+_NCCL_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import museinference_jl_amd as M
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+x = np.load({xfile!r})
+local = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0), device=0)
+prob = M.ShardedMuseProblem(local)
+assert prob.engine_comm          # nccl backend: the exchange goes through the engine's RCCL communicator
+res = M.muse(prob, [1.0, 0.5], rng=3, nsims=21, maxsteps=4, get_covariance=True)
+with open({out!r}, "wb") as f:
+    pickle.dump(dict(theta=res.theta, J=res.J, H=res.H, Sigma=res.Sigma, gs=np.array(res.gs)), f)
+local.close()
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_driver_over_engine_rccl_one_rank(gpu, M, O, tmp_path):
+    """ShardedMuseProblem on an nccl (RCCL) process group exchanges through muse_comm_* of the C ABI; with one
+    rank the whole muse/get_J/get_H run must equal the unsharded run bit for bit."""
+    import pickle
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    x, _ = O.sample_x_z("funnel", 3000, 5, M.DATA_SIM, [0.0, 0.0])
+    xfile = str(tmp_path / "x.npy")
+    np.save(xfile, x)
+    out = str(tmp_path / "res")
+    script = tmp_path / "worker.py"
+    script.write_text(_NCCL_WORKER.format(root=root, port=29300 + os.getpid() % 200, xfile=xfile, out=out))
+    p = subprocess.run([sys.executable, str(script)], timeout=300)
+    assert p.returncode == 0
+    single = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+    ref = M.muse(single, [1.0, 0.5], rng=3, nsims=21, maxsteps=4, get_covariance=True)
+    got = pickle.load(open(out, "rb"))
+    for k, want in (("theta", ref.theta), ("J", ref.J), ("H", ref.H), ("Sigma", ref.Sigma), ("gs", np.array(ref.gs))):
+        assert np.array_equal(got[k], want), k
+    single.close()
