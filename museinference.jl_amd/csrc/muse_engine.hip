@@ -265,15 +265,36 @@ struct FlushIf {
 };
 template <class V>
 __device__ __forceinline__ FlushIf<V> when(bool on, V& v) { return FlushIf<V>{v, on}; }
-struct LdsVec {  // a vector in LDS; p[ld] is a dummy slot that holds 0
+// A vector in LDS; p[ld], p[ld+1] is a dummy pair that holds 0.  Like BufVec2 it moves a thread's two adjacent
+// elements with one instruction (ds_read2_b64 / ds_write2_b64) and one address computation: the pair is read
+// at jj even (second half served at jj odd), a store is staged at jj even and issued at jj odd.
+struct LdsVec {
     lds_double* p;
     int ld;
+    mutable double c1;
+    double s0;
     __device__ __forceinline__ void bind(double* base, int64_t ld_) {
         p = (lds_double*)base;
         ld = (int)ld_;
     }
-    __device__ __forceinline__ double get(int, int i) const { return p[i < ld ? i : ld]; }
-    __device__ __forceinline__ void set(int, int i, double v) { p[i < ld ? i : ld] = v; }
+    __device__ __forceinline__ double get(int jj, int i) const {
+        if ((jj & 1) == 0) {
+            const lds_double* q = p + (i < ld ? i : ld);
+            const double d0 = q[0];
+            c1 = q[1];
+            return d0;
+        }
+        return c1;
+    }
+    __device__ __forceinline__ void set(int jj, int i, double v) {
+        if ((jj & 1) == 0) {
+            s0 = v;
+        } else {
+            lds_double* q = p + (i - 1 < ld ? i - 1 : ld);
+            q[0] = s0;
+            q[1] = v;
+        }
+    }
     __device__ __forceinline__ void clear() {}
     template <int UU>
     __device__ __forceinline__ void flush(int, int) {}
@@ -315,7 +336,13 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F
     }
 }
 
-__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+// Maxima are taken with v_max_f64 (one instruction; a NaN operand is DROPPED), on |values| that start from 0.
+// NaN propagation -- Julia's maximum(abs, g) is NaN if any element is -- comes from the sums reduced in the same
+// pass: a NaN element makes the pass's objective / directional-derivative sum NaN, and the caller then replaces
+// the maximum by NaN (nan_if).  (The explicit compare/select form cost 6 instructions per element and per
+// reduction step.)
+__device__ __forceinline__ double absmax(double a, double b) { return __builtin_fmax(a, __builtin_fabs(b)); }
+__device__ __forceinline__ double nan_if(bool c, double v) { return c ? __builtin_nan("") : v; }
 
 // Tell the compiler a value is workgroup-uniform (it is: every lane holds the same bits).  Control
 // flow that depends on it then compiles to scalar branches and its live state to SGPRs.
@@ -353,7 +380,7 @@ constexpr int kDppMirror = 0x140;      // row_mirror:      lane i <-> 15-i withi
 
 template <bool IS_MAX>
 __device__ __forceinline__ double combine(double a, double b) {
-    if constexpr (IS_MAX) return nanmax(a, b);
+    if constexpr (IS_MAX) return __builtin_fmax(a, b);
     else return a + b;
 }
 template <bool IS_MAX>
@@ -571,7 +598,7 @@ struct Solver {
             double acc = __hip_atomic_load(slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int c = 1; c < csize; ++c) {
                 const double v = __hip_atomic_load(slots + c * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc = k < KS ? acc + v : nanmax(acc, v);
+                acc = k < KS ? acc + v : __builtin_fmax(acc, v);
             }
             if (k < KS) sv[k] = uniform(acc);
             else mv[k - KS] = uniform(acc);
@@ -772,7 +799,7 @@ struct Solver {
                     s.set(jj, i, sd);
                     sum[1] = fma(gi, sd, sum[1]);
                 }
-                mx[0] = nanmax(mx[0], fabs(gi));
+                mx[0] = absmax(mx[0], gi);
             }, when(STORE_G, g), when(INIT_S, s));
         } else {
             stencil_pairs<USE_S>(c, sum[0], [](int, int) {}, [&](int u, int i0, double g0, double g1, double s0, double s1) {
@@ -781,13 +808,15 @@ struct Solver {
                     g.set(2 * u + 1, i0 + 1, g1);
                 }
                 if constexpr (USE_S) sum[1] = fma(g1, s1, fma(g0, s0, sum[1]));
-                mx[0] = nanmax(nanmax(mx[0], fabs(g0)), fabs(g1));
+                mx[0] = absmax(absmax(mx[0], g0), g1);
             }, when(STORE_G, g));
         }
+        if (iter_stamp == 0) stamp(stamp_p, 14);
         reduce<2, 1>(sum, mx);
+        if (iter_stamp == 0) stamp(stamp_p, 15);
         f = 0.5 * (sum[0] + a.f_const);
         dphi = sum[1];
-        gmax = mx[0];
+        gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
         f_calls += 1;
     }
 
@@ -1275,7 +1304,7 @@ struct Solver {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);
-                    mx[0] = nanmax(mx[0], fabs(zn - zo));
+                    mx[0] = absmax(mx[0], zn - zo);
                     if constexpr (Place::kResident) {
                         if (store) zout.set(jj, i, zn);
                     }
@@ -1295,8 +1324,13 @@ struct Solver {
                     reduce<0, 1>(none, mx);
                     reduce<MAXB, 0>(acc, none);
                 }
+                bool any_nan = false;  // a NaN step shows up in the score sums (NaN channel of the maximum)
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) score_acc[b] = acc[b];
+                for (int b = 0; b < MAXB; ++b) {
+                    score_acc[b] = acc[b];
+                    any_nan = any_nan || acc[b] != acc[b];
+                }
+                mx[0] = nan_if(any_nan, mx[0]);
                 score_ready = true;
             } else if constexpr (!Model::kStencil) {
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
@@ -1304,7 +1338,7 @@ struct Solver {
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
                     z.set(jj, i, zn);
-                    mx[0] = nanmax(mx[0], fabs(zn - zo));
+                    mx[0] = absmax(mx[0], zn - zo);
                     double unused = 0.0;
                     const double gn = Model::grad(ivk(i), x.get(jj, i), zn, unused);
                     const double dgi = gn - g.get(jj, i);
@@ -1317,13 +1351,14 @@ struct Solver {
                     s.set(jj, i, gn);
                 }, z, dxs, dgs, g, s);
                 reduce<3, 1>(sum, mx);
+                mx[0] = nan_if(sum[0] != sum[0], mx[0]);
             } else {
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);
-                    mx[0] = nanmax(mx[0], fabs(zn - zo));
+                    mx[0] = absmax(mx[0], zn - zo);
                     dxs.set(jj, i, dxi);
                 }, z, dxs);
                 pass_barrier();  // neighbours' z must be complete before the stencil reads them
@@ -1353,6 +1388,7 @@ struct Solver {
                         }
                     }, dgs, g, s);
                 reduce<3, 1>(sum, mx);
+                mx[0] = nan_if(sum[0] != sum[0], mx[0]);
             }
             if (iterations == 1) stamp(p, 5);
             if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
@@ -1625,6 +1661,8 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         if (tid == 0) {  // the dummy slot and the pad element (N odd) hold 0 for the kernel's lifetime
             lds_x[a.ld] = 0.0;
             lds_g[a.ld] = 0.0;
+            lds_x[a.ld + 1] = 0.0;
+            lds_g[a.ld + 1] = 0.0;
             if (a.N < a.ld) {
                 lds_x[a.N] = 0.0;
                 lds_g[a.N] = 0.0;

@@ -7,10 +7,11 @@ B.LIB_PATH = B.LIB_PATH.replace("libmuse_hip.so", __import__("os").environ.get("
 lib = M.load_library()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 n = 512
-prob = M.HipMuseProblem(None, model="funnel", ntheta=1, N=N)
-for _ in range(3): prob.map_and_score_batch(0,0,n,[1.0])
+NTH = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+prob = M.HipMuseProblem(None, model="funnel", ntheta=NTH, N=N)
+for _ in range(3): prob.map_and_score_batch(0,0,n,[1.0]*NTH)
 lib.muse_debug_stamps(prob._ctx, C.c_int64(n), None)
-prob.map_and_score_batch(0,0,n,[1.0])
+prob.map_and_score_batch(0,0,n,[1.0]*NTH)
 out = np.zeros((n,16), dtype=np.uint64)
 lib.muse_debug_stamps(prob._ctx, C.c_int64(n), out.ctypes.data_as(C.c_void_p))
 st = out[:, :8].astype(np.int64)
@@ -21,6 +22,7 @@ for k, nm in enumerate(names): print(f"  {nm:16s} {np.median(d[:,k]):10.0f}   ({
 print("  sample detail: start->sampler loop end", np.median(out[:,8].astype(np.int64)-st[:,0]), " ->z init end", np.median(out[:,9].astype(np.int64)-out[:,8].astype(np.int64)), " ->barrier end", np.median(st[:,1]-out[:,9].astype(np.int64)))
 o=out.astype(np.int64)
 print("  line search detail: pre-logic", np.median(o[:,10]-st[:,3]), " eval1", np.median(o[:,11]-o[:,10]), " logic1", np.median(o[:,12]-o[:,11]), " eval2", np.median(o[:,13]-o[:,12]), " post-logic", np.median(st[:,4]-o[:,13]))
+print("  first line-search evaluation: element loop", np.median(o[:,14]-o[:,10]), " reduction", np.median(o[:,15]-o[:,14]))
 print("total per problem", np.median(st[:,7]-st[:,0]), "cycles; first start -> last end:", (st[:,7].max()-st[:,0].min()), "cycles")
 order = np.argsort(st[:,0]); 
 print("start offsets of problems (cycles, sorted) sample:", (st[order,0]-st[:,0].min())[[0,1,100,255,256,300,511]])
