@@ -1166,9 +1166,14 @@ struct Solver {
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
         f_calls = 0;
         last_c = NAN;
+        // Resident policy, elementwise models: the initial evaluation leaves s = -g and g . s behind and does NOT
+        // store g (in LDS a store between the loads serialises the pass); the first update pass that needs the old
+        // gradient recomputes it from (x, z) -- bit-identical -- and stores the new one.  A solve that ends with
+        // its first line search (every isotropic problem) never writes or reads g at all.
         constexpr bool kFuseInit = Place::kResident && !Model::kStencil;
         double dphi_init;
-        eval<false, true, kFuseInit>(0.0, f, dphi_init, gmax);
+        eval<false, !kFuseInit, kFuseInit>(0.0, f, dphi_init, gmax);
+        bool g_stored = !kFuseInit;
         score_ready = false;
         stamp(p, 2);
         iterations = 0;
@@ -1258,6 +1263,15 @@ struct Solver {
             // ---- perform_linesearch!: reset a non-descent direction ------------------------------
             if (dphi_0 >= 0.0) {
                 pseudo = 1;
+                if constexpr (kFuseInit) {
+                    if (!g_stored) {  // (cannot happen after a finite, unconverged initial evaluation; kept for completeness)
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                            double unused = 0.0;
+                            g.set(jj, i, Model::grad(ivk(i), x.get(jj, i), z.get(jj, i), unused));
+                        }, g);
+                        g_stored = true;
+                    }
+                }
                 double sum[1] = {0.0}, mx[1] = {0.0};
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
@@ -1333,15 +1347,19 @@ struct Solver {
                 mx[0] = nan_if(any_nan, mx[0]);
                 score_ready = true;
             } else if constexpr (!Model::kStencil) {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                auto body = [&](auto have_g, int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
                     z.set(jj, i, zn);
                     mx[0] = absmax(mx[0], zn - zo);
                     double unused = 0.0;
-                    const double gn = Model::grad(ivk(i), x.get(jj, i), zn, unused);
-                    const double dgi = gn - g.get(jj, i);
+                    const double xi = x.get(jj, i), ivi = ivk(i);
+                    const double gn = Model::grad(ivi, xi, zn, unused);
+                    double go;
+                    if constexpr (decltype(have_g)::value) go = g.get(jj, i);
+                    else go = Model::grad(ivi, xi, zo, unused);  // what the initial evaluation computed
+                    const double dgi = gn - go;
                     sum[0] = fma(dxi, dgi, sum[0]);
                     sum[1] = fma(dgi, dgi, sum[1]);
                     sum[2] = fma(dxi, gn, sum[2]);
@@ -1349,7 +1367,16 @@ struct Solver {
                     dgs.set(jj, i, dgi);
                     g.set(jj, i, gn);
                     s.set(jj, i, gn);
-                }, z, dxs, dgs, g, s);
+                };
+                if (g_stored) {
+                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { body(std::true_type{}, jj, i); },
+                                         z, dxs, dgs, g, s);
+                } else {
+                    if constexpr (kFuseInit)
+                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { body(std::false_type{}, jj, i); },
+                                             z, dxs, dgs, g, s);
+                    g_stored = true;
+                }
                 reduce<3, 1>(sum, mx);
                 mx[0] = nan_if(sum[0] != sum[0], mx[0]);
             } else {
