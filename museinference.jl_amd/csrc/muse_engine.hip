@@ -643,17 +643,37 @@ struct Solver {
         v.bind(hist + (int64_t)(2 * slot + 1) * a.ld, a.ld);
         return v;
     }
-    __device__ __forceinline__ double ivk(int i) const {
-        if constexpr (MAXB == 1) return iv0;
-        else return a.tmap.iv[block_of<MAXB>(a, i)];
+    // Block (theta component) of the element in slot jj / at index i.  Resident policy: a thread's slots are the
+    // same elements in every pass of every problem of the launch, so their 3-bit block indices are looked up once
+    // per kernel (pk, 10 slots per word) and a pass extracts one with a single v_bfe_u32; streaming: compares.
+    unsigned pk[2];
+    __device__ __forceinline__ int blk(int jj, int i) const {
+        if constexpr (MAXB == 1) return 0;
+        else if constexpr (Place::kResident) return (int)((pk[jj / 10] >> (3 * (jj % 10))) & 7u);
+        else return block_of<MAXB>(a, i);
     }
-    __device__ __forceinline__ double sdk(int i) const {
+    __device__ __forceinline__ double ivk(int jj, int i) const {
+        if constexpr (MAXB == 1) return iv0;
+        else return a.tmap.iv[blk(jj, i)];
+    }
+    __device__ __forceinline__ double sdk(int jj, int i) const {
+        if constexpr (MAXB == 1) return sd0;
+        else return sh_sd[blk(jj, i)];
+    }
+    __device__ __forceinline__ double sdk_at(int i) const {  // element index only (rolled loops)
         if constexpr (MAXB == 1) return sd0;
         else return sh_sd[block_of<MAXB>(a, i)];
     }
-    __device__ __forceinline__ int blk(int i) const {
-        if constexpr (MAXB == 1) return 0;
-        else return block_of<MAXB>(a, i);
+    __device__ __forceinline__ void pack_blocks() {
+        pk[0] = pk[1] = 0u;
+        if constexpr (MAXB > 1 && Place::kResident) {
+            static_assert(2 * EPT <= 20, "two words of ten 3-bit slots");
+#pragma unroll
+            for (int jj = 0; jj < 2 * EPT; ++jj) {
+                const int i = 2 * (tid + (jj >> 1) * T) + (jj & 1);
+                pk[jj / 10] |= (unsigned)block_of<MAXB>(a, i) << (3 * (jj % 10));
+            }
+        }
     }
 
     // d(-logLike)/dz_i at the point whose components are given by zt(.), for the stencil model
@@ -668,7 +688,7 @@ struct Solver {
         const double rm = x.get1(im1) - fma(0.25, zm2 + z0, 0.5 * zm1);
         const double r0 = x.get1(i) - fma(0.25, zm1 + zp1, 0.5 * z0);
         const double rp = x.get1(ip1) - fma(0.25, z0 + zp2, 0.5 * zp1);
-        const double t = this->ivk(i) * z0;
+        const double t = this->ivk(0, i) * z0;
         t_out = t;
         z_out = z0;
         r_out = r0;
@@ -743,7 +763,7 @@ struct Solver {
                 const double r0 = xp.a - fma(0.25, ztL.b + ztp.b, 0.5 * ztp.a);  // r at i0
                 const double r1 = xp.b - fma(0.25, ztp.a + ztR.a, 0.5 * ztp.b);  // r at i0+1
                 const double r2 = xR - fma(0.25, ztp.b + ztR.b, 0.5 * ztR.a);    // r at i0+2
-                const double t0 = ivk(i0) * ztp.a, t1 = ivk(i0 + 1) * ztp.b;
+                const double t0 = ivk(0, i0) * ztp.a, t1 = ivk(1, i0 + 1) * ztp.b;
                 g0[u] = t0 - fma(0.25, rm + r1, 0.5 * r0);
                 g1[u] = t1 - fma(0.25, r0 + r2, 0.5 * r1);
                 tt[u][0] = t0; zz[u][0] = ztp.a; rr[u][0] = r0;
@@ -791,7 +811,7 @@ struct Solver {
                     si = s.get(jj, i);
                     zi = fma(c, si, zi);
                 }
-                const double gi = Model::grad(ivk(i), x.get(jj, i), zi, sum[0]);
+                const double gi = Model::grad(ivk(jj, i), x.get(jj, i), zi, sum[0]);
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
                 if constexpr (INIT_S) {
@@ -1082,8 +1102,8 @@ struct Solver {
                     const NormalPair np0 = normal_pair(a.seed, sim, (uint64_t)i0);
                     const NormalPair np1 = normal_pair(a.seed, sim, (uint64_t)(i0 + 1));
                     double zt0, xt0, zt1, xt1;
-                    Model::sample(sdk(i0), np0.n1, np0.n2, zt0, xt0);
-                    Model::sample(sdk(i0 + 1), np1.n1, np1.n2, zt1, xt1);
+                    Model::sample(sdk_at(i0), np0.n1, np0.n2, zt0, xt0);
+                    Model::sample(sdk_at(i0 + 1), np1.n1, np1.n2, zt1, xt1);
                     const bool valid1 = i0 + 1 < (int)N;
                     x.p[i0] = xt0;
                     g.p[i0] = zt0;
@@ -1111,11 +1131,11 @@ struct Solver {
                     const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
                     double zt, xt;
                     if constexpr (Model::kStencil) {
-                        zt = sdk(i) * np.n1;
+                        zt = sdk(jj, i) * np.n1;
                         xt = np.n2;                           // noise now, + A z after the barrier
                         s.set(jj, i, valid ? zt : 0.0);       // true z staged in the direction buffer
                     } else {
-                        Model::sample(sdk(i), np.n1, np.n2, zt, xt);
+                        Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
                     }
                     zt = valid ? zt : 0.0;
                     xt = valid ? xt : 0.0;
@@ -1267,7 +1287,7 @@ struct Solver {
                     if (!g_stored) {  // (cannot happen after a finite, unconverged initial evaluation; kept for completeness)
                         for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                             double unused = 0.0;
-                            g.set(jj, i, Model::grad(ivk(i), x.get(jj, i), z.get(jj, i), unused));
+                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), z.get(jj, i), unused));
                         }, g);
                         g_stored = true;
                     }
@@ -1326,7 +1346,7 @@ struct Solver {
                     if constexpr (MAXB == 1) {
                         acc[0] += t;
                     } else {
-                        const int k = blk(i);
+                        const int k = blk(jj, i);
 #pragma unroll
                         for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
                     }
@@ -1354,7 +1374,7 @@ struct Solver {
                     z.set(jj, i, zn);
                     mx[0] = absmax(mx[0], zn - zo);
                     double unused = 0.0;
-                    const double xi = x.get(jj, i), ivi = ivk(i);
+                    const double xi = x.get(jj, i), ivi = ivk(jj, i);
                     const double gn = Model::grad(ivi, xi, zn, unused);
                     double go;
                     if constexpr (decltype(have_g)::value) go = g.get(jj, i);
@@ -1487,7 +1507,7 @@ struct Solver {
             if constexpr (Model::kStencil) {
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                     const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
-                    t1.set(jj, i, blk(i) == j ? 0.5 * zt : 0.0);
+                    t1.set(jj, i, blk(jj, i) == j ? 0.5 * zt : 0.0);
                 }, t1);
                 pass_barrier();
                 for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); }, t2);
@@ -1504,7 +1524,7 @@ struct Solver {
                     const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
                     double bi;
                     if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - zt));
-                    else bi = blk(i) == j ? 0.5 * zt : 0.0;
+                    else bi = blk(jj, i) == j ? 0.5 * zt : 0.0;
                     v.set(jj, i, 0.0);
                     r.set(jj, i, bi);
                     pp.set(jj, i, bi);
@@ -1523,7 +1543,7 @@ struct Solver {
                     pass_barrier();
                     for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
                         const double pi = pp.get(jj, i);
-                        const double api = -(Aat(t1, i) + ivk(i) * pi);
+                        const double api = -(Aat(t1, i) + ivk(jj, i) * pi);
                         Ap.set(jj, i, api);
                         s1[0] = fma(pi, api, s1[0]);
                     }, Ap);
@@ -1532,7 +1552,7 @@ struct Solver {
                         const double pi = pp.get(jj, i);
                         double api;
                         if constexpr (Model::kId == MUSE_MODEL_NOISE) api = -((iv0 + 1.0) * pi);
-                        else api = -(pi + ivk(i) * pi);
+                        else api = -(pi + ivk(jj, i) * pi);
                         Ap.set(jj, i, api);
                         s1[0] = fma(pi, api, s1[0]);
                     }, Ap);
@@ -1570,11 +1590,11 @@ struct Solver {
                     acc[0] = fma(-iv0 * dd, vi, acc[0]);
                     acc[1] = fma(dd, 0.5 * (xi - ztrue.get(jj, i)), acc[1]);
                 } else {
-                    const double t = ivk(i) * zi;
+                    const double t = ivk(jj, i) * zi;
                     if constexpr (MAXB == 1) {
                         acc[0] = fma(t, vi, acc[0]);
                     } else {
-                        const int k = blk(i);
+                        const int k = blk(jj, i);
 #pragma unroll
                         for (int b = 0; b < MAXB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
                     }
@@ -1625,21 +1645,23 @@ struct Solver {
                     if constexpr (MAXB == 1) {
                         acc[0] += t;
                     } else {
-                        const int k = blk(i);
+                        const int k = blk(jj, i);
 #pragma unroll
                         for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
                     }
                 });
                 reduce<MAXB, 0>(acc, mx);
             }
-            if (tid == 0 && crank == 0) {
+            if (tid < MAXB && tid < a.ntheta && crank == 0) {  // lane b finishes and writes score component b
+                double mine = acc[0];
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
-                    if (b < a.ntheta) {
-                        const double cnt = (double)(a.bnd[b + 1] - a.bnd[b]);
-                        a.scores[(int64_t)p * a.ntheta + b] = 0.5 * (a.tmap.iv[b] * acc[b] - cnt);
-                    }
-                }
+                for (int b = 1; b < MAXB; ++b) mine = (tid == b) ? acc[b] : mine;
+                const double cnt = (double)(a.bnd32[tid < a.ntheta - 1 ? tid + 1 : 0] - a.bnd32[tid]);
+                const double cnt_last = (double)((int)a.N - a.bnd32[tid]);  // bnd32[ntheta] is a sentinel, not N
+                a.scores[(int64_t)p * a.ntheta + tid] =
+                    0.5 * (a.tmap.iv[tid] * mine - (tid == a.ntheta - 1 ? cnt_last : cnt));
+            }
+            if (tid == 0 && crank == 0) {
                 muse_info inf;
                 inf.iterations = iterations;
                 inf.f_calls = f_calls;
@@ -1702,6 +1724,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         const int csize = a.csize, cluster = blockIdx.x / csize, crank = blockIdx.x % csize;
         double* cl_scratch = a.scratch + (int64_t)cluster * a.scratch_stride;
         Solver<Model, Place> sv(a, tid, red, shs);
+        sv.pack_blocks();
         sv.crank = crank;
         sv.csize = csize;
         sv.tfirst = crank * T + tid;
@@ -1716,6 +1739,13 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         }
     } else {
         double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+        unsigned pk0, pk1;  // the thread's packed block indices: once per kernel, not per problem
+        {
+            Solver<Model, Place> s0(a, tid, red, shs);
+            s0.pack_blocks();
+            pk0 = s0.pk[0];
+            pk1 = s0.pk[1];
+        }
         for (;;) {
             __syncthreads();
             if (tid == 0) ticket[0] = atomicAdd(a.work_counter, 1);
@@ -1723,6 +1753,8 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
             const int p = __builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base;
             if (p >= a.nproblems) break;
             Solver<Model, Place> sv(a, tid, red, shs);
+            sv.pk[0] = pk0;
+            sv.pk[1] = pk1;
             if constexpr (IMPLICIT) sv.run_implicit(p, wg_scratch, lds_x, lds_g);
             else sv.run(p, wg_scratch, lds_x, lds_g);
         }
