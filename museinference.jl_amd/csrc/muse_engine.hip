@@ -1185,6 +1185,8 @@ struct Solver {
         const int N = (int)a.N;
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
         f_calls = 0;
+        iter_stamp = 99;
+        stamp_p = p;
         last_c = NAN;
         // Resident policy, elementwise models: the initial evaluation leaves s = -g and g . s behind and does NOT
         // store g (in LDS a store between the loads serialises the pass); the first update pass that needs the old
