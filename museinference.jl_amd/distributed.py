@@ -120,6 +120,22 @@ class ShardedMuseProblem:
         iall = self._rows_to_info(allrows[:, nth * nth:].reshape(n * nth * 2, ninfo)).reshape(n, nth, 2)
         return np.ascontiguousarray(Hall), iall
 
+    def implicit_H_batch(self, rng, sim_begin, sim_end, theta0, *, atol=1e-1, cg_maxiter=100):
+        """get_H! implicit-differentiation branch, sims sharded like the maps (src/muse.jl:335-405)."""
+        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
+        nth = np.atleast_1d(theta0).size
+        if hi > lo:
+            Hs, its = self.local.implicit_H_batch(rng, lo, hi, theta0, atol=atol, cg_maxiter=cg_maxiter)
+        else:
+            Hs, its = np.zeros((0, nth, nth)), np.zeros((0, nth), dtype=np.int32)
+        counts = [block_partition(sim_begin, sim_end, self.world, r) for r in range(self.world)]
+        counts = [h - l for l, h in counts]
+        rows = np.concatenate([Hs.reshape(hi - lo, nth * nth), its.astype(np.float64).reshape(hi - lo, nth)], axis=1)
+        allrows = self._allgather_rows(rows, counts)
+        n = allrows.shape[0]
+        return (np.ascontiguousarray(allrows[:, : nth * nth].reshape(n, nth, nth)),
+                allrows[:, nth * nth:].astype(np.int32))
+
     def get_zhat(self, slot_begin, slot_end):
         raise NotImplementedError("resident MAPs are sharded; read them from the owning rank's local problem")
 

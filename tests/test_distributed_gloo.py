@@ -24,9 +24,10 @@ local = OracleBatchedProblem(x, "funnel", 2, prior=M.GaussianPrior(0.0, 3.0), nt
 prob = M.ShardedMuseProblem(local)
 res = M.muse(prob, [1.0, 0.5], rng=3, nsims=13, maxsteps=4, get_covariance=True)
 g, info = prob.map_and_score_batch(3, 2, 9, [0.1, 0.2], include_data=True)
+Hi, its = prob.implicit_H_batch(3, 0, 5, [0.1, 0.2])
 with open({out!r} + str(rank), "wb") as f:
     pickle.dump(dict(theta=res.theta, J=res.J, H=res.H, Sigma=res.Sigma, gs=np.array(res.gs), g=g,
-                     iters=info["iterations"], nlocal=len(local._zhat)), f)
+                     iters=info["iterations"], nlocal=len(local._zhat), Hi=Hi, its=its), f)
 dist.destroy_process_group()
 """
 
@@ -51,9 +52,11 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     single = OracleBatchedProblem(x, "funnel", 2, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
     ref = M.muse(single, [1.0, 0.5], rng=3, nsims=13, maxsteps=4, get_covariance=True)
     gref, iref = single.map_and_score_batch(3, 2, 9, [0.1, 0.2], include_data=True)
+    Hiref, itsref = single.implicit_H_batch(3, 0, 5, [0.1, 0.2])
     for r in range(2):
         for k, want in (("theta", ref.theta), ("J", ref.J), ("H", ref.H), ("Sigma", ref.Sigma),
-                        ("gs", np.array(ref.gs)), ("g", gref), ("iters", iref["iterations"])):
+                        ("gs", np.array(ref.gs)), ("g", gref), ("iters", iref["iterations"]),
+                        ("Hi", Hiref), ("its", itsref)):
             assert np.array_equal(got[r][k], want), (r, k)
     # each rank solved only its own block (data element on rank 0)
     assert got[0]["nlocal"] + got[1]["nlocal"] >= 8 and got[1]["nlocal"] < 14
