@@ -91,6 +91,22 @@ __device__ __forceinline__ void sincospi_02(double t, double& sn, double& cs) {
     cs = ((n + 1) & 2) ? -b : b;
 }
 
+// IEEE sqrt for an argument in the normal range (here 2.2e-16 <= x <= 73): the correctly rounding
+// v_rsq_f64 + two Newton-Raphson steps that the compiler emits for sqrt(), without the rescaling and the
+// zero/infinity selects that only arguments outside that range need.
+__device__ __forceinline__ double sqrt_normal(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y;
+    const double h0 = 0.5 * y;
+    const double r0 = fma(-h0, s0, 0.5);
+    const double s1 = fma(s0, r0, s0);
+    const double h1 = fma(h0, r0, h0);
+    const double d0 = fma(-s1, s1, x);
+    const double s2 = fma(d0, h1, s1);
+    const double d1 = fma(-s2, s2, x);
+    return fma(d1, h1, s2);
+}
+
 __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, uint64_t sim, uint64_t i) {
     uint32_t w[4];
     philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)sim, (uint32_t)(sim >> 32), (uint32_t)seed,
@@ -98,11 +114,15 @@ __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, uint64_t sim, u
     // u = (k + 1/2) 2^-52 with k the 52 random bits: put k in the mantissa of a double in [1,2),
     // subtract 1 (exact) and add 2^-53 (exact: (2k+1) 2^-53 has 53 significant bits).  No int->fp
     // conversion instructions; the value is identical to ((double)k + 0.5) * 2^-52.
-    const uint64_t k1 = ((uint64_t)w[0] << 20) | (uint64_t)(w[1] >> 12);
-    const uint64_t k2 = ((uint64_t)w[2] << 20) | (uint64_t)(w[3] >> 12);
-    const double u1 = (__longlong_as_double((long long)(0x3FF0000000000000ull | k1)) - 1.0) + 1.1102230246251565404e-16;
-    const double u2 = (__longlong_as_double((long long)(0x3FF0000000000000ull | k2)) - 1.0) + 1.1102230246251565404e-16;
-    const double r = __builtin_sqrt(-2.0 * log_unit(u1));
+    // The 64-bit pattern 0x3FF0000000000000 | (w_a << 20) | (w_b >> 12), one v_alignbit_b32 per half:
+    //   low word  = ((w_a:w_b) >> 12)[31:0],  high word = ((0x3FF:w_a) >> 12)[31:0] = 0x3FF00000 | (w_a >> 12).
+    const double m1 = __hiloint2double((int)__builtin_amdgcn_alignbit(0x3FFu, w[0], 12),
+                                       (int)__builtin_amdgcn_alignbit(w[0], w[1], 12));
+    const double m2 = __hiloint2double((int)__builtin_amdgcn_alignbit(0x3FFu, w[2], 12),
+                                       (int)__builtin_amdgcn_alignbit(w[2], w[3], 12));
+    const double u1 = (m1 - 1.0) + 1.1102230246251565404e-16;
+    const double u2 = (m2 - 1.0) + 1.1102230246251565404e-16;
+    const double r = sqrt_normal(-2.0 * log_unit(u1));
     double sn, cs;
     sincospi_02(2.0 * u2, sn, cs);
     return NormalPair{r * cs, r * sn};
