@@ -150,12 +150,18 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     dt = time.perf_counter() - t0
     out["get_H_fd_maps_per_s"] = reps * (1 + 2 * nth * nH) / dt
     out["get_H_fd_nsims"] = nH
+    M.muse(prob, [1.0] * nth, rng=seed, nsims=nsims, get_covariance=True)  # first call: pinned result areas are allocated
     t0 = time.perf_counter()
     res = M.muse(prob, [1.0] * nth, rng=seed, nsims=nsims, get_covariance=True)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res30 = M.muse(prob, [1.0] * nth, rng=seed, nsims=nsims, maxsteps=30, theta_rtol=1e-12)
+    dt30 = time.perf_counter() - t0
     out["muse_run"] = {"wall_s": dt, "outer_iterations": len(res.history), "theta": [float(t) for t in res.theta],
                        "sigma": [float(t) for t in np.sqrt(np.diag(np.atleast_2d(res.Sigma)))],
-                       "note": "muse(prob, theta0=1; nsims, get_covariance=True): outer iterations + get_J! + get_H!, host algebra included"}
+                       "us_per_outer_iteration_30": 1e6 * dt30 / max(1, len(res30.history)),
+                       "note": "muse(prob, theta0=1; nsims, get_covariance=True): outer iterations (native muse_run) + get_J! + get_H!, "
+                               "host algebra included; us_per_outer_iteration_30 from a 30-iteration run"}
     prob.close()
     return out
 

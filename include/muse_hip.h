@@ -140,6 +140,34 @@ int muse_map_and_score_batch_async(muse_ctx* ctx, uint64_t seed, int64_t sim_beg
                                    int include_data, const double* theta, double atol, int z0_mode,
                                    int result_area);
 int muse_batch_wait(muse_ctx* ctx, int result_area, double* g_out, muse_info* info_out);
+/* The muse! outer loop itself (src/muse.jl:112-232) for the common case -- untransformed theta, the "sims"
+ * Jacobian update H^-1_like' = Diagonal(-1 ./ var(g_sims')) (src/muse.jl:188-191), constant alpha, identity
+ * `regularize`, a flat or independent-Gaussian prior (src/simple.jl:69-71) -- so that between two map launches
+ * the host spends microseconds, not an interpreter's per-iteration overhead: per iteration one
+ * (nsims+1)-element map (first from zero(z) or, with z0_warm, from the resident zhat; later ones warm,
+ * src/muse.jl:151,181), then g_like' = g_dat' - mean(g_sims') (:183), the prior gradient/Hessian (:184,207),
+ * H^-1_post' = inv(inv(H^-1_like') + H_prior') (:208), theta <- theta - alpha H^-1_post' g_post' (:224), and
+ * at the top of iterations i > 2 the convergence test sqrt(-(dtheta' H^-1_post' dtheta)) < theta_rtol on the
+ * last two records (:163-166).  Everything else (Broyden updates, callable alpha, transforms, checkpoints)
+ * stays with the host driver, which builds the same history records from these arrays.
+ * Outputs (host, caller-allocated for maxsteps iterations; n = number of iterations run, <= maxsteps):
+ *   theta_out [ntheta]                       result.theta, the iterate after the last step (src/muse.jl:230)
+ *   hist_out  [maxsteps][MUSE_RUN_HIST(ntheta)] per iteration: theta (where the map ran), g_like_dat,
+ *             g_like, g_prior, g_post, diag(H^-1_like), diag(H_prior) (ntheta each), H^-1_post
+ *             (ntheta x ntheta, row-major), wall seconds of the iteration
+ *   gsims_out [maxsteps][nsims][ntheta]      g_like_sims of every iteration (result.gs = the last one, :231)
+ *   info_out  [maxsteps][nsims+1]            solver infos, data element first (may be NULL) */
+typedef struct muse_run_options {
+    int32_t nsims, maxsteps;
+    double theta_rtol, atol, alpha;
+    int32_t prior_kind; /* 0 flat (src/interface.jl:120-121), 1 independent Gaussian */
+    int32_t z0_warm;    /* first iteration starts from the resident zhat (a z0 was given, src/muse.jl:151) */
+    double prior_mean[MUSE_MAX_THETA], prior_sigma[MUSE_MAX_THETA];
+} muse_run_options;
+#define MUSE_RUN_HIST(ntheta) (7 * (ntheta) + (ntheta) * (ntheta) + 1)
+int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
+             double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
+
 /* Resident MAP state: read back / restore zhat of slots [slot_begin, slot_end) ([n][N], row-major).
  * Serves save_MAPs (src/muse.jl:139-143,219) and checkpoint/resume (src/muse.jl:134-135,234). */
 int muse_get_zhat(muse_ctx* ctx, int64_t slot_begin, int64_t slot_end, double* out, int mem);

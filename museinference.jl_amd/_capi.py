@@ -25,6 +25,17 @@ INFO_DTYPE = np.dtype(
 )
 
 
+class RunOptions(C.Structure):
+    """struct muse_run_options of include/muse_hip.h"""
+    _fields_ = [("nsims", C.c_int32), ("maxsteps", C.c_int32), ("theta_rtol", C.c_double), ("atol", C.c_double),
+                ("alpha", C.c_double), ("prior_kind", C.c_int32), ("z0_warm", C.c_int32),
+                ("prior_mean", C.c_double * MAX_THETA), ("prior_sigma", C.c_double * MAX_THETA)]
+
+
+def run_hist_width(ntheta):
+    return 7 * ntheta + ntheta * ntheta + 1  # MUSE_RUN_HIST
+
+
 class MuseError(RuntimeError):
     """A libmuse_hip call returned a negative status."""
 
@@ -55,6 +66,7 @@ SIGNATURES = {
     "muse_map_and_score_batch": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _vp, _vp]),
     "muse_map_and_score_batch_async": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _i]),
     "muse_batch_wait": (_i, [_vp, _i, _vp, _vp]),
+    "muse_run": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_get_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_fd_jacobian_batch": (_i, [_vp, _u64, _i64, _i64, _vp, _vp, _d, _i, _i64, _vp, _vp]),

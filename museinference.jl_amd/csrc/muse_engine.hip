@@ -28,8 +28,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/muse_hip.h"
@@ -2538,6 +2540,122 @@ int muse_map_and_score_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int6
     int rc = muse_map_and_score_batch_async(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, 0);
     if (rc) return rc;
     return muse_batch_wait(c, 0, g_out, info_out);
+}
+
+// ---- the muse! outer loop in native host code (see muse_hip.h) ----------------------------------------
+// inverse of a small dense matrix (n <= MUSE_MAX_THETA) by Gauss-Jordan with partial pivoting; false if singular
+static bool small_inverse(int n, const double* A, double* inv) {
+    double M[kMaxTheta][2 * kMaxTheta];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            M[i][j] = A[i * n + j];
+            M[i][n + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < n; ++r)
+            if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+        if (!(fabs(M[piv][col]) > 0.0)) return false;
+        if (piv != col)
+            for (int j = 0; j < 2 * n; ++j) std::swap(M[piv][j], M[col][j]);
+        const double d = M[col][col];
+        for (int j = 0; j < 2 * n; ++j) M[col][j] /= d;
+        for (int r = 0; r < n; ++r) {
+            if (r == col) continue;
+            const double f = M[r][col];
+            if (f != 0.0)
+                for (int j = 0; j < 2 * n; ++j) M[r][j] -= f * M[col][j];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) inv[i * n + j] = M[i][n + j];
+    return true;
+}
+
+int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
+             double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !o || !niter_out || !theta_out || !hist_out || !gsims_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (o->nsims < 2 || o->maxsteps < 1) return fail(MUSE_ERR_INVALID, "muse_run needs nsims >= 2 and maxsteps >= 1");
+    if (o->prior_kind != 0 && o->prior_kind != 1) return fail(MUSE_ERR_INVALID, "prior_kind must be 0 (flat) or 1 (Gaussian)");
+    if (!c->has_data) return fail(MUSE_ERR_NODATA, "muse_run needs the observed data (muse_set_data)");
+    const int nt = c->ntheta, S = o->nsims;
+    const int64_t H = MUSE_RUN_HIST(nt);
+    double theta[kMaxTheta], gprior[kMaxTheta], hprior[kMaxTheta];
+    for (int k = 0; k < nt; ++k) theta[k] = theta0[k];
+    std::vector<double> g((size_t)(S + 1) * nt);
+    std::vector<muse_info> info((size_t)S + 1);
+    int n = 0;
+    for (int i = 1; i <= o->maxsteps; ++i) {
+        const double t_start = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                   std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-9;
+        if (i > 2) {  // convergence on the last two records (src/muse.jl:163-166)
+            const double* h1 = hist_out + (int64_t)(i - 2) * H;  // record i-1
+            const double* h0 = hist_out + (int64_t)(i - 3) * H;  // record i-2
+            const double* Hp = h1 + 7 * nt;
+            double q = 0.0;
+            for (int a_ = 0; a_ < nt; ++a_) {
+                double row = 0.0;
+                for (int b = 0; b < nt; ++b) row += Hp[a_ * nt + b] * (h1[b] - h0[b]);
+                q += (h1[a_] - h0[a_]) * row;
+            }
+            if (sqrt(-q > 0.0 ? -q : 0.0) < o->theta_rtol) break;
+        }
+        const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
+        rc = muse_map_and_score_batch(c, seed, 0, S, 1, theta, o->atol, z0_mode, g.data(), info.data());
+        if (rc) return rc;
+        double* h = hist_out + (int64_t)(i - 1) * H;
+        double* gs = gsims_out + (int64_t)(i - 1) * S * nt;
+        memcpy(gs, g.data() + nt, (size_t)S * nt * sizeof(double));
+        if (info_out) memcpy(info_out + (int64_t)(i - 1) * (S + 1), info.data(), ((size_t)S + 1) * sizeof(muse_info));
+        double Hlike[kMaxTheta * kMaxTheta], Hinv_like_inv[kMaxTheta * kMaxTheta], Hpost[kMaxTheta * kMaxTheta];
+        for (int k = 0; k < nt; ++k) {
+            double m = 0.0;
+            for (int s = 0; s < S; ++s) m += gs[(int64_t)s * nt + k];
+            m /= S;
+            double v = 0.0;
+            for (int s = 0; s < S; ++s) {
+                const double dlt = gs[(int64_t)s * nt + k] - m;
+                v += dlt * dlt;
+            }
+            v /= (S - 1);  // corrected (src/muse.jl:188)
+            if (o->prior_kind == 1) {
+                const double sg2 = o->prior_sigma[k] * o->prior_sigma[k];
+                gprior[k] = -(theta[k] - o->prior_mean[k]) / sg2;
+                hprior[k] = -1.0 / sg2;
+            } else {
+                gprior[k] = 0.0;
+                hprior[k] = 0.0;
+            }
+            h[k] = theta[k];
+            h[nt + k] = g[k];                    // g_like_dat
+            h[2 * nt + k] = g[k] - m;            // g_like  = g_dat - mean(g_sims)
+            h[3 * nt + k] = gprior[k];
+            h[4 * nt + k] = h[2 * nt + k] + gprior[k];  // g_post
+            h[5 * nt + k] = -1.0 / v;            // diag H^-1_like
+            h[6 * nt + k] = hprior[k];
+        }
+        // H^-1_post = inv(inv(H^-1_like) + H_prior): both diagonal here, kept general through the dense inverse
+        for (int a_ = 0; a_ < nt * nt; ++a_) Hlike[a_] = 0.0;
+        for (int k = 0; k < nt; ++k) Hlike[k * nt + k] = h[5 * nt + k];
+        if (!small_inverse(nt, Hlike, Hinv_like_inv)) return fail(MUSE_ERR_INVALID, "muse_run: singular H^-1_like (zero score variance)");
+        for (int k = 0; k < nt; ++k) Hinv_like_inv[k * nt + k] += hprior[k];
+        if (!small_inverse(nt, Hinv_like_inv, Hpost)) return fail(MUSE_ERR_INVALID, "muse_run: singular posterior Hessian");
+        for (int a_ = 0; a_ < nt * nt; ++a_) h[7 * nt + a_] = Hpost[a_];
+        for (int a_ = 0; a_ < nt; ++a_) {  // Newton-Raphson step (src/muse.jl:224)
+            double stp = 0.0;
+            for (int b = 0; b < nt; ++b) stp += Hpost[a_ * nt + b] * h[4 * nt + b];
+            theta[a_] = h[a_] - o->alpha * stp;
+        }
+        const double t_end = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                 std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-9;
+        h[7 * nt + nt * nt] = t_end - t_start;
+        n = i;
+    }
+    *niter_out = n;
+    for (int k = 0; k < nt; ++k) theta_out[k] = theta[k];
+    return MUSE_OK;
 }
 
 int muse_get_zhat(muse_ctx* c, int64_t b, int64_t e, double* out, int mem) {

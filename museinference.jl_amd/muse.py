@@ -118,8 +118,8 @@ def muse(prob, theta0, **kwargs):
 
 def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rtol=1e-1,
           grad_z_logLike_atol=1e-2, nsims=100, alpha=0.7, progress=False, pool=None,
-          regularize=lambda t: t, Hinv_like0=None, Hinv_update="sims", broyden_memory=math.inf,
-          checkpoint_filename=None, get_covariance=False, save_MAPs=False):
+          regularize=None, Hinv_like0=None, Hinv_update="sims", broyden_memory=math.inf,
+          checkpoint_filename=None, get_covariance=False, save_MAPs=False, native="auto"):
     """muse!(result, prob, θ₀; ...)   (src/muse.jl:112-250).
 
     Keyword names: θ_rtol -> theta_rtol, ∇z_logLike_atol -> grad_z_logLike_atol, α -> alpha,
@@ -128,6 +128,18 @@ def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rt
     `pool` is accepted for signature parity and ignored: the batch is one GPU launch.
     """
     result.rng = rng = int(_something(rng, result.rng, _default_rng()))
+    # `native`: run the whole outer loop in the library's host code (muse_run of the C ABI) when the options are
+    # the plain ones it implements -- a fresh run, "sims" Jacobian update, constant alpha, identity regularize,
+    # flat/Gaussian prior, untransformed theta, nothing to save per iteration; "auto" = whenever possible.
+    plain = (len(result.history) == 0 and regularize is None and Hinv_like0 is None and Hinv_update == "sims"
+             and not callable(alpha) and checkpoint_filename is None and save_MAPs is False and nsims >= 2
+             and getattr(type(prob), "supports_native_muse", False) and prob.native_prior() is not None)
+    if native is True and not plain:
+        raise ValueError("native=True needs the plain option set muse_run implements (see muse_hip.h)")
+    if native in (True, "auto") and plain:
+        return _muse_native(result, prob, _something(result.theta, theta0), rng, z0, maxsteps, theta_rtol,
+                            grad_z_logLike_atol, nsims, alpha, get_covariance)
+    regularize = (lambda t: t) if regularize is None else regularize
     theta_unreg = theta = prob.standardize_theta(_something(result.theta, theta0))
     theta_unreg_t = theta_t = np.atleast_1d(prob.transform_theta(theta))
     history = result.history
@@ -213,6 +225,39 @@ def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rt
     if get_covariance:
         get_J_(result, prob, rng=rng, nsims=nsims, grad_z_logLike_atol=grad_z_logLike_atol)
         get_H_(result, prob, rng=rng, nsims=max(1, nsims // 10), grad_z_logLike_atol=grad_z_logLike_atol)
+    return result
+
+
+def _muse_native(result, prob, theta0, rng, z0, maxsteps, theta_rtol, atol, nsims, alpha, get_covariance):
+    """muse! through muse_run: the same history records as muse_ builds, from the arrays the library returns."""
+    from .problem import check_optim_soln
+    theta0 = prob.standardize_theta(theta0)
+    nth = theta0.size
+    if z0 is not None:  # starting guess for every element's MAP (src/muse.jl:151)
+        prob.set_zhat(0, np.tile(np.asarray(z0, dtype=np.float64), (nsims + 1, 1)))
+    n, theta, hist, gs, info = prob.run_muse(rng, theta0, nsims=nsims, maxsteps=maxsteps, theta_rtol=theta_rtol,
+                                             atol=atol, alpha=float(alpha), z0_warm=z0 is not None)
+    for i in range(n):
+        h = hist[i]
+        th = h[0:nth].copy()
+        seg = lambda k: h[k * nth:(k + 1) * nth].copy()
+        Hinv_like = np.diag(seg(5))
+        check_optim_soln(info[i], "muse!")
+        result.history.append({
+            "θ": th, "θunreg": th, "θ′": th, "θunreg′": th,
+            "g_like_sims": gs[i], "g_like_dat′": seg(1), "g_like_sims′": gs[i], "g_like′": seg(2),
+            "g_prior′": seg(3), "g_post′": seg(4),
+            "H⁻¹_post′": h[7 * nth:7 * nth + nth * nth].reshape(nth, nth).copy(), "H_prior′": np.diag(seg(6)),
+            "H⁻¹_like′": Hinv_like, "H⁻¹_like_sims′": Hinv_like,
+            "ẑ_history_dat": info[i][0], "ẑ_history_sims": info[i][1:], "t": float(h[-1]),
+            "ẑ_dat": None, "ẑ_sims": [None] * nsims,
+        })
+        result.time += float(h[-1])
+    result.theta = theta
+    result.gs = list(gs[n - 1])
+    if get_covariance:
+        get_J_(result, prob, rng=rng, nsims=nsims, grad_z_logLike_atol=atol)
+        get_H_(result, prob, rng=rng, nsims=max(1, nsims // 10), grad_z_logLike_atol=atol)
     return result
 
 

@@ -164,6 +164,9 @@ class HipMuseProblem(AbstractMuseProblem):
     (src/muse.jl:426-442).
     """
 
+    supports_native_muse = True  # muse_() may hand the whole outer loop to muse_run (class attribute: wrappers
+                                 # that forward attribute access to a HipMuseProblem do not inherit it)
+
     def __init__(self, x, model="funnel", ntheta=1, prior=None, device=0, N=None):
         self._lib = _capi.load_library()
         if model not in _capi.MODELS:
@@ -308,6 +311,36 @@ class HipMuseProblem(AbstractMuseProblem):
         info = np.zeros(n, dtype=_capi.INFO_DTYPE)
         _capi.check(self._lib.muse_batch_wait(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
         return g, info
+
+    def native_prior(self):
+        """(kind, mean[nθ], sigma[nθ]) if the prior is one muse_run evaluates itself, else None."""
+        from .priors import FlatPrior, GaussianPrior
+        if type(self.prior) is FlatPrior:
+            return 0, np.zeros(self.ntheta), np.ones(self.ntheta)
+        if type(self.prior) is GaussianPrior:
+            return (1, np.broadcast_to(np.asarray(self.prior.mean, dtype=np.float64), (self.ntheta,)).copy(),
+                    np.broadcast_to(np.asarray(self.prior.sigma, dtype=np.float64), (self.ntheta,)).copy())
+        return None
+
+    def run_muse(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False):
+        """The muse! outer loop in the library's native host code (muse_run, include/muse_hip.h): returns
+        (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1])."""
+        kind, mean, sigma = self.native_prior()
+        o = _capi.RunOptions()
+        o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)
+        o.prior_kind, o.z0_warm = int(kind), int(bool(z0_warm))
+        for k in range(self.ntheta):
+            o.prior_mean[k], o.prior_sigma[k] = float(mean[k]), float(sigma[k])
+        th0 = self._theta(theta0)
+        W = _capi.run_hist_width(self.ntheta)
+        hist = np.zeros((maxsteps, W))
+        gs = np.zeros((maxsteps, nsims, self.ntheta))
+        info = np.zeros((maxsteps, nsims + 1), dtype=_capi.INFO_DTYPE)
+        theta = np.zeros(self.ntheta)
+        n = C.c_int32()
+        _capi.check(self._lib.muse_run(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
+                                       _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
+        return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
 
     def get_zhat(self, slot_begin, slot_end):
         out = np.empty((slot_end - slot_begin, self.N))

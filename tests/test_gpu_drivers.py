@@ -314,3 +314,43 @@ def test_sharded_driver_over_engine_rccl_one_rank(gpu, M, O, tmp_path):
     for k, want in (("theta", ref.theta), ("J", ref.J), ("H", ref.H), ("Sigma", ref.Sigma), ("gs", np.array(ref.gs))):
         assert np.array_equal(got[k], want), k
     single.close()
+
+
+@pytest.mark.parametrize("model,N,nth,theta0,prior", [
+    ("funnel", 10000, 1, [1.0], "gauss"), ("funnel", 3000, 4, [1.0, 0.5, -0.5, 2.0], "gauss"),
+    ("noise", 2000, 1, [0.8], "flat"), ("smooth", 1500, 2, [1.0, 0.3], "gauss")])
+def test_native_outer_loop_equals_host_driver(gpu, M, O, model, N, nth, theta0, prior):
+    """muse_run (the outer loop in the library's native host code) against the Python driver on the same
+    launches: the same number of iterations, every history record and the final theta/J/H/Sigma to 1e-12
+    (means and variances are summed in a different order: numpy's pairwise sums vs sequential)."""
+    x, _ = O.sample_x_z(model, N, 11, M.DATA_SIM, [0.0] * nth)
+    pr = M.GaussianPrior(0.0, 3.0) if prior == "gauss" else None
+    res = {}
+    for native in (False, True):
+        prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=pr)
+        res[native] = M.muse(prob, theta0, rng=5, nsims=64, maxsteps=12, theta_rtol=1e-3, get_covariance=True,
+                             native=native)
+        prob.close()
+    a, b = res[False], res[True]
+    assert len(a.history) == len(b.history) >= 3
+    for ha, hb in zip(a.history, b.history):
+        for k in ("θ", "θunreg", "θ′", "g_like_dat′", "g_like′", "g_prior′", "g_post′", "H⁻¹_post′", "H_prior′",
+                  "H⁻¹_like′", "H⁻¹_like_sims′", "g_like_sims", "g_like_sims′"):
+            np.testing.assert_allclose(np.asarray(hb[k]), np.asarray(ha[k]), rtol=1e-12, atol=1e-13, err_msg=k)
+        assert np.array_equal(hb["ẑ_history_sims"]["iterations"], ha["ẑ_history_sims"]["iterations"])
+        assert hb["ẑ_history_dat"]["f_calls"] == ha["ẑ_history_dat"]["f_calls"]
+    for k in ("theta", "J", "H", "Sigma"):
+        np.testing.assert_allclose(getattr(b, k), getattr(a, k), rtol=1e-10, err_msg=k)
+    np.testing.assert_allclose(np.array(b.gs), np.array(a.gs), rtol=1e-12, atol=1e-13)
+
+
+def test_native_outer_loop_options(gpu, M, O):
+    x, _ = O.sample_x_z("funnel", 2000, 3, M.DATA_SIM, [0.0])
+    prob = M.HipMuseProblem(x, model="funnel", prior=M.GaussianPrior(0.0, 3.0))
+    with pytest.raises(ValueError):
+        M.muse(prob, [1.0], rng=1, nsims=16, alpha=lambda i: 0.5, native=True)   # not a plain option set
+    r1 = M.muse(prob, [1.0], rng=1, nsims=16, maxsteps=3, z0=np.full(2000, 0.1), native=True)
+    r2 = M.muse(prob, [1.0], rng=1, nsims=16, maxsteps=3, z0=np.full(2000, 0.1), native=False)
+    np.testing.assert_allclose(r1.theta, r2.theta, rtol=1e-12)
+    assert len(r1.history) == len(r2.history) >= 2
+    prob.close()
