@@ -1902,7 +1902,7 @@ struct muse_ctx {
     int* error_flag = nullptr;           // pinned, device-mapped
     int debug = 0;
     unsigned int ticket_base = 0;  // value of the device ticket counter when the next launch starts
-    bool timing = true;            // record an event pair around every solver launch
+    bool timing = false;           // record an event pair around every solver launch (muse_set_timing; costs ~12 us per launch)
     unsigned long long* stamps = nullptr;
     int64_t stamps_cap = 0;
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
