@@ -91,17 +91,37 @@ struct BatchArgs {
     double* cl_part;               // [nclusters][2][csize][8] partial sums / maxima
     int* error_flag;               // set when a bounded cluster wait expires
     unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
+    // Standard normals of simulation streams already drawn inside the SAME host call (muse_run's later
+    // iterations re-draw every simulation at a new theta, the FD batch draws each simulation 2*ntheta times):
+    // [slot][2][ld], slot = sim - ncache_sim0.  mode 1: generate and store; mode 2: load instead of generating.
+    double* ncache;
+    int64_t ncache_sim0;
+    int ncache_count, ncache_mode;
+    int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
+    int pad3_;
+    int64_t norm_sim0;
 };
 
 struct ProblemDesc {
     int64_t sim;
+    int nslot;         // slot of the simulation's normals in the cache, -1: none
+    bool normals_only;
     int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
     int64_t zslot, z0slot;         // zslot < 0: zhat not stored
 };
 
 __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     ProblemDesc d;
-    if (a.kind == BATCH_STD) {
+    d.normals_only = false;
+    if (a.kind == BATCH_STD && p >= a.nstd) {
+        d.sim = a.norm_sim0 + (p - a.nstd);
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_ZERO;
+        d.tsample = -1;
+        d.zslot = -1;
+        d.z0slot = a.slot0;
+        d.normals_only = true;
+    } else if (a.kind == BATCH_STD) {
         const bool data = a.include_data && p == 0;
         d.sim = data ? -1 : a.sim_begin + p - (a.include_data ? 1 : 0);
         d.x_mode = (data || (a.debug & 2)) ? X_DATA : X_SAMPLE;
@@ -132,6 +152,8 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.zslot = a.slot0;
         d.z0slot = a.slot0;
     }
+    const int64_t ns = d.sim - a.ncache_sim0;
+    d.nslot = (a.ncache && d.sim >= 0 && ns >= 0 && ns < a.ncache_count) ? (int)ns : -1;
     return d;
 }
 
@@ -1051,6 +1073,7 @@ struct Solver {
 
     __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         begin<false>(p, wg_scratch, lds_x, lds_g);
+        if (d.normals_only) return;  // the element only filled its slot of the normals cache
         solve(p);
         finish(p);
     }
@@ -1097,20 +1120,54 @@ struct Solver {
                 // Sampler as a ROLLED loop over this thread's pairs (one or two Philox/Box-Muller
                 // chains in flight, not 2*EPT): x goes straight to LDS, the true z is staged in the
                 // (still unused) g area and picked up into registers below.
+                const int nmode = d.nslot >= 0 ? a.ncache_mode : 0;  // workgroup-uniform
+                rsrc_t n1r = make_rsrc(a.ncache, 0), n2r = n1r;
+                if (nmode != 0) {
+                    n1r = make_rsrc(a.ncache + (int64_t)(2 * d.nslot) * ld, ld * 8);
+                    n2r = make_rsrc(a.ncache + (int64_t)(2 * d.nslot + 1) * ld, ld * 8);
+                }
+                if (nmode == 2) {
+                    // the stream was drawn earlier in this host call: its normals come from HBM (all of the
+                    // thread's loads in flight at once; out-of-range pairs read zeros), not from the generator
+                    double c1[EPT][2], c2[EPT][2];
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) {
+                        const int i0 = 2 * (tid + j * T);
+                        load_f64x2(n1r, i0, c1[j][0], c1[j][1]);
+                        load_f64x2(n2r, i0, c2[j][0], c2[j][1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) {
+                        const int i0 = 2 * (tid + j * T);
+                        double zt0, xt0, zt1, xt1;
+                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0);
+                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1);
+                        const bool valid1 = i0 + 1 < (int)N;
+                        x.set(2 * j, i0, xt0);
+                        x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
+                        g.set(2 * j, i0, zt0);
+                        g.set(2 * j + 1, i0 + 1, valid1 ? zt1 : 0.0);
+                    }
+                } else {
 #pragma unroll 1
-                for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
-                    // both elements of the pair unconditionally (one basic block: their Philox/Box-Muller
-                    // chains interleave); for odd N the last pair's second element is the pad slot, kept at 0
-                    const NormalPair np0 = normal_pair(a.seed, sim, (uint64_t)i0);
-                    const NormalPair np1 = normal_pair(a.seed, sim, (uint64_t)(i0 + 1));
-                    double zt0, xt0, zt1, xt1;
-                    Model::sample(sdk_at(i0), np0.n1, np0.n2, zt0, xt0);
-                    Model::sample(sdk_at(i0 + 1), np1.n1, np1.n2, zt1, xt1);
-                    const bool valid1 = i0 + 1 < (int)N;
-                    x.p[i0] = xt0;
-                    g.p[i0] = zt0;
-                    x.p[i0 + 1] = valid1 ? xt1 : 0.0;
-                    g.p[i0 + 1] = valid1 ? zt1 : 0.0;
+                    for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
+                        // both elements of the pair unconditionally (one basic block: their Philox/Box-Muller
+                        // chains interleave); for odd N the last pair's second element is the pad slot, kept at 0
+                        const NormalPair np0 = normal_pair(a.seed, sim, (uint64_t)i0);
+                        const NormalPair np1 = normal_pair(a.seed, sim, (uint64_t)(i0 + 1));
+                        if (nmode == 1) {
+                            store_f64x2(n1r, i0, np0.n1, np1.n1);
+                            store_f64x2(n2r, i0, np0.n2, np1.n2);
+                        }
+                        double zt0, xt0, zt1, xt1;
+                        Model::sample(sdk_at(i0), np0.n1, np0.n2, zt0, xt0);
+                        Model::sample(sdk_at(i0 + 1), np1.n1, np1.n2, zt1, xt1);
+                        const bool valid1 = i0 + 1 < (int)N;
+                        x.p[i0] = xt0;
+                        g.p[i0] = zt0;
+                        x.p[i0 + 1] = valid1 ? xt1 : 0.0;
+                        g.p[i0 + 1] = valid1 ? zt1 : 0.0;
+                    }
                 }
                 z.clear();
                 s.clear();
@@ -1896,6 +1953,8 @@ struct muse_ctx {
     std::vector<hipEvent_t> prof_ev;
     int prof_count = 0;
     bool prof_on = false;
+    double* ncache = nullptr;            // normals cache [ncache_slots][2][ld] (muse_run, FD batches)
+    int64_t ncache_slots = 0;
     unsigned int* cl_counter = nullptr;  // cluster mode: [cl_cap] arrival counters
     double* cl_part = nullptr;           // [cl_cap][2][kMaxCluster][8]
     int cl_cap = 0;
@@ -1950,6 +2009,10 @@ static int choose_place(const muse_ctx* c) {
     if (c->N <= 4096) return P_R512x4;
     return P_R512x10;
 }
+static bool ncache_applies(const muse_ctx* c) {
+    static const bool off = getenv("MUSE_DEBUG_NO_NCACHE") != nullptr;  // tuning aid
+    return !off && choose_place(c) == P_R512x10;
+}
 static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1 || pl == P_C256) ? 256 : 512; }
 static int place_wgs_per_cu(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 4 : ((pl == P_R512x10) ? 1 : 2); }
 static size_t place_lds(const muse_ctx* c, int pl) {
@@ -1985,6 +2048,23 @@ static int ensure_scratch(muse_ctx* c, size_t doubles) {
         return fail(MUSE_ERR_ALLOC, "hipMalloc(scratch) failed");
     c->scratch_doubles = doubles;
     return MUSE_OK;
+}
+// The normals cache exists only where the sampler is a large share of a problem and the placement supports it
+// (the LDS-resident layout, 4096 < N <= kMaxResidentN); a failed allocation just means no caching.
+static bool ncache_applies(const muse_ctx* c);
+static bool ensure_ncache(muse_ctx* c, int64_t slots) {
+    if (!ncache_applies(c)) return false;
+    if (slots <= c->ncache_slots) return true;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    if (c->ncache) hipFree(c->ncache);
+    c->ncache = nullptr;
+    c->ncache_slots = 0;
+    if (hipMalloc(&c->ncache, (size_t)slots * 2 * c->ld * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    c->ncache_slots = slots;
+    return true;
 }
 // One pinned, device-mapped host block per result area: [cap*ntheta] scores then [cap] infos.  The
 // solver kernel writes an element's score and info straight into it (a few hundred posted PCIe
@@ -2223,7 +2303,7 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     muse_comm_destroy(c);
-    hipFree(c->cl_counter); hipFree(c->cl_part); hipHostFree(c->error_flag);
+    hipFree(c->cl_counter); hipFree(c->cl_part); hipHostFree(c->error_flag); hipFree(c->ncache);
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
     hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
@@ -2348,6 +2428,7 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     make_thetaset(c, theta, a.tmap);
     a.f_const = theta_const(c, theta);
     a.fid_slot = -1;
+    a.nstd = 0x7fffffff;  // no normals-only elements
 }
 
 int muse_sample_x_z(muse_ctx* c, uint64_t seed, int64_t sim, const double* theta, double* x_out, double* z_out,
@@ -2465,8 +2546,16 @@ int muse_zhat_at_theta(muse_ctx* c, const double* x, const double* z0, const dou
 // The batched map with the scores directed at `scores_dev` (any device-accessible buffer of n*ntheta
 // doubles; NULL = the area's pinned host block).  muse_comm.cpp points it at the send buffer of the
 // RCCL all-gather so that the scores never visit the host between the solver and the collective.
+static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                          const double* theta, double atol, int z0_mode, int area, double* scores_dev, int ncache_mode);
 int muse_internal_map_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
                             const double* theta, double atol, int z0_mode, int area, double* scores_dev) {
+    return map_async_impl(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, scores_dev, 0);
+}
+// ncache_mode 1: the batch also stores the normals of its simulations; 2: it loads them (same seed and range as the
+// storing batch of the same host call).  Silently 0 where the cache does not apply.
+static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                          const double* theta, double atol, int z0_mode, int area, double* scores_dev, int ncache_mode) {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!theta) return fail(MUSE_ERR_INVALID, "theta is NULL");
@@ -2494,6 +2583,12 @@ int muse_internal_map_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64
     a.slot0 = 0;
     a.scores = scores_dev ? scores_dev : c->scores_dev[area];
     a.info = c->info_dev[area];
+    if (ncache_mode != 0 && sim_end > sim_begin && ensure_ncache(c, sim_end - sim_begin)) {
+        a.ncache = c->ncache;
+        a.ncache_sim0 = sim_begin;
+        a.ncache_count = (int)(sim_end - sim_begin);
+        a.ncache_mode = ncache_mode;
+    }
     rc = launch_batch(c, a);
     if (rc) return rc;
     return enqueue_results_copy(c, area, n);
@@ -2603,7 +2698,11 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
             if (sqrt(-q > 0.0 ? -q : 0.0) < o->theta_rtol) break;
         }
         const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
-        rc = muse_map_and_score_batch(c, seed, 0, S, 1, theta, o->atol, z0_mode, g.data(), info.data());
+        // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
+        // standard normals, the later ones load them instead of running the generator again
+        rc = map_async_impl(c, seed, 0, S, 1, theta, o->atol, z0_mode, 0, nullptr, i == 1 ? 1 : 2);
+        if (rc) return rc;
+        rc = muse_batch_wait(c, 0, g.data(), info.data());
         if (rc) return rc;
         double* h = hist_out + (int64_t)(i - 1) * H;
         double* gs = gsims_out + (int64_t)(i - 1) * S * nt;
@@ -2700,7 +2799,12 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
     const int64_t nfid = fid_mode == 0 ? 1 : nsims;
     rc = ensure_zhat(c, nfid);
     if (rc) return rc;
-    rc = ensure_results(c, 1, n > nfid ? n : nfid);
+    // every simulation is drawn 2*ntheta times (same randoms, perturbed theta; src/muse.jl:426-432): its standard
+    // normals are generated once -- by its own fiducial problem (fid_mode 1) or by a normals-only element of the
+    // fiducial launch (fid_mode 0) -- and loaded by the perturbed problems
+    const bool cached = ensure_ncache(c, nsims);
+    const int64_t nprep = nfid + ((cached && fid_mode == 0) ? nsims : 0);
+    rc = ensure_results(c, 1, n > nprep ? n : nprep);
     if (rc) return rc;
     {
         BatchArgs a;
@@ -2708,7 +2812,15 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         a.kind = BATCH_STD;
         a.seed = seed;
         a.atol = atol;
-        a.nproblems = (int)nfid;
+        a.nproblems = (int)nprep;
+        a.nstd = (int)nfid;
+        a.norm_sim0 = sim_begin;
+        if (cached) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = sim_begin;
+            a.ncache_count = (int)nsims;
+            a.ncache_mode = 1;
+        }
         a.include_data = 0;
         a.z0_mode = MUSE_Z0_ZERO;
         a.store_zhat = 1;
@@ -2743,6 +2855,12 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         a.tsample = c->tsample_dev;
         a.scores = c->scores_dev[1];
         a.info = c->info_dev[1];
+        if (cached) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = sim_begin;
+            a.ncache_count = (int)nsims;
+            a.ncache_mode = 2;
+        }
         rc = launch_batch(c, a);
         if (rc) return rc;
     }
