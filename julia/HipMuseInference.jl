@@ -133,6 +133,27 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
     result
 end
 
+# The same loop run by the library's native host code (muse_run of include/muse_hip.h): for a flat or
+# independent-Gaussian prior (prior_kind, mean, sigma), constant α and the default "sims" Jacobian update the
+# host spends microseconds between two map launches.  Returns (θ, history matrix, per-iteration sim scores).
+struct MuseRunOptions
+    nsims::Int32; maxsteps::Int32
+    θ_rtol::Float64; atol::Float64; α::Float64
+    prior_kind::Int32; z0_warm::Int32
+    prior_mean::NTuple{8,Float64}; prior_sigma::NTuple{8,Float64}
+end
+function muse_run(prob::HipMuseProblem, seed::Integer, θ₀; nsims=100, maxsteps=50, θ_rtol=1e-1, ∇z_logLike_atol=1e-2,
+                  α=0.7, prior_kind=0, prior_mean=ntuple(_ -> 0.0, 8), prior_sigma=ntuple(_ -> 1.0, 8))
+    nθ = prob.nθ; W = 7nθ + nθ^2 + 1                      # MUSE_RUN_HIST(ntheta)
+    opt = Ref(MuseRunOptions(nsims, maxsteps, θ_rtol, ∇z_logLike_atol, α, prior_kind, 0, prior_mean, prior_sigma))
+    n = Ref{Int32}(0); θ = Vector{Float64}(undef, nθ)
+    hist = Matrix{Float64}(undef, W, maxsteps); gs = Array{Float64}(undef, nθ, nsims, maxsteps)
+    check(ccall((:muse_run, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Ptr{Float64}, Ref{MuseRunOptions}, Ref{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                prob.ctx, seed, standardizeθ(prob, θ₀), opt, n, θ, hist, gs, C_NULL))
+    θ, hist[:, 1:n[]], gs[:, :, 1:n[]]
+end
+
 function get_J!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=result.rng, nsims=100, ∇z_logLike_atol=1e-2, kwargs...)
     θ₀ = standardizeθ(prob, something(θ₀, result.θ))
     existing = length(result.gs)

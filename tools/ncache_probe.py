@@ -17,3 +17,11 @@ print("FD batch kernels us (prep, FD):", np.round(prob.profile_end() * 1e3, 1))
 prob.profile_begin(8)
 prob.fd_jacobian_batch(0, 0, 512, [1.0], [0.05])
 print("FD batch 512 sims kernels us (prep, FD):", np.round(prob.profile_end() * 1e3, 1))
+p4 = M.HipMuseProblem(x, model="funnel", ntheta=4)
+p4.fd_jacobian_batch(0, 0, 64, [1.0] * 4, [0.05] * 4)
+p4.profile_begin(8)
+import time
+t0 = time.perf_counter()
+p4.fd_jacobian_batch(0, 0, 64, [1.0] * 4, [0.05] * 4)
+dt = time.perf_counter() - t0
+print("configs[3] per-GPU share (ntheta=4, 64 sims -> 512 FD problems): kernels us (prep, FD):", np.round(p4.profile_end() * 1e3, 1), "wall us", round(dt * 1e6, 1))
