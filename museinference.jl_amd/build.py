@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmuse_hip.so")
 SOURCES = [os.path.join(CSRC, "muse_engine.hip"), os.path.join(CSRC, "muse_comm.cpp")]
-HEADERS = [os.path.join(CSRC, "rng.hpp"), os.path.join(_HERE, "..", "include", "muse_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "solver.hpp")] + \
+    [os.path.join(_HERE, "..", "include", "muse_hip.h")]
 # -ffp-contract=off: the sampler's log/sincos sequences and the model gradients are defined in terms
 # of individually rounded IEEE operations (bit-equal to a host evaluation of the same sequence).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -1,0 +1,130 @@
+// args.hpp -- constants, the kernel argument block and the element -> problem map of the MUSE engine (see muse_engine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/muse_hip.h"
+
+namespace muse {
+
+
+constexpr int kM = 10;         // L-BFGS memory (Optim.LBFGS default m)
+constexpr int kMaxIter = 1000;  // Optim.Options default iterations
+constexpr int kMaxTheta = MUSE_MAX_THETA;
+constexpr int kResultAreas = 4;
+constexpr int kMaxCluster = 16;
+constexpr int64_t kClusterMinN = 65536;  // N >= this: several workgroups cooperate on one problem
+constexpr int64_t kMaxResidentN = 10000;
+
+// HagerZhang() defaults of LineSearches.jl
+constexpr double kHzDelta = 0.1, kHzSigma = 0.9, kHzRho = 5.0, kHzEpsilon = 1e-6, kHzGamma = 0.66, kHzPsi3 = 0.1;
+constexpr int kHzLinesearchMax = 50, kHzIterFiniteMax = 52;
+constexpr double kEps = 2.220446049250313e-16;
+
+struct ThetaSet {
+    double theta[kMaxTheta];
+    double sd[kMaxTheta];  // exp(theta/2), host libm
+    double iv[kMaxTheta];  // exp(-theta),  host libm
+};
+
+enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
+enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
+enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2, BATCH_IMPLICIT = 3 };
+
+struct BatchArgs {
+    int64_t N, ld;
+    int ntheta, kind;
+    int64_t bnd[kMaxTheta + 1];  // block k = elements [bnd[k], bnd[k+1])
+    int bnd32[kMaxTheta + 1];    // the same, 32-bit (N < 2^28), for the per-element block lookup
+    int pad0_;
+    uint64_t seed;
+    double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
+    int nproblems, include_data, z0_mode, store_zhat;
+    int cg_maxiter;   // BATCH_IMPLICIT: IterativeSolvers.cg maxiter (reference default 100)
+    int debug;        // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
+    int64_t sim_begin, fid_slot, slot0;
+    ThetaSet tmap;                 // theta of the MAP problem and of the score
+    const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
+    const double* x_data;          // [ld]
+    const double* x_given;         // BATCH_SINGLE: [ld]
+    double* zhat;                  // [slots][ld]
+    double* scores;                // [nproblems][ntheta]
+    muse_info* info;               // [nproblems]
+    double* scratch;               // per workgroup
+    int64_t scratch_stride;        // doubles per workgroup
+    int* work_counter;             // monotonically increasing ticket counter (never reset)
+    int ticket_base, pad2_;        // this launch's tickets are work_counter values base .. base+nproblems-1
+    // cluster mode (several workgroups per problem): csize workgroups 0..csize-1 of cluster blockIdx/csize
+    int csize, nclusters;
+    unsigned int* cl_counter;      // [nclusters] arrival counters (zeroed per launch)
+    double* cl_part;               // [nclusters][2][csize][8] partial sums / maxima
+    int* error_flag;               // set when a bounded cluster wait expires
+    unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
+    // Standard normals of simulation streams already drawn inside the SAME host call (muse_run's later
+    // iterations re-draw every simulation at a new theta, the FD batch draws each simulation 2*ntheta times):
+    // [slot][2][ld], slot = sim - ncache_sim0.  mode 1: generate and store; mode 2: load instead of generating.
+    double* ncache;
+    int64_t ncache_sim0;
+    int ncache_count, ncache_mode;
+    int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
+    int pad3_;
+    int64_t norm_sim0;
+};
+
+struct ProblemDesc {
+    int64_t sim;
+    int nslot;         // slot of the simulation's normals in the cache, -1: none
+    bool normals_only;
+    int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
+    int64_t zslot, z0slot;         // zslot < 0: zhat not stored
+};
+
+__device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
+    ProblemDesc d;
+    d.normals_only = false;
+    if (a.kind == BATCH_STD && p >= a.nstd) {
+        d.sim = a.norm_sim0 + (p - a.nstd);
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_ZERO;
+        d.tsample = -1;
+        d.zslot = -1;
+        d.z0slot = a.slot0;
+        d.normals_only = true;
+    } else if (a.kind == BATCH_STD) {
+        const bool data = a.include_data && p == 0;
+        d.sim = data ? -1 : a.sim_begin + p - (a.include_data ? 1 : 0);
+        d.x_mode = (data || (a.debug & 2)) ? X_DATA : X_SAMPLE;
+        d.z0_mode = (data && a.z0_mode == Z0_TRUE) ? Z0_ZERO : a.z0_mode;
+        d.tsample = -1;
+        d.zslot = a.store_zhat ? a.slot0 + p : -1;
+        d.z0slot = a.slot0 + p;
+    } else if (a.kind == BATCH_FD) {
+        const int per = 2 * a.ntheta;
+        d.sim = a.sim_begin + p / per;
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_COPY;
+        d.tsample = p % per;
+        d.zslot = -1;
+        d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + p / per;
+    } else if (a.kind == BATCH_IMPLICIT) {
+        d.sim = a.sim_begin + p;
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_ZERO;  // zhat_guess_from_truth = zero(z) (src/muse.jl:343, src/interface.jl:184-186)
+        d.tsample = -1;
+        d.zslot = -1;
+        d.z0slot = a.slot0;
+    } else {
+        d.sim = -1;
+        d.x_mode = X_GIVEN;
+        d.z0_mode = Z0_WARM;
+        d.tsample = -1;
+        d.zslot = a.slot0;
+        d.z0slot = a.slot0;
+    }
+    const int64_t ns = d.sim - a.ncache_sim0;
+    d.nslot = (a.ncache && d.sim >= 0 && ns >= 0 && ns < a.ncache_count) ? (int)ns : -1;
+    return d;
+}
+
+
+}  // namespace muse

@@ -1,0 +1,92 @@
+// models.hpp -- the compiled-in models, the storage policies (placements) and the HagerZhang point type (see muse_engine.hip).
+#pragma once
+#include <type_traits>
+
+#include "vec.hpp"
+
+namespace muse {
+
+// ------------------------------------------------------------------------------------------------
+// Models.  grad() returns d(-logLike)/dz_i and adds the element's share of -2 logLike (without the
+// constant) to facc; the score is assembled from per-block sums of score_term().
+template <int MAXB = kMaxTheta>
+__device__ __forceinline__ int block_of(const BatchArgs& a, int i) {
+    int k = 0;
+#pragma unroll
+    for (int b = 1; b < MAXB; ++b) k += (i >= a.bnd32[b]) ? 1 : 0;  // bnd32[b] = INT_MAX for b >= ntheta
+    return k;
+}
+
+template <int MAXB_>
+struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
+    static constexpr int MAXB = MAXB_;
+    static constexpr bool kStencil = false;
+    static constexpr int kId = MUSE_MODEL_FUNNEL;
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+        z = sd * n1;
+        x = z + n2;
+    }
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+        const double r = x - z, t = iv * z;
+        facc = fma(t, z, fma(r, r, facc));
+        return t - r;
+    }
+    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
+};
+struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
+    static constexpr int MAXB = 1;
+    static constexpr bool kStencil = false;
+    static constexpr int kId = MUSE_MODEL_NOISE;
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+        z = n1;
+        x = n1 + sd * n2;
+    }
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+        const double r = x - z, t = iv * r;
+        facc = fma(z, z, fma(t, r, facc));
+        return z - t;
+    }
+    __device__ static __forceinline__ double score_term(double x, double z) {
+        const double r = x - z;
+        return r * r;
+    }
+};
+template <int MAXB_>
+struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4); streaming policy only
+    static constexpr int MAXB = MAXB_;
+    static constexpr bool kStencil = true;
+    static constexpr int kId = MUSE_MODEL_SMOOTH;
+    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Storage policies.
+template <int T_, bool CLUSTER = false, int U_ = 4>
+struct PlaceStreaming {
+    static constexpr int T = T_, EPT = 0, U = U_;  // U pairs of a thread per trip of a streaming pass
+    // two waves per SIMD: 2 workgroups of 256 threads (cluster mode sizes its grid from that) or 1 of 512 per CU,
+    // i.e. a budget of 256 registers per lane
+    static constexpr int kWavesPerEu = 2;
+    static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
+    using VX = BufChunk<U_>;
+    using VG = VX; using VZ = VX; using VS = VX;
+    using VH = VX;
+};
+template <int T_, int EPT_, bool XG_LDS>
+struct PlaceResident {
+    static constexpr int T = T_, EPT = EPT_, U = 1;
+    static constexpr int kWavesPerEu = 1;  // no lower bound beyond the launch bounds
+    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = false;
+    using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
+    using VG = VX;
+    using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;
+    using VH = BufVec2;  // history vectors and zhat in HBM: 16-byte accesses
+};
+
+struct HzPoint {
+    double a, v, d;  // alpha, phi(alpha), dphi(alpha)
+    int id;          // evaluation sequence number (0 = the point alpha=0)
+};
+
+
+}  // namespace muse

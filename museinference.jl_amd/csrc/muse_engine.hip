@@ -35,1710 +35,9 @@
 #include <vector>
 
 #include "../../include/muse_hip.h"
-#include "rng.hpp"
+#include "solver.hpp"
 
 namespace muse {
-
-constexpr int kM = 10;         // L-BFGS memory (Optim.LBFGS default m)
-constexpr int kMaxIter = 1000;  // Optim.Options default iterations
-constexpr int kMaxTheta = MUSE_MAX_THETA;
-constexpr int kResultAreas = 4;
-constexpr int kMaxCluster = 16;
-constexpr int64_t kClusterMinN = 65536;  // N >= this: several workgroups cooperate on one problem
-constexpr int64_t kMaxResidentN = 10000;
-
-// HagerZhang() defaults of LineSearches.jl
-constexpr double kHzDelta = 0.1, kHzSigma = 0.9, kHzRho = 5.0, kHzEpsilon = 1e-6, kHzGamma = 0.66, kHzPsi3 = 0.1;
-constexpr int kHzLinesearchMax = 50, kHzIterFiniteMax = 52;
-constexpr double kEps = 2.220446049250313e-16;
-
-struct ThetaSet {
-    double theta[kMaxTheta];
-    double sd[kMaxTheta];  // exp(theta/2), host libm
-    double iv[kMaxTheta];  // exp(-theta),  host libm
-};
-
-enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
-enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
-enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2, BATCH_IMPLICIT = 3 };
-
-struct BatchArgs {
-    int64_t N, ld;
-    int ntheta, kind;
-    int64_t bnd[kMaxTheta + 1];  // block k = elements [bnd[k], bnd[k+1])
-    int bnd32[kMaxTheta + 1];    // the same, 32-bit (N < 2^28), for the per-element block lookup
-    int pad0_;
-    uint64_t seed;
-    double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
-    int nproblems, include_data, z0_mode, store_zhat;
-    int cg_maxiter;   // BATCH_IMPLICIT: IterativeSolvers.cg maxiter (reference default 100)
-    int debug;        // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
-    int64_t sim_begin, fid_slot, slot0;
-    ThetaSet tmap;                 // theta of the MAP problem and of the score
-    const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
-    const double* x_data;          // [ld]
-    const double* x_given;         // BATCH_SINGLE: [ld]
-    double* zhat;                  // [slots][ld]
-    double* scores;                // [nproblems][ntheta]
-    muse_info* info;               // [nproblems]
-    double* scratch;               // per workgroup
-    int64_t scratch_stride;        // doubles per workgroup
-    int* work_counter;             // monotonically increasing ticket counter (never reset)
-    int ticket_base, pad2_;        // this launch's tickets are work_counter values base .. base+nproblems-1
-    // cluster mode (several workgroups per problem): csize workgroups 0..csize-1 of cluster blockIdx/csize
-    int csize, nclusters;
-    unsigned int* cl_counter;      // [nclusters] arrival counters (zeroed per launch)
-    double* cl_part;               // [nclusters][2][csize][8] partial sums / maxima
-    int* error_flag;               // set when a bounded cluster wait expires
-    unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
-    // Standard normals of simulation streams already drawn inside the SAME host call (muse_run's later
-    // iterations re-draw every simulation at a new theta, the FD batch draws each simulation 2*ntheta times):
-    // [slot][2][ld], slot = sim - ncache_sim0.  mode 1: generate and store; mode 2: load instead of generating.
-    double* ncache;
-    int64_t ncache_sim0;
-    int ncache_count, ncache_mode;
-    int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
-    int pad3_;
-    int64_t norm_sim0;
-};
-
-struct ProblemDesc {
-    int64_t sim;
-    int nslot;         // slot of the simulation's normals in the cache, -1: none
-    bool normals_only;
-    int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
-    int64_t zslot, z0slot;         // zslot < 0: zhat not stored
-};
-
-__device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
-    ProblemDesc d;
-    d.normals_only = false;
-    if (a.kind == BATCH_STD && p >= a.nstd) {
-        d.sim = a.norm_sim0 + (p - a.nstd);
-        d.x_mode = X_SAMPLE;
-        d.z0_mode = Z0_ZERO;
-        d.tsample = -1;
-        d.zslot = -1;
-        d.z0slot = a.slot0;
-        d.normals_only = true;
-    } else if (a.kind == BATCH_STD) {
-        const bool data = a.include_data && p == 0;
-        d.sim = data ? -1 : a.sim_begin + p - (a.include_data ? 1 : 0);
-        d.x_mode = (data || (a.debug & 2)) ? X_DATA : X_SAMPLE;
-        d.z0_mode = (data && a.z0_mode == Z0_TRUE) ? Z0_ZERO : a.z0_mode;
-        d.tsample = -1;
-        d.zslot = a.store_zhat ? a.slot0 + p : -1;
-        d.z0slot = a.slot0 + p;
-    } else if (a.kind == BATCH_FD) {
-        const int per = 2 * a.ntheta;
-        d.sim = a.sim_begin + p / per;
-        d.x_mode = X_SAMPLE;
-        d.z0_mode = Z0_COPY;
-        d.tsample = p % per;
-        d.zslot = -1;
-        d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + p / per;
-    } else if (a.kind == BATCH_IMPLICIT) {
-        d.sim = a.sim_begin + p;
-        d.x_mode = X_SAMPLE;
-        d.z0_mode = Z0_ZERO;  // zhat_guess_from_truth = zero(z) (src/muse.jl:343, src/interface.jl:184-186)
-        d.tsample = -1;
-        d.zslot = -1;
-        d.z0slot = a.slot0;
-    } else {
-        d.sim = -1;
-        d.x_mode = X_GIVEN;
-        d.z0_mode = Z0_WARM;
-        d.tsample = -1;
-        d.zslot = a.slot0;
-        d.z0slot = a.slot0;
-    }
-    const int64_t ns = d.sim - a.ncache_sim0;
-    d.nslot = (a.ncache && d.sim >= 0 && ns >= 0 && ns < a.ncache_count) ? (int)ns : -1;
-    return d;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Vec accessors: (jj, i) = (register slot, element index).  Register vectors ignore i, memory
-// vectors ignore jj; the solver source is written once against this interface.
-//
-// Every access is UNCONDITIONAL (no `if (i < N)` around it), so the compiler can issue all of a
-// thread's loads of a pass back to back and expose the memory latency once, not once per element:
-//   * a thread's slots beyond the vector are "phantom zeros": register slots are cleared, HBM vectors
-//     sit behind range-checked buffer descriptors (out-of-range loads return 0, stores are dropped),
-//     LDS vectors redirect out-of-range indices to a dummy slot that holds 0;
-//   * vectors are padded to an even length ld >= N and the pad element is kept at 0;
-//   * every model maps (x, z) = (0, 0) to a zero gradient / zero objective and score terms, so the
-//     phantoms contribute exact zeros to every reduction and write zeros back.
-typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) rsrc_t;
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) double lds_double;
-// words shared between workgroups inside a launch are accessed through GLOBAL (never flat) pointers
-typedef __attribute__((address_space(1))) double gf64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-typedef __attribute__((address_space(1))) int gi32;
-
-// Buffer descriptor over `bytes` bytes at `base` (both workgroup-uniform; the readfirstlanes make
-// that provable so that no waterfall loop is generated around the buffer instructions).
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
-    const uint64_t b = (uint64_t)base;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0,
-                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
-
-template <int NR>
-struct RegVec {
-    double r[NR > 0 ? NR : 1];
-    __device__ __forceinline__ double get(int jj, int) const { return r[jj]; }
-    __device__ __forceinline__ void set(int jj, int, double v) { r[jj] = v; }
-    // Unconditional definition of every slot at the point where a problem first defines the vector:
-    // otherwise the previous problem's values stay live across the persistent loop.
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int j = 0; j < (NR > 0 ? NR : 1); ++j) r[j] = 0.0;
-    }
-    template <int UU>
-    __device__ __forceinline__ void flush(int, int) {}
-};
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int off8(int i) { return (int)((unsigned)i << 3); }  // byte offset of element i (may exceed 2^31: unsigned)
-__device__ __forceinline__ double load_f64(const rsrc_t& rs, int i) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off8(i), 0, 0);
-    return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
-}
-__device__ __forceinline__ void load_f64x2(const rsrc_t& rs, int i, double& d0, double& d1) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off8(i), 0, 0);
-    d0 = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
-    d1 = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
-}
-__device__ __forceinline__ void store_f64x2(const rsrc_t& rs, int i, double d0, double d1) {
-    const long long b0 = __double_as_longlong(d0), b1 = __double_as_longlong(d1);
-    u32x4 v;
-    v.x = (unsigned)(b0 & 0xffffffffll);
-    v.y = (unsigned)(b0 >> 32);
-    v.z = (unsigned)(b1 & 0xffffffffll);
-    v.w = (unsigned)(b1 >> 32);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off8(i), 0, 0);
-}
-// A vector in HBM, resident policy (history pairs, zhat): the element loop visits a thread's two
-// adjacent elements (jj even then jj odd) back to back, so the pair moves with ONE 16-byte buffer
-// instruction: the load is issued at jj even and its second half served at jj odd; a store is staged at
-// jj even and issued at jj odd (buffer_load/store_dwordx4, 1 KiB per wave-instruction).
-struct BufVec2 {
-    rsrc_t rsrc;
-    mutable double c0, c1;
-    __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
-    __device__ __forceinline__ double get(int jj, int i) const {
-        if ((jj & 1) == 0) {
-            load_f64x2(rsrc, i, c0, c1);
-            return c0;
-        }
-        return c1;
-    }
-    __device__ __forceinline__ void set(int jj, int i, double d) {
-        if ((jj & 1) == 0) c0 = d;
-        else store_f64x2(rsrc, i - 1, c0, d);
-    }
-    __device__ __forceinline__ void clear() {}
-    template <int UU>
-    __device__ __forceinline__ void flush(int, int) {}
-};
-// A vector in HBM, streaming policy.  A streaming pass handles U of a thread's pairs per trip
-// ("chunk", jj = 2u, 2u+1): gets are 16-byte loads issued where they appear, sets are STAGED in
-// registers and written by flush() after the chunk's U element bodies have run.  Inside a chunk no
-// store sits between the loads, so the compiler issues all of the chunk's loads back to back and a wave
-// has U x (vectors read) 1-KiB requests in flight per trip -- with the stores interleaved (hipcc cannot
-// prove the buffers distinct) every pair's loads waited for the previous pair's store to issue and a
-// pass paid one memory round trip per pair.  get1() is an 8-byte load at an arbitrary element (stencil
-// neighbours).
-template <int U>
-struct BufChunk {
-    rsrc_t rsrc;
-    mutable double c1[U];
-    double st[2 * U];
-    __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
-    __device__ __forceinline__ double get(int jj, int i) const {
-        if ((jj & 1) == 0) {
-            double d0;
-            load_f64x2(rsrc, i, d0, c1[jj >> 1]);
-            return d0;
-        }
-        return c1[jj >> 1];
-    }
-    __device__ __forceinline__ double get1(int i) const { return load_f64(rsrc, i); }
-    __device__ __forceinline__ void set(int jj, int, double d) { st[jj] = d; }
-    __device__ __forceinline__ void clear() {}
-    // the UU (<= U) pairs i0, i0 + 2*pstride, ... of the trip that started at element i0
-    template <int UU>
-    __device__ __forceinline__ void flush(int i0, int pstride) {
-        static_assert(UU <= U, "trip longer than the staging area");
-#pragma unroll
-        for (int u = 0; u < UU; ++u) store_f64x2(rsrc, i0 + 2 * u * pstride, st[2 * u], st[2 * u + 1]);
-    }
-};
-// flush-list entry for a vector that a pass writes only under a (workgroup-uniform) condition
-template <class V>
-struct FlushIf {
-    V& v;
-    bool on;
-    template <int UU>
-    __device__ __forceinline__ void flush(int i0, int pstride) {
-        if (on) v.template flush<UU>(i0, pstride);
-    }
-};
-template <class V>
-__device__ __forceinline__ FlushIf<V> when(bool on, V& v) { return FlushIf<V>{v, on}; }
-// A vector in LDS; p[ld], p[ld+1] is a dummy pair that holds 0.  Like BufVec2 it moves a thread's two adjacent
-// elements with one instruction (ds_read2_b64 / ds_write2_b64) and one address computation: the pair is read
-// at jj even (second half served at jj odd), a store is staged at jj even and issued at jj odd.
-struct LdsVec {
-    lds_double* p;
-    int ld;
-    mutable double c1;
-    double s0;
-    __device__ __forceinline__ void bind(double* base, int64_t ld_) {
-        p = (lds_double*)base;
-        ld = (int)ld_;
-    }
-    __device__ __forceinline__ double get(int jj, int i) const {
-        if ((jj & 1) == 0) {
-            const lds_double* q = p + (i < ld ? i : ld);
-            const double d0 = q[0];
-            c1 = q[1];
-            return d0;
-        }
-        return c1;
-    }
-    __device__ __forceinline__ void set(int jj, int i, double v) {
-        if ((jj & 1) == 0) {
-            s0 = v;
-        } else {
-            lds_double* q = p + (i - 1 < ld ? i - 1 : ld);
-            q[0] = s0;
-            q[1] = v;
-        }
-    }
-    __device__ __forceinline__ void clear() {}
-    template <int UU>
-    __device__ __forceinline__ void flush(int, int) {}
-};
-
-// Element loop of one thread: pairs q = tid + j*T, elements 2q and 2q+1, in increasing j; no bounds
-// checks (see above).  EPT > 0: compile-time trip count, fully unrolled (register slots are static).
-// EPT == 0 (streaming): U pairs per trip with jj = 2u, 2u+1; the vectors the pass writes are listed
-// after the body and flushed once per trip (BufChunk).  A trip may reach up to U-1 pairs past the end
-// of the vector: those are phantom zeros like every other out-of-range slot.
-// Element indices are 32-bit (N < 2^28), and tid is laundered through an empty asm so that the
-// per-slot offsets are recomputed in each pass (two integer ops) instead of being hoisted out of
-// the persistent loop and held -- or spilled -- for the kernel's lifetime.
-template <int T, int EPT, int U, class F, class... W>
-__device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F&& f, W&&... written) {
-    int t = tfirst;
-    asm volatile("" : "+v"(t));
-    if constexpr (EPT > 0) {
-        (void)pstride;
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int i0 = 2 * (t + j * T);
-            f(2 * j, i0);
-            f(2 * j + 1, i0 + 1);
-        }
-    } else {
-        // streaming: pairs tfirst, tfirst + pstride, ... (pstride = T, or csize*T in cluster mode)
-        const int n = (int)ld;
-#pragma unroll 1
-        for (int i0 = 2 * t; i0 < n; i0 += 2 * U * pstride) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 2 * u * pstride;
-                f(2 * u, i);
-                f(2 * u + 1, i + 1);
-            }
-            (written.template flush<U>(i0, pstride), ...);
-        }
-    }
-}
-
-// Maxima are taken with v_max_f64 (one instruction; a NaN operand is DROPPED), on |values| that start from 0.
-// NaN propagation -- Julia's maximum(abs, g) is NaN if any element is -- comes from the sums reduced in the same
-// pass: a NaN element makes the pass's objective / directional-derivative sum NaN, and the caller then replaces
-// the maximum by NaN (nan_if).  (The explicit compare/select form cost 6 instructions per element and per
-// reduction step.)
-__device__ __forceinline__ double absmax(double a, double b) { return __builtin_fmax(a, __builtin_fabs(b)); }
-__device__ __forceinline__ double nan_if(bool c, double v) { return c ? __builtin_nan("") : v; }
-
-// Tell the compiler a value is workgroup-uniform (it is: every lane holds the same bits).  Control
-// flow that depends on it then compiles to scalar branches and its live state to SGPRs.
-__device__ __forceinline__ double uniform(double v) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// ---- fixed-shape all-reduce over the workgroup: KS sums and KM NaN-propagating maxima ------------
-// Within a wave: four DPP exchange steps (xor 1, xor 2, half-row mirror, row mirror -- full-rate VALU
-// moves, no LDS crossbar) leave each 16-lane row's total in all of its lanes; the four row totals are
-// read with v_readlane into SGPRs and combined in a fixed order, so the wave total is a scalar.
-// Across waves: lane 0 of each wave stores its total to LDS, ONE barrier, then lane l of every wave
-// reads wave (l mod NW)'s total and a DPP butterfly over NW lanes + v_readfirstlane leaves the
-// workgroup total in SGPRs of every wave.  The tree is the same for every thread, launch and GPU.
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-}
-__device__ __forceinline__ double read_lane(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7-i within 8
-constexpr int kDppMirror = 0x140;      // row_mirror:      lane i <-> 15-i within 16
-
-template <bool IS_MAX>
-__device__ __forceinline__ double combine(double a, double b) {
-    if constexpr (IS_MAX) return __builtin_fmax(a, b);
-    else return a + b;
-}
-template <bool IS_MAX>
-__device__ __forceinline__ double wave_total(double v) {
-    v = combine<IS_MAX>(v, dpp_move<kDppXor1>(v));
-    v = combine<IS_MAX>(v, dpp_move<kDppXor2>(v));
-    v = combine<IS_MAX>(v, dpp_move<kDppHalfMirror>(v));
-    v = combine<IS_MAX>(v, dpp_move<kDppMirror>(v));
-    const double r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
-    return combine<IS_MAX>(combine<IS_MAX>(r0, r1), combine<IS_MAX>(r2, r3));
-}
-template <bool IS_MAX, int NW>
-__device__ __forceinline__ double lanes_total(double v) {  // butterfly over the first NW (<= 16) lanes of a row
-    if constexpr (NW >= 2) v = combine<IS_MAX>(v, dpp_move<kDppXor1>(v));
-    if constexpr (NW >= 4) v = combine<IS_MAX>(v, dpp_move<kDppXor2>(v));
-    if constexpr (NW >= 8) v = combine<IS_MAX>(v, dpp_move<kDppHalfMirror>(v));
-    if constexpr (NW >= 16) v = combine<IS_MAX>(v, dpp_move<kDppMirror>(v));
-    return uniform(v);
-}
-
-template <int T, int KS, int KM>
-__device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], double (&m)[KM > 0 ? KM : 1],
-                                                double* red, int& parity, int tid) {
-    constexpr int NW = T / 64, K = KS + KM;
-    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "workgroup must be 2^k waves");
-    static_assert(K <= 8, "reduction scratch holds 8 values per wave");
-#pragma unroll
-    for (int k = 0; k < KS; ++k) s[k] = wave_total<false>(s[k]);
-#pragma unroll
-    for (int k = 0; k < KM; ++k) m[k] = wave_total<true>(m[k]);
-    double* buf = red + parity * (NW * 8);
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) buf[wave * K + k] = s[k];
-#pragma unroll
-        for (int k = 0; k < KM; ++k) buf[wave * K + KS + k] = m[k];
-    }
-    __syncthreads();
-    const int src = (tid & (NW - 1)) * K;
-#pragma unroll
-    for (int k = 0; k < KS; ++k) s[k] = lanes_total<false, NW>(buf[src + k]);
-#pragma unroll
-    for (int k = 0; k < KM; ++k) m[k] = lanes_total<true, NW>(buf[src + KS + k]);
-    parity ^= 1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Models.  grad() returns d(-logLike)/dz_i and adds the element's share of -2 logLike (without the
-// constant) to facc; the score is assembled from per-block sums of score_term().
-template <int MAXB = kMaxTheta>
-__device__ __forceinline__ int block_of(const BatchArgs& a, int i) {
-    int k = 0;
-#pragma unroll
-    for (int b = 1; b < MAXB; ++b) k += (i >= a.bnd32[b]) ? 1 : 0;  // bnd32[b] = INT_MAX for b >= ntheta
-    return k;
-}
-
-template <int MAXB_>
-struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
-    static constexpr int MAXB = MAXB_;
-    static constexpr bool kStencil = false;
-    static constexpr int kId = MUSE_MODEL_FUNNEL;
-    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
-        z = sd * n1;
-        x = z + n2;
-    }
-    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
-        const double r = x - z, t = iv * z;
-        facc = fma(t, z, fma(r, r, facc));
-        return t - r;
-    }
-    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
-};
-struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
-    static constexpr int MAXB = 1;
-    static constexpr bool kStencil = false;
-    static constexpr int kId = MUSE_MODEL_NOISE;
-    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
-        z = n1;
-        x = n1 + sd * n2;
-    }
-    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
-        const double r = x - z, t = iv * r;
-        facc = fma(z, z, fma(t, r, facc));
-        return z - t;
-    }
-    __device__ static __forceinline__ double score_term(double x, double z) {
-        const double r = x - z;
-        return r * r;
-    }
-};
-template <int MAXB_>
-struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4); streaming policy only
-    static constexpr int MAXB = MAXB_;
-    static constexpr bool kStencil = true;
-    static constexpr int kId = MUSE_MODEL_SMOOTH;
-    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
-};
-
-// ------------------------------------------------------------------------------------------------
-// Storage policies.
-template <int T_, bool CLUSTER = false, int U_ = 4>
-struct PlaceStreaming {
-    static constexpr int T = T_, EPT = 0, U = U_;  // U pairs of a thread per trip of a streaming pass
-    // two waves per SIMD: 2 workgroups of 256 threads (cluster mode sizes its grid from that) or 1 of 512 per CU,
-    // i.e. a budget of 256 registers per lane
-    static constexpr int kWavesPerEu = 2;
-    static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
-    using VX = BufChunk<U_>;
-    using VG = VX; using VZ = VX; using VS = VX;
-    using VH = VX;
-};
-template <int T_, int EPT_, bool XG_LDS>
-struct PlaceResident {
-    static constexpr int T = T_, EPT = EPT_, U = 1;
-    static constexpr int kWavesPerEu = 1;  // no lower bound beyond the launch bounds
-    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = false;
-    using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
-    using VG = VX;
-    using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;
-    using VH = BufVec2;  // history vectors and zhat in HBM: 16-byte accesses
-};
-
-struct HzPoint {
-    double a, v, d;  // alpha, phi(alpha), dphi(alpha)
-    int id;          // evaluation sequence number (0 = the point alpha=0)
-};
-
-// ------------------------------------------------------------------------------------------------
-template <class Model, class Place>
-struct Solver {
-    static constexpr int T = Place::T, EPT = Place::EPT, U = Place::U, MAXB = Model::MAXB;
-    const BatchArgs& a;
-    const int tid;
-    double* red;
-    double* sh_rho;    // [kM]
-    double* sh_gam;    // [kM]
-    double* sh_alpha;  // [kM]
-    int parity;
-    typename Place::VX x;
-    typename Place::VG g;
-    typename Place::VZ z;
-    typename Place::VS s;
-    double* hist;  // [kM][2][ld] in HBM
-    double iv0, sd0;   // MAXB == 1: coefficients in registers
-    double* sh_sd;     // MAXB > 1: sampling sd[k] in LDS (the MAP iv[k] is read from the LDS argument block)
-    int f_calls;
-    int iter_stamp, stamp_p;  // diagnostic build: which evaluation of the first line search
-    double last_c, last_gmax;
-    // element ownership: thread pairs tfirst + k*pstride (cluster mode: the cluster acts as one csize*T block)
-    int tfirst, pstride;
-    int crank, csize;          // this workgroup's rank in its cluster, cluster size
-    unsigned int cl_epoch;     // cluster reductions done so far in this launch
-    bool cl_aborted;           // a bounded wait expired: stop waiting
-    unsigned int* cl_counter;  // this cluster's arrival counter
-    double* cl_part;           // this cluster's partial slots [2][csize][8]
-
-    __device__ Solver(const BatchArgs& a_, int tid_, double* red_, double* shs) : a(a_), tid(tid_), red(red_), parity(0) {
-        sh_rho = shs;
-        sh_gam = shs + kM;
-        sh_alpha = shs + 2 * kM;
-        sh_sd = shs + 3 * kM;
-        tfirst = tid_;
-        pstride = T;
-        crank = 0;
-        csize = 1;
-        cl_epoch = 0;
-        cl_aborted = false;
-        cl_counter = nullptr;
-        cl_part = nullptr;
-    }
-
-    // Cluster all-reduce (Guideline 16 of the CDNA guide: placement-independent release/acquire).
-    // Each workgroup has reduced to workgroup-uniform values; lane 0 publishes them with write-through
-    // stores, releases at agent scope (which also makes the pass's vector stores visible to the other
-    // workgroups of the cluster -- the stencil model reads neighbours across workgroups), arrives on
-    // the cluster's monotonic counter and polls it (bounded) for this epoch; one agent-scope acquire,
-    // then every thread reads the csize partials with L1-bypassing loads and combines them in rank
-    // order.  Partial slots alternate between two buffers by epoch parity (WAR safe).
-    template <int KS, int KM>
-    __device__ __forceinline__ void cluster_allreduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
-        constexpr int K = KS + KM;
-        cl_epoch += 1;
-        gf64* slots = (gf64*)(cl_part + (size_t)(cl_epoch & 1u) * csize * 8);
-        gu32* counter = (gu32*)cl_counter;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
-        __syncthreads();
-        if (tid == 0) {
-            gf64* mine = slots + crank * 8;
-#pragma unroll
-            for (int k = 0; k < KS; ++k) __hip_atomic_store(mine + k, sv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < KM; ++k) __hip_atomic_store(mine + KS + k, mv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = cl_epoch * (unsigned)csize;
-            unsigned spins = 0;
-            // bounded (about a second): a cluster whose members are not all resident must not hang the
-            // GPU; after one expiry this workgroup never waits again and the host reports the error
-            while (!cl_aborted && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 22)) {
-                    __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    cl_aborted = true;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double acc = __hip_atomic_load(slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int c = 1; c < csize; ++c) {
-                const double v = __hip_atomic_load(slots + c * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc = k < KS ? acc + v : __builtin_fmax(acc, v);
-            }
-            if (k < KS) sv[k] = uniform(acc);
-            else mv[k - KS] = uniform(acc);
-        }
-    }
-    // Workgroup reduction, then (cluster mode) the cluster reduction.
-    template <int KS, int KM>
-    __device__ __forceinline__ void reduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
-        block_allreduce<T, KS, KM>(sv, mv, red, parity, tid);
-        if constexpr (Place::kCluster) cluster_allreduce<KS, KM>(sv, mv);
-    }
-    // Orders this pass's vector stores before the next pass's neighbour reads (stencil model).
-    __device__ __forceinline__ void pass_barrier() {
-        if constexpr (Place::kCluster) {
-            double z1[1] = {0.0}, z2[1] = {0.0};
-            cluster_allreduce<1, 0>(z1, z2);
-        } else {
-            __syncthreads();
-        }
-    }
-    // In-kernel stamps (cdna_hip_programming.md §7): diagnostic build only; values leave through a
-    // buffer of their own and no output is computed from them.
-    __device__ __forceinline__ void stamp(int p, int k) const {
-#ifdef MUSE_STAMPS
-        if (tid == 0 && a.stamps) {
-            unsigned long long t;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-            a.stamps[(size_t)p * 16 + k] = t;
-        }
-#else
-        (void)p; (void)k;
-#endif
-    }
-    using VH = typename Place::VH;
-    __device__ __forceinline__ VH hdx(int slot) const {
-        VH v;
-        v.bind(hist + (int64_t)(2 * slot) * a.ld, a.ld);
-        return v;
-    }
-    __device__ __forceinline__ VH hdg(int slot) const {
-        VH v;
-        v.bind(hist + (int64_t)(2 * slot + 1) * a.ld, a.ld);
-        return v;
-    }
-    // Block (theta component) of the element in slot jj / at index i.  Resident policy: a thread's slots are the
-    // same elements in every pass of every problem of the launch, so their 3-bit block indices are looked up once
-    // per kernel (pk, 10 slots per word) and a pass extracts one with a single v_bfe_u32; streaming: compares.
-    unsigned pk[2];
-    __device__ __forceinline__ int blk(int jj, int i) const {
-        if constexpr (MAXB == 1) return 0;
-        else if constexpr (Place::kResident) return (int)((pk[jj / 10] >> (3 * (jj % 10))) & 7u);
-        else return block_of<MAXB>(a, i);
-    }
-    __device__ __forceinline__ double ivk(int jj, int i) const {
-        if constexpr (MAXB == 1) return iv0;
-        else return a.tmap.iv[blk(jj, i)];
-    }
-    __device__ __forceinline__ double sdk(int jj, int i) const {
-        if constexpr (MAXB == 1) return sd0;
-        else return sh_sd[blk(jj, i)];
-    }
-    __device__ __forceinline__ double sdk_at(int i) const {  // element index only (rolled loops)
-        if constexpr (MAXB == 1) return sd0;
-        else return sh_sd[block_of<MAXB>(a, i)];
-    }
-    __device__ __forceinline__ void pack_blocks() {
-        pk[0] = pk[1] = 0u;
-        if constexpr (MAXB > 1 && Place::kResident) {
-            static_assert(2 * EPT <= 20, "two words of ten 3-bit slots");
-#pragma unroll
-            for (int jj = 0; jj < 2 * EPT; ++jj) {
-                const int i = 2 * (tid + (jj >> 1) * T) + (jj & 1);
-                pk[jj / 10] |= (unsigned)block_of<MAXB>(a, i) << (3 * (jj % 10));
-            }
-        }
-    }
-
-    // d(-logLike)/dz_i at the point whose components are given by zt(.), for the stencil model
-    // (streaming only: neighbours come from HBM/L1).  The element's share of -2 logLike is
-    // fma(t, z0, fma(r0, r0, .)) with the returned (t, z0, r0).
-    template <class ZT>
-    __device__ __forceinline__ double stencil_grad(ZT&& zt, int i, double& t_out, double& z_out, double& r_out) const {
-        const int N = (int)a.N;
-        auto wrap = [&](int k) { return k < 0 ? k + N : (k >= N ? k - N : k); };
-        const int im2 = wrap(i - 2), im1 = wrap(i - 1), ip1 = wrap(i + 1), ip2 = wrap(i + 2);
-        const double zm2 = zt(im2), zm1 = zt(im1), z0 = zt(i), zp1 = zt(ip1), zp2 = zt(ip2);
-        const double rm = x.get1(im1) - fma(0.25, zm2 + z0, 0.5 * zm1);
-        const double r0 = x.get1(i) - fma(0.25, zm1 + zp1, 0.5 * z0);
-        const double rp = x.get1(ip1) - fma(0.25, z0 + zp2, 0.5 * zp1);
-        const double t = this->ivk(0, i) * z0;
-        t_out = t;
-        z_out = z0;
-        r_out = r0;
-        return t - fma(0.25, rm + rp, 0.5 * r0);
-    }
-
-    // ---- stencil model, pair-wise --------------------------------------------------------------
-    // A lane loads its own element pair of z, s, x with one 16-byte buffer instruction each and gets the
-    // neighbouring pairs from the adjacent lanes with DPP wave shifts (lanes of a wave own consecutive
-    // pairs); the two edge lanes of a wave fetch their outer neighbour pair from memory with loads that
-    // every lane issues but whose offset is out of range (no memory access) for the 62 inner lanes, and
-    // the few pairs that touch the periodic wrap or the pad element are patched element-wise afterwards.
-    // U pairs per trip: all loads of the trip are issued before anything is stored (see BufChunk).  The
-    // arithmetic (operand order included) is that of stencil_grad, and a thread accumulates its elements'
-    // shares of the objective in element order, so every path gives the same bits.
-    struct Pair {
-        double a, b;
-    };
-    __device__ __forceinline__ static Pair load_pair(const rsrc_t& rs, int i0) {
-        Pair p;
-        load_f64x2(rs, i0, p.a, p.b);
-        return p;
-    }
-    static constexpr int kDppWaveShr1 = 0x138;  // lane L reads lane L-1
-    static constexpr int kDppWaveShl1 = 0x130;  // lane L reads lane L+1
-    static constexpr int kOutOfRange = 0x10000000;  // element index beyond any vector (N < 2^28): loads give 0
-
-    // For every pair this thread owns: pre(u, i0) first (the caller's own loads of the trip), then
-    // body(u, i0, g0, g1, s0, s1) with g = d(-logLike)/dz at z + c s (at z when !USE_S), zero for the pad
-    // element; adds the pairs' shares of -2 logLike to facc; flushes the `written` vectors once per trip.
-    template <bool USE_S, class P, class F, class... W>
-    __device__ __forceinline__ void stencil_pairs(double c, double& facc, P&& pre, F&& body, W&&... written) {
-        const int N = (int)a.N, n = (int)a.ld, lane = tid & 63;
-        int t = tfirst;
-        asm volatile("" : "+v"(t));
-        auto ztf = [&](int k) {
-            double v = z.get1(k);
-            if constexpr (USE_S) v = fma(c, s.get1(k), v);
-            return v;
-        };
-#pragma unroll 1
-        for (int ic = 2 * t; ic < n; ic += 2 * U * pstride) {
-            double g0[U], g1[U], tt[U][2], zz[U][2], rr[U][2];
-            Pair spv[U];
-            bool interior[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i0 = ic + 2 * u * pstride;
-                interior[u] = i0 >= 2 && i0 + 3 < N;  // the 6-element window has no wrap and no pad
-                const Pair zp = load_pair(z.rsrc, i0), xp = load_pair(x.rsrc, i0);
-                // the outer neighbour pair of an edge lane; every other lane aims out of range
-                const bool edge = interior[u] && (lane == 0 || lane == 63);
-                const int ie = edge ? (lane == 0 ? i0 - 2 : i0 + 2) : kOutOfRange;
-                const int ix = edge ? (lane == 0 ? i0 - 1 : i0 + 2) : kOutOfRange;
-                Pair ze = load_pair(z.rsrc, ie);
-                const double xe = x.get1(ix);
-                Pair sp{0.0, 0.0}, ztp = zp;
-                if constexpr (USE_S) {
-                    sp = load_pair(s.rsrc, i0);
-                    const Pair se = load_pair(s.rsrc, ie);
-                    ztp = Pair{fma(c, sp.a, zp.a), fma(c, sp.b, zp.b)};
-                    ze = Pair{fma(c, se.a, ze.a), fma(c, se.b, ze.b)};
-                }
-                pre(u, i0);
-                spv[u] = sp;
-                Pair ztL{dpp_move<kDppWaveShr1>(ztp.a), dpp_move<kDppWaveShr1>(ztp.b)};
-                Pair ztR{dpp_move<kDppWaveShl1>(ztp.a), dpp_move<kDppWaveShl1>(ztp.b)};
-                double xL = dpp_move<kDppWaveShr1>(xp.b), xR = dpp_move<kDppWaveShl1>(xp.a);
-                if (lane == 0) { ztL = ze; xL = xe; }
-                if (lane == 63) { ztR = ze; xR = xe; }
-                const double rm = xL - fma(0.25, ztL.a + ztp.a, 0.5 * ztL.b);    // r at i0-1
-                const double r0 = xp.a - fma(0.25, ztL.b + ztp.b, 0.5 * ztp.a);  // r at i0
-                const double r1 = xp.b - fma(0.25, ztp.a + ztR.a, 0.5 * ztp.b);  // r at i0+1
-                const double r2 = xR - fma(0.25, ztp.b + ztR.b, 0.5 * ztR.a);    // r at i0+2
-                const double t0 = ivk(0, i0) * ztp.a, t1 = ivk(1, i0 + 1) * ztp.b;
-                g0[u] = t0 - fma(0.25, rm + r1, 0.5 * r0);
-                g1[u] = t1 - fma(0.25, r0 + r2, 0.5 * r1);
-                tt[u][0] = t0; zz[u][0] = ztp.a; rr[u][0] = r0;
-                tt[u][1] = t1; zz[u][1] = ztp.b; rr[u][1] = r1;
-            }
-            // wrap-around, pad and out-of-range pairs: element-wise with modular neighbour indices
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i0 = ic + 2 * u * pstride;
-                if (!interior[u]) {
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const int i = i0 + v;
-                        double gt = 0.0, t_ = 0.0, z_ = 0.0, r_ = 0.0;
-                        if (i < N) gt = stencil_grad(ztf, i, t_, z_, r_);
-                        (v == 0 ? g0[u] : g1[u]) = gt;
-                        tt[u][v] = t_; zz[u][v] = z_; rr[u][v] = r_;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i0 = ic + 2 * u * pstride;
-                facc = fma(tt[u][0], zz[u][0], fma(rr[u][0], rr[u][0], facc));
-                facc = fma(tt[u][1], zz[u][1], fma(rr[u][1], rr[u][1], facc));
-                body(u, i0, g0[u], g1[u], spv[u].a, spv[u].b);
-            }
-            (written.template flush<U>(ic, pstride), ...);
-        }
-    }
-
-    // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
-    //    dphi = grad . s and gmax = ||grad||_inf; the gradient itself is stored (into g) only when
-    //    STORE_G -- a line-search trial needs just the three scalars.  One pass, one barrier.
-    //    INIT_S (resident policy, where s lives in registers): the pass also sets the steepest-descent
-    //    direction s = -g and returns dphi = g . s, exactly as the separate pass would.
-    template <bool USE_S, bool STORE_G, bool INIT_S = false>
-    __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
-        double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
-        if constexpr (!Model::kStencil) {
-            for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
-                double zi = z.get(jj, i);
-                double si = 0.0;
-                if constexpr (USE_S) {
-                    si = s.get(jj, i);
-                    zi = fma(c, si, zi);
-                }
-                const double gi = Model::grad(ivk(jj, i), x.get(jj, i), zi, sum[0]);
-                if constexpr (STORE_G) g.set(jj, i, gi);
-                if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
-                if constexpr (INIT_S) {
-                    const double sd = -gi;
-                    s.set(jj, i, sd);
-                    sum[1] = fma(gi, sd, sum[1]);
-                }
-                mx[0] = absmax(mx[0], gi);
-            }, when(STORE_G, g), when(INIT_S, s));
-        } else {
-            stencil_pairs<USE_S>(c, sum[0], [](int, int) {}, [&](int u, int i0, double g0, double g1, double s0, double s1) {
-                if constexpr (STORE_G) {
-                    g.set(2 * u, i0, g0);
-                    g.set(2 * u + 1, i0 + 1, g1);
-                }
-                if constexpr (USE_S) sum[1] = fma(g1, s1, fma(g0, s0, sum[1]));
-                mx[0] = absmax(absmax(mx[0], g0), g1);
-            }, when(STORE_G, g));
-        }
-        if (iter_stamp == 0) stamp(stamp_p, 14);
-        reduce<2, 1>(sum, mx);
-        if (iter_stamp == 0) stamp(stamp_p, 15);
-        f = 0.5 * (sum[0] + a.f_const);
-        dphi = sum[1];
-        gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
-        f_calls += 1;
-    }
-
-    // phi(c), dphi(c) of the line search (the NLSolversBase objective cache is last_c/last_phi).
-    __device__ __forceinline__ void phidphi(double c, double& phi, double& dphi) {
-        double gm;
-        eval<true, false>(c, phi, dphi, gm);
-        last_c = c;
-        last_gmax = gm;
-        last_phi = phi;
-    }
-
-    __device__ __forceinline__ static bool finite2(double p, double d) { return isfinite(p) && isfinite(d); }
-    __device__ __forceinline__ static double eps_of(double b) {
-        const double ab = fabs(b);
-        return __longlong_as_double(__double_as_longlong(ab) + 1) - ab;
-    }
-    __device__ __forceinline__ static double nextup(double v) {  // nextfloat for finite v
-        if (v == 0.0) return 4.9406564584124654e-324;
-        const long long b = __double_as_longlong(v);
-        return __longlong_as_double(v > 0.0 ? b + 1 : b - 1);
-    }
-    __device__ __forceinline__ static bool wolfe(double c, double phi_c, double dphi_c, double phi_0, double dphi_0,
-                                                 double phi_lim) {
-        const bool w1 = (kHzDelta * dphi_0 >= (phi_c - phi_0) / c) && (dphi_c >= kHzSigma * dphi_0);
-        const bool w2 = ((2.0 * kHzDelta - 1.0) * dphi_0 >= dphi_c) && (dphi_c >= kHzSigma * dphi_0) && (phi_c <= phi_lim);
-        return w1 || w2;
-    }
-    __device__ __forceinline__ static double secant(const HzPoint& p, const HzPoint& q) {
-        return (p.a * q.d - q.a * p.d) / (q.d - p.d);
-    }
-
-    // HagerZhang line search (LineSearches.jl defaults) from the InitialStatic guess c0, written as a
-    // state machine around ONE evaluation site so that the evaluation pass is instantiated once:
-    //   S_INIT   first trial (shrunk by psi3 while non-finite)
-    //   S_EXPAND bracketing expansion c *= rho           (HZ stages B0-B3)
-    //   S_BIS    bisection of [A,B] with dphi(B) < 0      (HZ stage U3, theta = 1/2)
-    //   S_SEC1/2 the two secant steps of secant2          (HZ stages S1-S4)
-    //   S_MID    bisection step of the main loop when the secant steps shrink too slowly
-    //   S_FINAL  re-evaluation at the accepted step when it was not the last trial (update_g!)
-    // Points carry an evaluation id so that "which endpoint did update() replace" (HZ U0-U3) is an
-    // id comparison, as the index comparisons of the published algorithm.
-    // Returns true on success.  On failure (LineSearchException / failed assertion) alpha is the step
-    // Optim falls back to.  On success last_phi/last_gmax are the scalars at z + alpha s.
-    __device__ bool linesearch(double c0, double phi_0, double dphi_0, double& alpha) {
-        enum { S_INIT, S_EXPAND, S_BIS, S_SEC1, S_SEC2, S_MID, S_FINAL };
-        enum { CONT_BRACKET, CONT_UPD1, CONT_UPD2, CONT_UPD3 };
-        alpha = 0.0;
-        if (!finite2(phi_0, dphi_0)) return false;
-        if (dphi_0 >= kEps * fabs(phi_0)) return false;  // not a descent direction
-        if (dphi_0 >= 0.0 || c0 <= kEps) return true;    // alpha = 0, nothing evaluated
-        const double phi_lim = phi_0 + kHzEpsilon * fabs(phi_0);
-        const HzPoint P0{0.0, phi_0, dphi_0, 0};
-        HzPoint A = P0, B = P0, C = P0, prev = P0, a0 = P0, b0 = P0;
-        double alphamax = INFINITY, cold = 0.0, fail_alpha = 0.0, c = c0;
-        int state = S_INIT, cont = CONT_BRACKET, iter = 1, iterfinite = 1, nid = 1;
-        bool ok = true;
-        for (;;) {
-            double phi, dphi;
-            if (iter_stamp < 3) stamp(stamp_p, 10 + 2 * iter_stamp);
-            phidphi(c, phi, dphi);
-            if (iter_stamp < 3) stamp(stamp_p, 11 + 2 * iter_stamp);
-            iter_stamp += 1;
-            const bool fin = finite2(phi, dphi);
-            switch (state) {
-                case S_INIT:
-                    if (!fin) {
-                        if (iterfinite < kHzIterFiniteMax) { iterfinite += 1; c *= kHzPsi3; continue; }
-                        alpha = 0.0;
-                        goto L_DONE;
-                    }
-                    C = HzPoint{c, phi, dphi, nid++};
-                    goto L_BRACKET_TOP;
-                case S_EXPAND:
-                    if (!fin) {
-                        if (c > nextup(cold) && iterfinite < kHzIterFiniteMax) {
-                            alphamax = c;
-                            iterfinite += 1;
-                            c = (cold + c) / 2.0;
-                            continue;
-                        }
-                        alpha = cold;
-                        goto L_DONE;
-                    }
-                    C = HzPoint{c, phi, dphi, nid++};
-                    iter += 1;
-                    goto L_BRACKET_TOP;
-                case S_BIS: {
-                    if (!fin) goto L_FAIL;
-                    const HzPoint D{c, phi, dphi, nid++};
-                    if (D.d >= 0.0) { B = D; goto L_BISECT_RETURN; }
-                    if (D.v <= phi_lim) A = D;
-                    else B = D;
-                    goto L_BISECT_TOP;
-                }
-                case S_SEC1:
-                    if (!fin) goto L_FAIL;
-                    C = HzPoint{c, phi, dphi, nid++};
-                    if (wolfe(c, phi, dphi, phi_0, dphi_0, phi_lim)) { alpha = c; goto L_DONE; }
-                    cont = CONT_UPD1;
-                    goto L_UPDATE;
-                case S_SEC2:
-                    if (!fin) goto L_FAIL;
-                    C = HzPoint{c, phi, dphi, nid++};
-                    if (wolfe(c, phi, dphi, phi_0, dphi_0, phi_lim)) { alpha = c; goto L_DONE; }
-                    cont = CONT_UPD2;
-                    goto L_UPDATE;
-                case S_MID:
-                    if (!fin) goto L_FAIL;
-                    C = HzPoint{c, phi, dphi, nid++};
-                    cont = CONT_UPD3;
-                    goto L_UPDATE;
-                default:  // S_FINAL
-                    return ok;
-            }
-        L_BRACKET_TOP:
-            if (!(iter < kHzLinesearchMax)) { alpha = 0.0; goto L_FAIL_KEEP; }  // never bracketed
-            if (C.d >= 0.0) {
-                A = prev;  // the latest point with phi <= phi_lim and dphi < 0 (HZ look-back)
-                B = C;
-                iter += 1;
-                goto L_MAIN_TOP;
-            } else if (C.v > phi_lim) {
-                A = P0;
-                B = C;
-                cont = CONT_BRACKET;
-                fail_alpha = 0.0;
-                goto L_BISECT_ENTER;
-            } else {
-                cold = C.a;
-                if (nextup(cold) >= alphamax) { alpha = cold; goto L_DONE; }
-                prev = C;
-                c = cold * kHzRho;
-                if (c > alphamax) c = alphamax;
-                iterfinite = 1;
-                state = S_EXPAND;
-                continue;
-            }
-        L_UPDATE:  // HZ stages U0-U3 on (A, B) with the new point C
-            if (!(A.d < 0.0 && A.v <= phi_lim && B.d >= 0.0 && B.a > A.a)) goto L_FAIL;
-            if (C.a < A.a || C.a > B.a) goto L_UPDATE_RETURN;
-            if (C.d >= 0.0) { B = C; goto L_UPDATE_RETURN; }
-            if (C.v <= phi_lim) { A = C; goto L_UPDATE_RETURN; }
-            B = C;
-        L_BISECT_ENTER:
-            if (!(A.d < 0.0 && A.v <= phi_lim && B.d < 0.0 && B.v > phi_lim && B.a > A.a)) goto L_FAIL;
-        L_BISECT_TOP:
-            if (B.a - A.a > eps_of(B.a)) {
-                c = (A.a + B.a) / 2.0;
-                state = S_BIS;
-                continue;
-            }
-        L_BISECT_RETURN:
-            if (cont == CONT_BRACKET) { iter += 1; goto L_MAIN_TOP; }
-        L_UPDATE_RETURN:
-            if (cont == CONT_UPD1) {
-                const bool updB = (B.id == C.id), updA = (A.id == C.id);
-                double c2 = C.a;
-                if (updB) c2 = secant(b0, B);
-                else if (updA) c2 = secant(a0, A);
-                if ((updA || updB) && A.a <= c2 && c2 <= B.a) {
-                    c = c2;
-                    state = S_SEC2;
-                    continue;
-                }
-            }
-            if (cont == CONT_UPD3) { iter += 1; goto L_MAIN_TOP; }
-            // after secant2 (CONT_UPD1 without a second step, or CONT_UPD2)
-            if (!(B.a > A.a)) { alpha = A.a; goto L_FAIL_KEEP; }
-            if (B.a - A.a < kHzGamma * (b0.a - a0.a)) {
-                if (nextup(a0.v) >= b0.v && nextup(A.v) >= B.v) { alpha = A.a; goto L_DONE; }  // flat
-                iter += 1;
-                goto L_MAIN_TOP;
-            }
-            fail_alpha = A.a;
-            c = (A.a + B.a) / 2.0;
-            state = S_MID;
-            continue;
-        L_MAIN_TOP:
-            if (!(iter < kHzLinesearchMax)) { alpha = A.a; goto L_FAIL_KEEP; }
-            a0 = A;
-            b0 = B;
-            if (!(b0.a > a0.a)) { alpha = a0.a; goto L_FAIL_KEEP; }
-            if (b0.a - a0.a <= eps_of(b0.a)) { alpha = a0.a; goto L_DONE; }
-            fail_alpha = a0.a;
-            if (!(a0.d < 0.0 && b0.d >= 0.0)) goto L_FAIL;
-            c = secant(a0, b0);
-            if (!isfinite(c)) goto L_FAIL;
-            state = S_SEC1;
-            continue;
-        L_FAIL:
-            alpha = fail_alpha;
-        L_FAIL_KEEP:
-            ok = false;
-        L_DONE:
-            // update_g!: NLSolversBase re-evaluates unless z + alpha s is the point evaluated last
-            if (!ok) return false;
-            if (alpha == last_c) return true;
-            c = alpha;
-            state = S_FINAL;
-        }
-    }
-
-    // -- one element: sample/load x, MAP by L-BFGS, score.
-    // state of the element being processed, shared by the phases begin -> solve -> finish
-    ProblemDesc d;
-    double f, gmax;
-    int iterations, hist_words, status;
-    double* extra;  // one more scratch vector (streaming): the simulation's true z for the implicit-diff H
-
-    __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
-        begin<false>(p, wg_scratch, lds_x, lds_g);
-        if (d.normals_only) return;  // the element only filled its slot of the normals cache
-        solve(p);
-        finish(p);
-    }
-
-    // -- phase 1: bind storage, produce x and the starting point
-    template <bool KEEP_ZTRUE>
-    __device__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
-        d = describe(a, p);
-        const int64_t N = a.N, ld = a.ld;
-        stamp(p, 0);
-        iv0 = a.tmap.iv[0];
-        sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.tmap.sd[0];
-        if constexpr (MAXB > 1) {
-            // FD batches sample at a theta that differs from the MAP theta
-            if (tid < MAXB) sh_sd[tid] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tid] : a.tmap.sd[tid];
-            __syncthreads();
-        }
-        // bind storage
-        const double* zmem = nullptr;
-        if constexpr (Place::kResident) {
-            hist = wg_scratch;
-            if constexpr (Place::kXgLds) {
-                x.bind(lds_x, ld);
-                g.bind(lds_g, ld);
-            }
-        } else {
-            x.bind(wg_scratch, ld);
-            g.bind(wg_scratch + ld, ld);
-            s.bind(wg_scratch + 2 * ld, ld);
-            zmem = d.zslot >= 0 ? a.zhat + d.zslot * ld : wg_scratch + 3 * ld;
-            z.bind(zmem, ld);
-            hist = wg_scratch + 4 * ld;
-            extra = hist + (int64_t)2 * kM * ld;
-        }
-        const double* z0ptr = a.zhat + d.z0slot * ld;
-        VH z0src;
-        z0src.bind(z0ptr, ld);
-        const bool z_in_place = (!Place::kResident) && (d.z0_mode == Z0_WARM || d.z0_mode == Z0_COPY) && (z0ptr == zmem);
-
-        // ---- x and the starting point ---------------------------------------------------------
-        if (d.x_mode == X_SAMPLE) {
-            const uint64_t sim = (uint64_t)d.sim;
-            if constexpr (Place::kResident && Place::kXgLds) {
-                // Sampler as a ROLLED loop over this thread's pairs (one or two Philox/Box-Muller
-                // chains in flight, not 2*EPT): x goes straight to LDS, the true z is staged in the
-                // (still unused) g area and picked up into registers below.
-                const int nmode = d.nslot >= 0 ? a.ncache_mode : 0;  // workgroup-uniform
-                rsrc_t n1r = make_rsrc(a.ncache, 0), n2r = n1r;
-                if (nmode != 0) {
-                    n1r = make_rsrc(a.ncache + (int64_t)(2 * d.nslot) * ld, ld * 8);
-                    n2r = make_rsrc(a.ncache + (int64_t)(2 * d.nslot + 1) * ld, ld * 8);
-                }
-                if (nmode == 2) {
-                    // the stream was drawn earlier in this host call: its normals come from HBM (all of the
-                    // thread's loads in flight at once; out-of-range pairs read zeros), not from the generator
-                    double c1[EPT][2], c2[EPT][2];
-#pragma unroll
-                    for (int j = 0; j < EPT; ++j) {
-                        const int i0 = 2 * (tid + j * T);
-                        load_f64x2(n1r, i0, c1[j][0], c1[j][1]);
-                        load_f64x2(n2r, i0, c2[j][0], c2[j][1]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < EPT; ++j) {
-                        const int i0 = 2 * (tid + j * T);
-                        double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0);
-                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1);
-                        const bool valid1 = i0 + 1 < (int)N;
-                        x.set(2 * j, i0, xt0);
-                        x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
-                        g.set(2 * j, i0, zt0);
-                        g.set(2 * j + 1, i0 + 1, valid1 ? zt1 : 0.0);
-                    }
-                } else {
-#pragma unroll 1
-                    for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
-                        // both elements of the pair unconditionally (one basic block: their Philox/Box-Muller
-                        // chains interleave); for odd N the last pair's second element is the pad slot, kept at 0
-                        const NormalPair np0 = normal_pair(a.seed, sim, (uint64_t)i0);
-                        const NormalPair np1 = normal_pair(a.seed, sim, (uint64_t)(i0 + 1));
-                        if (nmode == 1) {
-                            store_f64x2(n1r, i0, np0.n1, np1.n1);
-                            store_f64x2(n2r, i0, np0.n2, np1.n2);
-                        }
-                        double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk_at(i0), np0.n1, np0.n2, zt0, xt0);
-                        Model::sample(sdk_at(i0 + 1), np1.n1, np1.n2, zt1, xt1);
-                        const bool valid1 = i0 + 1 < (int)N;
-                        x.p[i0] = xt0;
-                        g.p[i0] = zt0;
-                        x.p[i0 + 1] = valid1 ? xt1 : 0.0;
-                        g.p[i0 + 1] = valid1 ? zt1 : 0.0;
-                    }
-                }
-                z.clear();
-                s.clear();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
-                    else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.get(jj, i));
-                    else z.set(jj, i, z0src.get(jj, i));
-                });
-            } else {
-                x.clear(); g.clear(); z.clear(); s.clear();
-                VH ztrue;
-                if constexpr (KEEP_ZTRUE) ztrue.bind(extra, ld);
-                // streaming: ONE pair per trip (two Philox/Box-Muller chains in flight, as in the rolled
-                // resident sampler) -- the pass is generator-bound and loads nothing; a warm start is
-                // copied by a pass of its own below
-                constexpr int US = Place::kResident ? U : 1;
-                const bool z_from_sample = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
-                for_elems<T, EPT, US>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const bool valid = i < N;  // phantom slots run the generator but keep zeros
-                    const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
-                    double zt, xt;
-                    if constexpr (Model::kStencil) {
-                        zt = sdk(jj, i) * np.n1;
-                        xt = np.n2;                           // noise now, + A z after the barrier
-                        s.set(jj, i, valid ? zt : 0.0);       // true z staged in the direction buffer
-                    } else {
-                        Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
-                    }
-                    zt = valid ? zt : 0.0;
-                    xt = valid ? xt : 0.0;
-                    if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
-                    x.set(jj, i, xt);
-                    if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
-                    else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
-                    else if constexpr (Place::kResident) z.set(jj, i, z0src.get(jj, i));
-                }, when(Model::kStencil, s), when(KEEP_ZTRUE, ztrue), x, when(z_from_sample, z));
-                if constexpr (!Place::kResident) {
-                    if (!z_from_sample && !z_in_place)
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); }, z);
-                }
-            }
-            if constexpr (Model::kStencil) {
-                pass_barrier();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const bool valid = i < N;
-                    const int ic = valid ? i : 0;
-                    const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
-                    const double az = fma(0.25, s.get1(im) + s.get1(ip), 0.5 * s.get1(ic));
-                    const double xv = az + x.get(jj, i);
-                    x.set(jj, i, valid ? xv : 0.0);
-                }, x);
-            }
-        } else {
-            VH xs;
-            xs.bind(d.x_mode == X_DATA ? a.x_data : a.x_given, ld);
-            x.clear(); g.clear(); z.clear(); s.clear();
-            const bool z_zero = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
-            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                x.set(jj, i, xs.get(jj, i));
-                if (z_zero) z.set(jj, i, 0.0);
-                else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
-            }, x, when(z_zero || !z_in_place, z));
-        }
-        stamp(p, 9);
-        if constexpr (Model::kStencil) pass_barrier();  // x (and the start z) complete before neighbours read them
-        else __syncthreads();
-
-        stamp(p, 1);
-    }
-
-    // -- phase 2: zhat_at_theta -- Optim LBFGS + HagerZhang on -logLike from the z prepared by begin()
-    __device__ void solve(int p) {
-        const int64_t ld = a.ld;
-        const int N = (int)a.N;
-        // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
-        f_calls = 0;
-        iter_stamp = 99;
-        stamp_p = p;
-        last_c = NAN;
-        // Resident policy, elementwise models: the initial evaluation leaves s = -g and g . s behind and does NOT
-        // store g (in LDS a store between the loads serialises the pass); the first update pass that needs the old
-        // gradient recomputes it from (x, z) -- bit-identical -- and stores the new one.  A solve that ends with
-        // its first line search (every isotropic problem) never writes or reads g at all.
-        constexpr bool kFuseInit = Place::kResident && !Model::kStencil;
-        double dphi_init;
-        eval<false, !kFuseInit, kFuseInit>(0.0, f, dphi_init, gmax);
-        bool g_stored = !kFuseInit;
-        score_ready = false;
-        stamp(p, 2);
-        iterations = 0;
-        hist_words = 0;
-        int pseudo = 0, counter_f_tol = 0;
-        status = MUSE_STATUS_MAXITER;
-        bool done = false;
-        if (!isfinite(f) || !isfinite(gmax)) { status = MUSE_STATUS_NONFINITE; done = true; }
-        else if (gmax <= a.atol) { status = MUSE_STATUS_G_CONVERGED; done = true; }
-        if (a.debug & 1) done = true;
-
-        double dot0 = 0.0;      // dot(dx_newest, g) prepared by the update pass
-        bool have_pair = false;  // the update pass of the previous iteration stored a usable pair
-        while (!done && iterations < kMaxIter) {
-            iterations += 1;
-            pseudo += 1;
-            // ---- twoloop!: s = -H g ------------------------------------------------------------
-            const int upper = pseudo - 1, lower = (pseudo - kM) > 1 ? (pseudo - kM) : 1;
-            const int h = upper >= lower ? upper - lower + 1 : 0;
-            double dphi_0;
-            if (kFuseInit && iterations == 1) {
-                dphi_0 = dphi_init;  // s = -g and g . s came with the initial evaluation
-            } else if (h == 0 || !have_pair) {
-                double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double gi = g.get(jj, i), si = -gi;
-                    s.set(jj, i, si);
-                    sum[0] = fma(gi, si, sum[0]);
-                }, s);
-                reduce<1, 0>(sum, mx);
-                dphi_0 = sum[0];
-            } else {
-                hist_words += h;
-                double dot = dot0;
-                // backward pass (q lives in s; the update pass left q = g there)
-                for (int index = upper; index >= lower; --index) {
-                    const int slot = (index - 1) % kM;
-                    const double al = sh_rho[slot] * dot;
-                    if ((tid & 63) == 0) sh_alpha[slot] = al;  // lane 0 of EVERY wave: a wave reads back its own write (no barrier needed)
-                    const VH dgp = hdg(slot);
-                    double sum[1] = {0.0}, mx[1] = {0.0};
-                    if (index > lower) {
-                        const VH dxn = hdx((index - 2) % kM);
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                            const double qi = fma(-al, dgp.get(jj, i), s.get(jj, i));
-                            s.set(jj, i, qi);
-                            sum[0] = fma(dxn.get(jj, i), qi, sum[0]);
-                        }, s);
-                    } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
-                        const double gam = sh_gam[(upper - 1) % kM];
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                            const double dgi = dgp.get(jj, i);
-                            const double si = gam * fma(-al, dgi, s.get(jj, i));
-                            s.set(jj, i, si);
-                            sum[0] = fma(dgi, si, sum[0]);
-                        }, s);
-                    }
-                    reduce<1, 0>(sum, mx);
-                    dot = sum[0];
-                }
-                // forward pass
-                for (int index = lower; index <= upper; ++index) {
-                    const int slot = (index - 1) % kM;
-                    const double beta = sh_rho[slot] * dot;
-                    const double coef = sh_alpha[slot] - beta;
-                    const VH dxp = hdx(slot);
-                    double sum[1] = {0.0}, mx[1] = {0.0};
-                    if (index < upper) {
-                        const VH dgn = hdg(index % kM);
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                            const double si = fma(dxp.get(jj, i), coef, s.get(jj, i));
-                            s.set(jj, i, si);
-                            sum[0] = fma(dgn.get(jj, i), si, sum[0]);
-                        }, s);
-                    } else {
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                            const double si = -fma(dxp.get(jj, i), coef, s.get(jj, i));
-                            s.set(jj, i, si);
-                            sum[0] = fma(g.get(jj, i), si, sum[0]);
-                        }, s);
-                    }
-                    reduce<1, 0>(sum, mx);
-                    dot = sum[0];
-                }
-                dphi_0 = dot;
-            }
-            // ---- perform_linesearch!: reset a non-descent direction ------------------------------
-            if (dphi_0 >= 0.0) {
-                pseudo = 1;
-                if constexpr (kFuseInit) {
-                    if (!g_stored) {  // (cannot happen after a finite, unconverged initial evaluation; kept for completeness)
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                            double unused = 0.0;
-                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), z.get(jj, i), unused));
-                        }, g);
-                        g_stored = true;
-                    }
-                }
-                double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double gi = g.get(jj, i), si = -gi;
-                    s.set(jj, i, si);
-                    sum[0] = fma(gi, si, sum[0]);
-                }, s);
-                reduce<1, 0>(sum, mx);
-                dphi_0 = sum[0];
-            }
-            if (iterations == 1) stamp(p, 3);
-            const double phi_0 = f, f_prev = f;
-            last_c = NAN;  // no trial evaluated yet in this line search
-            last_phi = f;
-            last_gmax = gmax;
-            double alpha;
-            iter_stamp = iterations == 1 ? 0 : 99;
-            stamp_p = p;
-            const bool ls_ok = linesearch(1.0, phi_0, dphi_0, alpha);
-            if (iterations == 1) stamp(p, 4);
-            // ---- update_g! / assess_convergence: the scalars at z + alpha s are those of the last
-            //      evaluation (or of the current point when the step is a no-op) ---------------------
-            const double f_new = last_phi, gmax_new = last_gmax;
-            const bool g_conv = gmax_new <= a.atol;
-            const bool f_conv = fabs(f_new - f_prev) <= 0.0;
-            const int cft = f_conv ? counter_f_tol + 1 : 0;
-            const bool stop_hint = !ls_ok || g_conv || cft > 1 || !isfinite(gmax_new);
-            // ---- fused update pass: z += alpha s; gradient at the new point recomputed (bit-equal
-            //      to the trial evaluation); (dx, dg) stored; g <- new gradient; q <- g -----------------
-            const int slot_new = (pseudo - 1) % kM;
-            VH dxs = hdx(slot_new);
-            VH dgs = hdg(slot_new);
-            const bool keep = !stop_hint;
-            double sum[3] = {0.0, 0.0, 0.0}, mx[1] = {0.0};
-            if (!keep) {
-                // ---- the solve ends with this step (whatever x_converged says): z += alpha s, and in the same
-                //      pass what finish() would compute from the final z -- the score terms and the zhat store
-                double acc[MAXB];
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-                VH zout;
-                const bool store = Place::kResident && d.zslot >= 0;  // streaming: z already lives in its zhat slot
-                if (store) zout.bind(a.zhat + d.zslot * ld, ld);
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double zo = z.get(jj, i), si = s.get(jj, i);
-                    const double zn = fma(alpha, si, zo);
-                    z.set(jj, i, zn);
-                    mx[0] = absmax(mx[0], zn - zo);
-                    if constexpr (Place::kResident) {
-                        if (store) zout.set(jj, i, zn);
-                    }
-                    const double t = Model::score_term(x.get(jj, i), zn);
-                    if constexpr (MAXB == 1) {
-                        acc[0] += t;
-                    } else {
-                        const int k = blk(jj, i);
-#pragma unroll
-                        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
-                    }
-                }, z);
-                if constexpr (MAXB + 1 <= 8) {
-                    reduce<MAXB, 1>(acc, mx);
-                } else {
-                    double none[1] = {0.0};
-                    reduce<0, 1>(none, mx);
-                    reduce<MAXB, 0>(acc, none);
-                }
-                bool any_nan = false;  // a NaN step shows up in the score sums (NaN channel of the maximum)
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
-                    score_acc[b] = acc[b];
-                    any_nan = any_nan || acc[b] != acc[b];
-                }
-                mx[0] = nan_if(any_nan, mx[0]);
-                score_ready = true;
-            } else if constexpr (!Model::kStencil) {
-                auto body = [&](auto have_g, int jj, int i) {
-                    const double zo = z.get(jj, i), si = s.get(jj, i);
-                    const double dxi = alpha * si;
-                    const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
-                    z.set(jj, i, zn);
-                    mx[0] = absmax(mx[0], zn - zo);
-                    double unused = 0.0;
-                    const double xi = x.get(jj, i), ivi = ivk(jj, i);
-                    const double gn = Model::grad(ivi, xi, zn, unused);
-                    double go;
-                    if constexpr (decltype(have_g)::value) go = g.get(jj, i);
-                    else go = Model::grad(ivi, xi, zo, unused);  // what the initial evaluation computed
-                    const double dgi = gn - go;
-                    sum[0] = fma(dxi, dgi, sum[0]);
-                    sum[1] = fma(dgi, dgi, sum[1]);
-                    sum[2] = fma(dxi, gn, sum[2]);
-                    dxs.set(jj, i, dxi);
-                    dgs.set(jj, i, dgi);
-                    g.set(jj, i, gn);
-                    s.set(jj, i, gn);
-                };
-                if (g_stored) {
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { body(std::true_type{}, jj, i); },
-                                         z, dxs, dgs, g, s);
-                } else {
-                    if constexpr (kFuseInit)
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { body(std::false_type{}, jj, i); },
-                                             z, dxs, dgs, g, s);
-                    g_stored = true;
-                }
-                reduce<3, 1>(sum, mx);
-                mx[0] = nan_if(sum[0] != sum[0], mx[0]);
-            } else {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double zo = z.get(jj, i), si = s.get(jj, i);
-                    const double dxi = alpha * si;
-                    const double zn = fma(alpha, si, zo);
-                    z.set(jj, i, zn);
-                    mx[0] = absmax(mx[0], zn - zo);
-                    dxs.set(jj, i, dxi);
-                }, z, dxs);
-                pass_barrier();  // neighbours' z must be complete before the stencil reads them
-                double unused = 0.0;
-                double dxv[U][2], gov[U][2];
-                stencil_pairs<false>(0.0, unused,
-                    [&](int u, int i0) {  // this trip's own loads, issued with the stencil's
-                        dxv[u][0] = dxs.get(2 * u, i0);
-                        dxv[u][1] = dxs.get(2 * u + 1, i0 + 1);
-                        gov[u][0] = g.get(2 * u, i0);
-                        gov[u][1] = g.get(2 * u + 1, i0 + 1);
-                    },
-                    [&](int u, int i0, double gn0, double gn1, double, double) {
-                        const double gnv[2] = {gn0, gn1};
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int i = i0 + v;
-                            const double gn = gnv[v];
-                            const double dxi = dxv[u][v];
-                            const double dgi = gn - gov[u][v];
-                            sum[0] = fma(dxi, dgi, sum[0]);
-                            sum[1] = fma(dgi, dgi, sum[1]);
-                            sum[2] = fma(dxi, gn, sum[2]);
-                            dgs.set(2 * u + v, i, dgi);
-                            g.set(2 * u + v, i, gn);
-                            s.set(2 * u + v, i, gn);
-                        }
-                    }, dgs, g, s);
-                reduce<3, 1>(sum, mx);
-                mx[0] = nan_if(sum[0] != sum[0], mx[0]);
-            }
-            if (iterations == 1) stamp(p, 5);
-            if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
-                status = MUSE_STATUS_LINESEARCH_FAILED;
-                f = last_phi;
-                gmax = last_gmax;
-                break;
-            }
-            f = f_new;
-            gmax = gmax_new;
-            counter_f_tol = cft;
-            const bool x_conv = mx[0] <= 0.0;
-            done = stop_hint || x_conv;
-            if (g_conv) status = MUSE_STATUS_G_CONVERGED;
-            else if (x_conv) status = MUSE_STATUS_X_CONVERGED;
-            else if (cft > 1) status = MUSE_STATUS_F_CONVERGED;
-            if (!isfinite(gmax)) status = MUSE_STATUS_NONFINITE;
-            // ---- update_h!: rho = 1/(dx.dg); an infinite rho drops the history ----------------------
-            have_pair = false;
-            if (keep) {
-                const double rho_it = 1.0 / sum[0];
-                if (isinf(rho_it)) {
-                    pseudo = 0;
-                } else {
-                    if ((tid & 63) == 0) {  // every wave writes the identical value and later reads its own write
-                        sh_rho[slot_new] = rho_it;
-                        sh_gam[slot_new] = sum[0] / sum[1];
-                    }
-                    have_pair = true;
-                }
-                dot0 = sum[2];
-            }
-        }
-
-        stamp(p, 6);
-    }
-
-    // ------------------------------------------------------------------------------------------
-    // get_H! implicit-differentiation branch for one simulation (src/muse.jl:335-405):
-    //   H = H1 - dFdtheta^T A^{-1} dFdtheta1,  A = Hessian_z logLike at (x, zhat, theta0),
-    // A^{-1} by conjugate gradients (IterativeSolvers.cg: x0 = 0, reltol sqrt(eps), abstol 0, maxiter).
-    // The reference gets the derivative operands by nested AD; for the compiled-in models they are
-    // closed forms (see oracle/muse_oracle.c, mo_implicit_H, for the list).  Streaming policy only:
-    // the CG vectors reuse the solver's g, s and history buffers; z_true sits in the extra vector.
-    // Writes H[p] (row-major ntheta x ntheta) and the CG iteration count of column j to info[p*ntheta+j].
-    __device__ void run_implicit(int p, double* wg_scratch, double* lds_x, double* lds_g) {
-        begin<true>(p, wg_scratch, lds_x, lds_g);
-        solve(p);
-        const int64_t ld = a.ld;
-        const int N = (int)a.N, nth = a.ntheta;
-        VH ztrue, v, r, pp, Ap, t1, t2;
-        ztrue.bind(extra, ld);
-        v.bind(wg_scratch + ld, ld);       // g buffer
-        r.bind(wg_scratch + 2 * ld, ld);   // s buffer
-        pp.bind(hist, ld);
-        Ap.bind(hist + ld, ld);
-        t1.bind(hist + 2 * ld, ld);
-        t2.bind(hist + 3 * ld, ld);
-        auto Aat = [&](const VH& w, int i) {  // (A w)_i, periodic (1/4, 1/2, 1/4); the pad element maps to 0
-            const bool valid = i < N;
-            const int ic = valid ? i : 0;
-            const int im = ic == 0 ? N - 1 : ic - 1, ip = ic == N - 1 ? 0 : ic + 1;
-            const double a0 = fma(0.25, w.get1(im) + w.get1(ip), 0.5 * w.get1(ic));
-            return valid ? a0 : 0.0;
-        };
-        for (int j = 0; j < nth; ++j) {
-            // ---- right-hand side b = dFdtheta1[:, j]; v = 0, r = p = b --------------------------------
-            double sum[1] = {0.0}, mx[1] = {0.0};
-            if constexpr (Model::kStencil) {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
-                    t1.set(jj, i, blk(jj, i) == j ? 0.5 * zt : 0.0);
-                }, t1);
-                pass_barrier();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); }, t2);
-                pass_barrier();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double bi = Aat(t2, i);
-                    v.set(jj, i, 0.0);
-                    r.set(jj, i, bi);
-                    pp.set(jj, i, bi);
-                    sum[0] = fma(bi, bi, sum[0]);
-                }, v, r, pp);
-            } else {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
-                    double bi;
-                    if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - zt));
-                    else bi = blk(jj, i) == j ? 0.5 * zt : 0.0;
-                    v.set(jj, i, 0.0);
-                    r.set(jj, i, bi);
-                    pp.set(jj, i, bi);
-                    sum[0] = fma(bi, bi, sum[0]);
-                }, v, r, pp);
-            }
-            reduce<1, 0>(sum, mx);
-            double rr = sum[0];
-            const double tol = __builtin_sqrt(kEps) * __builtin_sqrt(rr);
-            int it = 0;
-            while (it < a.cg_maxiter && !(__builtin_sqrt(rr) <= tol)) {
-                // ---- Ap = A_hess p, p.Ap -----------------------------------------------------------
-                double s1[1] = {0.0};
-                if constexpr (Model::kStencil) {
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t1.set(jj, i, Aat(pp, i)); }, t1);
-                    pass_barrier();
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                        const double pi = pp.get(jj, i);
-                        const double api = -(Aat(t1, i) + ivk(jj, i) * pi);
-                        Ap.set(jj, i, api);
-                        s1[0] = fma(pi, api, s1[0]);
-                    }, Ap);
-                } else {
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                        const double pi = pp.get(jj, i);
-                        double api;
-                        if constexpr (Model::kId == MUSE_MODEL_NOISE) api = -((iv0 + 1.0) * pi);
-                        else api = -(pi + ivk(jj, i) * pi);
-                        Ap.set(jj, i, api);
-                        s1[0] = fma(pi, api, s1[0]);
-                    }, Ap);
-                }
-                reduce<1, 0>(s1, mx);
-                const double alpha = rr / s1[0];
-                // ---- v += alpha p ; r -= alpha Ap ; r.r ---------------------------------------------
-                double s2[1] = {0.0};
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    v.set(jj, i, fma(alpha, pp.get(jj, i), v.get(jj, i)));
-                    const double ri = fma(-alpha, Ap.get(jj, i), r.get(jj, i));
-                    r.set(jj, i, ri);
-                    s2[0] = fma(ri, ri, s2[0]);
-                }, v, r);
-                reduce<1, 0>(s2, mx);
-                const double beta = s2[0] / rr;
-                rr = s2[0];
-                // ---- p = r + beta p (its stores are ordered before the next stencil read by pass_barrier)
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    pp.set(jj, i, fma(beta, pp.get(jj, i), r.get(jj, i)));
-                }, pp);
-                if constexpr (Model::kStencil) pass_barrier();
-                it += 1;
-            }
-            // ---- H[:, j] = H1[:, j] - dFdtheta^T v ----------------------------------------------------
-            constexpr int KA = Model::kId == MUSE_MODEL_NOISE ? 2 : MAXB;  // noise: [dFdtheta^T v, H1 sum]
-            double acc[KA];
-#pragma unroll
-            for (int b = 0; b < KA; ++b) acc[b] = 0.0;
-            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                const double zi = z.get(jj, i), vi = v.get(jj, i);
-                if constexpr (Model::kId == MUSE_MODEL_NOISE) {
-                    const double xi = x.get(jj, i);
-                    const double dd = xi - zi;
-                    acc[0] = fma(-iv0 * dd, vi, acc[0]);
-                    acc[1] = fma(dd, 0.5 * (xi - ztrue.get(jj, i)), acc[1]);
-                } else {
-                    const double t = ivk(jj, i) * zi;
-                    if constexpr (MAXB == 1) {
-                        acc[0] = fma(t, vi, acc[0]);
-                    } else {
-                        const int k = blk(jj, i);
-#pragma unroll
-                        for (int b = 0; b < MAXB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
-                    }
-                }
-            });
-            reduce<KA, 0>(acc, mx);
-            if (tid == 0 && crank == 0) {
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
-                    if (b < nth) {
-                        double h1 = 0.0;
-                        if constexpr (Model::kId == MUSE_MODEL_NOISE) h1 = iv0 * acc[1];
-                        a.scores[((int64_t)p * nth + b) * nth + j] = h1 - acc[b];
-                    }
-                }
-                muse_info inf;
-                inf.iterations = it;
-                inf.f_calls = f_calls;
-                inf.status = status;
-                inf.hist_words = hist_words;
-                inf.f_min = f;
-                inf.gnorm = gmax;
-                a.info[(int64_t)p * nth + j] = inf;
-            }
-        }
-    }
-
-    // -- phase 3: zhat out, score grad_theta logLike(x, zhat, theta), solver info
-    __device__ void finish(int p) {
-        const int64_t ld = a.ld;
-        {
-            double acc[MAXB], mx[1] = {0.0};
-            if (score_ready) {  // the solve's last pass already did both (see solve())
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) acc[b] = score_acc[b];
-            } else {
-                VH zout;
-                const bool store = Place::kResident && d.zslot >= 0;
-                if (store) zout.bind(a.zhat + d.zslot * ld, ld);
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double zi = z.get(jj, i);
-                    if constexpr (Place::kResident) {
-                        if (store) zout.set(jj, i, zi);
-                    }
-                    const double t = Model::score_term(x.get(jj, i), zi);
-                    if constexpr (MAXB == 1) {
-                        acc[0] += t;
-                    } else {
-                        const int k = blk(jj, i);
-#pragma unroll
-                        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
-                    }
-                });
-                reduce<MAXB, 0>(acc, mx);
-            }
-            if (tid < MAXB && tid < a.ntheta && crank == 0) {  // lane b finishes and writes score component b
-                double mine = acc[0];
-#pragma unroll
-                for (int b = 1; b < MAXB; ++b) mine = (tid == b) ? acc[b] : mine;
-                const double cnt = (double)(a.bnd32[tid < a.ntheta - 1 ? tid + 1 : 0] - a.bnd32[tid]);
-                const double cnt_last = (double)((int)a.N - a.bnd32[tid]);  // bnd32[ntheta] is a sentinel, not N
-                a.scores[(int64_t)p * a.ntheta + tid] =
-                    0.5 * (a.tmap.iv[tid] * mine - (tid == a.ntheta - 1 ? cnt_last : cnt));
-            }
-            if (tid == 0 && crank == 0) {
-                muse_info inf;
-                inf.iterations = iterations;
-                inf.f_calls = f_calls;
-                inf.status = (status <= MUSE_STATUS_F_CONVERGED && !isfinite(f)) ? MUSE_STATUS_NONFINITE : status;
-                inf.hist_words = hist_words;
-                inf.f_min = f;
-                inf.gnorm = gmax;
-                a.info[p] = inf;
-            }
-        }
-        stamp(p, 7);
-    }
-    double last_phi;
-    double score_acc[MAXB];  // per-block sums of the score terms when the solve's last pass computed them
-    bool score_ready;
-};
 
 constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS copy of the kernel arguments
 
