@@ -338,8 +338,53 @@ struct Solver {
         f_calls += 1;
     }
 
+    // The initial evaluation of the resident elementwise layout, fused with the FIRST line-search trial: the
+    // steepest-descent direction s = -g is known element by element, so the same pass also evaluates the objective
+    // at z + c0 s (InitialStatic: c0 = 1) -- what the line search would ask for first -- and one 6-value reduction
+    // replaces two passes with a 3-value reduction each.  The trial's scalars wait in trial_*; the line search
+    // consumes them (and counts the evaluation) only if it gets that far.
+    double trial_c, trial_phi, trial_dphi, trial_gmax;
+    bool have_trial;
+    __device__ __forceinline__ void eval_init_with_trial(double c0, double& f, double& dphi, double& gmax) {
+        double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
+        for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
+            const double zi = z.get(jj, i), xi = x.get(jj, i), ivi = ivk(jj, i);
+            const double gi = Model::grad(ivi, xi, zi, sum[0]);
+            const double sd = -gi;
+            s.set(jj, i, sd);
+            sum[1] = fma(gi, sd, sum[1]);
+            mx[0] = absmax(mx[0], gi);
+            const double zt = fma(c0, sd, zi);  // exactly the trial point eval<true, false>(c0) would form
+            const double gt = Model::grad(ivi, xi, zt, sum[2]);
+            sum[3] = fma(gt, sd, sum[3]);
+            mx[1] = absmax(mx[1], gt);
+        }, s);
+        reduce<4, 2>(sum, mx);
+        f = 0.5 * (sum[0] + a.f_const);
+        dphi = sum[1];
+        gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
+        f_calls += 1;
+        trial_c = c0;
+        trial_phi = 0.5 * (sum[2] + a.f_const);
+        trial_dphi = sum[3];
+        trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
+        have_trial = true;
+    }
+
     // phi(c), dphi(c) of the line search (the NLSolversBase objective cache is last_c/last_phi).
     __device__ __forceinline__ void phidphi(double c, double& phi, double& dphi) {
+        if (have_trial) {
+            have_trial = false;
+            if (c == trial_c) {  // the first trial of the first line search: evaluated with the initial point
+                phi = trial_phi;
+                dphi = trial_dphi;
+                last_c = c;
+                last_gmax = trial_gmax;
+                last_phi = phi;
+                f_calls += 1;
+                return;
+            }
+        }
         double gm;
         eval<true, false>(c, phi, dphi, gm);
         last_c = c;
@@ -727,7 +772,9 @@ struct Solver {
         // its first line search (every isotropic problem) never writes or reads g at all.
         constexpr bool kFuseInit = Place::kResident && !Model::kStencil;
         double dphi_init;
-        eval<false, !kFuseInit, kFuseInit>(0.0, f, dphi_init, gmax);
+        have_trial = false;
+        if constexpr (kFuseInit) eval_init_with_trial(1.0, f, dphi_init, gmax);
+        else eval<false, true, false>(0.0, f, dphi_init, gmax);
         bool g_stored = !kFuseInit;
         score_ready = false;
         stamp(p, 2);
@@ -845,6 +892,7 @@ struct Solver {
             iter_stamp = iterations == 1 ? 0 : 99;
             stamp_p = p;
             const bool ls_ok = linesearch(1.0, phi_0, dphi_0, alpha);
+            have_trial = false;  // only the first line search can use the trial evaluated with the initial point
             if (iterations == 1) stamp(p, 4);
             // ---- update_g! / assess_convergence: the scalars at z + alpha s are those of the last
             //      evaluation (or of the current point when the step is a no-op) ---------------------
