@@ -296,14 +296,27 @@ struct Solver {
     // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
     //    dphi = grad . s and gmax = ||grad||_inf; the gradient itself is stored (into g) only when
     //    STORE_G -- a line-search trial needs just the three scalars.  One pass, one barrier.
+    // An element pass whose body needs the current z: f(zz, jj, i) with zz a std::bool_constant -- true where z is
+    // still the unwritten zero start of the streaming policy (the body then uses 0 and issues no load).
+    template <class F, class... W>
+    __device__ __forceinline__ void for_elems_zz(F&& f, W&&... written) {
+        if constexpr (!Place::kResident && !Model::kStencil) {
+            if (z_zero) {
+                for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) { f(std::true_type{}, jj, i); }, written...);
+                return;
+            }
+        }
+        for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) { f(std::false_type{}, jj, i); }, written...);
+    }
+
     //    INIT_S (resident policy, where s lives in registers): the pass also sets the steepest-descent
     //    direction s = -g and returns dphi = g . s, exactly as the separate pass would.
-    template <bool USE_S, bool STORE_G, bool INIT_S = false>
+    template <bool USE_S, bool STORE_G, bool INIT_S = false, bool ZZ = false>
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
             for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
-                double zi = z.get(jj, i);
+                double zi = ZZ ? 0.0 : z.get(jj, i);  // ZZ: z is still the (unwritten) zero start
                 double si = 0.0;
                 if constexpr (USE_S) {
                     si = s.get(jj, i);
@@ -345,6 +358,11 @@ struct Solver {
     // consumes them (and counts the evaluation) only if it gets that far.
     double trial_c, trial_phi, trial_dphi, trial_gmax;
     bool have_trial;
+    // Streaming policy, elementwise models, start from zero(z) or the true z: begin() has already made the initial
+    // evaluation and the first trial inside the sampler pass (the values were in registers there), and with a
+    // zero start z is not written at all until the first update ("z_zero": passes take z = 0 instead of reading it).
+    bool init_done, z_zero;
+    double init_f, init_dphi, init_gmax;
     __device__ __forceinline__ void eval_init_with_trial(double c0, double& f, double& dphi, double& gmax) {
         double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
         for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
@@ -386,7 +404,12 @@ struct Solver {
             }
         }
         double gm;
-        eval<true, false>(c, phi, dphi, gm);
+        if constexpr (!Place::kResident && !Model::kStencil) {
+            if (z_zero) eval<true, false, false, true>(c, phi, dphi, gm);
+            else eval<true, false>(c, phi, dphi, gm);
+        } else {
+            eval<true, false>(c, phi, dphi, gm);
+        }
         last_c = c;
         last_gmax = gm;
         last_phi = phi;
@@ -602,6 +625,9 @@ struct Solver {
     __device__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         d = describe(a, p);
         const int64_t N = a.N, ld = a.ld;
+        init_done = false;
+        z_zero = false;
+        have_trial = false;
         stamp(p, 0);
         iv0 = a.tmap.iv[0];
         sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.tmap.sd[0];
@@ -704,6 +730,49 @@ struct Solver {
                 // copied by a pass of its own below
                 constexpr int US = Place::kResident ? U : 1;
                 const bool z_from_sample = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
+                if constexpr (!Place::kResident && !Model::kStencil) {
+                    if (z_from_sample && !d.normals_only) {
+                        // sampler + initial evaluation + first line-search trial in ONE pass over values that are in
+                        // registers anyway (see eval_init_with_trial for the arithmetic, which is identical): the pass
+                        // writes x and s = -g only (and z when the start is the true z) -- against write x, z; read
+                        // x, z, write g; read g, write s; read z, s, x of the four passes it replaces
+                        const bool ztrue_start = d.z0_mode == Z0_TRUE;
+                        double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
+                        for_elems<T, EPT, 1>(ld, tfirst, pstride, [&](int jj, int i) {
+                            const bool valid = i < N;
+                            const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+                            double zt, xt;
+                            Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
+                            zt = valid ? zt : 0.0;
+                            xt = valid ? xt : 0.0;
+                            if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
+                            x.set(jj, i, xt);
+                            const double z0v = ztrue_start ? zt : 0.0;
+                            if (ztrue_start) z.set(jj, i, zt);
+                            const double ivi = ivk(jj, i);
+                            const double gi = Model::grad(ivi, xt, z0v, sum[0]);
+                            const double sd = -gi;
+                            s.set(jj, i, sd);
+                            sum[1] = fma(gi, sd, sum[1]);
+                            mx[0] = absmax(mx[0], gi);
+                            const double zt1 = fma(1.0, sd, z0v);
+                            const double gt = Model::grad(ivi, xt, zt1, sum[2]);
+                            sum[3] = fma(gt, sd, sum[3]);
+                            mx[1] = absmax(mx[1], gt);
+                        }, when(KEEP_ZTRUE, ztrue), x, s, when(ztrue_start, z));
+                        reduce<4, 2>(sum, mx);
+                        init_f = 0.5 * (sum[0] + a.f_const);
+                        init_dphi = sum[1];
+                        init_gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
+                        trial_c = 1.0;
+                        trial_phi = 0.5 * (sum[2] + a.f_const);
+                        trial_dphi = sum[3];
+                        trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
+                        init_done = true;
+                        z_zero = !ztrue_start;
+                    }
+                }
+                if (!init_done)
                 for_elems<T, EPT, US>(ld, tfirst, pstride, [&](int jj, int i) {
                     const bool valid = i < N;  // phantom slots run the generator but keep zeros
                     const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
@@ -724,7 +793,7 @@ struct Solver {
                     else if constexpr (Place::kResident) z.set(jj, i, z0src.get(jj, i));
                 }, when(Model::kStencil, s), when(KEEP_ZTRUE, ztrue), x, when(z_from_sample, z));
                 if constexpr (!Place::kResident) {
-                    if (!z_from_sample && !z_in_place)
+                    if (!init_done && !z_from_sample && !z_in_place)
                         for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); }, z);
                 }
             }
@@ -772,10 +841,21 @@ struct Solver {
         // its first line search (every isotropic problem) never writes or reads g at all.
         constexpr bool kFuseInit = Place::kResident && !Model::kStencil;
         double dphi_init;
-        have_trial = false;
-        if constexpr (kFuseInit) eval_init_with_trial(1.0, f, dphi_init, gmax);
-        else eval<false, true, false>(0.0, f, dphi_init, gmax);
-        bool g_stored = !kFuseInit;
+        bool init_fused = kFuseInit;  // s = -g and g . s are in hand when the first iteration starts
+        if (init_done) {              // begin() evaluated the initial point (and the first trial) while sampling
+            f = init_f;
+            dphi_init = init_dphi;
+            gmax = init_gmax;
+            f_calls = 1;
+            have_trial = true;
+            init_fused = true;
+        } else if constexpr (kFuseInit) {
+            eval_init_with_trial(1.0, f, dphi_init, gmax);
+        } else {
+            have_trial = false;
+            eval<false, true, false>(0.0, f, dphi_init, gmax);
+        }
+        bool g_stored = !init_fused;
         score_ready = false;
         stamp(p, 2);
         iterations = 0;
@@ -796,7 +876,7 @@ struct Solver {
             const int upper = pseudo - 1, lower = (pseudo - kM) > 1 ? (pseudo - kM) : 1;
             const int h = upper >= lower ? upper - lower + 1 : 0;
             double dphi_0;
-            if (kFuseInit && iterations == 1) {
+            if (init_fused && iterations == 1) {
                 dphi_0 = dphi_init;  // s = -g and g . s came with the initial evaluation
             } else if (h == 0 || !have_pair) {
                 double sum[1] = {0.0}, mx[1] = {0.0};
@@ -865,11 +945,12 @@ struct Solver {
             // ---- perform_linesearch!: reset a non-descent direction ------------------------------
             if (dphi_0 >= 0.0) {
                 pseudo = 1;
-                if constexpr (kFuseInit) {
+                if constexpr (!Model::kStencil) {
                     if (!g_stored) {  // (cannot happen after a finite, unconverged initial evaluation; kept for completeness)
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems_zz([&](auto zz, int jj, int i) {
                             double unused = 0.0;
-                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), z.get(jj, i), unused));
+                            const double zi = decltype(zz)::value ? 0.0 : z.get(jj, i);
+                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), zi, unused));
                         }, g);
                         g_stored = true;
                     }
@@ -917,8 +998,8 @@ struct Solver {
                 VH zout;
                 const bool store = Place::kResident && d.zslot >= 0;  // streaming: z already lives in its zhat slot
                 if (store) zout.bind(a.zhat + d.zslot * ld, ld);
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
-                    const double zo = z.get(jj, i), si = s.get(jj, i);
+                for_elems_zz([&](auto zz, int jj, int i) {
+                    const double zo = decltype(zz)::value ? 0.0 : z.get(jj, i), si = s.get(jj, i);
                     const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);
                     mx[0] = absmax(mx[0], zn - zo);
@@ -950,8 +1031,8 @@ struct Solver {
                 mx[0] = nan_if(any_nan, mx[0]);
                 score_ready = true;
             } else if constexpr (!Model::kStencil) {
-                auto body = [&](auto have_g, int jj, int i) {
-                    const double zo = z.get(jj, i), si = s.get(jj, i);
+                auto body = [&](auto have_g, auto zz, int jj, int i) {
+                    const double zo = decltype(zz)::value ? 0.0 : z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);  // the same point the accepted trial evaluated
                     z.set(jj, i, zn);
@@ -972,12 +1053,9 @@ struct Solver {
                     s.set(jj, i, gn);
                 };
                 if (g_stored) {
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { body(std::true_type{}, jj, i); },
-                                         z, dxs, dgs, g, s);
+                    for_elems_zz([&](auto zz, int jj, int i) { body(std::true_type{}, zz, jj, i); }, z, dxs, dgs, g, s);
                 } else {
-                    if constexpr (kFuseInit)
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { body(std::false_type{}, jj, i); },
-                                             z, dxs, dgs, g, s);
+                    for_elems_zz([&](auto zz, int jj, int i) { body(std::false_type{}, zz, jj, i); }, z, dxs, dgs, g, s);
                     g_stored = true;
                 }
                 reduce<3, 1>(sum, mx);
@@ -1020,6 +1098,7 @@ struct Solver {
                 reduce<3, 1>(sum, mx);
                 mx[0] = nan_if(sum[0] != sum[0], mx[0]);
             }
+            z_zero = false;  // z has been written
             if (iterations == 1) stamp(p, 5);
             if (!ls_ok) {  // Optim keeps value(d)/gradient(d) of the last evaluated point
                 status = MUSE_STATUS_LINESEARCH_FAILED;
@@ -1050,6 +1129,12 @@ struct Solver {
                     have_pair = true;
                 }
                 dot0 = sum[2];
+            }
+        }
+        if constexpr (!Place::kResident && !Model::kStencil) {
+            if (z_zero) {  // no step was taken from a zero start (converged at once / non-finite): z = 0 goes to memory now
+                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { z.set(jj, i, 0.0); }, z);
+                z_zero = false;
             }
         }
 
