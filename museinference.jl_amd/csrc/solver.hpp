@@ -730,7 +730,7 @@ struct Solver {
                 // copied by a pass of its own below
                 constexpr int US = Place::kResident ? U : 1;
                 const bool z_from_sample = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
-                if constexpr (!Place::kResident && !Model::kStencil) {
+                if constexpr (!Model::kStencil) {  // (the LDS-resident layout has its own rolled sampler above)
                     if (z_from_sample && !d.normals_only) {
                         // sampler + initial evaluation + first line-search trial in ONE pass over values that are in
                         // registers anyway (see eval_init_with_trial for the arithmetic, which is identical): the pass
@@ -748,7 +748,7 @@ struct Solver {
                             if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
                             x.set(jj, i, xt);
                             const double z0v = ztrue_start ? zt : 0.0;
-                            if (ztrue_start) z.set(jj, i, zt);
+                            if (Place::kResident || ztrue_start) z.set(jj, i, z0v);  // registers: always defined
                             const double ivi = ivk(jj, i);
                             const double gi = Model::grad(ivi, xt, z0v, sum[0]);
                             const double sd = -gi;
@@ -759,7 +759,7 @@ struct Solver {
                             const double gt = Model::grad(ivi, xt, zt1, sum[2]);
                             sum[3] = fma(gt, sd, sum[3]);
                             mx[1] = absmax(mx[1], gt);
-                        }, when(KEEP_ZTRUE, ztrue), x, s, when(ztrue_start, z));
+                        }, when(KEEP_ZTRUE, ztrue), x, s, when(Place::kResident || ztrue_start, z));
                         reduce<4, 2>(sum, mx);
                         init_f = 0.5 * (sum[0] + a.f_const);
                         init_dphi = sum[1];
@@ -769,7 +769,7 @@ struct Solver {
                         trial_dphi = sum[3];
                         trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
                         init_done = true;
-                        z_zero = !ztrue_start;
+                        z_zero = !ztrue_start && !Place::kResident;
                     }
                 }
                 if (!init_done)
