@@ -67,7 +67,7 @@ struct BatchArgs {
     int64_t ncache_sim0;
     int ncache_count, ncache_mode;
     int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
-    int pad3_;
+    int imp_split;  // BATCH_IMPLICIT: elements per simulation (1: all H columns in one element; ntheta: one each)
     int64_t norm_sim0;
 };
 
@@ -107,7 +107,7 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.zslot = -1;
         d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + p / per;
     } else if (a.kind == BATCH_IMPLICIT) {
-        d.sim = a.sim_begin + p;
+        d.sim = a.sim_begin + p / (a.imp_split > 1 ? a.imp_split : 1);
         d.x_mode = X_SAMPLE;
         d.z0_mode = Z0_ZERO;  // zhat_guess_from_truth = zero(z) (src/muse.jl:343, src/interface.jl:184-186)
         d.tsample = -1;

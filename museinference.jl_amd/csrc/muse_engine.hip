@@ -1198,7 +1198,11 @@ int muse_implicit_H_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     a.seed = seed;
     a.atol = atol;
     a.cg_maxiter = cg_maxiter;
-    a.nproblems = (int)nsims;
+    // few simulations and several theta components: one element per (simulation, H column), so that the batch
+    // fills the GPU (each element repeats the simulation's sample and its atol MAP, cheap next to nθ CG solves)
+    const int64_t slots = (int64_t)c->num_cus * 2 / (c->N >= kClusterMinN ? cluster_size(c->N) : 1);
+    a.imp_split = (nt > 1 && nsims * 2 <= slots) ? nt : 1;
+    a.nproblems = (int)(nsims * a.imp_split);
     a.sim_begin = sim_begin;
     a.slot0 = 0;
     a.scores = c->scores_dev[2];

@@ -1169,7 +1169,12 @@ struct Solver {
             const double a0 = fma(0.25, w.get1(im) + w.get1(ip), 0.5 * w.get1(ic));
             return valid ? a0 : 0.0;
         };
-        for (int j = 0; j < nth; ++j) {
+        // imp_split == ntheta: this element is ONE column of one simulation's H (few simulations, many theta: the
+        // columns spread over the GPU, each repeating the cheap atol = 1e-1 MAP); imp_split == 1: all columns
+        const int split = a.imp_split > 1 ? a.imp_split : 1;
+        const int64_t psim = p / split;
+        const int j_lo = split > 1 ? p % split : 0, j_hi = split > 1 ? j_lo + 1 : nth;
+        for (int j = j_lo; j < j_hi; ++j) {
             // ---- right-hand side b = dFdtheta1[:, j]; v = 0, r = p = b --------------------------------
             double sum[1] = {0.0}, mx[1] = {0.0};
             if constexpr (Model::kStencil) {
@@ -1275,7 +1280,7 @@ struct Solver {
                     if (b < nth) {
                         double h1 = 0.0;
                         if constexpr (Model::kId == MUSE_MODEL_NOISE) h1 = iv0 * acc[1];
-                        a.scores[((int64_t)p * nth + b) * nth + j] = h1 - acc[b];
+                        a.scores[(psim * nth + b) * nth + j] = h1 - acc[b];
                     }
                 }
                 muse_info inf;
@@ -1285,7 +1290,7 @@ struct Solver {
                 inf.hist_words = hist_words;
                 inf.f_min = f;
                 inf.gnorm = gmax;
-                a.info[(int64_t)p * nth + j] = inf;
+                a.info[psim * nth + j] = inf;
             }
         }
     }
