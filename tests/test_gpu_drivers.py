@@ -318,7 +318,8 @@ def test_sharded_driver_over_engine_rccl_one_rank(gpu, M, O, tmp_path):
 
 @pytest.mark.parametrize("model,N,nth,theta0,prior", [
     ("funnel", 10000, 1, [1.0], "gauss"), ("funnel", 3000, 4, [1.0, 0.5, -0.5, 2.0], "gauss"),
-    ("noise", 2000, 1, [0.8], "flat"), ("smooth", 1500, 2, [1.0, 0.3], "gauss")])
+    ("noise", 2000, 1, [0.8], "flat"), ("smooth", 1500, 2, [1.0, 0.3], "gauss"),
+    ("funnel", 9999, 2, [0.8, 0.2], "gauss"), ("noise", 8191, 1, [0.3], "gauss")])   # odd N in the normals-cache layout
 def test_native_outer_loop_equals_host_driver(gpu, M, O, model, N, nth, theta0, prior):
     """muse_run (the outer loop in the library's native host code) against the Python driver on the same
     launches: the same number of iterations, every history record and the final theta/J/H/Sigma to 1e-12

@@ -111,7 +111,8 @@ def test_resident_equals_streaming_bitwise(gpu, M, model, N, nth, theta):
     assert np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("model,N,nth,theta", [CASES[0], CASES[6], CASES[7], CASES[11], ("funnel", 70001, 2, [0.3, -0.2])])
+@pytest.mark.parametrize("model,N,nth,theta", [CASES[0], CASES[6], CASES[7], CASES[11], ("funnel", 70001, 2, [0.3, -0.2]),
+                                               ("funnel", 9999, 3, [0.4, 1.1, -0.3]), ("noise", 7777, 1, [0.6])])
 @pytest.mark.parametrize("fid_mode", [0, 1])
 def test_fd_jacobian(gpu, M, O, model, N, nth, theta, fid_mode):
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
