@@ -317,6 +317,9 @@ def main():
             "kernel": "map_score_kernel", "kernel_ms_mean": 1e3 * mean_kernel_s,
             "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
             "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "achieved = algorithmic bytes (SURVEY 8.d3 accounting) / kernel time; at N <= 10^4 the accounted vectors live in "
+                    "registers/LDS, so achieved exceeds the HBM peak and `traffic` (PMC, profiles/) is what HBM really moved; "
+                    "the resident kernel is VALU-issue-bound (DESIGN.md 6)",
             "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
                         "hist_pairs_mean": float(info["hist_words"].mean())},
         },
