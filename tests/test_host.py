@@ -168,3 +168,34 @@ def test_get_H_implicit_diff_host(M, O, funnel512):
     assert len(res.metadata["implicit_diff_cg_hists"]) == 6 and res.Sigma is not None
     M.get_H_(res, prob, nsims=6, implicit_diff=True)   # already have 6: no new sims (src/muse.jl:317-319)
     assert len(res.Hs) == 6
+
+
+def test_bench_accounting_helpers():
+    """bench.py's algorithmic-bytes accounting (words = 1 + 5E + Σ_k(4h_k + 4) + 2) and the
+    thread budget of the CPU baseline."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(HERE), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import museinference_jl_amd as M
+    from museinference_jl_amd import _capi
+    info = np.zeros(3, dtype=_capi.INFO_DTYPE)
+    info["f_calls"], info["iterations"], info["hist_words"] = [3, 3, 5], [1, 1, 2], [0, 0, 1]
+    # funnel at theta != 0: E=3, K=1 -> 22 words; third sim E=5, K=2, one pair used -> 1 + 25 + (4 + 8) + 2 = 40
+    assert bench.algorithmic_bytes(info, 10) == 8 * 10 * (22 + 22 + 40)
+    assert 1 <= bench.usable_cores(4) <= 4
+    assert bench.measured_traffic("no_such_workload") is None
+    assert set(bench.WORKLOADS) >= {"funnel_1e4", "funnel_512", "noise_1e6", "funnel4_1e4", "smooth_1e5"}
+
+
+def test_native_path_selection(M, O, funnel512):
+    """muse_(native="auto") only hands the loop to the library for problems that declare the capability; the
+    oracle-backed problem (and any wrapper that merely forwards attributes) stays on the host driver."""
+    from oracle_problem import OracleBatchedProblem
+    prob = OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0))
+    assert not getattr(type(prob), "supports_native_muse", False)
+    r = M.muse(prob, [1.0], rng=0, nsims=8, maxsteps=2)          # "auto": falls through to the host driver
+    assert len(r.history) == 2
+    with pytest.raises(ValueError):
+        M.muse(prob, [1.0], rng=0, nsims=8, maxsteps=2, native=True)
+    assert M.HipMuseProblem.supports_native_muse and not getattr(M.ShardedMuseProblem, "supports_native_muse", False)
