@@ -339,8 +339,13 @@ struct Solver {
                     g.set(2 * u + 1, i0 + 1, g1);
                 }
                 if constexpr (USE_S) sum[1] = fma(g1, s1, fma(g0, s0, sum[1]));
+                if constexpr (INIT_S) {  // the steepest-descent direction and g . s with the initial evaluation
+                    s.set(2 * u, i0, -g0);
+                    s.set(2 * u + 1, i0 + 1, -g1);
+                    sum[1] = fma(g1, -g1, fma(g0, -g0, sum[1]));
+                }
                 mx[0] = absmax(absmax(mx[0], g0), g1);
-            }, when(STORE_G, g));
+            }, when(STORE_G, g), when(INIT_S, s));
         }
         if (iter_stamp == 0) stamp(stamp_p, 14);
         reduce<2, 1>(sum, mx);
@@ -853,9 +858,10 @@ struct Solver {
             eval_init_with_trial(1.0, f, dphi_init, gmax);
         } else {
             have_trial = false;
-            eval<false, true, false>(0.0, f, dphi_init, gmax);
+            eval<false, true, Model::kStencil>(0.0, f, dphi_init, gmax);  // stencil: g stored, s = -g with it
+            if constexpr (Model::kStencil) init_fused = true;
         }
-        bool g_stored = !init_fused;
+        bool g_stored = !init_fused || Model::kStencil;
         score_ready = false;
         stamp(p, 2);
         iterations = 0;
