@@ -154,6 +154,25 @@ function muse_run(prob::HipMuseProblem, seed::Integer, θ₀; nsims=100, maxstep
     θ, hist[:, 1:n[]], gs[:, :, 1:n[]]
 end
 
+# One process per GPU (e.g. MPI.jl ranks or Distributed workers pinned to devices): after
+#   id = rank == 0 ? comm_unique_id() : nothing;  id = bcast(id);  comm_init(prob, nranks, rank, id)
+# every rank solves its own block of sims and receives everybody's scores through ONE RCCL all-gather on the device.
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:muse_comm_unique_id, libmuse_hip), Cint, (Ptr{UInt8},), id)); id
+end
+comm_init(prob::HipMuseProblem, nranks, rank, id) =
+    check(ccall((:muse_comm_init, libmuse_hip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), prob.ctx, nranks, rank, id))
+function map_and_score_batch_gathered(prob::HipMuseProblem, seed::Integer, mysims::UnitRange, θ, nranks, rows_per_rank;
+                                      include_data=false, atol=1e-2, z0_mode=0, area=0)
+    check(ccall((:muse_map_and_score_batch_gather_async, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Cint, Ptr{Float64}, Float64, Cint, Int64, Cint),
+                prob.ctx, seed, first(mysims), last(mysims) + 1, include_data, standardizeθ(prob, θ), atol, z0_mode, rows_per_rank, area))
+    g = Array{Float64}(undef, prob.nθ, rows_per_rank, nranks)     # [nθ, row, rank] column-major = C's [rank][row][nθ]
+    check(ccall((:muse_batch_wait_gathered, libmuse_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Cvoid}), prob.ctx, area, g, C_NULL))
+    g
+end
+
 function get_J!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=result.rng, nsims=100, ∇z_logLike_atol=1e-2, kwargs...)
     θ₀ = standardizeθ(prob, something(θ₀, result.θ))
     existing = length(result.gs)
