@@ -259,6 +259,7 @@ struct muse_ctx {
     int cl_cap = 0;
     int* error_flag = nullptr;           // pinned, device-mapped
     int debug = 0;
+    int split = 0;                 // muse_set_element_split: 0 = by N alone, >= 2 = workgroups per element
     unsigned int ticket_base = 0;  // value of the device ticket counter when the next launch starts
     bool timing = false;           // record an event pair around every solver launch (muse_set_timing; costs ~12 us per launch)
     unsigned long long* stamps = nullptr;
@@ -289,11 +290,14 @@ constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil mod
 
 enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5 };
 
-// Cluster size: a function of N alone (results must not depend on how many problems share a launch).
-static int cluster_size(int64_t N) {
+// Cluster size: a function of N alone (results must not depend on how many problems share a launch), unless the
+// caller asked for a split (muse_set_element_split: results then depend on (N, split), still not on the launch).
+static int cluster_size(const muse_ctx* c) {
+    if (c->split >= 2) return c->split;
     if (const char* e = getenv("MUSE_DEBUG_CLUSTER_SIZE")) return atoi(e);  // tuning aid
-    return N >= 4194304 ? 16 : (N >= kClusterMinN ? 4 : 1);
+    return c->N >= 4194304 ? 16 : (c->N >= kClusterMinN ? 4 : 1);
 }
+static bool use_cluster(const muse_ctx* c) { return c->split >= 2 || c->N >= kClusterMinN; }
 
 // Workgroup size is a function of N alone (256 threads for N <= 512, else 512), so that the
 // streaming and the resident policy reduce in the same order and give bitwise equal results.
@@ -302,7 +306,7 @@ static int choose_place(const muse_ctx* c) {
     // cluster mode: for the stencil model the neighbours owned by other workgroups become visible through
     // the agent-scope release/acquire of the cluster reduction that ends every pass (pass_barrier where a
     // pass has no reduction)
-    if (c->N >= kClusterMinN) return P_C256;
+    if (use_cluster(c)) return P_C256;
     if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN) return small ? P_S256 : P_S512;
     if (small) return P_R256x1;
     if (c->N <= 4096) return P_R512x4;
@@ -433,14 +437,14 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.debug = c->debug;
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     const bool implicit = a.kind == BATCH_IMPLICIT;
-    const int pl = implicit ? (c->N >= kClusterMinN ? P_C256 : P_S512) : choose_place(c);
+    const int pl = implicit ? (use_cluster(c) ? P_C256 : P_S512) : choose_place(c);
     int grid = c->num_cus * place_wgs_per_cu(pl);
     a.csize = 1;
     a.nclusters = 0;
     if (pl == P_C256) {
         // every workgroup of a cluster must be resident at once (they wait for each other): size the grid
         // from 2 workgroups of 256 threads per CU, which the kernel's register budget always admits
-        a.csize = cluster_size(c->N);
+        a.csize = cluster_size(c);
         int ncl = grid / a.csize;
         if (ncl > a.nproblems) ncl = a.nproblems;
         if (ncl < 1) ncl = 1;
@@ -649,6 +653,23 @@ int muse_set_placement(muse_ctx* c, int placement) {
     c->placement = placement;
     return MUSE_OK;
 }
+int muse_set_element_split(muse_ctx* c, int split) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    if (split != 0 && split != 1 && split != 2 && split != 4 && split != 8 && split != 16)
+        return fail(MUSE_ERR_INVALID, "split must be 0 (by N alone), 1, 2, 4, 8 or 16");
+    if (split > kMaxCluster) return fail(MUSE_ERR_INVALID, "split exceeds the largest cluster");
+    c->split = split == 1 ? 0 : split;
+    return MUSE_OK;
+}
+// A bounded cluster wait that expired inside a solver kernel leaves the pinned error word set; every entry point
+// that has synchronised with the launch reports (and clears) it instead of returning the launch's garbage.
+static int check_error_flag(muse_ctx* c) {
+    if (*c->error_flag) {
+        *c->error_flag = 0;
+        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident)");
+    }
+    return MUSE_OK;
+}
 int muse_synchronize(muse_ctx* c) {
     int rc = check_ctx(c);
     if (rc) return rc;
@@ -838,6 +859,8 @@ int muse_zhat_at_theta(muse_ctx* c, const double* x, const double* z0, const dou
     rc = enqueue_results_copy(c, kResultAreas - 1, 1);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_error_flag(c);
+    if (rc) return rc;
     if (info) *info = c->info_pin[kResultAreas - 1][0];
     return MUSE_OK;
 }
@@ -919,10 +942,8 @@ int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {
     if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
     rc = muse_wait_event(c->area_done[area]);  // this area only: later launches keep running
     if (rc) return rc;
-    if (*c->error_flag) {
-        *c->error_flag = 0;
-        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident)");
-    }
+    rc = check_error_flag(c);
+    if (rc) return rc;
     const int64_t n = c->res_n[area];
     if (g_out && n) memcpy(g_out, c->scores_pin[area], (size_t)n * c->ntheta * sizeof(double));
     if (info_out && n) memcpy(info_out, c->info_pin[area], (size_t)n * sizeof(muse_info));
@@ -994,7 +1015,10 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
                 for (int b = 0; b < nt; ++b) row += Hp[a_ * nt + b] * (h1[b] - h0[b]);
                 q += (h1[a_] - h0[a_]) * row;
             }
-            if (sqrt(-q > 0.0 ? -q : 0.0) < o->theta_rtol) break;
+            // sqrt of a negative argument is a DomainError in the reference (an H^-1_post' that is not negative
+            // definite); a NaN compares false and the loop goes on
+            if (-q < 0.0) return fail(MUSE_ERR_INVALID, "muse_run: DomainError in the convergence test: dtheta' H^-1_post' dtheta > 0 (H^-1_post' is not negative definite)");
+            if (sqrt(-q) < o->theta_rtol) break;
         }
         const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
         // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
@@ -1166,6 +1190,8 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
     rc = enqueue_results_copy(c, 1, n);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_error_flag(c);
+    if (rc) return rc;
     const double* g = c->scores_pin[1];
     for (int64_t s = 0; s < nsims; ++s)
         for (int j = 0; j < nt; ++j) {
@@ -1200,7 +1226,7 @@ int muse_implicit_H_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     a.cg_maxiter = cg_maxiter;
     // few simulations and several theta components: one element per (simulation, H column), so that the batch
     // fills the GPU (each element repeats the simulation's sample and its atol MAP, cheap next to nθ CG solves)
-    const int64_t slots = (int64_t)c->num_cus * 2 / (c->N >= kClusterMinN ? cluster_size(c->N) : 1);
+    const int64_t slots = (int64_t)c->num_cus * 2 / (use_cluster(c) ? cluster_size(c) : 1);
     a.imp_split = (nt > 1 && nsims * 2 <= slots) ? nt : 1;
     a.nproblems = (int)(nsims * a.imp_split);
     a.sim_begin = sim_begin;
@@ -1212,10 +1238,8 @@ int muse_implicit_H_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     rc = enqueue_results_copy(c, 2, nsims * nt);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (*c->error_flag) {
-        *c->error_flag = 0;
-        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel");
-    }
+    rc = check_error_flag(c);
+    if (rc) return rc;
     memcpy(Hs_out, c->scores_pin[2], (size_t)nsims * nt * nt * sizeof(double));
     if (cg_iters_out)
         for (int64_t k = 0; k < nsims * nt; ++k) cg_iters_out[k] = c->info_pin[2][k].iterations;

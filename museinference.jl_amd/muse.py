@@ -157,7 +157,11 @@ def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rt
         t0 = time.perf_counter()
         if i > 2:  # convergence on the last two recorded iterates (src/muse.jl:163-166)
             d = history[-1]["θ′"] - history[-2]["θ′"]
-            if math.sqrt(max(-(d @ history[-1]["H⁻¹_post′"] @ d), 0.0)) < theta_rtol:
+            q = -(d @ history[-1]["H⁻¹_post′"] @ d)
+            if q < 0:  # Julia's sqrt of a negative number: DomainError (H⁻¹_post′ not negative definite)
+                raise ValueError("DomainError in the convergence test: Δθ′ᵀ H⁻¹_post′ Δθ′ > 0 "
+                                 "(H⁻¹_post′ is not negative definite)")
+            if math.sqrt(q) < theta_rtol:  # a NaN compares false: the loop goes on, as in the reference
                 break
         # MUSE gradient: the (nsims+1)-element map (src/muse.jl:169-181)
         z0_mode = _capi.Z0_WARM if (not first or z0 is not None) else _capi.Z0_ZERO

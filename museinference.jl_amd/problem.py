@@ -205,6 +205,14 @@ class HipMuseProblem(AbstractMuseProblem):
         """-1 auto, 0 streaming, 1 resident (bitwise-identical results; for tests/benchmarks)."""
         _capi.check(self._lib.muse_set_placement(self._ctx, int(placement)))
 
+    def set_element_split(self, split):
+        """Workgroups per map element: 0/1 = by N alone (default), 2/4/8/16 = that many workgroups share one
+        element (for launches with fewer elements than compute units: the per-GPU share of a strongly scaled
+        map, the axis choice of src/muse.jl:327-333).  Results depend on the split (summation tree), not on the
+        batch or the GPU count."""
+        _capi.check(self._lib.muse_set_element_split(self._ctx, int(split)))
+        self.element_split = int(split)
+
     def set_stream(self, hip_stream):
         _capi.check(self._lib.muse_set_stream(self._ctx, _capi.ptr(hip_stream) if hip_stream else None))
 
@@ -436,8 +444,17 @@ class PositiveThetaProblem(AbstractMuseProblem):
         self.x = base.x
         self.prior_v = as_prior(prior)
 
-    def __getattr__(self, name):  # N, ntheta, get_zhat, set_zhat, ...
-        return getattr(self.base, name)
+    # Attributes of the wrapped problem that mean the same thing in the variance parametrisation.  Anything that
+    # takes or returns theta-space quantities (the batched seams, the per-simulation operators) is defined
+    # explicitly below with its chain rule -- a blanket forward would hand variances to an engine that expects
+    # log-variances.
+    _FORWARDED = ("N", "ntheta", "model", "device", "get_zhat", "set_zhat", "close", "synchronize", "set_timing",
+                  "last_kernel_ms", "set_placement", "set_element_split")
+
+    def __getattr__(self, name):
+        if name in PositiveThetaProblem._FORWARDED:
+            return getattr(self.base, name)
+        raise AttributeError(f"{type(self).__name__} has no attribute {name!r}")
 
     def standardize_theta(self, v):
         return np.atleast_1d(np.asarray(v, dtype=np.float64)).copy()
@@ -500,3 +517,13 @@ class PositiveThetaProblem(AbstractMuseProblem):
         """Finite differences in the untransformed space through the engine's θ′-space FD is not the same
         stencil; fall back to the element-by-element path of get_H_ (which calls the per-sim operators)."""
         raise NotImplementedError
+
+    def implicit_H_batch(self, rng, sim_begin, sim_end, v0, **kw):
+        """The implicit-differentiation H (src/muse.jl:335-405) in the variance parametrisation: the engine
+        returns H′[i][j] = d g′_i / d θ′_j at θ′ = log v0 (the derivative acts on the sampling θ only, the score
+        is taken at the fixed θ0); with g_i = g′_i / v0_i and d/dv_j = (1/v0_j) d/dθ′_j,  H = H′ / (v0 v0ᵀ)."""
+        if not hasattr(self.base, "implicit_H_batch"):
+            raise NotImplementedError("the wrapped problem has no implicit_H_batch seam")
+        v0 = np.atleast_1d(np.asarray(v0, dtype=np.float64))
+        Hs, its = self.base.implicit_H_batch(rng, sim_begin, sim_end, np.log(v0), **kw)
+        return Hs / np.outer(v0, v0)[None, :, :], its

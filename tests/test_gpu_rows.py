@@ -1,0 +1,279 @@
+"""-m gpu: the SURVEY.md §8 rows beyond the plain map, on the HIP path -- BASELINE.json's configs at their own
+sizes (configs[2] at nsims = 128, configs[3]'s finite-difference H at 64 sims, configs[4]'s N = 10^5 / 8 theta),
+the muse! keyword variants (row f2), checkpoint / resume / save_MAPs (row f3), theta transforms (row f4), the
+element split of strongly scaled maps (row e2) and cluster placement under the gathered (RCCL) map."""
+import os
+
+import numpy as np
+import pytest
+
+from test_host import LogNormalVariancePrior, check_outer_variants
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---- BASELINE.json configs at their own sizes ------------------------------------------------------
+def test_config5_smooth_1e5_8theta_vs_oracle(gpu, M, O):
+    """configs[4]: hierarchical linear-Gaussian (stencil) model, N = 10^5, 8 theta blocks -- cluster placement.
+    Two sims against the oracle.  Iteration-count parity is empirical, not a theorem (tree vs
+    sequential sums can move an evaluation count on long solves); where the counts agree the scores must agree to
+    rtol 1e-10, and in any case to the accuracy the MAP tolerance implies."""
+    N, nth, atol = 100000, 8, 1e-2
+    th = [1.0, 2.0, 3.0, 0.5, 0.0, -1.0, 1.5, 2.5]
+    prob = M.HipMuseProblem(None, model="smooth", ntheta=nth, N=N)
+    g, info = prob.map_and_score_batch(21, 0, 2, th, atol=atol, z0_mode=0)
+    go, zo, io = O.map_and_score_batch("smooth", N, 21, 0, 2, th, atol=atol, z0_mode=0, nthreads=2)
+    assert np.all(info["status"] == 0) and np.all(io["status"] == 0)
+    zh = prob.get_zhat(0, 2)
+    for k in range(2):
+        if (info["iterations"][k], info["f_calls"][k]) == (io["iterations"][k], io["f_calls"][k]):
+            np.testing.assert_allclose(g[k], go[k], rtol=1e-10)
+            np.testing.assert_allclose(zh[k], zo[k], rtol=0, atol=1e-9)
+        else:  # both converged to ||grad||_inf <= atol on different paths: |dz| <= 2 atol / lambda_min(Hessian)
+            lam = np.exp(-max(th))
+            assert np.abs(zh[k] - zo[k]).max() <= 2 * atol / lam
+            np.testing.assert_allclose(g[k], go[k], rtol=0, atol=2 * atol / lam * np.sqrt(N))
+    prob.close()
+
+
+def test_config5_smooth_1e5_full_cluster_load(gpu, M):
+    """configs[4] per-GPU share (128 elements, every CU carrying two workgroups of a cluster): all converged, no
+    cluster-timeout flag (a MuseError would be raised), two launches bitwise equal."""
+    N, nth = 100000, 8
+    th = [1.0] * nth
+    prob = M.HipMuseProblem(None, model="smooth", ntheta=nth, N=N)
+    g1, i1 = prob.map_and_score_batch(0, 0, 128, th, atol=1e-2, z0_mode=0)
+    g2, i2 = prob.map_and_score_batch(0, 0, 128, th, atol=1e-2, z0_mode=0)
+    assert np.all(i1["status"] == 0)
+    assert np.array_equal(g1, g2) and np.array_equal(i1, i2)
+    assert i1["iterations"].min() >= 3
+    prob.close()
+
+
+def test_config3_noise_1e6_nsims128(gpu, M):
+    """configs[2] at its own size: N = 10^6, nsims = 128 (128 clusters of 4 workgroups = the full 512-workgroup
+    grid): every solve converged, closed-form MAP and score on three sims, score moments over the batch."""
+    N, S, theta = 1000000, 128, 0.5
+    prob = M.HipMuseProblem(None, model="noise", ntheta=1, N=N)
+    g, info = prob.map_and_score_batch(3, 0, S, [theta], atol=1e-2, z0_mode=0)
+    assert np.all(info["status"] == 0)
+    e = np.exp(theta)
+    for k in (0, 64, 127):
+        x, _ = prob.sample_x_z(M.SimRng(3, k), [theta])
+        zh = prob.get_zhat(k, k + 1)[0]
+        np.testing.assert_allclose(zh, x / (1 + e), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(g[k, 0], 0.5 * (np.exp(-theta) * np.sum((x - zh) ** 2) - N), rtol=1e-11)
+    # E[s] = -N / (2 (1 + e^theta)),  Var[s] = N e^{2 theta} / (2 (1 + e^theta)^2)  (same algebra)
+    mean, var = -N / (2 * (1 + e)), N * e**2 / (2 * (1 + e) ** 2)
+    assert abs(g.mean() - mean) < 4 * np.sqrt(var / S)
+    prob.close()
+
+
+def test_config4_fd_jacobian_64_sims(gpu, M, O):
+    """configs[3]: 4-block funnel, N = 10^4, finite-difference H at 64 sims (512 perturbed MAPs + normals-only
+    elements in the fiducial launch): spot checks against the oracle, the closed-form CRN Jacobian on the diagonal
+    blocks, H = mean(Hs) against J (Gaussian model: H = J up to Monte-Carlo error)."""
+    N, nth, S = 10000, 4, 64
+    th = np.array([1.0, 0.5, -0.5, 2.0])
+    step = np.full(nth, 0.05)
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
+    Hs, info = prob.fd_jacobian_batch(11, 0, S, th, step, atol=1e-2, fid_mode=0)
+    assert np.all(info["status"] == 0)
+    _, zfid, _ = O.map_and_score_batch("funnel", N, 11, M.MASTER_SIM, M.MASTER_SIM + 1, th, atol=1e-2, z0_mode=0)
+    for s in (0, 31, 63):
+        Ho = O.fd_jacobian("funnel", N, 11, s, th, step, zfid[0], atol=1e-2)
+        np.testing.assert_allclose(Hs[s], Ho, rtol=1e-8, atol=1e-8 * np.abs(Ho).max())
+    H = Hs.mean(axis=0)
+    Jexact = 0.5 * (N / nth) * np.exp(2 * th) / (1 + np.exp(th)) ** 2          # per block: N_k e^{2θ}/(2(1+e^θ)²)
+    assert np.all(np.abs(np.diag(H) / Jexact - 1) < 5 / np.sqrt(S * N / nth) + 2e-3)   # FD truncation O(step²)
+    off = H - np.diag(np.diag(H))
+    assert np.abs(off).max() < 1e-6 * Jexact.max()                            # blocks are independent
+    prob.close()
+
+
+# ---- row f2: muse! keyword variants on the HIP path ---------------------------------------------------
+def test_outer_loop_variants_on_hip(gpu, M):
+    """Broyden / diagonal-Broyden (with memory limit, with a user H^-1_like'), callable alpha + regularize, and
+    the transformed-theta front-end, each a full muse! run on HipMuseProblem against the golden trajectories of the
+    independent restatement (tests/muse_reference.py on the oracle's map).  rtol 1e-8: the scores agree to 1e-10
+    and the Newton iteration propagates them."""
+    def make(x, prior="gauss"):
+        return M.HipMuseProblem(x, model="funnel", ntheta=4, prior=M.GaussianPrior(0.0, 3.0) if prior == "gauss" else None)
+    check_outer_variants(M, make, rtol=1e-8)
+
+
+def test_native_muse_run_matches_independent_restatement(gpu, M):
+    """muse_run (the outer loop in the library's C host code) against the golden trajectory whose algebra comes
+    from tests/muse_reference.py -- Newton step, diagonal H^-1 = -1/var, H^-1_post', convergence test."""
+    d = np.load(os.path.join(HERE, "golden", "muse_trajectory.npz"))
+    prob = M.HipMuseProblem(d["x"], model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    for native in (True, False):
+        res = M.muse(prob, [1.0], rng=42, nsims=32, get_covariance=True, native=native)
+        np.testing.assert_allclose(np.array([h["θ"] for h in res.history]), d["thetas"], rtol=1e-9)
+        np.testing.assert_allclose(np.array([h["g_like′"] for h in res.history]), d["g_like"], rtol=1e-9)
+        np.testing.assert_allclose(np.array([h["H⁻¹_post′"] for h in res.history]), d["Hinv_post"], rtol=1e-9)
+        np.testing.assert_allclose(res.theta, d["theta"], rtol=1e-8)
+        np.testing.assert_allclose(res.J, d["J"], rtol=1e-9)
+        np.testing.assert_allclose(np.array(res.Hs), d["Hs"], rtol=1e-7)
+        np.testing.assert_allclose(res.Sigma, d["Sigma"], rtol=1e-7)
+    d4 = np.load(os.path.join(HERE, "golden", "muse_outer_variants.npz"))
+    p4 = M.HipMuseProblem(d4["x"], model="funnel", ntheta=4, prior=M.GaussianPrior(0.0, 3.0))
+    res = M.muse(p4, [1.0] * 4, rng=1, nsims=24, maxsteps=7, theta_rtol=0.0, native=True)
+    np.testing.assert_allclose(np.array([h["θ"] for h in res.history]), d4["sims_thetas"][:-1], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(res.theta, d4["sims_thetas"][-1], rtol=1e-8, atol=1e-8)
+    # (muse_run's DomainError exit cannot be provoked through its own option set: -1/var < 0 and a flat or Gaussian
+    #  prior keep H^-1_post' negative definite; the Python driver's exit is tested on CPU with a user H^-1_like'.)
+    p4.close()
+    prob.close()
+
+
+# ---- row f3: checkpoint / resume / save_MAPs on the HIP path ---------------------------------------------
+def test_checkpoint_resume_and_saved_maps_on_hip(gpu, M, O, tmp_path):
+    N = 3000
+    x, _ = O.sample_x_z("funnel", N, 5, M.DATA_SIM, [0.0])
+    kw = dict(rng=11, nsims=16, theta_rtol=0.0, grad_z_logLike_atol=1e-9)
+    prob = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    full = M.muse(prob, [1.0], maxsteps=4, save_MAPs=True, **kw)
+    h = full.history[-1]
+    # history's saved MAPs are the resident slots at that iteration: the last record equals what the context holds
+    assert np.array_equal(h["ẑ_dat"], prob.get_zhat(0, 1)[0])
+    assert np.array_equal(np.array(h["ẑ_sims"]), prob.get_zhat(1, 17))
+    np.testing.assert_allclose(h["ẑ_dat"], x / (1 + np.exp(-h["θ"][0])), rtol=0, atol=1e-8)   # closed-form MAP
+    # a preprocessing hook (src/muse.jl:102-104: e.g. device -> host conversion) is applied to every saved MAP
+    r = M.muse(prob, [1.0], maxsteps=1, save_MAPs=lambda z: float(np.sum(z)), **kw)
+    assert isinstance(r.history[0]["ẑ_dat"], float) and len(r.history[0]["ẑ_sims"]) == 16
+    # checkpoint after every iteration (src/muse.jl:234), resume from the file in a NEW problem object
+    ck = str(tmp_path / "ck.pkl")
+    M.muse(prob, [1.0], maxsteps=2, checkpoint_filename=ck, **kw)
+    prob.close()
+    res = M.load_result(ck)
+    assert len(res.history) == 2 and res.rng == 11
+    prob2 = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    M.muse_(res, prob2, maxsteps=4, nsims=16, theta_rtol=0.0, grad_z_logLike_atol=1e-9)
+    assert len(res.history) == 4
+    # a resumed run restarts its MAPs from zero(z) (src/muse.jl:151), so the iterates agree to the MAP tolerance
+    np.testing.assert_allclose(res.theta, full.theta, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(res.history[2]["θ"], full.history[2]["θ"], rtol=1e-12)   # θ of record 3 = step of record 2
+    M.get_J_(res, prob2, nsims=16)
+    M.get_H_(res, prob2, nsims=2)
+    assert res.Sigma is not None and res.dist.σ > 0
+    prob2.close()
+
+
+# ---- row f4: theta transforms on the HIP path --------------------------------------------------------------
+def test_positive_theta_front_end_on_hip(gpu, M, O):
+    N, nth = 2000, 2
+    x, _ = O.sample_x_z("funnel", N, 9, M.DATA_SIM, [0.0] * nth)
+    base = M.HipMuseProblem(x, model="funnel", ntheta=nth)
+    prob = M.PositiveThetaProblem(base, prior=LogNormalVariancePrior())
+    res = M.check_self_consistency(prob, [1.7, 0.6], atol=1e-2)       # src/interface.jl:209-230, reference atol
+    assert max(res.values()) < 1e-4
+    # scores_in_both_spaces through the batched HIP seam against the per-simulation operators
+    v = np.array([1.7, 0.6])
+    g_eng, info = prob.map_and_score_batch(4, 0, 5, v, include_data=True, atol=1e-8)
+    g_u, g_t = prob.scores_in_both_spaces(g_eng, v, np.log(v))
+    zh = base.get_zhat(0, 6)
+    for e in range(6):
+        xe = x if e == 0 else base.sample_x_z(M.SimRng(4, e - 1), np.log(v))[0]
+        np.testing.assert_allclose(g_u[e], prob.grad_theta_logLike(xe, zh[e], v, M.UnTransformedθ), rtol=1e-10)
+        np.testing.assert_allclose(g_t[e], prob.grad_theta_logLike(xe, zh[e], np.log(v), M.Transformedθ), rtol=1e-10)
+    # a full run in the transformed space lands where the log-variance run does
+    r_t = M.muse(prob, [np.e, np.e], rng=4, nsims=40, get_covariance=True)
+    r_u = M.muse(M.HipMuseProblem(x, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0)), [1.0, 1.0], rng=4,
+                 nsims=40, get_covariance=True)
+    np.testing.assert_allclose(np.log(r_t.theta), r_u.theta, atol=5e-3)
+    v_hat = r_t.theta
+    np.testing.assert_allclose(r_t.H * np.outer(v_hat, v_hat), r_u.H, rtol=2e-2, atol=2e-2 * np.abs(r_u.H).max())
+    # implicit-diff H in the variance space = engine H / (v vᵀ)  (no silent pass-through of variances)
+    Hs_v, _ = prob.implicit_H_batch(4, 0, 3, v)
+    Hs_t, _ = base.implicit_H_batch(4, 0, 3, np.log(v))
+    np.testing.assert_allclose(Hs_v, Hs_t / np.outer(v, v), rtol=1e-14)
+    base.close()
+
+
+# ---- row e2: one element split over several workgroups (strongly scaled maps) -------------------------------
+@pytest.mark.parametrize("model,N,nth,theta", [
+    ("funnel", 10000, 1, [1.0]), ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0]), ("noise", 8191, 1, [0.3]),
+    ("smooth", 6000, 3, [1.0, 2.0, 0.5]), ("funnel", 777, 1, [-0.5])])
+@pytest.mark.parametrize("split", [2, 4, 8])
+def test_element_split_vs_oracle_and_invariances(gpu, M, O, model, N, nth, theta, split):
+    """64 elements on 256 compute units: `split` workgroups per element.  Against the oracle (identical counts,
+    scores rtol 1e-10, MAPs 1e-9); bitwise run to run; bitwise independent of the batch (a sim's result does not
+    depend on how many elements share the launch -- what makes an N-GPU run equal the 1-GPU run at the same split);
+    and within 1e-12 relative of the unsplit result (the split only changes the summation tree)."""
+    xdata, _ = O.sample_x_z(model, N, 77, M.DATA_SIM, np.zeros(nth))
+    prob = M.HipMuseProblem(xdata, model=model, ntheta=nth)
+    g0, i0 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
+    prob.set_element_split(split)
+    g, info = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
+    zh = prob.get_zhat(0, 25)
+    go, zo, io = O.map_and_score_batch(model, N, 42, 0, 24, theta, atol=1e-2, x_data=xdata, z0_mode=0)
+    same = (info["iterations"] == io["iterations"]) & (info["f_calls"] == io["f_calls"])
+    assert same.mean() >= 0.9 and np.array_equal(info["status"], io["status"])
+    np.testing.assert_allclose(g[same], go[same], rtol=1e-10)
+    np.testing.assert_allclose(zh[same], zo[same], rtol=0, atol=1e-9)
+    g2, info2 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
+    assert np.array_equal(g, g2) and np.array_equal(info, info2) and np.array_equal(zh, prob.get_zhat(0, 25))
+    gp, ip = prob.map_and_score_batch(42, 10, 17, theta, atol=1e-2)
+    assert np.array_equal(gp, g[11:18]) and np.array_equal(ip, info[11:18])
+    same0 = (info["iterations"] == i0["iterations"]) & (info["f_calls"] == i0["f_calls"])
+    np.testing.assert_allclose(g[same0], g0[same0], rtol=1e-12)
+    # warm restart at the MAPs: no iteration, identical scores
+    g3, i3 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2, z0_mode=M.Z0_WARM)
+    assert np.all(i3["iterations"] == 0) and np.array_equal(g3, g)
+    prob.set_element_split(0)
+    g4, _ = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
+    assert np.array_equal(g4, g0)
+    prob.close()
+
+
+def test_element_split_drivers_and_errors(gpu, M, O):
+    """A whole muse! + get_J! + get_H! (FD and implicit) run with split elements: same estimates as the unsplit run to
+    the accuracy the split's summation order allows; bad splits are rejected."""
+    x, _ = O.sample_x_z("funnel", 10000, 5, M.DATA_SIM, [0.0, 0.0])
+    a = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+    b = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+    b.set_element_split(4)
+    ra = M.muse(a, [1.0, 0.5], rng=3, nsims=31, maxsteps=4, get_covariance=True)
+    rb = M.muse(b, [1.0, 0.5], rng=3, nsims=31, maxsteps=4, get_covariance=True)
+    np.testing.assert_allclose(rb.theta, ra.theta, rtol=1e-9)
+    np.testing.assert_allclose(rb.J, ra.J, rtol=1e-9)
+    np.testing.assert_allclose(rb.H, ra.H, rtol=1e-6, atol=1e-6 * np.abs(ra.H).max())
+    Ha, _ = a.implicit_H_batch(3, 0, 3, ra.theta)
+    Hb, _ = b.implicit_H_batch(3, 0, 3, ra.theta)
+    np.testing.assert_allclose(Hb, Ha, rtol=1e-8, atol=1e-8 * np.abs(Ha).max())
+    with pytest.raises(M.MuseError):
+        b.set_element_split(3)
+    with pytest.raises(M.MuseError):
+        b.set_element_split(32)
+    a.close()
+    b.close()
+
+
+# ---- cluster placement under the gathered (RCCL) map -------------------------------------------------------
+@pytest.mark.parametrize("model,N,nth,theta,nel,split", [
+    ("smooth", 66001, 2, [1.0, 2.5], 128, 0),      # cluster placement by N
+    ("funnel", 10000, 1, [1.0], 64, 4)])           # cluster placement by split (the strongly scaled bench shape)
+def test_cluster_placement_under_gathered_map(gpu, M, model, N, nth, theta, nel, split):
+    """muse_map_and_score_batch_gather_async with workgroup clusters: the RCCL all-gather of step k runs on the
+    high-priority stream while the cluster solver of step k+1 is resident and spinning on its counters.  One rank,
+    pipelined over the four result areas: no cluster-timeout flag, bitwise equal to the plain map."""
+    p = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    if split:
+        p.set_element_split(split)
+    p.comm_init(1, 0, M.HipMuseProblem.comm_unique_id())
+    ref = [p.map_and_score_batch(0, b, b + nel, theta) for b in (0, nel, 2 * nel)]
+    pend, out = [], []
+    for k in range(9):
+        b = (k % 3) * nel
+        n = p.map_and_score_batch_gather_async(0, b, b + nel, theta, nel, result_area=k % 4)
+        pend.append((n, k % 4))
+        if len(pend) > 3:
+            out.append(p.batch_wait_gathered(nel, nel, pend.pop(0)[1]))
+    while pend:
+        out.append(p.batch_wait_gathered(nel, nel, pend.pop(0)[1]))
+    for k, (g_all, info) in enumerate(out):
+        assert np.array_equal(g_all[0], ref[k % 3][0]) and np.array_equal(info, ref[k % 3][1])
+        assert np.all(info["status"] == 0)
+    p.close()

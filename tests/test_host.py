@@ -26,6 +26,92 @@ def test_muse_trajectory_matches_golden(M, O, funnel512):
     np.testing.assert_allclose(res.J, d["J"], rtol=1e-12)
     np.testing.assert_allclose(res.H, d["H"], rtol=1e-10)
     np.testing.assert_allclose(res.Sigma, d["Sigma"], rtol=1e-10)
+    np.testing.assert_allclose(np.array(res.Hs), d["Hs"], rtol=1e-10)
+    np.testing.assert_allclose(np.array([h["g_like′"] for h in res.history]), d["g_like"], rtol=1e-12)
+    np.testing.assert_allclose(np.array([h["H⁻¹_post′"] for h in res.history]), d["Hinv_post"], rtol=1e-12)
+
+
+# keyword sets of tests/golden/make_golden.py::outer_loop_variants (the golden side is tests/muse_reference.py,
+# an independent restatement of src/muse.jl:159-232; the product side is museinference.jl_amd/muse.py)
+OUTER_VARIANTS = {
+    "sims": dict(),
+    "broyden": dict(Hinv_update="broyden"),
+    "diagonal_broyden": dict(Hinv_update="diagonal_broyden"),
+    "broyden_mem2": dict(Hinv_update="broyden", broyden_memory=2),
+    "broyden_H0": dict(Hinv_update="broyden", Hinv_like0=np.diag([-0.02] * 4)),
+    "alpha_regularize": dict(alpha=lambda i: 1.0 / (1 + i), regularize=lambda t: np.clip(t, -0.5, 0.8)),
+}
+
+
+class LogNormalVariancePrior:
+    """log v ~ N(0, 3²) as a density over the variances v (analytic logpdf/grad/hess)."""
+
+    def logpdf(self, v):
+        return float(np.sum(-np.log(v) ** 2 / 18.0 - np.log(v)))
+
+    def grad(self, v):
+        return -np.log(v) / (9.0 * v) - 1.0 / v
+
+    def hess(self, v):
+        return np.diag((np.log(v) - 1.0) / (9.0 * v**2) + 1.0 / v**2)
+
+
+def check_outer_variants(M, make_problem, rtol):
+    """Rows f2/f4: every muse! keyword variant on the 4-block funnel against the independent restatement."""
+    d = np.load(os.path.join(HERE, "golden", "muse_outer_variants.npz"))
+    for name, kw in OUTER_VARIANTS.items():
+        res = M.muse(make_problem(d["x"]), [1.0] * 4, rng=1, nsims=24, maxsteps=7, theta_rtol=0.0, native=False, **kw)
+        thetas = np.array([h["θ"] for h in res.history])
+        # result.θ is the UN-regularised iterate (src/muse.jl:230); the golden's last row is the same quantity
+        np.testing.assert_allclose(thetas, d[name + "_thetas"][:-1], rtol=rtol, atol=rtol, err_msg=name)
+        np.testing.assert_allclose(res.theta, d[name + "_thetas"][-1], rtol=rtol, atol=rtol, err_msg=name)
+        for key, field in (("_Hinv_like", "H⁻¹_like′"), ("_Hinv_post", "H⁻¹_post′"), ("_g_post", "g_post′")):
+            np.testing.assert_allclose(np.array([h[field] for h in res.history]), d[name + key], rtol=rtol, atol=rtol,
+                                       err_msg=name + key)
+    prob = M.PositiveThetaProblem(make_problem(d["x"], prior=None), prior=LogNormalVariancePrior())
+    res = M.muse(prob, [np.e] * 4, rng=1, nsims=24, maxsteps=5, theta_rtol=0.0)
+    np.testing.assert_allclose(np.array([h["θ"] for h in res.history]), d["positive_thetas"][:-1], rtol=rtol)
+    np.testing.assert_allclose(res.theta, d["positive_thetas"][-1], rtol=rtol)
+    np.testing.assert_allclose(np.array(res.gs), d["positive_gs"], rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(np.array([h["g_like′"] for h in res.history]), d["positive_g_like_t"], rtol=rtol, atol=rtol)
+
+
+def test_outer_loop_variants_match_independent_restatement(M, O):
+    def make(x, prior="gauss"):
+        return OracleBatchedProblem(x, "funnel", 4, prior=M.GaussianPrior(0.0, 3.0) if prior == "gauss" else None)
+    check_outer_variants(M, make, rtol=1e-10)
+
+
+def test_convergence_test_domain_error(M, O, funnel512):
+    """sqrt of a negative number in the convergence test is a DomainError in the reference (src/muse.jl:165): an
+    H⁻¹_post′ that is not negative definite must not read as 'converged'."""
+    prob = OracleBatchedProblem(funnel512, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0))
+    with pytest.raises(ValueError, match="DomainError"):
+        M.muse(prob, [1.0], rng=0, nsims=8, maxsteps=5, Hinv_like0=[[+0.01]], Hinv_update="broyden", theta_rtol=1e-3)
+
+
+def test_positive_theta_wrapper_forwards_only_safe_attributes(M, O, funnel512):
+    """the variance front-end must not leak θ-space seams of the wrapped problem."""
+    base = OracleBatchedProblem(funnel512, "funnel", 1)
+    prob = M.PositiveThetaProblem(base, prior=LogNormalVariancePrior())
+    assert prob.N == 512 and prob.ntheta == 1
+    with pytest.raises(AttributeError):
+        prob.run_muse
+    v0 = np.array([1.3])
+    Hs_v, its = prob.implicit_H_batch(3, 0, 2, v0, atol=1e-1, cg_maxiter=50)
+    Hs_t, its_t = base.implicit_H_batch(3, 0, 2, np.log(v0), atol=1e-1, cg_maxiter=50)
+    np.testing.assert_allclose(Hs_v, Hs_t / v0[0] ** 2, rtol=1e-14)
+    # ... and that is the derivative the finite-difference branch takes in the variance space
+    res = M.MuseResult(theta=v0.copy(), rng=3)
+    M.get_J_(res, prob, nsims=12)
+    M.get_H_(res, prob, nsims=2, implicit_diff=True)
+    Himp = res.H.copy()
+    res.Hs, res.H = [], None
+    M.get_H_(res, prob, nsims=2, step=[1e-4], grad_z_logLike_atol=1e-10, fid_mode=1)
+    res2 = M.MuseResult(theta=v0.copy(), rng=3, gs=list(res.gs))
+    Hs_tight, _ = prob.implicit_H_batch(3, 0, 2, v0, atol=1e-10)
+    np.testing.assert_allclose(res.H, Hs_tight.mean(axis=0), rtol=1e-5)
+    assert abs(Himp[0, 0] / res.H[0, 0] - 1) < 0.05
 
 
 def test_reference_acceptance_criterion(M, O, funnel512):
