@@ -6,12 +6,20 @@ batch, sample (x, z) ~ P(x, z | θ), find the latent MAP ẑ by L-BFGS/HagerZhan
 ẑ₀ = 0 to ||∇z||∞ <= 1e-2, and evaluate the score ∇θ logP(x, ẑ | θ) -- the get_J!/muse! map body of
 the reference (src/muse.jl:169-176, :508-525), one launch per batch.  Workload at N=1 GPU:
 BASELINE.json configs[1], Neal's funnel, 10^4-dim z, 1-dim θ (θ = 1), nsims = 512, fp64, synthetic
-(Philox) data.  With --gpus N every rank runs its own 512-sim block of a 512*N-sim map (weak scaling;
-sims are independent) and the per-rank score blocks are exchanged with one all-gather per step (RCCL).
+(Philox) data.  With --gpus N the map is sharded over the ranks and the per-rank score blocks are exchanged with
+one all-gather per step (RCCL): --scaling strong (the default for N > 1; BASELINE.json's north star) keeps the
+512 sims of the step and gives every rank a contiguous block of 512/N of them, each element split over
+min(8, CUs / elements) workgroups; --scaling weak gives every rank its own 512-sim block of a 512*N-sim map.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
-  roofline      algorithmic HBM bytes of the solver kernel per launch / its mean launch duration
-                (HIP events on the launch stream), against the 8 TB/s HBM peak
+  roofline      the solver kernel against the bound that actually binds it, from its mean launch duration measured
+                live (HIP events on the launch stream): "hbm" -- compulsory HBM bytes of the placement the launch
+                used / duration against the 8 TB/s peak -- for the streaming placements; "valu" -- the kernel's
+                VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (SIMDs x duration x clock),
+                quoted in fp64-FMA-slot TFLOP/s against the 78.6 TFLOP/s vector peak -- for the register/LDS
+                resident placements, whose vectors never leave the chip.  Both objects are always present
+                (`roofline.hbm`, `roofline.valu`); SURVEY 8.d3's accounting figure is kept as
+                `algorithmic_bytes_d3` and is not a roofline.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: "port") timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -26,7 +34,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 WORKLOADS = {
     # name: (model, N, ntheta, theta, nsims)
     "funnel_1e4": ("funnel", 10000, 1, [1.0], 512),        # BASELINE.json configs[1] (headline)
@@ -37,8 +44,15 @@ WORKLOADS = {
 }
 
 
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 78.6    # fp64 vector peak: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
+PROFILE_TAG = "r02"
+
+
 def algorithmic_bytes(info, N):
-    """SURVEY.md §8(d3) / BASELINE.md §3: words = 1 + 5E + Σ_k(4 h_k + 4) + 2 per sim, 8 B words."""
+    """SURVEY.md §8(d3) / BASELINE.md §3: words = 1 + 5E + Σ_k(4 h_k + 4) + 2 per sim, 8 B words.  An accounting
+    figure that is independent of how much the kernel keeps on chip -- reported as `algorithmic_bytes_d3`."""
     E = info["f_calls"].astype(np.int64)
     K = info["iterations"].astype(np.int64)
     H = info["hist_words"].astype(np.int64)
@@ -46,20 +60,79 @@ def algorithmic_bytes(info, N):
     return int(8 * N * words.sum())
 
 
+def compulsory_bytes(info, N, placement):
+    """HBM bytes a launch MUST move in the placement it ran in (cold start from zero(z), converged solves), from the
+    kernel's own per-sim counters E = f_calls, K = iterations, H = Σ_k h_k (history pairs used):
+      resident  (z, s in registers, x, g in registers/LDS): zhat out; per kept iteration the pair (dx, dg) out;
+                the two-loop recursion reads 4 history vectors per pair used:        1 + 2 (K-1) + 4 H
+      streaming, elementwise models: the sampler pass also makes the initial evaluation and the first trial and
+                writes x, s (2); every further trial reads z, s, x (3; z is skipped while it is the unwritten
+                zero: 2); a kept update reads z, s, x, g and writes z, dx, dg, g, s (9; the first one has neither z
+                nor g to read: 7); the last update reads z, s, x and writes z (4; 3 from the zero start);
+                8 words per history pair used (q is read and written once per pair in this placement)
+      streaming, stencil model: sampler writes s (the true z, staged), x, z (3) and the A z pass reads s, x and
+                writes x (3); initial evaluation reads z, x, writes g, s (4); a trial reads z, s, x (3); a kept
+                update is two passes, 4 + 7 = 11; the last update 4; 8 per history pair used."""
+    E = info["f_calls"].astype(np.int64)
+    K = info["iterations"].astype(np.int64)
+    H = info["hist_words"].astype(np.int64)
+    kept = np.maximum(K - 1, 0)
+    if placement == "resident":
+        words = 1 + 2 * kept + 4 * H
+    elif placement == "stencil":
+        words = 6 + 4 + 3 * np.maximum(E - 1, 0) + 11 * kept + 4 * (K > 0) + 8 * H
+    else:
+        first = (K == 1)  # the solve ended with its first line search: z stayed virtual until the last update
+        trials = np.maximum(E - 2, 0)
+        words = np.where(first, 2 + 2 * trials + 3,
+                         2 + 2 * np.minimum(trials, 1) + 3 * np.maximum(trials - 1, 0) + 7 + 9 * np.maximum(kept - 1, 0)
+                         + 4 * (K > 0) + 8 * H)
+    return int(8 * N * words.sum())
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources: profiles/ numbers are quoted only for the sources they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "museinference.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_row(workload):
+    """The workload's row of profiles/<tag>_summary.csv (rocprofv3 passes of this same command: tools/profile.sh,
+    condensed by tools/summarize_profiles.py), or (None, reason).  A row measured on other kernel sources, or on
+    another kernel than the launch used, is NOT quoted."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_summary.csv")
+    if not os.path.exists(path):
+        return None, f"profiles/{PROFILE_TAG}_summary.csv not found"
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["workload"] == workload:
+                if row.get("csrc_sha16") != csrc_fingerprint():
+                    return None, (f"profiles/{PROFILE_TAG}_summary.csv was measured on kernel sources {row.get('csrc_sha16')}, "
+                                  f"this tree is {csrc_fingerprint()}: re-run tools/profile.sh")
+                return row, None
+    return None, "workload not profiled"
+
+
 def measured_traffic(workload):
-    """HBM bytes per solver launch from the committed rocprofv3 PMC passes (profiles/r01_summary.csv:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB,
-    the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM).  None if not profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_summary.csv")
+    """HBM bytes per solver launch from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, the factor 2 being the gfx950 FETCH_SIZE correction of
+    MI355X_MICROARCH.md §HBM).  None (with the reason on stderr) if there is no current profile."""
+    row, why = profile_row(workload)
+    if row is None:
+        if why != "workload not profiled":
+            print(f"[bench] roofline.traffic unavailable: {why}", file=sys.stderr)
+        return None
     try:
-        import csv
-        with open(path) as f:
-            for row in csv.DictReader(f):
-                if row["workload"] == workload:
-                    return float(row["hbm_traffic_MB"]) * 1e6
-    except OSError:
-        pass
-    return None
+        return float(row["hbm_traffic_MB"]) * 1e6
+    except (KeyError, ValueError):
+        return None
 
 
 def usable_cores(limit):
@@ -173,6 +246,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="funnel_1e4", choices=sorted(WORKLOADS))
     ap.add_argument("--placement", type=int, default=-1, help="-1 auto, 0 streaming, 1 resident")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="with --gpus N > 1: strong (default) = the step's nsims shared by the ranks, weak = nsims per rank")
+    ap.add_argument("--split", type=int, default=-1, help="workgroups per element (-1: by the rank's element count)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="repeat the timed region (EXACTLY --steps steps between barriers, every time) until this much "
+                         "time has been measured; ms_per_step is the mean over the repetitions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed muse!/get_H! rates")
     args = ap.parse_args()
@@ -201,7 +280,28 @@ def main():
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=local_rank)
     if args.placement >= 0:
         prob.set_placement(args.placement)
-    sim0 = rank * nsims  # this rank's block of the global map
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    if scaling == "strong":
+        # the step's nsims sims are shared by the ranks: contiguous blocks (the reference's pmap over a worker pool
+        # splits the same list, src/muse.jl:169 with src/util.jl:74-83); the gathered block is padded to the largest
+        sim_lo, sim_hi = M.block_partition(0, nsims, world, rank)
+        rows = -(-nsims // world)
+        total_sims = nsims
+    else:
+        sim_lo, sim_hi = rank * nsims, (rank + 1) * nsims  # this rank's block of the global nsims*world map
+        rows = nsims
+        total_sims = nsims * world
+    nlocal = sim_hi - sim_lo
+    # fewer elements than compute units: the element itself is the remaining parallel axis (src/muse.jl:327-333
+    # chooses the longer axis; here: `split` workgroups per element).  The same split on every rank.
+    cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    split = args.split
+    if split < 0:
+        split = 1
+        while split < 4 and 2 * split * rows <= cus and N > 512:  # 8 never paid (tools/split_bench.py)
+            split *= 2
+    if split > 1:
+        prob.set_element_split(split)
     gather_buf = None
     collective = None
     if sharded:
@@ -219,7 +319,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         collective = "rccl-capi" if int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch" else "torch"
         if collective == "torch":
-            gather_buf = [torch.empty(nsims * nth, dtype=torch.float64, device="cuda") for _ in range(world)]
+            gather_buf = [torch.empty(rows * nth, dtype=torch.float64, device="cuda") for _ in range(world)]
 
     AREAS = 4
     host_t = [0.0, 0.0]  # host seconds spent enqueueing / waiting+collecting (reported under "host_us_per_step")
@@ -231,10 +331,10 @@ def main():
         for k in range(K):
             t_enq0 = time.perf_counter()
             if collective == "rccl-capi":
-                n = prob.map_and_score_batch_gather_async(seed, sim0, sim0 + nsims, theta, nsims, atol=1e-2,
+                n = prob.map_and_score_batch_gather_async(seed, sim_lo, sim_hi, theta, rows, atol=1e-2,
                                                           z0_mode=M.Z0_ZERO, result_area=k % AREAS)
             else:
-                n = prob.map_and_score_batch_async(seed, sim0, sim0 + nsims, theta, atol=1e-2, z0_mode=M.Z0_ZERO,
+                n = prob.map_and_score_batch_async(seed, sim_lo, sim_hi, theta, atol=1e-2, z0_mode=M.Z0_ZERO,
                                                    result_area=k % AREAS)
             host_t[0] += time.perf_counter() - t_enq0
             pending.append((k % AREAS, n))
@@ -248,13 +348,14 @@ def main():
     def finish(item, collect):
         area, n = item
         if collective == "rccl-capi":
-            g_all, info = prob.batch_wait_gathered(n, nsims, area)  # [world, nsims, nth]: every rank holds all scores
-            g = g_all[rank]
+            g_all, info = prob.batch_wait_gathered(n, rows, area)  # [world, rows, nth]: every rank holds all scores
+            g = g_all[rank][:n]
         else:
             g, info = prob.batch_wait(n, area)
             if collective == "torch":
-                t = torch.from_numpy(np.ascontiguousarray(g.reshape(-1))).cuda()
-                dist.all_gather(gather_buf, t)
+                pad = np.zeros(rows * nth)
+                pad[: g.size] = g.reshape(-1)
+                dist.all_gather(gather_buf, torch.from_numpy(pad).cuda())
         if collect is not None:
             collect.append((g, info))
 
@@ -264,24 +365,38 @@ def main():
         torch.cuda.synchronize()
         prob.synchronize()
 
-    # timed region: EXACTLY `steps` steps, no per-launch timing events (pure throughput)
+    # timed region: EXACTLY `steps` steps between barriers, no per-launch timing events (pure throughput); repeated
+    # (warm, same bracket every time) until --min-seconds have been measured, so that a 20-step request is not a
+    # 1.3 ms sample.  Every rank runs the same number of repetitions (rank 0 decides).
     prob.set_timing(False)
     run_steps(args.warmup)
     barrier()
+    rounds = []
     results = []
-    host_t[0] = host_t[1] = 0.0
-    t0 = time.perf_counter()
-    run_steps(args.steps, results)
-    barrier()
-    dt = time.perf_counter() - t0
+    while True:
+        results.clear()
+        host_t[0] = host_t[1] = 0.0
+        t0 = time.perf_counter()
+        run_steps(args.steps, results)
+        barrier()
+        dt = time.perf_counter() - t0
+        if sharded:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        rounds.append(dt)
+        more = 1 if (sum(rounds) < args.min_seconds and len(rounds) < 100000) else 0
+        if sharded:
+            flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device="cuda")
+            dist.broadcast(flag, src=0)
+            more = int(flag.item())
+        if not more:
+            break
+    dt = sum(rounds) / len(rounds)
     host_us = {"enqueue": 1e6 * host_t[0] / args.steps, "wait_and_collect": 1e6 * host_t[1] / args.steps}
-    if sharded:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     # roofline leg: the same steps again with a HIP event pair around every solver launch, recorded on
     # the stream the kernel is launched on
-    nprof = min(args.steps, 256)
+    nprof = min(max(args.steps, 64), 256)
     prob.profile_begin(nprof + 8)
     run_steps(nprof)
     barrier()
@@ -289,41 +404,65 @@ def main():
 
     g, info = results[-1]
     assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
-    alg_bytes = algorithmic_bytes(info, N)
     mean_kernel_s = float(kernel_ms.mean()) * 1e-3
-    achieved = alg_bytes / mean_kernel_s / 1e9
+    resident = model != "smooth" and N <= M.load_library().muse_max_resident_n() and args.placement != 0
+    placement = "resident" if resident else ("stencil" if model == "smooth" else "streaming")
+    comp_bytes = compulsory_bytes(info, N, placement)
+    prow, why = profile_row(args.workload) if (world == 1 and split == 1) else (None, "profiles/ hold the 1-GPU, unsplit launch")
+    traffic = measured_traffic(args.workload) if prow is not None else None
+    hbm = {"bound": "hbm", "achieved": comp_bytes / mean_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": comp_bytes / mean_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+           "compulsory_bytes_per_launch": comp_bytes,
+           "traffic_GBps": None if traffic is None else traffic / mean_kernel_s / 1e9}
+    valu = None
+    if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
+        # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
+        # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
+        # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
+        busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
+        fr = busy / (N_SIMD * mean_kernel_s * CLOCK_HZ)
+        valu = {"bound": "valu", "achieved": fr * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fr,
+                "traffic": traffic, "valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
+                "clock_hz_assumed": CLOCK_HZ,
+                "note": "fp64-FMA issue-slot equivalents: VALU-active cycles / (1024 SIMDs x kernel time x 2.4 GHz)"}
+    primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
+    primary.update({
+        "kernel": "map_score_kernel", "placement": placement, "kernel_ms_mean": 1e3 * mean_kernel_s,
+        "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
+        "algorithmic_bytes_d3": algorithmic_bytes(info, N),
+        "hbm": hbm, "valu": valu,
+        "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
+        "profile_note": why,
+        "note": ("resident placement: z, s, x, g never leave registers/LDS, the HBM leg only carries zhat out (and the "
+                 "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes)"
+                 if placement == "resident" else
+                 "streaming placement: achieved = compulsory bytes of the passes the solves made / kernel time"),
+        "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
+                    "hist_pairs_mean": float(info["hist_words"].mean())},
+    })
 
     out = {
         "metric": "MC sims/sec (MAP+score)",
-        "value": world * nsims * args.steps / dt,
+        "value": total_sims * args.steps / dt,
         "unit": "sims/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: Neal's funnel family model={model}, N={N}-dim z, {nth}-dim theta, "
-                               f"nsims={nsims} per GPU per step, cold start z0=0, atol=1e-2",
-                   "theta": theta, "sims_per_step_total": world * nsims,
-                   "parallelism": f"sims sharded over {world} GPU(s), one all-gather of scores per step"
+                               f"nsims={total_sims} per step ({nlocal} on this rank), cold start z0=0, atol=1e-2",
+                   "theta": theta, "sims_per_step_total": total_sims, "element_split": split,
+                   "parallelism": f"sims sharded over {world} GPU(s) ({scaling} scaling), one all-gather of scores per step"
                                   + (f" ({collective})" if collective else "")},
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
-            "kernel": "map_score_kernel", "kernel_ms_mean": 1e3 * mean_kernel_s,
-            "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "achieved = algorithmic bytes (SURVEY 8.d3 accounting) / kernel time; at N <= 10^4 the accounted vectors live in "
-                    "registers/LDS, so achieved exceeds the HBM peak and `traffic` (PMC, profiles/) is what HBM really moved; "
-                    "the resident kernel is VALU-issue-bound (DESIGN.md 6)",
-            "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
-                        "hist_pairs_mean": float(info["hist_words"].mean())},
-        },
-        "kernel_sims_per_s": nsims / mean_kernel_s,
+        "timed_rounds": len(rounds), "timed_seconds": sum(rounds),
+        "ms_per_step_min_round": 1e3 * min(rounds) / args.steps, "ms_per_step_max_round": 1e3 * max(rounds) / args.steps,
+        "roofline": primary,
+        "kernel_sims_per_s": nlocal / mean_kernel_s,
         "host_us_per_step": host_us,
     }
     if rank == 0 and world == 1 and not sharded and not args.no_extra:

@@ -194,6 +194,16 @@ int muse_fd_jacobian_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int6
                            const double* theta0, const double* step, double atol, int fid_mode,
                            int64_t fid_sim, double* Hs_out, muse_info* info_out);
 
+/* The same finite differences over a range of COLUMNS of the list (sim_begin, column 0), (sim_begin, column 1), ...:
+ * element e in [col_begin, col_end) is column e % ntheta of the Jacobian of simulation sim_begin + e / ntheta.  This is
+ * the reference's other parallel axis -- get_H! maps over Jacobian columns instead of sims when there are more of them
+ * (src/muse.jl:327-333, pjacobian's pool, src/util.jl:9-27) -- and what lets ranks share `nsims * ntheta` units evenly
+ * when nsims is small (the reference default is nsims = 10, src/muse.jl:303).  A range may begin and end inside a
+ * simulation's Jacobian.  cols_out [n][ntheta] host, cols[e][i] = d g_i / d theta_(e % ntheta); info_out [n][2]. */
+int muse_fd_jacobian_columns(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
+                             const double* theta0, const double* step, double atol, int fid_mode, int64_t fid_sim,
+                             double* cols_out, muse_info* info_out);
+
 /* The get_H! implicit-differentiation branch (src/muse.jl:335-405) for sims sim_begin..sim_end-1:
  *   H = H1 - dFdtheta^T A^{-1} dFdtheta1, A = Hessian_z logLike at (x, zhat, theta0), A^{-1} by conjugate
  *   gradients (IterativeSolvers.cg defaults: x0 = 0, reltol sqrt(eps), maxiter = cg_maxiter, reference 100);
@@ -203,6 +213,10 @@ int muse_fd_jacobian_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int6
  * metadata[:implicit_diff_cg_hists] of src/muse.jl:405). */
 int muse_implicit_H_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0,
                           double atol, int cg_maxiter, double* Hs_out, int32_t* cg_iters_out);
+/* ... and over a range of columns of the same list (see muse_fd_jacobian_columns): cols_out [n][ntheta],
+ * cg_iters_out [n] (may be NULL). */
+int muse_implicit_H_columns(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
+                            const double* theta0, double atol, int cg_maxiter, double* cols_out, int32_t* cg_iters_out);
 
 /* ---- multi-GPU exchange of the per-sim accumulators (RCCL over xGMI) --------------------------- */
 /* Collectives C1-C3 of SURVEY.md §2: gather of per-rank score blocks (so that every rank reduces

@@ -72,6 +72,8 @@ SIGNATURES = {
     "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_fd_jacobian_batch": (_i, [_vp, _u64, _i64, _i64, _vp, _vp, _d, _i, _i64, _vp, _vp]),
     "muse_implicit_H_batch": (_i, [_vp, _u64, _i64, _i64, _vp, _d, _i, _vp, _vp]),
+    "muse_fd_jacobian_columns": (_i, [_vp, _u64, _i64, _i64, _i64, _vp, _vp, _d, _i, _i64, _vp, _vp]),
+    "muse_implicit_H_columns": (_i, [_vp, _u64, _i64, _i64, _i64, _vp, _d, _i, _vp, _vp]),
     "muse_comm_unique_id": (_i, [_vp]),
     "muse_comm_init": (_i, [_vp, _i, _i, _vp]),
     "muse_comm_destroy": (_i, [_vp]),

@@ -13,6 +13,7 @@ constexpr int kMaxIter = 1000;  // Optim.Options default iterations
 constexpr int kMaxTheta = MUSE_MAX_THETA;
 constexpr int kResultAreas = 4;
 constexpr int kMaxCluster = 16;
+constexpr int kClusterSlotDoubles = 2 * kMaxCluster * 8 * 2;  // two parities x members x 8 values x 2 granules
 constexpr int64_t kClusterMinN = 65536;  // N >= this: several workgroups cooperate on one problem
 constexpr int64_t kMaxResidentN = 10000;
 
@@ -53,12 +54,15 @@ struct BatchArgs {
     double* scratch;               // per workgroup
     int64_t scratch_stride;        // doubles per workgroup
     int* work_counter;             // monotonically increasing ticket counter (never reset)
-    int ticket_base, pad2_;        // this launch's tickets are work_counter values base .. base+nproblems-1
+    int ticket_base;               // this launch's tickets are work_counter values base .. base+nproblems-1
+    int p0;                        // BATCH_FD / BATCH_IMPLICIT: the batch starts at this element of sim_begin's own list
+                                   // (a column range that begins inside a simulation's Jacobian)
     // cluster mode (several workgroups per problem): csize workgroups 0..csize-1 of cluster blockIdx/csize
     int csize, nclusters;
     unsigned int* cl_counter;      // [nclusters] arrival counters (zeroed per launch)
-    double* cl_part;               // [nclusters][2][csize][8] partial sums / maxima
-    int* error_flag;               // set when a bounded cluster wait expires
+    double* cl_part;               // [nclusters][kClusterSlotDoubles]: partial sums / maxima, or their tagged granules
+    unsigned int* cl_state;        // [nclusters] epoch reached by the cluster's granule exchange (persists across launches)
+    int* error_flag;               // [0] set when a bounded cluster wait expires; [1] the largest epoch reported
     unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
     // Standard normals of simulation streams already drawn inside the SAME host call (muse_run's later
     // iterations re-draw every simulation at a new theta, the FD batch draws each simulation 2*ntheta times):
@@ -99,15 +103,15 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.zslot = a.store_zhat ? a.slot0 + p : -1;
         d.z0slot = a.slot0 + p;
     } else if (a.kind == BATCH_FD) {
-        const int per = 2 * a.ntheta;
-        d.sim = a.sim_begin + p / per;
+        const int per = 2 * a.ntheta, pp = p + a.p0;
+        d.sim = a.sim_begin + pp / per;
         d.x_mode = X_SAMPLE;
         d.z0_mode = Z0_COPY;
-        d.tsample = p % per;
+        d.tsample = pp % per;
         d.zslot = -1;
-        d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + p / per;
+        d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + pp / per;
     } else if (a.kind == BATCH_IMPLICIT) {
-        d.sim = a.sim_begin + p / (a.imp_split > 1 ? a.imp_split : 1);
+        d.sim = a.sim_begin + (p + a.p0) / (a.imp_split > 1 ? a.imp_split : 1);
         d.x_mode = X_SAMPLE;
         d.z0_mode = Z0_ZERO;  // zhat_guess_from_truth = zero(z) (src/muse.jl:343, src/interface.jl:184-186)
         d.tsample = -1;

@@ -72,11 +72,14 @@ struct PlaceStreaming {
     using VG = VX; using VZ = VX; using VS = VX;
     using VH = VX;
 };
-template <int T_, int EPT_, bool XG_LDS>
+// CLUSTER (registers only): csize workgroups share one element, thread pairs (crank*T + tid) + j*csize*T -- the
+// per-GPU share of a strongly scaled map, where a launch has fewer elements than the GPU has compute units.
+template <int T_, int EPT_, bool XG_LDS, bool CLUSTER = false>
 struct PlaceResident {
+    static_assert(!(XG_LDS && CLUSTER), "the LDS layout addresses x and g by global element index");
     static constexpr int T = T_, EPT = EPT_, U = 1;
     static constexpr int kWavesPerEu = 1;  // no lower bound beyond the launch bounds
-    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = false;
+    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = CLUSTER;
     using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
     using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;

@@ -64,7 +64,8 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     }
     __syncthreads();
     const BatchArgs& a = *reinterpret_cast<const BatchArgs*>(args_lds);
-    double* lds_x = args_lds + kArgsDoubles;  // [ld + 2]: elements, dummy slot (index ld), pad
+    double* exch = args_lds + kArgsDoubles;   // cluster placements: [kMaxCluster][8] values of the epoch's exchange
+    double* lds_x = exch + (Place::kCluster ? kMaxCluster * 8 : 0);  // [ld + 2]: elements, dummy slot (index ld), pad
     double* lds_g = lds_x + a.ld + 2;         // [ld + 2]
     if constexpr (Place::kXgLds) {
         if (tid == 0) {  // the dummy slot and the pad element (N odd) hold 0 for the kernel's lifetime
@@ -84,18 +85,26 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         const int csize = a.csize, cluster = blockIdx.x / csize, crank = blockIdx.x % csize;
         double* cl_scratch = a.scratch + (int64_t)cluster * a.scratch_stride;
         Solver<Model, Place> sv(a, tid, red, shs);
-        sv.pack_blocks();
         sv.crank = crank;
         sv.csize = csize;
         sv.tfirst = crank * T + tid;
         sv.pstride = csize * T;
+        sv.pack_blocks();
         sv.cl_counter = a.cl_counter + cluster;
-        sv.cl_part = a.cl_part + (size_t)cluster * 2 * csize * 8;
+        sv.cl_part = a.cl_part + (size_t)cluster * kClusterSlotDoubles;
+        sv.exch = exch;
+        if constexpr (!Model::kStencil) sv.cl_epoch = a.cl_state[cluster];  // granule tags continue across launches
         for (int p = cluster; p < a.nproblems; p += a.nclusters) {
             sv.parity = 0;
             __syncthreads();
             if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);
             else sv.run(p, cl_scratch, lds_x, lds_g);
+        }
+        if constexpr (!Model::kStencil) {
+            if (tid == 0 && crank == 0) {
+                a.cl_state[cluster] = sv.cl_epoch;
+                if (cluster == 0) a.error_flag[1] = (int)(sv.cl_epoch >> 1);  // the host resets the tags long before a wrap
+            }
         }
     } else {
         double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
@@ -255,7 +264,8 @@ struct muse_ctx {
     double* ncache = nullptr;            // normals cache [ncache_slots][2][ld] (muse_run, FD batches)
     int64_t ncache_slots = 0;
     unsigned int* cl_counter = nullptr;  // cluster mode: [cl_cap] arrival counters
-    double* cl_part = nullptr;           // [cl_cap][2][kMaxCluster][8]
+    double* cl_part = nullptr;           // [cl_cap][kClusterSlotDoubles]
+    unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
     int* error_flag = nullptr;           // pinned, device-mapped
     int debug = 0;
@@ -288,7 +298,10 @@ static double theta_const(const muse_ctx* c, const double* theta) {
 #endif
 constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil model (register budget: see tools/regs.py)
 
-enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5 };
+// P_CRx: register-resident clusters of 2 / 4 / 8 workgroups of 512 threads with 5 / 3 / 2 pairs per thread
+// (capacity 5120 / 6144 / 8192 pairs >= kMaxResidentN / 2), selected by muse_set_element_split.
+enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5, P_CR2 = 6, P_CR4 = 7, P_CR8 = 8 };
+static bool place_is_cluster(int pl) { return pl >= P_C256; }
 
 // Cluster size: a function of N alone (results must not depend on how many problems share a launch), unless the
 // caller asked for a split (muse_set_element_split: results then depend on (N, split), still not on the launch).
@@ -306,6 +319,8 @@ static int choose_place(const muse_ctx* c) {
     // cluster mode: for the stencil model the neighbours owned by other workgroups become visible through
     // the agent-scope release/acquire of the cluster reduction that ends every pass (pass_barrier where a
     // pass has no reduction)
+    if (c->split >= 2 && c->split <= 8 && c->model != MUSE_MODEL_SMOOTH && c->placement != 0 && c->N <= kMaxResidentN)
+        return c->split == 2 ? P_CR2 : (c->split == 4 ? P_CR4 : P_CR8);
     if (use_cluster(c)) return P_C256;
     if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN) return small ? P_S256 : P_S512;
     if (small) return P_R256x1;
@@ -317,9 +332,14 @@ static bool ncache_applies(const muse_ctx* c) {
     return !off && choose_place(c) == P_R512x10;
 }
 static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1 || pl == P_C256) ? 256 : 512; }
-static int place_wgs_per_cu(int pl) { return (pl == P_S256 || pl == P_R256x1) ? 4 : ((pl == P_R512x10) ? 1 : 2); }
+// workgroups per CU the grid is sized from (cluster placements: every member must be resident at once, and the
+// register budget of the 512-thread resident kernels admits one workgroup per CU for certain, two only sometimes)
+static int place_wgs_per_cu(int pl) {
+    return (pl == P_S256 || pl == P_R256x1) ? 4 : ((pl == P_R512x10 || pl >= P_CR2) ? 1 : 2);
+}
 static size_t place_lds(const muse_ctx* c, int pl) {
     size_t fixed = (size_t)(2 * (place_threads(pl) / 64) * 8 + 42 + kArgsDoubles) * sizeof(double);
+    if (place_is_cluster(pl)) fixed += (size_t)kMaxCluster * 8 * sizeof(double);
     if (pl == P_R512x10) fixed += (size_t)2 * (c->ld + 2) * sizeof(double);
     return fixed;
 }
@@ -408,6 +428,9 @@ static int launch_place(muse_ctx* c, const BatchArgs& a, int pl, int grid, size_
             case P_R512x4: return launch_one<Model, PlaceResident<512, 4, false>>(c, a, grid, lds);
             case P_R512x10: return launch_one<Model, PlaceResident<512, 10, true>>(c, a, grid, lds);
             case P_C256: return launch_one<Model, PlaceStreaming<256, true>>(c, a, grid, lds);
+            case P_CR2: return launch_one<Model, PlaceResident<512, 5, false, true>>(c, a, grid, lds);
+            case P_CR4: return launch_one<Model, PlaceResident<512, 3, false, true>>(c, a, grid, lds);
+            case P_CR8: return launch_one<Model, PlaceResident<512, 2, false, true>>(c, a, grid, lds);
             case P_S256: return launch_one<Model, PlaceStreaming<256>>(c, a, grid, lds);
             default: return launch_one<Model, PlaceStreaming<512>>(c, a, grid, lds);
         }
@@ -441,33 +464,44 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     int grid = c->num_cus * place_wgs_per_cu(pl);
     a.csize = 1;
     a.nclusters = 0;
-    if (pl == P_C256) {
-        // every workgroup of a cluster must be resident at once (they wait for each other): size the grid
-        // from 2 workgroups of 256 threads per CU, which the kernel's register budget always admits
+    if (place_is_cluster(pl)) {
+        // every workgroup of a cluster must be resident at once (they wait for each other): the grid is sized from
+        // a workgroup count per CU that the kernel's register budget always admits
         a.csize = cluster_size(c);
         int ncl = grid / a.csize;
         if (ncl > a.nproblems) ncl = a.nproblems;
         if (ncl < 1) ncl = 1;
         a.nclusters = ncl;
         grid = ncl * a.csize;
-        if (ncl > c->cl_cap) {
+        const bool wrap = c->error_flag[1] > 0x30000000;  // granule tags (epoch numbers) are 32-bit: start over in time
+        if (ncl > c->cl_cap || wrap) {
             HIPCHK(hipStreamSynchronize(c->stream));
+            const int cap = ncl > c->cl_cap ? ncl : c->cl_cap;
             if (c->cl_counter) HIPCHK(hipFree(c->cl_counter));
             if (c->cl_part) HIPCHK(hipFree(c->cl_part));
-            HIPCHK(hipMalloc(&c->cl_counter, (size_t)ncl * sizeof(unsigned int)));
-            HIPCHK(hipMalloc(&c->cl_part, (size_t)ncl * 2 * kMaxCluster * 8 * sizeof(double)));
-            c->cl_cap = ncl;
+            if (c->cl_state) HIPCHK(hipFree(c->cl_state));
+            c->cl_counter = nullptr; c->cl_part = nullptr; c->cl_state = nullptr; c->cl_cap = 0;
+            HIPCHK(hipMalloc(&c->cl_counter, (size_t)cap * sizeof(unsigned int)));
+            HIPCHK(hipMalloc(&c->cl_part, (size_t)cap * kClusterSlotDoubles * sizeof(double)));
+            HIPCHK(hipMalloc(&c->cl_state, (size_t)cap * sizeof(unsigned int)));
+            HIPCHK(hipMemsetAsync(c->cl_part, 0, (size_t)cap * kClusterSlotDoubles * sizeof(double), c->stream));
+            HIPCHK(hipMemsetAsync(c->cl_state, 0, (size_t)cap * sizeof(unsigned int), c->stream));
+            c->error_flag[1] = 0;
+            c->cl_cap = cap;
         }
-        HIPCHK(hipMemsetAsync(c->cl_counter, 0, (size_t)ncl * sizeof(unsigned int), c->stream));
+        // the release/acquire form (stencil model) counts arrivals from zero in every launch
+        if (c->model == MUSE_MODEL_SMOOTH)
+            HIPCHK(hipMemsetAsync(c->cl_counter, 0, (size_t)ncl * sizeof(unsigned int), c->stream));
         a.cl_counter = c->cl_counter;
         a.cl_part = c->cl_part;
+        a.cl_state = c->cl_state;
     } else {
         if (grid > a.nproblems) grid = a.nproblems;
         if (grid < 1) grid = 1;
     }
     a.error_flag = c->error_flag;
     a.scratch_stride = place_scratch_vectors(pl) * c->ld;
-    int rc = ensure_scratch(c, (size_t)(pl == P_C256 ? a.nclusters : grid) * a.scratch_stride);
+    int rc = ensure_scratch(c, (size_t)(place_is_cluster(pl) ? a.nclusters : grid) * a.scratch_stride);
     if (rc) return rc;
     a.scratch = c->scratch;
     const size_t lds = place_lds(c, pl);
@@ -478,7 +512,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         c->ticket_base = 0;
     }
     a.ticket_base = (int)c->ticket_base;
-    c->ticket_base += (unsigned)a.nproblems + (unsigned)grid;
+    if (!place_is_cluster(pl)) c->ticket_base += (unsigned)a.nproblems + (unsigned)grid;  // clusters draw no tickets
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->prof_on && (size_t)(2 * c->prof_count + 1) < c->prof_ev.size()) {
         e0 = c->prof_ev[2 * c->prof_count];
@@ -556,7 +590,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     HIPCHK(hipMalloc(&c->counter, 16));
     HIPCHK(hipMemset(c->counter, 0, 16));
     HIPCHK(hipHostMalloc(&c->error_flag, 64, hipHostMallocDefault));
-    *c->error_flag = 0;
+    c->error_flag[0] = c->error_flag[1] = 0;
     HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&c->tsample_dev, 2 * kMaxTheta * sizeof(ThetaSet)));
@@ -606,7 +640,7 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     muse_comm_destroy(c);
-    hipFree(c->cl_counter); hipFree(c->cl_part); hipHostFree(c->error_flag); hipFree(c->ncache);
+    hipFree(c->cl_counter); hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag); hipFree(c->ncache);
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
     hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
@@ -1103,24 +1137,24 @@ int muse_set_zhat(muse_ctx* c, int64_t b, int64_t e, const double* in, int mem) 
     return MUSE_OK;
 }
 
-int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0,
-                           const double* step, double atol, int fid_mode, int64_t fid_sim, double* Hs_out,
+// Columns [e_begin, e_end) of the list (sim_begin, column 0), (sim_begin, column 1), ... : element e is column
+// e % ntheta of the finite-difference Jacobian of simulation sim_begin + e / ntheta.  cols_out [e_end-e_begin][ntheta]
+// (cols[e][i] = d g_i / d theta_j), info_out [e_end-e_begin][2] (plus, minus).
+static int fd_columns_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t e_begin, int64_t e_end, const double* theta0,
+                           const double* step, double atol, int fid_mode, int64_t fid_sim, double* cols_out,
                            muse_info* info_out) {
-    int rc = check_ctx(c);
-    if (rc) return rc;
-    if (!theta0 || !step || !Hs_out) return fail(MUSE_ERR_INVALID, "NULL argument");
-    if (sim_end < sim_begin || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad sim range");
-    if (fid_mode != 0 && fid_mode != 1) return fail(MUSE_ERR_INVALID, "fid_mode must be 0 or 1");
-    const int64_t nsims = sim_end - sim_begin;
-    if (nsims == 0) return MUSE_OK;
     const int nt = c->ntheta;
-    const int64_t n = nsims * 2 * nt;
+    const int64_t ne = e_end - e_begin;
+    if (ne == 0) return MUSE_OK;
+    const int64_t n = ne * 2;
     if (n > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
     for (int j = 0; j < nt; ++j)
         if (!(step[j] != 0.0) || !isfinite(step[j])) return fail(MUSE_ERR_INVALID, "step must be finite and non-zero");
+    const int64_t s_lo = sim_begin + e_begin / nt, s_hi = sim_begin + (e_end - 1) / nt + 1;  // simulations touched
+    const int64_t nsims = s_hi - s_lo;
     // 1. fiducial MAPs at theta0 from zero(z) (src/muse.jl:417-423)
     const int64_t nfid = fid_mode == 0 ? 1 : nsims;
-    rc = ensure_zhat(c, nfid);
+    int rc = ensure_zhat(c, nfid);
     if (rc) return rc;
     // every simulation is drawn 2*ntheta times (same randoms, perturbed theta; src/muse.jl:426-432): its standard
     // normals are generated once -- by its own fiducial problem (fid_mode 1) or by a normals-only element of the
@@ -1137,24 +1171,24 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         a.atol = atol;
         a.nproblems = (int)nprep;
         a.nstd = (int)nfid;
-        a.norm_sim0 = sim_begin;
+        a.norm_sim0 = s_lo;
         if (cached) {
             a.ncache = c->ncache;
-            a.ncache_sim0 = sim_begin;
+            a.ncache_sim0 = s_lo;
             a.ncache_count = (int)nsims;
             a.ncache_mode = 1;
         }
         a.include_data = 0;
         a.z0_mode = MUSE_Z0_ZERO;
         a.store_zhat = 1;
-        a.sim_begin = fid_mode == 0 ? fid_sim : sim_begin;
+        a.sim_begin = fid_mode == 0 ? fid_sim : s_lo;
         a.slot0 = 0;
         a.scores = c->scores_dev[1];
         a.info = c->info_dev[1];
         rc = launch_batch(c, a);
         if (rc) return rc;
     }
-    // 2. the 2*ntheta perturbed simulations per sim, MAP and score at theta0
+    // 2. the perturbed simulations (plus, minus per column), MAP and score at theta0
     std::vector<double> th(nt);
     for (int j = 0; j < nt; ++j) {
         for (int s = 0; s < 2; ++s) {
@@ -1172,7 +1206,8 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         a.seed = seed;
         a.atol = atol;
         a.nproblems = (int)n;
-        a.sim_begin = sim_begin;
+        a.sim_begin = s_lo;
+        a.p0 = (int)(2 * (e_begin - (s_lo - sim_begin) * nt));  // the range may begin inside s_lo's Jacobian
         a.fid_slot = fid_mode == 0 ? 0 : -1;
         a.slot0 = 0;
         a.tsample = c->tsample_dev;
@@ -1180,7 +1215,7 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         a.info = c->info_dev[1];
         if (cached) {
             a.ncache = c->ncache;
-            a.ncache_sim0 = sim_begin;
+            a.ncache_sim0 = s_lo;
             a.ncache_count = (int)nsims;
             a.ncache_mode = 2;
         }
@@ -1193,14 +1228,100 @@ int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
     rc = check_error_flag(c);
     if (rc) return rc;
     const double* g = c->scores_pin[1];
-    for (int64_t s = 0; s < nsims; ++s)
-        for (int j = 0; j < nt; ++j) {
-            const double* gp = g + ((s * nt + j) * 2 + 0) * nt;
-            const double* gm = g + ((s * nt + j) * 2 + 1) * nt;
-            for (int i = 0; i < nt; ++i) Hs_out[(s * nt + i) * nt + j] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
-        }
+    for (int64_t e = 0; e < ne; ++e) {
+        const int j = (int)((e_begin + e) % nt);
+        const double* gp = g + (e * 2 + 0) * nt;
+        const double* gm = g + (e * 2 + 1) * nt;
+        // central_fdm(3,1): grid (-1, 0, 1), coefficients (-1/2, 0, 1/2) (src/muse.jl:300, src/util.jl:13)
+        for (int i = 0; i < nt; ++i) cols_out[e * nt + i] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
+    }
     if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
     return MUSE_OK;
+}
+
+int muse_fd_jacobian_columns(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
+                             const double* theta0, const double* step, double atol, int fid_mode, int64_t fid_sim,
+                             double* cols_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !step || !cols_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (col_end < col_begin || col_begin < 0 || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad column range");
+    if (fid_mode != 0 && fid_mode != 1) return fail(MUSE_ERR_INVALID, "fid_mode must be 0 or 1");
+    return fd_columns_impl(c, seed, sim_begin, col_begin, col_end, theta0, step, atol, fid_mode, fid_sim, cols_out, info_out);
+}
+
+int muse_fd_jacobian_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0,
+                           const double* step, double atol, int fid_mode, int64_t fid_sim, double* Hs_out,
+                           muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !step || !Hs_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (sim_end < sim_begin || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad sim range");
+    if (fid_mode != 0 && fid_mode != 1) return fail(MUSE_ERR_INVALID, "fid_mode must be 0 or 1");
+    const int nt = c->ntheta;
+    const int64_t nsims = sim_end - sim_begin;
+    if (nsims == 0) return MUSE_OK;
+    std::vector<double> cols((size_t)nsims * nt * nt);
+    rc = fd_columns_impl(c, seed, sim_begin, 0, nsims * nt, theta0, step, atol, fid_mode, fid_sim, cols.data(), info_out);
+    if (rc) return rc;
+    for (int64_t s = 0; s < nsims; ++s)  // the per-sim Jacobian is the hcat of its columns (src/util.jl:25)
+        for (int j = 0; j < nt; ++j)
+            for (int i = 0; i < nt; ++i) Hs_out[(s * nt + i) * nt + j] = cols[((size_t)(s * nt + j)) * nt + i];
+    return MUSE_OK;
+}
+
+// Columns [e_begin, e_end) of the same list for the implicit-differentiation H; per_column: one element per column
+// (each repeats the simulation's sample and its atol MAP), else one element per simulation (whole simulations only).
+static int implicit_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t e_begin, int64_t e_end, bool per_column,
+                         const double* theta0, double atol, int cg_maxiter, double* cols_out, int32_t* cg_iters_out) {
+    const int nt = c->ntheta;
+    const int64_t ne = e_end - e_begin;
+    if (ne == 0) return MUSE_OK;
+    if (ne > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
+    const int64_t s_lo = sim_begin + e_begin / nt, s_hi = sim_begin + (e_end - 1) / nt + 1;
+    const int64_t nsims = s_hi - s_lo;
+    int rc = ensure_zhat(c, 1);
+    if (rc) return rc;
+    rc = ensure_results(c, 2, nsims * nt);
+    if (rc) return rc;
+    BatchArgs a;
+    base_args(c, a, theta0);
+    a.kind = BATCH_IMPLICIT;
+    a.seed = seed;
+    a.atol = atol;
+    a.cg_maxiter = cg_maxiter;
+    a.imp_split = per_column ? nt : 1;
+    a.p0 = per_column ? (int)(e_begin - (s_lo - sim_begin) * nt) : 0;
+    a.nproblems = (int)(per_column ? ne : nsims);
+    a.sim_begin = s_lo;
+    a.slot0 = 0;
+    a.scores = c->scores_dev[2];  // [nsims][ntheta][ntheta], H[s][i][j]: only the requested columns are written
+    a.info = c->info_dev[2];
+    rc = launch_batch(c, a);
+    if (rc) return rc;
+    rc = enqueue_results_copy(c, 2, nsims * nt);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_error_flag(c);
+    if (rc) return rc;
+    for (int64_t e = 0; e < ne; ++e) {
+        const int64_t el = e_begin + e - (s_lo - sim_begin) * nt;  // position in the list that starts at s_lo
+        const int64_t s = el / nt;
+        const int j = (int)(el % nt);
+        for (int i = 0; i < nt; ++i) cols_out[e * nt + i] = c->scores_pin[2][(s * nt + i) * nt + j];
+        if (cg_iters_out) cg_iters_out[e] = c->info_pin[2][s * nt + j].iterations;
+    }
+    return MUSE_OK;
+}
+
+int muse_implicit_H_columns(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
+                            const double* theta0, double atol, int cg_maxiter, double* cols_out, int32_t* cg_iters_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !cols_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (col_end < col_begin || col_begin < 0 || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad column range");
+    if (cg_maxiter < 1) return fail(MUSE_ERR_INVALID, "cg_maxiter must be >= 1");
+    return implicit_impl(c, seed, sim_begin, col_begin, col_end, true, theta0, atol, cg_maxiter, cols_out, cg_iters_out);
 }
 
 int muse_implicit_H_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0, double atol,
@@ -1214,35 +1335,16 @@ int muse_implicit_H_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     if (nsims == 0) return MUSE_OK;
     const int nt = c->ntheta;
     if (nsims * nt > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
-    rc = ensure_zhat(c, 1);
-    if (rc) return rc;
-    rc = ensure_results(c, 2, nsims * nt);
-    if (rc) return rc;
-    BatchArgs a;
-    base_args(c, a, theta0);
-    a.kind = BATCH_IMPLICIT;
-    a.seed = seed;
-    a.atol = atol;
-    a.cg_maxiter = cg_maxiter;
     // few simulations and several theta components: one element per (simulation, H column), so that the batch
-    // fills the GPU (each element repeats the simulation's sample and its atol MAP, cheap next to nθ CG solves)
+    // fills the GPU (each element repeats the simulation's sample and its atol MAP, cheap next to ntheta CG solves)
     const int64_t slots = (int64_t)c->num_cus * 2 / (use_cluster(c) ? cluster_size(c) : 1);
-    a.imp_split = (nt > 1 && nsims * 2 <= slots) ? nt : 1;
-    a.nproblems = (int)(nsims * a.imp_split);
-    a.sim_begin = sim_begin;
-    a.slot0 = 0;
-    a.scores = c->scores_dev[2];
-    a.info = c->info_dev[2];
-    rc = launch_batch(c, a);
+    const bool per_column = nt > 1 && nsims * 2 <= slots;
+    std::vector<double> cols((size_t)nsims * nt * nt);
+    rc = implicit_impl(c, seed, sim_begin, 0, nsims * nt, per_column, theta0, atol, cg_maxiter, cols.data(), cg_iters_out);
     if (rc) return rc;
-    rc = enqueue_results_copy(c, 2, nsims * nt);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    rc = check_error_flag(c);
-    if (rc) return rc;
-    memcpy(Hs_out, c->scores_pin[2], (size_t)nsims * nt * nt * sizeof(double));
-    if (cg_iters_out)
-        for (int64_t k = 0; k < nsims * nt; ++k) cg_iters_out[k] = c->info_pin[2][k].iterations;
+    for (int64_t s = 0; s < nsims; ++s)
+        for (int j = 0; j < nt; ++j)
+            for (int i = 0; i < nt; ++i) Hs_out[(s * nt + i) * nt + j] = cols[((size_t)(s * nt + j)) * nt + i];
     return MUSE_OK;
 }
 

@@ -31,11 +31,13 @@ struct Solver {
     double last_c, last_gmax;
     // element ownership: thread pairs tfirst + k*pstride (cluster mode: the cluster acts as one csize*T block)
     int tfirst, pstride;
+    __device__ __forceinline__ int ps() const { return Place::kCluster ? pstride : T; }  // a constant without clusters
     int crank, csize;          // this workgroup's rank in its cluster, cluster size
     unsigned int cl_epoch;     // cluster reductions done so far in this launch
     bool cl_aborted;           // a bounded wait expired: stop waiting
     unsigned int* cl_counter;  // this cluster's arrival counter
-    double* cl_part;           // this cluster's partial slots [2][csize][8]
+    double* cl_part;           // this cluster's partial slots [2][csize][8] / granules [2][csize][8][2]
+    double* exch;              // LDS [kMaxCluster][8]: the epoch's values of every member (granule exchange)
 
     __device__ Solver(const BatchArgs& a_, int tid_, double* red_, double* shs) : a(a_), tid(tid_), red(red_), parity(0) {
         sh_rho = shs;
@@ -50,6 +52,7 @@ struct Solver {
         cl_aborted = false;
         cl_counter = nullptr;
         cl_part = nullptr;
+        exch = nullptr;
     }
 
     // Cluster all-reduce (Guideline 16 of the CDNA guide: placement-independent release/acquire).
@@ -102,11 +105,80 @@ struct Solver {
             else mv[k - KS] = uniform(acc);
         }
     }
-    // Workgroup reduction, then (cluster mode) the cluster reduction.
+    // Cluster all-reduce of the elementwise models.  Only these K scalars cross workgroups (every thread reads and
+    // writes its own elements of every vector, in every pass), so no fence is involved: no L2 write-back, no L1
+    // invalidate.  A value travels as two 8-byte granules {32-bit half, 32-bit tag}, each written by ONE
+    // write-through store (MI355X_MICROARCH.md, price list row "handoff-1to1": an aligned 8-byte granule is not
+    // torn, and data-tagged granules need no ordering against a separate flag).  The tag is the cluster's epoch
+    // number, which keeps growing from launch to launch (BatchArgs::cl_state), so a granule is this epoch's exactly
+    // when its tag says so.  Wave 0 publishes the workgroup's 2K granules with one store instruction and then sweeps
+    // the cluster's csize*2K granules (one 8-byte L1-bypassing load per lane and sweep) until every tag matches; the
+    // other waves get the values through LDS.  Buffers alternate by epoch parity: a workgroup reaches epoch e+2 only
+    // after every member has published e+1, i.e. after every member has consumed epoch e.  Combination in rank
+    // order, as cluster_allreduce: the two give the same bits.
+    template <int KS, int KM>
+    __device__ __forceinline__ void cluster_exchange(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
+        constexpr int K = KS + KM;
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        cl_epoch += 1;
+        gu64* gran = (gu64*)cl_part + (size_t)(cl_epoch & 1u) * (kMaxCluster * 16);
+        if (tid < 64) {
+            const int lane = tid;
+            if (lane < 2 * K) {  // granule (value k = lane >> 1, half h = lane & 1) of this workgroup
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double vk = k < KS ? sv[k < KS ? k : 0] : mv[k >= KS ? k - KS : 0];
+                    v = (lane >> 1) == k ? vk : v;
+                }
+                const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+                const unsigned half = (lane & 1) ? (unsigned)(b >> 32) : (unsigned)(b & 0xffffffffull);
+                __hip_atomic_store(gran + crank * 16 + lane, ((unsigned long long)cl_epoch << 32) | half, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int total = csize * 16;  // granule q = rank*16 + k*2 + h; the live ones have k < K
+            unsigned spins = 0;
+            for (int q0 = 0; q0 < total; q0 += 64) {
+                const int q = q0 + lane;
+                const bool live = q < total && (q & 15) < 2 * K;
+                unsigned long long gv = 0;
+                for (;;) {
+                    bool ok = true;
+                    if (live) {
+                        gv = __hip_atomic_load(gran + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (unsigned)(gv >> 32) == cl_epoch;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || cl_aborted) break;
+                    // bounded (about a second): members that are not all resident must not hang the GPU
+                    if (++spins > (1u << 21)) {
+                        __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        cl_aborted = true;
+                    }
+                }
+                if (live) reinterpret_cast<unsigned*>(exch)[q] = (unsigned)(gv & 0xffffffffull);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double acc = exch[k];
+            for (int c = 1; c < csize; ++c) {
+                const double v = exch[c * 8 + k];
+                acc = k < KS ? acc + v : __builtin_fmax(acc, v);
+            }
+            if (k < KS) sv[k < KS ? k : 0] = uniform(acc);
+            else mv[k >= KS ? k - KS : 0] = uniform(acc);
+        }
+    }
+    // Workgroup reduction, then (cluster mode) the cluster reduction.  The stencil model's passes read neighbours
+    // that other workgroups wrote: it needs the release/acquire form; the elementwise models exchange scalars only.
     template <int KS, int KM>
     __device__ __forceinline__ void reduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
         block_allreduce<T, KS, KM>(sv, mv, red, parity, tid);
-        if constexpr (Place::kCluster) cluster_allreduce<KS, KM>(sv, mv);
+        if constexpr (Place::kCluster) {
+            if constexpr (Model::kStencil) cluster_allreduce<KS, KM>(sv, mv);
+            else cluster_exchange<KS, KM>(sv, mv);
+        }
     }
     // Orders this pass's vector stores before the next pass's neighbour reads (stencil model).
     __device__ __forceinline__ void pass_barrier() {
@@ -168,7 +240,7 @@ struct Solver {
             static_assert(2 * EPT <= 20, "two words of ten 3-bit slots");
 #pragma unroll
             for (int jj = 0; jj < 2 * EPT; ++jj) {
-                const int i = 2 * (tid + (jj >> 1) * T) + (jj & 1);
+                const int i = 2 * (tfirst + (jj >> 1) * ps()) + (jj & 1);
                 pk[jj / 10] |= (unsigned)block_of<MAXB>(a, i) << (3 * (jj % 10));
             }
         }
@@ -302,11 +374,11 @@ struct Solver {
     __device__ __forceinline__ void for_elems_zz(F&& f, W&&... written) {
         if constexpr (!Place::kResident && !Model::kStencil) {
             if (z_zero) {
-                for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) { f(std::true_type{}, jj, i); }, written...);
+                for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) { f(std::true_type{}, jj, i); }, written...);
                 return;
             }
         }
-        for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) { f(std::false_type{}, jj, i); }, written...);
+        for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) { f(std::false_type{}, jj, i); }, written...);
     }
 
     //    INIT_S (resident policy, where s lives in registers): the pass also sets the steepest-descent
@@ -315,7 +387,7 @@ struct Solver {
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
-            for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
+            for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) {
                 double zi = ZZ ? 0.0 : z.get(jj, i);  // ZZ: z is still the (unwritten) zero start
                 double si = 0.0;
                 if constexpr (USE_S) {
@@ -370,7 +442,7 @@ struct Solver {
     double init_f, init_dphi, init_gmax;
     __device__ __forceinline__ void eval_init_with_trial(double c0, double& f, double& dphi, double& gmax) {
         double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
-        for_elems<T, EPT, U>(a.ld, tfirst, pstride, [&](int jj, int i) {
+        for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) {
             const double zi = z.get(jj, i), xi = x.get(jj, i), ivi = ivk(jj, i);
             const double gi = Model::grad(ivi, xi, zi, sum[0]);
             const double sd = -gi;
@@ -721,7 +793,7 @@ struct Solver {
                 }
                 z.clear();
                 s.clear();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, g.get(jj, i));
                     else z.set(jj, i, z0src.get(jj, i));
@@ -743,7 +815,7 @@ struct Solver {
                         // x, z, write g; read g, write s; read z, s, x of the four passes it replaces
                         const bool ztrue_start = d.z0_mode == Z0_TRUE;
                         double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
-                        for_elems<T, EPT, 1>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, 1>(ld, tfirst, ps(), [&](int jj, int i) {
                             const bool valid = i < N;
                             const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
                             double zt, xt;
@@ -778,7 +850,7 @@ struct Solver {
                     }
                 }
                 if (!init_done)
-                for_elems<T, EPT, US>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, US>(ld, tfirst, ps(), [&](int jj, int i) {
                     const bool valid = i < N;  // phantom slots run the generator but keep zeros
                     const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
                     double zt, xt;
@@ -799,12 +871,12 @@ struct Solver {
                 }, when(Model::kStencil, s), when(KEEP_ZTRUE, ztrue), x, when(z_from_sample, z));
                 if constexpr (!Place::kResident) {
                     if (!init_done && !z_from_sample && !z_in_place)
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); }, z);
+                        for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); }, z);
                 }
             }
             if constexpr (Model::kStencil) {
                 pass_barrier();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const bool valid = i < N;
                     const int ic = valid ? i : 0;
                     const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
@@ -818,7 +890,7 @@ struct Solver {
             xs.bind(d.x_mode == X_DATA ? a.x_data : a.x_given, ld);
             x.clear(); g.clear(); z.clear(); s.clear();
             const bool z_zero = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
-            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+            for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                 x.set(jj, i, xs.get(jj, i));
                 if (z_zero) z.set(jj, i, 0.0);
                 else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
@@ -886,7 +958,7 @@ struct Solver {
                 dphi_0 = dphi_init;  // s = -g and g . s came with the initial evaluation
             } else if (h == 0 || !have_pair) {
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] = fma(gi, si, sum[0]);
@@ -905,14 +977,14 @@ struct Solver {
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index > lower) {
                         const VH dxn = hdx((index - 2) % kM);
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                             const double qi = fma(-al, dgp.get(jj, i), s.get(jj, i));
                             s.set(jj, i, qi);
                             sum[0] = fma(dxn.get(jj, i), qi, sum[0]);
                         }, s);
                     } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
                         const double gam = sh_gam[(upper - 1) % kM];
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                             const double dgi = dgp.get(jj, i);
                             const double si = gam * fma(-al, dgi, s.get(jj, i));
                             s.set(jj, i, si);
@@ -931,13 +1003,13 @@ struct Solver {
                     double sum[1] = {0.0}, mx[1] = {0.0};
                     if (index < upper) {
                         const VH dgn = hdg(index % kM);
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                             const double si = fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(dgn.get(jj, i), si, sum[0]);
                         }, s);
                     } else {
-                        for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                        for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                             const double si = -fma(dxp.get(jj, i), coef, s.get(jj, i));
                             s.set(jj, i, si);
                             sum[0] = fma(g.get(jj, i), si, sum[0]);
@@ -962,7 +1034,7 @@ struct Solver {
                     }
                 }
                 double sum[1] = {0.0}, mx[1] = {0.0};
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double gi = g.get(jj, i), si = -gi;
                     s.set(jj, i, si);
                     sum[0] = fma(gi, si, sum[0]);
@@ -1067,7 +1139,7 @@ struct Solver {
                 reduce<3, 1>(sum, mx);
                 mx[0] = nan_if(sum[0] != sum[0], mx[0]);
             } else {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double zo = z.get(jj, i), si = s.get(jj, i);
                     const double dxi = alpha * si;
                     const double zn = fma(alpha, si, zo);
@@ -1139,7 +1211,7 @@ struct Solver {
         }
         if constexpr (!Place::kResident && !Model::kStencil) {
             if (z_zero) {  // no step was taken from a zero start (converged at once / non-finite): z = 0 goes to memory now
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { z.set(jj, i, 0.0); }, z);
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { z.set(jj, i, 0.0); }, z);
                 z_zero = false;
             }
         }
@@ -1178,20 +1250,21 @@ struct Solver {
         // imp_split == ntheta: this element is ONE column of one simulation's H (few simulations, many theta: the
         // columns spread over the GPU, each repeating the cheap atol = 1e-1 MAP); imp_split == 1: all columns
         const int split = a.imp_split > 1 ? a.imp_split : 1;
-        const int64_t psim = p / split;
-        const int j_lo = split > 1 ? p % split : 0, j_hi = split > 1 ? j_lo + 1 : nth;
+        const int plist = p + a.p0;  // position in the list that starts at sim_begin's first column
+        const int64_t psim = plist / split;
+        const int j_lo = split > 1 ? plist % split : 0, j_hi = split > 1 ? j_lo + 1 : nth;
         for (int j = j_lo; j < j_hi; ++j) {
             // ---- right-hand side b = dFdtheta1[:, j]; v = 0, r = p = b --------------------------------
             double sum[1] = {0.0}, mx[1] = {0.0};
             if constexpr (Model::kStencil) {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
                     t1.set(jj, i, blk(jj, i) == j ? 0.5 * zt : 0.0);
                 }, t1);
                 pass_barrier();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); }, t2);
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { t2.set(jj, i, Aat(t1, i)); }, t2);
                 pass_barrier();
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double bi = Aat(t2, i);
                     v.set(jj, i, 0.0);
                     r.set(jj, i, bi);
@@ -1199,7 +1272,7 @@ struct Solver {
                     sum[0] = fma(bi, bi, sum[0]);
                 }, v, r, pp);
             } else {
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
                     double bi;
                     if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - zt));
@@ -1218,16 +1291,16 @@ struct Solver {
                 // ---- Ap = A_hess p, p.Ap -----------------------------------------------------------
                 double s1[1] = {0.0};
                 if constexpr (Model::kStencil) {
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) { t1.set(jj, i, Aat(pp, i)); }, t1);
+                    for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { t1.set(jj, i, Aat(pp, i)); }, t1);
                     pass_barrier();
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                    for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                         const double pi = pp.get(jj, i);
                         const double api = -(Aat(t1, i) + ivk(jj, i) * pi);
                         Ap.set(jj, i, api);
                         s1[0] = fma(pi, api, s1[0]);
                     }, Ap);
                 } else {
-                    for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                    for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                         const double pi = pp.get(jj, i);
                         double api;
                         if constexpr (Model::kId == MUSE_MODEL_NOISE) api = -((iv0 + 1.0) * pi);
@@ -1240,7 +1313,7 @@ struct Solver {
                 const double alpha = rr / s1[0];
                 // ---- v += alpha p ; r -= alpha Ap ; r.r ---------------------------------------------
                 double s2[1] = {0.0};
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     v.set(jj, i, fma(alpha, pp.get(jj, i), v.get(jj, i)));
                     const double ri = fma(-alpha, Ap.get(jj, i), r.get(jj, i));
                     r.set(jj, i, ri);
@@ -1250,7 +1323,7 @@ struct Solver {
                 const double beta = s2[0] / rr;
                 rr = s2[0];
                 // ---- p = r + beta p (its stores are ordered before the next stencil read by pass_barrier)
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     pp.set(jj, i, fma(beta, pp.get(jj, i), r.get(jj, i)));
                 }, pp);
                 if constexpr (Model::kStencil) pass_barrier();
@@ -1261,7 +1334,7 @@ struct Solver {
             double acc[KA];
 #pragma unroll
             for (int b = 0; b < KA; ++b) acc[b] = 0.0;
-            for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+            for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                 const double zi = z.get(jj, i), vi = v.get(jj, i);
                 if constexpr (Model::kId == MUSE_MODEL_NOISE) {
                     const double xi = x.get(jj, i);
@@ -1315,7 +1388,7 @@ struct Solver {
                 if (store) zout.bind(a.zhat + d.zslot * ld, ld);
 #pragma unroll
                 for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
-                for_elems<T, EPT, U>(ld, tfirst, pstride, [&](int jj, int i) {
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                     const double zi = z.get(jj, i);
                     if constexpr (Place::kResident) {
                         if (store) zout.set(jj, i, zi);

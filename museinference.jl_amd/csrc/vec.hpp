@@ -184,10 +184,10 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F
     int t = tfirst;
     asm volatile("" : "+v"(t));
     if constexpr (EPT > 0) {
-        (void)pstride;
+        // pstride == T for a single workgroup (the caller passes the constant), csize*T in cluster mode
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int i0 = 2 * (t + j * T);
+            const int i0 = 2 * (t + j * pstride);
             f(2 * j, i0);
             f(2 * j + 1, i0 + 1);
         }

@@ -38,6 +38,7 @@ class ShardedMuseProblem:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._device = device
+        self._last_nslots = None
         if engine_comm is None:
             engine_comm = dist.get_backend(group) == "nccl" and hasattr(local, "comm_init")
         self.engine_comm = bool(engine_comm)
@@ -88,6 +89,8 @@ class ShardedMuseProblem:
                             z0_mode=_capi.Z0_ZERO):
         lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
         data_here = include_data and self.rank == 0
+        if include_data:
+            self._last_nslots = (sim_end - sim_begin) + 1
         g, info = self.local.map_and_score_batch(rng, lo, hi, theta, include_data=data_here, atol=atol,
                                                  z0_mode=z0_mode)
         counts = []
@@ -100,10 +103,31 @@ class ShardedMuseProblem:
         return np.ascontiguousarray(allrows[:, :nth]), self._rows_to_info(allrows[:, nth:])
 
     def fd_jacobian_batch(self, rng, sim_begin, sim_end, theta0, step, *, atol=1e-2, fid_mode=0, fid_sim=None):
+        """get_H!'s finite-difference map.  The reference parallelises over whichever of sims / Jacobian columns is
+        longer (src/muse.jl:327-333); here the flattened list of (sim, column) units is cut into contiguous blocks,
+        one per rank, so that nsims = 3, nθ = 4 on two ranks is 6 columns (12 MAPs) each -- a block may begin and end
+        inside a simulation's Jacobian.  Problems without the column seam are sharded by sims."""
         from .problem import MASTER_SIM
         fid_sim = MASTER_SIM if fid_sim is None else fid_sim
-        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
         nth = np.atleast_1d(theta0).size
+        ninfo = len(_capi.INFO_DTYPE.names)
+        if hasattr(self.local, "fd_jacobian_columns"):
+            ncol = (sim_end - sim_begin) * nth
+            lo, hi = block_partition(0, ncol, self.world, self.rank)
+            if hi > lo:
+                cols, info = self.local.fd_jacobian_columns(rng, sim_begin, lo, hi, theta0, step, atol=atol,
+                                                            fid_mode=fid_mode, fid_sim=fid_sim)
+            else:
+                cols, info = np.zeros((0, nth)), np.zeros((0, 2), dtype=_capi.INFO_DTYPE)
+            counts = [h - l for l, h in (block_partition(0, ncol, self.world, r) for r in range(self.world))]
+            rows = np.concatenate([cols, self._info_to_rows(info).reshape(hi - lo, 2 * ninfo)], axis=1)
+            allrows = self._allgather_rows(rows, counts)
+            n = sim_end - sim_begin
+            # the per-sim Jacobian is the hcat of its columns (src/util.jl:25): Hs[s][i][j] = cols[s*nθ + j][i]
+            Hall = allrows[:, :nth].reshape(n, nth, nth).transpose(0, 2, 1)
+            iall = self._rows_to_info(allrows[:, nth:].reshape(n * nth * 2, ninfo)).reshape(n, nth, 2)
+            return np.ascontiguousarray(Hall), iall
+        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
         if hi > lo:
             Hs, info = self.local.fd_jacobian_batch(rng, lo, hi, theta0, step, atol=atol, fid_mode=fid_mode,
                                                     fid_sim=fid_sim)
@@ -111,7 +135,6 @@ class ShardedMuseProblem:
             Hs, info = np.zeros((0, nth, nth)), np.zeros((0, nth, 2), dtype=_capi.INFO_DTYPE)
         counts = [block_partition(sim_begin, sim_end, self.world, r) for r in range(self.world)]
         counts = [h - l for l, h in counts]
-        ninfo = len(_capi.INFO_DTYPE.names)
         rows = np.concatenate([Hs.reshape(hi - lo, nth * nth),
                                self._info_to_rows(info).reshape(hi - lo, nth * 2 * ninfo)], axis=1)
         allrows = self._allgather_rows(rows, counts)
@@ -121,9 +144,23 @@ class ShardedMuseProblem:
         return np.ascontiguousarray(Hall), iall
 
     def implicit_H_batch(self, rng, sim_begin, sim_end, theta0, *, atol=1e-1, cg_maxiter=100):
-        """get_H! implicit-differentiation branch, sims sharded like the maps (src/muse.jl:335-405)."""
-        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
+        """get_H! implicit-differentiation branch (src/muse.jl:335-405), the (sim, column) units shared like the
+        finite-difference ones."""
         nth = np.atleast_1d(theta0).size
+        if hasattr(self.local, "implicit_H_columns"):
+            ncol = (sim_end - sim_begin) * nth
+            lo, hi = block_partition(0, ncol, self.world, self.rank)
+            if hi > lo:
+                cols, its = self.local.implicit_H_columns(rng, sim_begin, lo, hi, theta0, atol=atol, cg_maxiter=cg_maxiter)
+            else:
+                cols, its = np.zeros((0, nth)), np.zeros(0, dtype=np.int32)
+            counts = [h - l for l, h in (block_partition(0, ncol, self.world, r) for r in range(self.world))]
+            rows = np.concatenate([cols, its.astype(np.float64).reshape(hi - lo, 1)], axis=1)
+            allrows = self._allgather_rows(rows, counts)
+            n = sim_end - sim_begin
+            return (np.ascontiguousarray(allrows[:, :nth].reshape(n, nth, nth).transpose(0, 2, 1)),
+                    allrows[:, nth].astype(np.int32).reshape(n, nth))
+        lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
         if hi > lo:
             Hs, its = self.local.implicit_H_batch(rng, lo, hi, theta0, atol=atol, cg_maxiter=cg_maxiter)
         else:
@@ -136,8 +173,36 @@ class ShardedMuseProblem:
         return (np.ascontiguousarray(allrows[:, : nth * nth].reshape(n, nth, nth)),
                 allrows[:, nth * nth:].astype(np.int32))
 
-    def get_zhat(self, slot_begin, slot_end):
-        raise NotImplementedError("resident MAPs are sharded; read them from the owning rank's local problem")
+    # -- resident MAPs.  Slots follow the element order of the LAST map: [data] + sims, the data element and the first
+    #    block on rank 0, every rank's block in its local slots from 0 (rank 0: after the data element).
+    def _slot_owner(self, nslots):
+        """(rank, local slot) of every global slot 0..nslots-1 for a map of nslots elements that included the data."""
+        nsims = nslots - 1
+        owners = [(0, 0)]
+        for r in range(self.world):
+            lo, hi = block_partition(0, nsims, self.world, r)
+            owners += [(r, (s - lo) + (1 if r == 0 else 0)) for s in range(lo, hi)]
+        return owners
 
-    def set_zhat(self, slot_begin, zs):
-        raise NotImplementedError("resident MAPs are sharded; set them on the owning rank's local problem")
+    def get_zhat(self, slot_begin, slot_end, nslots=None):
+        """MAPs of global slots [slot_begin, slot_end) of the last (nsims+1)-element muse! map, gathered from the owning
+        ranks (save_MAPs, src/muse.jl:139-143,219).  nslots = nsims + 1 of that map (default: what the last sharded
+        map_and_score_batch with include_data used)."""
+        nslots = self._last_nslots if nslots is None else nslots
+        owners = self._slot_owner(nslots)[slot_begin:slot_end]
+        mine = [ls for (r, ls) in owners if r == self.rank]
+        rows = np.zeros((len(mine), self.local.N))
+        for k, ls in enumerate(mine):
+            rows[k] = self.local.get_zhat(ls, ls + 1)[0]
+        counts = [sum(1 for (r, _) in owners if r == q) for q in range(self.world)]
+        allrows = self._allgather_rows(rows, counts)      # concatenated in rank order = slot order (blocks are contiguous)
+        return allrows
+
+    def set_zhat(self, slot_begin, zs, nslots=None):
+        """Starting guesses for global slots slot_begin.. (z₀ of muse!, src/muse.jl:151): every rank keeps its own rows."""
+        zs = np.atleast_2d(np.asarray(zs, dtype=np.float64))
+        nslots = slot_begin + zs.shape[0] if nslots is None else nslots
+        self._last_nslots = nslots
+        for k, (r, ls) in enumerate(self._slot_owner(nslots)[slot_begin:slot_begin + zs.shape[0]]):
+            if r == self.rank:
+                self.local.set_zhat(ls, zs[k:k + 1])

@@ -387,6 +387,31 @@ class HipMuseProblem(AbstractMuseProblem):
                                                     float(atol), int(cg_maxiter), _capi.ptr(Hs), _capi.ptr(its)))
         return Hs, its
 
+    def fd_jacobian_columns(self, rng, sim_begin, col_begin, col_end, theta0, step, *, atol=1e-2, fid_mode=0,
+                            fid_sim=MASTER_SIM):
+        """Columns [col_begin, col_end) of the list (sim_begin, column 0), (sim_begin, column 1), ...: the reference's
+        other parallel axis for get_H! (Jacobian columns, src/muse.jl:327-333).  Returns (cols [n, nθ] with
+        cols[e][i] = d g_i / d θ_(e mod nθ), info [n, 2])."""
+        th = self._theta(theta0)
+        st = _capi.f8(step, self.ntheta)
+        n = col_end - col_begin
+        cols = np.empty((n, self.ntheta))
+        info = np.zeros((n, 2), dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_fd_jacobian_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th),
+                                                       _capi.ptr(st), float(atol), int(fid_mode), int(fid_sim),
+                                                       _capi.ptr(cols), _capi.ptr(info)))
+        return cols, info
+
+    def implicit_H_columns(self, rng, sim_begin, col_begin, col_end, theta0, *, atol=1e-1, cg_maxiter=100):
+        """The same column range for the implicit-differentiation H: (cols [n, nθ], cg iteration counts [n])."""
+        th = self._theta(theta0)
+        n = col_end - col_begin
+        cols = np.empty((n, self.ntheta))
+        its = np.zeros(n, dtype=np.int32)
+        _capi.check(self._lib.muse_implicit_H_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th),
+                                                      float(atol), int(cg_maxiter), _capi.ptr(cols), _capi.ptr(its)))
+        return cols, its
+
     # -- RCCL exchange (C1-C3 of SURVEY.md §2) through the C ABI, for hosts without torch.distributed
     @staticmethod
     def comm_unique_id():

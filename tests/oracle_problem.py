@@ -82,6 +82,23 @@ class OracleBatchedProblem(OracleMuseProblem):
         info = np.zeros((sim_end - sim_begin, th.size, 2), dtype=M._capi.INFO_DTYPE)
         return np.array(Hs).reshape(sim_end - sim_begin, th.size, th.size), info
 
+    def fd_jacobian_columns(self, rng, sim_begin, col_begin, col_end, theta0, step, *, atol=1e-2, fid_mode=0,
+                            fid_sim=M.MASTER_SIM):
+        nth = np.atleast_1d(theta0).size
+        s_lo, s_hi = sim_begin + col_begin // nth, sim_begin + (col_end - 1) // nth + 1
+        Hs, _ = self.fd_jacobian_batch(rng, s_lo, s_hi, theta0, step, atol=atol, fid_mode=fid_mode, fid_sim=fid_sim)
+        self.fd_maps_done = getattr(self, "fd_maps_done", 0) + 2 * (col_end - col_begin)
+        cols = Hs.transpose(0, 2, 1).reshape(-1, nth)[col_begin - (s_lo - sim_begin) * nth:][: col_end - col_begin]
+        return np.ascontiguousarray(cols), np.zeros((col_end - col_begin, 2), dtype=M._capi.INFO_DTYPE)
+
+    def implicit_H_columns(self, rng, sim_begin, col_begin, col_end, theta0, *, atol=1e-1, cg_maxiter=100):
+        nth = np.atleast_1d(theta0).size
+        s_lo, s_hi = sim_begin + col_begin // nth, sim_begin + (col_end - 1) // nth + 1
+        Hs, its = self.implicit_H_batch(rng, s_lo, s_hi, theta0, atol=atol, cg_maxiter=cg_maxiter)
+        off = col_begin - (s_lo - sim_begin) * nth
+        cols = Hs.transpose(0, 2, 1).reshape(-1, nth)[off:][: col_end - col_begin]
+        return np.ascontiguousarray(cols), np.asarray(its).reshape(-1)[off:][: col_end - col_begin].astype(np.int32)
+
     def implicit_H_batch(self, rng, sim_begin, sim_end, theta0, *, atol=1e-1, cg_maxiter=100):
         seed = rng.seed if isinstance(rng, M.SimRng) else int(rng)
         out = [O.implicit_H(self.model, self.N, seed, s, theta0, atol, cg_maxiter) for s in range(sim_begin, sim_end)]

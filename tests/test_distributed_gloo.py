@@ -25,9 +25,19 @@ prob = M.ShardedMuseProblem(local)
 res = M.muse(prob, [1.0, 0.5], rng=3, nsims=13, maxsteps=4, get_covariance=True)
 g, info = prob.map_and_score_batch(3, 2, 9, [0.1, 0.2], include_data=True)
 Hi, its = prob.implicit_H_batch(3, 0, 5, [0.1, 0.2])
+# get_H! with few sims and several theta: the (sim, column) units are shared, not the sims (src/muse.jl:327-333)
+x4, _ = O.sample_x_z("funnel", 200, 6, M.DATA_SIM, [0.0] * 4)
+local4 = OracleBatchedProblem(x4, "funnel", 4, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+prob4 = M.ShardedMuseProblem(local4)
+H4, _ = prob4.fd_jacobian_batch(9, 0, 3, [0.3, 0.1, -0.2, 0.5], [0.05] * 4, atol=1e-3, fid_mode=0)
+Hi4, its4 = prob4.implicit_H_batch(9, 0, 3, [0.3, 0.1, -0.2, 0.5])
+# save_MAPs and a starting guess z0 under sharding: slots are gathered from / scattered to their owners
+r2 = M.muse(prob, [1.0, 0.5], rng=3, nsims=5, maxsteps=2, save_MAPs=True, z0=np.full(256, 0.05))
 with open({out!r} + str(rank), "wb") as f:
     pickle.dump(dict(theta=res.theta, J=res.J, H=res.H, Sigma=res.Sigma, gs=np.array(res.gs), g=g,
-                     iters=info["iterations"], nlocal=len(local._zhat), Hi=Hi, its=its), f)
+                     iters=info["iterations"], nlocal=len(local._zhat), Hi=Hi, its=its, H4=H4, Hi4=Hi4, its4=its4,
+                     fd_maps=local4.fd_maps_done, zdat=r2.history[-1]["ẑ_dat"], zsims=np.array(r2.history[-1]["ẑ_sims"]),
+                     theta2=r2.theta), f)
 dist.destroy_process_group()
 """
 
@@ -60,3 +70,16 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
             assert np.array_equal(got[r][k], want), (r, k)
     # each rank solved only its own block (data element on rank 0)
     assert got[0]["nlocal"] + got[1]["nlocal"] >= 8 and got[1]["nlocal"] < 14
+    # get_H! at nsims = 3, ntheta = 4: 12 (sim, column) units, 6 per rank = 12 perturbed MAPs each; same H bit for bit
+    x4, _ = O.sample_x_z("funnel", 200, 6, M.DATA_SIM, [0.0] * 4)
+    s4 = OracleBatchedProblem(x4, "funnel", 4, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+    H4, _ = s4.fd_jacobian_batch(9, 0, 3, [0.3, 0.1, -0.2, 0.5], [0.05] * 4, atol=1e-3, fid_mode=0)
+    Hi4, its4 = s4.implicit_H_batch(9, 0, 3, [0.3, 0.1, -0.2, 0.5])
+    single2 = OracleBatchedProblem(x, "funnel", 2, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+    r2 = M.muse(single2, [1.0, 0.5], rng=3, nsims=5, maxsteps=2, save_MAPs=True, z0=np.full(256, 0.05))
+    for r in range(2):
+        assert got[r]["fd_maps"] == 12
+        assert np.array_equal(got[r]["H4"], H4) and np.array_equal(got[r]["Hi4"], Hi4) and np.array_equal(got[r]["its4"], its4)
+        assert np.array_equal(got[r]["theta2"], r2.theta)
+        assert np.array_equal(got[r]["zdat"], r2.history[-1]["ẑ_dat"])
+        assert np.array_equal(got[r]["zsims"], np.array(r2.history[-1]["ẑ_sims"]))

@@ -215,13 +215,13 @@ def test_element_split_vs_oracle_and_invariances(gpu, M, O, model, N, nth, theta
     np.testing.assert_allclose(zh[same], zo[same], rtol=0, atol=1e-9)
     g2, info2 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
     assert np.array_equal(g, g2) and np.array_equal(info, info2) and np.array_equal(zh, prob.get_zhat(0, 25))
-    gp, ip = prob.map_and_score_batch(42, 10, 17, theta, atol=1e-2)
-    assert np.array_equal(gp, g[11:18]) and np.array_equal(ip, info[11:18])
     same0 = (info["iterations"] == i0["iterations"]) & (info["f_calls"] == i0["f_calls"])
     np.testing.assert_allclose(g[same0], g0[same0], rtol=1e-12)
     # warm restart at the MAPs: no iteration, identical scores
     g3, i3 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2, z0_mode=M.Z0_WARM)
     assert np.all(i3["iterations"] == 0) and np.array_equal(g3, g)
+    gp, ip = prob.map_and_score_batch(42, 10, 17, theta, atol=1e-2)      # (overwrites the resident MAPs of slots 0..6)
+    assert np.array_equal(gp, g[11:18]) and np.array_equal(ip, info[11:18])
     prob.set_element_split(0)
     g4, _ = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
     assert np.array_equal(g4, g0)
@@ -277,3 +277,29 @@ def test_cluster_placement_under_gathered_map(gpu, M, model, N, nth, theta, nel,
         assert np.array_equal(g_all[0], ref[k % 3][0]) and np.array_equal(info, ref[k % 3][1])
         assert np.all(info["status"] == 0)
     p.close()
+
+
+# ---- get_H! over Jacobian columns (the reference's other parallel axis, src/muse.jl:327-333) ----------------
+@pytest.mark.parametrize("model,N,nth,theta", [
+    ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0]), ("smooth", 2000, 3, [1.0, 2.0, 0.5]), ("funnel", 70001, 2, [0.3, 0.1])])
+@pytest.mark.parametrize("fid_mode", [0, 1])
+def test_H_column_ranges_equal_whole_jacobians(gpu, M, model, N, nth, theta, fid_mode):
+    """A column range that begins and ends inside a simulation's Jacobian gives exactly the columns of the
+    whole-simulation call, for the finite-difference and the implicit-differentiation branch."""
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    step = np.full(nth, 0.05)
+    nsims, s0 = 3, 2
+    Hs, info = prob.fd_jacobian_batch(11, s0, s0 + nsims, theta, step, atol=1e-2, fid_mode=fid_mode)
+    allcols = Hs.transpose(0, 2, 1).reshape(nsims * nth, nth)
+    for lo, hi in ((0, nsims * nth), (1, nth + 1), (nth - 1, 2 * nth + 1), (nsims * nth - 1, nsims * nth)):
+        cols, ci = prob.fd_jacobian_columns(11, s0, lo, hi, theta, step, atol=1e-2, fid_mode=fid_mode)
+        assert np.array_equal(cols, allcols[lo:hi]), (lo, hi)
+        assert np.array_equal(ci, info.reshape(nsims * nth, 2)[lo:hi])
+    Hi, its = prob.implicit_H_batch(11, s0, s0 + nsims, theta)
+    icol = Hi.transpose(0, 2, 1).reshape(nsims * nth, nth)
+    for lo, hi in ((1, nth + 1), (nth - 1, 2 * nth + 1)):
+        cols, ci = prob.implicit_H_columns(11, s0, lo, hi, theta)
+        assert np.array_equal(cols, icol[lo:hi]) and np.array_equal(ci, its.reshape(-1)[lo:hi])
+    with pytest.raises((M.MuseError, ValueError)):
+        prob.fd_jacobian_columns(11, 0, 5, 2, theta, step)
+    prob.close()

@@ -6,9 +6,10 @@ from museinference_jl_amd import build as B, _capi
 B.LIB_PATH = B.LIB_PATH.replace("libmuse_hip.so", __import__("os").environ.get("MUSE_STAMPS_LIB", "libmuse_hip_stamps.so"))
 lib = M.load_library()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-n = 512
 NTH = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 prob = M.HipMuseProblem(None, model="funnel", ntheta=NTH, N=N)
+if len(sys.argv) > 4: prob.set_element_split(int(sys.argv[4]))
 for _ in range(3): prob.map_and_score_batch(0,0,n,[1.0]*NTH)
 lib.muse_debug_stamps(prob._ctx, C.c_int64(n), None)
 prob.map_and_score_batch(0,0,n,[1.0]*NTH)
@@ -25,4 +26,4 @@ print("  line search detail: pre-logic", np.median(o[:,10]-st[:,3]), " eval1", n
 print("  first line-search evaluation: element loop", np.median(o[:,14]-o[:,10]), " reduction", np.median(o[:,15]-o[:,14]))
 print("total per problem", np.median(st[:,7]-st[:,0]), "cycles; first start -> last end:", (st[:,7].max()-st[:,0].min()), "cycles")
 order = np.argsort(st[:,0]); 
-print("start offsets of problems (cycles, sorted) sample:", (st[order,0]-st[:,0].min())[[0,1,100,255,256,300,511]])
+print("start offsets of problems (cycles, sorted) sample:", (st[order,0]-st[:,0].min())[[0,1,n//5,n//2-1,n//2,n-1]])

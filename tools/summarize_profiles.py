@@ -3,11 +3,17 @@ kernel-stats CSV of the --kernel-trace --stats run, and one summary row with the
 duration and the PMC counters of the separate --pmc passes (averages per solver launch).
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE under-reports by 2x on gfx950
 (MI355X_MICROARCH.md, HBM / rocprofv3 section); both counters are in KiB."""
-import csv, glob, os, shutil, sys
+import csv, glob, importlib.util, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+_bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bench)
+# the kernel sources the passes ran on: tools/profile.sh records it on the GPU box (the same tree), else this tree's
+_shafile = os.path.join(ROOT, "gpurun_out", "prof", "csrc_sha16.txt")
+CSRC_SHA = open(_shafile).read().strip() if os.path.exists(_shafile) else _bench.csrc_fingerprint()
 PROF = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 workloads = sorted({os.path.basename(d)[len("trace_"):] for d in glob.glob(os.path.join(PROF, "trace_*"))})
 
 
@@ -38,7 +44,7 @@ for w in workloads:
         c.update(counters(d + w))
     fetch, write = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
     hbm_mb = (2 * fetch + write) * 1024 / 1e6 if fetch is not None and write is not None else ""
-    rows.append({"workload": w, "kernel": k["Name"][:90], "calls": k["Calls"], "avg_us": float(k["AverageNs"]) / 1e3,
+    rows.append({"workload": w, "csrc_sha16": CSRC_SHA, "kernel": k["Name"][:120], "calls": k["Calls"], "avg_us": float(k["AverageNs"]) / 1e3,
                  "min_us": float(k["MinNs"]) / 1e3, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                  "hbm_traffic_MB": hbm_mb, **{n: c.get(n, "") for n in
                  ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU",
