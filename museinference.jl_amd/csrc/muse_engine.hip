@@ -521,6 +521,9 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     }
     const bool timed = c->timing || c->prof_on;
     if (timed) HIPCHK(hipEventRecord(e0, c->stream));
+#ifdef MUSE_INSPECT  // development aid (tools/regs.py --one): instantiate ONE kernel, for a quick look at its assembly
+    rc = launch_one<MUSE_INSPECT>(c, a, grid, lds);
+#else
     if (implicit) {
         if (c->model == MUSE_MODEL_NOISE) rc = launch_place_implicit<NoiseModel>(c, a, pl, grid, lds);
         else if (c->model == MUSE_MODEL_FUNNEL)
@@ -542,6 +545,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         rc = c->ntheta <= 2   ? launch_place<SmoothModel<2>>(c, a, pl, grid, lds)
              : c->ntheta <= 4 ? launch_place<SmoothModel<4>>(c, a, pl, grid, lds)
                               : launch_place<SmoothModel<kMaxTheta>>(c, a, pl, grid, lds);
+#endif
     if (rc) return rc;
     if (timed) {
         HIPCHK(hipEventRecord(e1, c->stream));

@@ -73,6 +73,10 @@ template <int T, int KS, int KM>
 __device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], double (&m)[KM > 0 ? KM : 1],
                                                 double* red, int& parity, int tid) {
     constexpr int NW = T / 64, K = KS + KM;
+    // (laundered: otherwise the LDS addresses derived from tid are computed once per kernel, live -- and, in the
+    // register-bound placements, spilled to scratch -- across the persistent loop, and every reduction waits for a
+    // scratch reload before its LDS write)
+    asm volatile("" : "+v"(tid));
     static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "workgroup must be 2^k waves");
     static_assert(K <= 8, "reduction scratch holds 8 values per wave");
 #pragma unroll

@@ -504,8 +504,12 @@ struct Solver {
     }
     __device__ __forceinline__ static bool wolfe(double c, double phi_c, double dphi_c, double phi_0, double dphi_0,
                                                  double phi_lim) {
-        const bool w1 = (kHzDelta * dphi_0 >= (phi_c - phi_0) / c) && (dphi_c >= kHzSigma * dphi_0);
-        const bool w2 = ((2.0 * kHzDelta - 1.0) * dphi_0 >= dphi_c) && (dphi_c >= kHzSigma * dphi_0) && (phi_c <= phi_lim);
+        // the constants are materialised here (two moves each): hoisted to the kernel's entry they stay live across
+        // the persistent loop and, in the register-bound placements, come back from scratch in every line search
+        double delta = kHzDelta, sigma = kHzSigma, delta2 = 2.0 * kHzDelta - 1.0;
+        if constexpr (Place::kResident) asm volatile("" : "+v"(delta), "+v"(sigma), "+v"(delta2));
+        const bool w1 = (delta * dphi_0 >= (phi_c - phi_0) / c) && (dphi_c >= sigma * dphi_0);
+        const bool w2 = (delta2 * dphi_0 >= dphi_c) && (dphi_c >= sigma * dphi_0) && (phi_c <= phi_lim);
         return w1 || w2;
     }
     __device__ __forceinline__ static double secant(const HzPoint& p, const HzPoint& q) {
@@ -752,15 +756,17 @@ struct Solver {
                     // the stream was drawn earlier in this host call: its normals come from HBM (all of the
                     // thread's loads in flight at once; out-of-range pairs read zeros), not from the generator
                     double c1[EPT][2], c2[EPT][2];
+                    int tl = tid;
+                    asm volatile("" : "+v"(tl));  // per-slot offsets recomputed here, not held across the kernel
 #pragma unroll
                     for (int j = 0; j < EPT; ++j) {
-                        const int i0 = 2 * (tid + j * T);
+                        const int i0 = 2 * (tl + j * T);
                         load_f64x2(n1r, i0, c1[j][0], c1[j][1]);
                         load_f64x2(n2r, i0, c2[j][0], c2[j][1]);
                     }
 #pragma unroll
                     for (int j = 0; j < EPT; ++j) {
-                        const int i0 = 2 * (tid + j * T);
+                        const int i0 = 2 * (tl + j * T);
                         double zt0, xt0, zt1, xt1;
                         Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0);
                         Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1);
@@ -1404,14 +1410,16 @@ struct Solver {
                 });
                 reduce<MAXB, 0>(acc, mx);
             }
-            if (tid < MAXB && tid < a.ntheta && crank == 0) {  // lane b finishes and writes score component b
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            if (tl < MAXB && tl < a.ntheta && crank == 0) {  // lane b finishes and writes score component b
                 double mine = acc[0];
 #pragma unroll
-                for (int b = 1; b < MAXB; ++b) mine = (tid == b) ? acc[b] : mine;
-                const double cnt = (double)(a.bnd32[tid < a.ntheta - 1 ? tid + 1 : 0] - a.bnd32[tid]);
-                const double cnt_last = (double)((int)a.N - a.bnd32[tid]);  // bnd32[ntheta] is a sentinel, not N
-                a.scores[(int64_t)p * a.ntheta + tid] =
-                    0.5 * (a.tmap.iv[tid] * mine - (tid == a.ntheta - 1 ? cnt_last : cnt));
+                for (int b = 1; b < MAXB; ++b) mine = (tl == b) ? acc[b] : mine;
+                const double cnt = (double)(a.bnd32[tl < a.ntheta - 1 ? tl + 1 : 0] - a.bnd32[tl]);
+                const double cnt_last = (double)((int)a.N - a.bnd32[tl]);  // bnd32[ntheta] is a sentinel, not N
+                a.scores[(int64_t)p * a.ntheta + tl] =
+                    0.5 * (a.tmap.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
             }
             if (tid == 0 && crank == 0) {
                 muse_info inf;

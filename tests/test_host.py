@@ -269,6 +269,12 @@ def test_bench_accounting_helpers():
     info["f_calls"], info["iterations"], info["hist_words"] = [3, 3, 5], [1, 1, 2], [0, 0, 1]
     # funnel at theta != 0: E=3, K=1 -> 22 words; third sim E=5, K=2, one pair used -> 1 + 25 + (4 + 8) + 2 = 40
     assert bench.algorithmic_bytes(info, 10) == 8 * 10 * (22 + 22 + 40)
+    # compulsory HBM bytes of the placement that ran: resident = zhat out (+ pairs and two-loop reads for K > 1);
+    # streaming elementwise K = 1, E = 3 = 7 words (x, s | s, x | s, x, z)
+    assert bench.compulsory_bytes(info, 10, "resident") == 8 * 10 * (1 + 1 + (1 + 2 + 4))
+    assert bench.compulsory_bytes(info[:2], 10, "streaming") == 8 * 10 * (7 + 7)
+    assert bench.compulsory_bytes(info[2:], 10, "stencil") == 8 * 10 * (6 + 4 + 3 * 4 + 11 + 4 + 8)
+    assert len(bench.csrc_fingerprint()) == 16
     assert 1 <= bench.usable_cores(4) <= 4
     assert bench.measured_traffic("no_such_workload") is None
     assert set(bench.WORKLOADS) >= {"funnel_1e4", "funnel_512", "noise_1e6", "funnel4_1e4", "smooth_1e5"}

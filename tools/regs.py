@@ -1,11 +1,67 @@
-"""Diagnostic: register / spill / scratch figures of every solver kernel variant from the device assembly
-(hipcc -S --cuda-device-only ... -o file.s)."""
-import re, sys
-txt = open(sys.argv[1]).read()
-for b in txt.split('  - .agpr_count:')[1:]:
-    name = re.search(r'\.name:\s+(\S+)', b).group(1)
-    if 'map_score' not in name:
-        continue
-    g = lambda k: re.search(r'\.%s:\s+(\d+)' % k, b).group(1)
-    short = name.replace('_ZN4muse16map_score_kernelINS_', '').replace('EvNS_9BatchArgsE', '')
-    print(f"{short:70s} vgpr {g('vgpr_count'):>3s} agpr {b.split(chr(10))[0].strip():>3s} vspill {g('vgpr_spill_count'):>3s} sspill {g('sgpr_spill_count'):>3s} scratch {g('private_segment_fixed_size')}")
+"""Registers / spills / scratch of the solver kernel variants, from the device assembly.
+
+  python tools/regs.py file.s           report every map_score_kernel variant of an assembly file
+                                        (hipcc -S --cuda-device-only ... muse_engine.hip -o file.s: ~2.5 min for all)
+  python tools/regs.py --check          compile ONLY the hot instantiations (-DMUSE_INSPECT=..., a few seconds each)
+                                        and fail if one of them spills vector registers to scratch
+The hot instantiations: the resident kernels of BASELINE.json configs[1] (funnel, 1 theta) and of the noise model
+at N <= 10^4 must have vgpr_spill_count == 0 (a spilled value comes back from scratch in the line search and in
+every reduction); the other variants are reported with their budget."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "museinference.jl_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-S", "--cuda-device-only"]
+# (instantiation, largest tolerated vgpr_spill_count)
+HOT = [
+    ("FunnelModel<1>, PlaceResident<512, 10, true>", 0),
+    ("NoiseModel, PlaceResident<512, 10, true>", 0),
+    ("FunnelModel<4>, PlaceResident<512, 10, true>", 24),
+    ("FunnelModel<1>, PlaceResident<512, 3, false, true>", 4),
+    ("NoiseModel, PlaceStreaming<256, true>", 0),
+    ("SmoothModel<8>, PlaceStreaming<256, true, 4>", 28),
+]
+
+
+def report(path):
+    rows = []
+    txt = open(path).read()
+    for b in txt.split('  - .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', b).group(1)
+        if 'map_score' not in name:
+            continue
+        g = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, b).group(1))
+        short = name.replace('_ZN4muse16map_score_kernelINS_', '').replace('EvNS_9BatchArgsE', '')
+        rows.append((short, g('vgpr_count'), g('vgpr_spill_count'), g('sgpr_spill_count'), g('private_segment_fixed_size')))
+    return rows
+
+
+def compile_one(inst, out):
+    hipcc = "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc] + FLAGS + ["-DMUSE_INSPECT=" + inst, os.path.join(CSRC, "muse_engine.hip"), "-o", out],
+                          cwd=CSRC, stderr=subprocess.DEVNULL)
+
+
+def check():
+    bad = []
+    with tempfile.TemporaryDirectory() as d:
+        for inst, limit in HOT:
+            out = os.path.join(d, "one.s")
+            compile_one(inst, out)
+            (short, vgpr, vspill, sspill, scratch), = report(out)
+            ok = vspill <= limit
+            print(f"{inst:55s} vgpr {vgpr:3d} vspill {vspill:3d} (limit {limit:2d}) sspill {sspill:3d} scratch {scratch:3d} {'ok' if ok else 'FAIL'}")
+            if not ok:
+                bad.append(inst)
+    return bad
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        sys.exit(1 if check() else 0)
+    for short, vgpr, vspill, sspill, scratch in report(sys.argv[1]):
+        print(f"{short:70s} vgpr {vgpr:3d} vspill {vspill:3d} sspill {sspill:3d} scratch {scratch}")
