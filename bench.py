@@ -267,13 +267,22 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
     sharded = world > 1 or os.environ.get("MUSE_BENCH_FORCE_DIST") == "1"  # the env var exercises the N>1 path on one GPU
+    # MUSE_BENCH_BACKEND=gloo (development aid): several ranks on ONE GPU, gloo collectives on host tensors -- exercises the
+    # partition / padding / gather logic of the N > 1 path on a one-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("MUSE_BENCH_BACKEND", "nccl")
+    tdev = "cuda" if backend == "nccl" else "cpu"
+    if backend != "nccl":
+        local_rank = 0
     if sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     model, N, nth, theta, nsims = WORKLOADS[args.workload]
     seed = 0
@@ -309,17 +318,19 @@ def main():
         # second stream from C).  Fallback, agreed on by all ranks: torch.distributed's all_gather.
         ok = 1
         try:
+            if backend != "nccl":
+                raise RuntimeError("gloo test mode")
             uid = [M.HipMuseProblem.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             prob.comm_init(world, rank, uid[0])
         except Exception as e:  # noqa: BLE001 -- any failure means "use the fallback", on every rank
             print(f"[bench rank {rank}] engine RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         collective = "rccl-capi" if int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch" else "torch"
         if collective == "torch":
-            gather_buf = [torch.empty(rows * nth, dtype=torch.float64, device="cuda") for _ in range(world)]
+            gather_buf = [torch.empty(rows * nth, dtype=torch.float64, device=tdev) for _ in range(world)]
 
     AREAS = 4
     host_t = [0.0, 0.0]  # host seconds spent enqueueing / waiting+collecting (reported under "host_us_per_step")
@@ -355,7 +366,7 @@ def main():
             if collective == "torch":
                 pad = np.zeros(rows * nth)
                 pad[: g.size] = g.reshape(-1)
-                dist.all_gather(gather_buf, torch.from_numpy(pad).cuda())
+                dist.all_gather(gather_buf, torch.from_numpy(pad).to(tdev))
         if collect is not None:
             collect.append((g, info))
 
@@ -381,13 +392,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if sharded:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         rounds.append(dt)
         more = 1 if (sum(rounds) < args.min_seconds and len(rounds) < 100000) else 0
         if sharded:
-            flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device=tdev)
             dist.broadcast(flag, src=0)
             more = int(flag.item())
         if not more:
@@ -470,11 +481,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, N, theta, seed)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    if rank == 0:
-        print(json.dumps(out))
     if sharded:
         prob.close()
         dist.destroy_process_group()
+    if rank == 0:  # last: RCCL writes its own banner to stdout while the communicator is set up and torn down
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

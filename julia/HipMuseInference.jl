@@ -113,7 +113,8 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
             sqrt(-(Δθ' * history[end].H⁻¹_post′ * Δθ)) < θ_rtol && break
         end
         z0_mode = i == length(history) + 1 ? 0 : 2     # zero(z) first, then warm starts (src/muse.jl:151,181)
-        gs, _ = map_and_score_batch(prob, seed, 0:nsims-1, θ; include_data=true, atol=∇z_logLike_atol, z0_mode)
+        t₀ = time()
+        gs, infos = map_and_score_batch(prob, seed, 0:nsims-1, θ; include_data=true, atol=∇z_logLike_atol, z0_mode)
         g_like_dat, g_like_sims = gs[1], gs[2:end]
         g_like′ = g_like_dat .- mean(g_like_sims)
         g_prior′ = MuseInference.AD.gradient(MuseInference.AD.ForwardDiffBackend(), θ -> logPriorθ(prob, θ), θ)[1]
@@ -121,7 +122,12 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
         H⁻¹_like′ = Diagonal(-1 ./ var(g_like_sims))
         H_prior′ = MuseInference.AD.hessian(MuseInference.AD.ForwardDiffBackend(), θ -> logPriorθ(prob, θ), θ)[1]
         H⁻¹_post′ = inv(inv(H⁻¹_like′) + H_prior′)
-        push!(history, (;θ, θ′=θ, g_like_sims, g_like′, g_prior′, g_post′, H⁻¹_post′, H_prior′, H⁻¹_like′))
+        # the reference's record, all 19 fields (src/muse.jl:211-221); this problem type has identity transforms,
+        # no `regularize` and the "sims" Jacobian update, so several fields coincide
+        push!(history, (;θ, θunreg=θ, θ′=θ, θunreg′=θ, g_like_sims, g_like_dat′=g_like_dat, g_like_sims′=g_like_sims,
+                        g_like′, g_prior′, g_post′, H⁻¹_post′, H_prior′, H⁻¹_like′, H⁻¹_like_sims′=H⁻¹_like′,
+                        ẑ_history_dat=infos[1], ẑ_history_sims=infos[2:end], t=time()-t₀, ẑ_dat=nothing,
+                        ẑ_sims=fill(nothing, nsims)))
         θ = θ .- α .* (H⁻¹_post′ * g_post′)
         result.θ = θ
         result.gs = g_like_sims
@@ -131,6 +137,22 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
         get_H!(result, prob; rng=seed, nsims=max(1, nsims ÷ 10), ∇z_logLike_atol)
     end
     result
+end
+
+# Workgroups per map element (include/muse_hip.h: muse_set_element_split) -- for launches with fewer elements than
+# the GPU has compute units, e.g. a rank's share of a strongly scaled map.
+set_element_split(prob::HipMuseProblem, split::Integer) =
+    check(ccall((:muse_set_element_split, libmuse_hip), Cint, (Ptr{Cvoid}, Cint), prob.ctx, split))
+
+# Columns [col_begin, col_end) of the list (sim_begin, column 0), (sim_begin, column 1), ...: the unit a worker takes when
+# get_H! maps over Jacobian columns instead of sims (src/muse.jl:327-333).  Returns an nθ x n matrix of columns.
+function fd_jacobian_columns(prob::HipMuseProblem, seed::Integer, sim_begin, col_begin, col_end, θ₀, step; atol=1e-2)
+    cols = Matrix{Float64}(undef, prob.nθ, col_end - col_begin)
+    check(ccall((:muse_fd_jacobian_columns, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Cint, Int64, Ptr{Float64}, Ptr{Cvoid}),
+                prob.ctx, seed, sim_begin, col_begin, col_end, standardizeθ(prob, θ₀), collect(Float64, step), atol, 0, (1 << 62) - 1,
+                cols, C_NULL))
+    cols
 end
 
 # The same loop run by the library's native host code (muse_run of include/muse_hip.h): for a flat or

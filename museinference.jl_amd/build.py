@@ -2,6 +2,9 @@
 
 The shared library is kept next to this file so that it travels with a repository snapshot to a
 GPU box (it is git-ignored, not gpurun-ignored).  hipcc cross-compiles without a GPU present.
+Three translation units, each compiled to an object of its own and rebuilt only when it (or a header it
+includes) changed: muse_kernels.hip holds ALL device code (minutes: every model x placement instantiation of
+the solver kernel), muse_engine.cpp the host side and the C ABI (seconds), muse_comm.cpp the RCCL layer.
 """
 import os
 import shutil
@@ -10,37 +13,72 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmuse_hip.so")
-SOURCES = [os.path.join(CSRC, "muse_engine.hip"), os.path.join(CSRC, "muse_comm.cpp")]
-HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "solver.hpp")] + \
-    [os.path.join(_HERE, "..", "include", "muse_hip.h")]
+OBJ_DIR = os.path.join(_HERE, "build")
+_API = os.path.join(_HERE, "..", "include", "muse_hip.h")
+_KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "solver.hpp")]
+# source -> (headers it depends on, extra flags)
 # -ffp-contract=off: the sampler's log/sincos sequences and the model gradients are defined in terms
 # of individually rounded IEEE operations (bit-equal to a host evaluation of the same sequence).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-value"]
+UNITS = {
+    "muse_kernels.hip": (_KERNEL_HEADERS + [_API], ["--offload-arch=gfx950", "-O3", "-ffp-contract=off"]),
+    # host code: plain C++ against the HIP runtime API (no device pass)
+    "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), _API], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
+    "muse_comm.cpp": ([_API], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
+}
+COMMON_FLAGS = ["-std=c++17", "-fPIC", "-Wno-unused-value"]
+SOURCES = [os.path.join(CSRC, s) for s in UNITS]
+HEADERS = _KERNEL_HEADERS + [_API]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in deps)
 
 
 def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    return _stale(LIB_PATH, SOURCES + HEADERS)
 
 
-def build_extension(force=False, verbose=False):
-    """Compile the HIP engine; returns the path of the shared library."""
-    if not force and not needs_build():
+def build_extension(force=False, verbose=False, defines=(), lib_path=None):
+    """Compile the HIP engine; returns the path of the shared library.  `defines` (e.g. ["-DMUSE_STAMPS"]) and
+    `lib_path` build a diagnostic variant next to the product library (objects are not cached for those)."""
+    lib_path = lib_path or LIB_PATH
+    variant = bool(defines) or lib_path != LIB_PATH
+    if not force and not variant and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmuse_hip.so")
-    tmp = LIB_PATH + ".tmp"
-    cmd = [hipcc] + HIPCC_FLAGS + SOURCES + ["-o", tmp, "-ldl"]
+    obj_dir = OBJ_DIR + ("_variant" if variant else "")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, procs = [], []
+    for src, (deps, flags) in UNITS.items():
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or variant or _stale(obj, [path] + deps):
+            cmd = [hipcc] + COMMON_FLAGS + flags + list(defines) + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:  # the units compile side by side
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    tmp = lib_path + ".tmp"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-ldl"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
+    os.replace(tmp, lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_extension(force=True, verbose=True))
+    import sys
+    if "--stamps" in sys.argv:  # the -DMUSE_STAMPS diagnostic build read by tools/stamps.py
+        print(build_extension(force=True, verbose=True, defines=["-DMUSE_STAMPS"],
+                              lib_path=os.path.join(_HERE, "libmuse_hip_stamps.so")))
+    else:
+        print(build_extension(force=True, verbose=True))

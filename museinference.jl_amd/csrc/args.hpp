@@ -1,4 +1,4 @@
-// args.hpp -- constants, the kernel argument block and the element -> problem map of the MUSE engine (see muse_engine.hip).
+// args.hpp -- constants, the kernel argument block and the element -> problem map of the MUSE engine (see muse_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,6 +31,15 @@ struct ThetaSet {
 enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
 enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
 enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2, BATCH_IMPLICIT = 3 };
+
+// Storage policies / launch shapes of the solver kernel (models.hpp has the types).  P_CRx: register-resident clusters of
+// 2 / 4 / 8 workgroups of 512 threads with 5 / 3 / 2 pairs per thread (capacity 5120 / 6144 / 8192 pairs >=
+// kMaxResidentN / 2), selected by muse_set_element_split.
+enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5, P_CR2 = 6, P_CR4 = 7, P_CR8 = 8 };
+#ifndef MUSE_STENCIL_U
+#define MUSE_STENCIL_U 4
+#endif
+constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil model (register budget: see tools/regs.py)
 
 struct BatchArgs {
     int64_t N, ld;
@@ -83,6 +92,7 @@ struct ProblemDesc {
     int64_t zslot, z0slot;         // zslot < 0: zhat not stored
 };
 
+#ifdef __HIPCC__
 __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     ProblemDesc d;
     d.normals_only = false;
@@ -129,6 +139,18 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     d.nslot = (a.ncache && d.sim >= 0 && ns >= 0 && ns < a.ncache_count) ? (int)ns : -1;
     return d;
 }
+#endif  // __HIPCC__
+
+// launch shims of muse_kernels.hip (the only translation unit that holds device code)
+struct LaunchShape {
+    int model, ntheta, place, grid;
+    bool implicit;
+    size_t lds;
+};
+hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);
+hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t stream);
+hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t stream);
+constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS copy of the kernel arguments
 
 
 }  // namespace muse

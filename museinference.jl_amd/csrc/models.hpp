@@ -1,4 +1,4 @@
-// models.hpp -- the compiled-in models, the storage policies (placements) and the HagerZhang point type (see muse_engine.hip).
+// models.hpp -- the compiled-in models, the storage policies (placements) and the HagerZhang point type (see muse_kernels.hip).
 #pragma once
 #include <type_traits>
 

@@ -76,7 +76,7 @@ bool load_rccl() {
 }
 }  // namespace
 
-// accessors implemented in muse_engine.hip (the context layout is private to that file)
+// accessors implemented in muse_engine.cpp (the context layout is private to that file)
 extern "C" {
 int muse_ctx_comm_slot(muse_ctx* ctx, void*** comm, int* device, void** stream);
 int muse_ctx_comm_buffer(muse_ctx* ctx, size_t doubles, double** buf);

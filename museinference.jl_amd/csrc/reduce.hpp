@@ -1,4 +1,4 @@
-// reduce.hpp -- workgroup-uniform scalars and the fixed-shape workgroup all-reduce (see muse_engine.hip).
+// reduce.hpp -- workgroup-uniform scalars and the fixed-shape workgroup all-reduce (see muse_kernels.hip).
 #pragma once
 #include "args.hpp"
 

@@ -1,4 +1,4 @@
-// solver.hpp -- one element of a batch: sample_x_z -> L-BFGS/HagerZhang MAP over z -> grad_theta score (see muse_engine.hip).
+// solver.hpp -- one element of a batch: sample_x_z -> L-BFGS/HagerZhang MAP over z -> grad_theta score (see muse_kernels.hip).
 #pragma once
 #include <math.h>
 

@@ -1,4 +1,4 @@
-// vec.hpp -- vector accessors of the two storage policies and the per-thread element loop (see muse_engine.hip).
+// vec.hpp -- vector accessors of the two storage policies and the per-thread element loop (see muse_kernels.hip).
 #pragma once
 #include "args.hpp"
 

@@ -1,4 +1,4 @@
-// Cost of the solver's workgroup reduction (block_allreduce of muse_engine.hip, copied below by tools/mk_redbench.py)
+// Cost of the solver's workgroup reduction (block_allreduce of csrc/reduce.hpp)
 // at the solver's occupancy: 512 threads per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

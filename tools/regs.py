@@ -1,7 +1,7 @@
 """Registers / spills / scratch of the solver kernel variants, from the device assembly.
 
   python tools/regs.py file.s           report every map_score_kernel variant of an assembly file
-                                        (hipcc -S --cuda-device-only ... muse_engine.hip -o file.s: ~2.5 min for all)
+                                        (hipcc -S --cuda-device-only ... muse_kernels.hip -o file.s: ~2.5 min for all)
   python tools/regs.py --check          compile ONLY the hot instantiations (-DMUSE_INSPECT=..., a few seconds each)
                                         and fail if one of them spills vector registers to scratch
 The hot instantiations: the resident kernels of BASELINE.json configs[1] (funnel, 1 theta) and of the noise model
@@ -42,7 +42,7 @@ def report(path):
 
 def compile_one(inst, out):
     hipcc = "/opt/rocm/bin/hipcc"
-    subprocess.check_call([hipcc] + FLAGS + ["-DMUSE_INSPECT=" + inst, os.path.join(CSRC, "muse_engine.hip"), "-o", out],
+    subprocess.check_call([hipcc] + FLAGS + ["-DMUSE_INSPECT=" + inst, os.path.join(CSRC, "muse_kernels.hip"), "-o", out],
                           cwd=CSRC, stderr=subprocess.DEVNULL)
 
 
