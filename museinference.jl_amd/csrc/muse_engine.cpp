@@ -178,6 +178,12 @@ static bool ensure_ncache(muse_ctx* c, int64_t slots) {
     c->ncache_slots = 0;
     if (hipMalloc(&c->ncache, (size_t)slots * 2 * c->ld * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError();
+        static bool warned = false;
+        if (!warned) {  // the results are the same bits either way; only the generator runs again
+            fprintf(stderr, "[libmuse_hip] normals cache of %lld slots not allocated: simulations are re-drawn by the generator\n",
+                    (long long)slots);
+            warned = true;
+        }
         return false;
     }
     c->ncache_slots = slots;
@@ -212,7 +218,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         a.bnd32[k] = k < c->ntheta ? (int)c->bnd[k] : 0x7fffffff;
     }
     a.x_data = c->x_data;
-    a.zhat = c->zhat;
+    if (!a.zhat) a.zhat = c->zhat;
     a.work_counter = c->counter;
     a.debug = c->debug;
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
@@ -620,11 +626,8 @@ int muse_zhat_at_theta(muse_ctx* c, const double* x, const double* z0, const dou
     a.x_given = dx;
     a.scores = c->scores_dev[kResultAreas - 1];
     a.info = c->info_dev[kResultAreas - 1];
-    // run with zhat pointing at the tmp z vector (slot 0 of a 1-slot view)
-    double* saved = c->zhat;
-    c->zhat = dz;
+    a.zhat = dz;  // the element's z lives in the tmp vector (slot 0 of a one-slot view), not in the batch slots
     rc = launch_batch(c, a);
-    c->zhat = saved;
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(z_out, dz, (size_t)c->N * sizeof(double), out_kind(mem), c->stream));
     rc = enqueue_results_copy(c, kResultAreas - 1, 1);

@@ -1,13 +1,39 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeds.
 
 Tolerances (fp64, stated per north_star): the sampler is bit-exact; scores/logLike rtol 1e-10;
-MAPs agree to 1e-9 absolute when both sides follow the same L-BFGS path (same iteration and
-evaluation counts are asserted).
+MAPs agree to 1e-9 absolute when both sides follow the same L-BFGS path.
+
+Iteration-count parity is empirical, not a theorem: the kernel reduces in a fixed tree, the oracle
+sequentially, and over a long solve the O(sqrt(N) eps) difference of a dot product can move an evaluation count by one
+or two.  Every case committed here follows the same path today and `assert_same_path_or_close` says so loudly if a
+future change moves one: equal counts => the tight tolerances; different counts => both solves must still have
+converged and agree to what the MAP tolerance implies, |dz|_inf <= 2 atol / lambda_min(Hessian) (lambda_min >= 1 for the
+elementwise models, >= e^{-theta_max} for the stencil model), scores to the same accuracy.
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def assert_same_path_or_close(info, io, z, zo, g, go, atol, theta, model, ctx=""):
+    """info/io: solver infos (GPU / oracle) of the same elements; z, zo: MAPs [n, N]; g, go: scores [n, ntheta] or None."""
+    info, io = np.atleast_1d(info), np.atleast_1d(io)
+    z, zo = np.atleast_2d(z), np.atleast_2d(zo)
+    assert np.array_equal(info["status"], io["status"]), ctx
+    same = (info["iterations"] == io["iterations"]) & (info["f_calls"] == io["f_calls"])
+    np.testing.assert_allclose(z[same], zo[same], rtol=0, atol=1e-9, err_msg=ctx)
+    if g is not None:
+        np.testing.assert_allclose(np.atleast_2d(g)[same], np.atleast_2d(go)[same], rtol=1e-10, err_msg=ctx)
+    if not same.all():  # (never taken by a committed case: see the module docstring)
+        lam = 1.0 if model != "smooth" else float(np.exp(-np.max(theta)))
+        bound = 2 * atol / lam
+        assert np.abs(z[~same] - zo[~same]).max() <= bound, ctx
+        if g is not None:
+            N = z.shape[1]
+            np.testing.assert_allclose(np.atleast_2d(g)[~same], np.atleast_2d(go)[~same], rtol=0,
+                                       atol=bound * np.sqrt(N) * (1 + np.abs(zo[~same]).max()), err_msg=ctx)
+    return same
 
 CASES = [  # (model, N, ntheta, theta)
     ("funnel", 512, 1, [1.0]),
@@ -65,10 +91,12 @@ def test_zhat_at_theta(gpu, M, O, model, N, nth, theta, atol):
     z0 = np.zeros(N)
     zh, info = prob.zhat_at_theta(x, z0, theta, atol)
     zo, io = O.zhat_at_theta(model, x, z0, theta, atol)
-    assert info["status"] == io["status"]
-    assert (info["iterations"], info["f_calls"]) == (io["iterations"], io["f_calls"])
+    ioa = np.zeros(1, dtype=M._capi.INFO_DTYPE)
+    for k in io:
+        ioa[k] = io[k]
+    same = assert_same_path_or_close(np.array([info]), ioa, zh, zo, None, None, atol, theta, model)
+    assert same.all(), "a committed case left the oracle's L-BFGS path (see the module docstring)"
     assert info["hist_words"] == io["hist_words"]
-    np.testing.assert_allclose(zh, zo, rtol=0, atol=1e-9)
     np.testing.assert_allclose(info["f_min"], io["f_min"], rtol=1e-11)
     prob.close()
 
@@ -81,12 +109,9 @@ def test_map_and_score_batch(gpu, M, O, model, N, nth, theta, z0_mode):
     nsims = 6 if N > 20000 else 19
     g, info = prob.map_and_score_batch(42, 3, 3 + nsims, theta, include_data=True, atol=1e-2, z0_mode=z0_mode)
     go, zo, io = O.map_and_score_batch(model, N, 42, 3, 3 + nsims, theta, atol=1e-2, x_data=xdata, z0_mode=z0_mode)
-    assert np.array_equal(info["iterations"], io["iterations"])
-    assert np.array_equal(info["f_calls"], io["f_calls"])
-    assert np.array_equal(info["status"], io["status"])
-    np.testing.assert_allclose(g, go, rtol=1e-10)
     zh = prob.get_zhat(0, nsims + 1)
-    np.testing.assert_allclose(zh, zo, rtol=0, atol=1e-9)
+    same = assert_same_path_or_close(info, io, zh, zo, g, go, 1e-2, theta, model)
+    assert same.all(), "a committed case left the oracle's L-BFGS path (see the module docstring)"
     # warm restart from the resident MAPs at a nearby theta
     th2 = np.asarray(theta) + 0.05
     g2, info2 = prob.map_and_score_batch(42, 3, 3 + nsims, th2, include_data=True, atol=1e-2, z0_mode=M.Z0_WARM)
@@ -185,10 +210,9 @@ def test_fuzz_sizes_and_models(gpu, M, O):
             g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=1e-4, z0_mode=0)
             go, zo, io = O.map_and_score_batch(model, N, seed, s0, s0 + n, theta, atol=1e-4, z0_mode=0, nthreads=4)
             ctx = f"{model} N={N} ntheta={nth}"
-            assert np.array_equal(info["iterations"], io["iterations"]) and np.array_equal(info["f_calls"], io["f_calls"]), ctx
-            assert np.array_equal(info["status"], io["status"]), ctx
+            same = assert_same_path_or_close(info, io, prob.get_zhat(0, n), zo, None, None, 1e-4, theta, model, ctx)
+            assert same.all(), ctx + ": left the oracle's L-BFGS path (see the module docstring)"
             np.testing.assert_allclose(g, go, rtol=1e-9, atol=1e-9, err_msg=ctx)
-            np.testing.assert_allclose(prob.get_zhat(0, n), zo, rtol=0, atol=1e-9, err_msg=ctx)
             x, z = prob.sample_x_z(M.SimRng(seed, s0), theta)
             xo, zz = O.sample_x_z(model, N, seed, s0, theta)
             assert np.array_equal(x, xo) and np.array_equal(z, zz), ctx
