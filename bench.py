@@ -96,7 +96,7 @@ def csrc_fingerprint():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "museinference.jl_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        if f.endswith((".hip", ".hpp")):  # device code only: muse_kernels.hip and the headers it includes
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -307,7 +307,10 @@ def main():
     split = args.split
     if split < 0:
         split = 1
-        while split < 4 and 2 * split * rows <= cus and N > 512:  # 8 never paid (tools/split_bench.py)
+        # (resident placements only: above muse_max_resident_n, and for the stencil model, the cluster size is a function
+        # of N alone already; 8 never paid, tools/split_bench.py)
+        splittable = model != "smooth" and 512 < N <= M.load_library().muse_max_resident_n()
+        while splittable and split < 4 and 2 * split * rows <= cus:
             split *= 2
     if split > 1:
         prob.set_element_split(split)
