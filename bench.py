@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="repeat the timed region (EXACTLY --steps steps between barriers, every time) until this much "
                          "time has been measured; ms_per_step is the mean over the repetitions")
+    ap.add_argument("--nsims", type=int, default=0, help="development aid: sims per step instead of the workload's own "
+                    "(e.g. 64 = one rank's share of the strongly scaled 8-GPU step, on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed muse!/get_H! rates")
     args = ap.parse_args()
@@ -285,6 +287,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     model, N, nth, theta, nsims = WORKLOADS[args.workload]
+    if args.nsims > 0:
+        nsims = args.nsims
     seed = 0
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=local_rank)
     if args.placement >= 0:

@@ -13,7 +13,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/muse_hip.h"
 
@@ -55,6 +59,25 @@ struct CommState {
     hipEvent_t kdone[kAreas] = {nullptr};  // solver launch of the area finished (recorded on the solver stream)
     hipEvent_t gdone[kAreas] = {nullptr};  // gathered block landed in recv_pin (recorded on cstream)
     bool pending[kAreas] = {false};
+    // The collective of a gathered map is enqueued by a worker thread of the communicator: the caller's thread returns
+    // as soon as the solver is launched (measured on the host: solver launch 7.5 us; stream-wait + ncclAllGather +
+    // event 14-18 us -- in one thread the N > 1 step was host-bound at ~25 us of enqueueing against a 22 us solver).
+    // One communicator, one collective stream: a gather occupies that stream for 35-40 us (one rank), which is what
+    // bounds a strongly scaled step; duplicates of the communicator (ncclCommSplit) on streams of their own, one per
+    // result area, were measured to make everything worse (collective kernels of several steps resident at once take
+    // the CUs the cluster solver needs: 85 us per step against 37).
+    std::thread worker;
+    std::mutex mu;                   // serialises every use of `comm` (RCCL: one thread at a time) and the worker's error
+    std::mutex qmu;                  // the queue
+    std::condition_variable cv;
+    int queue[kAreas] = {0};         // areas whose gather is to be enqueued, FIFO
+    int q_head = 0, q_tail = 0;      // monotonically increasing positions (mod kAreas)
+    std::atomic<int> enqueued[kAreas];  // 1: the area's gather has been handed to the collective stream
+    bool stop = false;
+    int device = 0;
+    int worker_rc = 0;               // first error of the worker (reported by muse_batch_wait_gathered)
+    std::string worker_err;
+    CommState() { for (int a = 0; a < kAreas; ++a) enqueued[a].store(0); }
 };
 
 bool load_rccl() {
@@ -111,6 +134,46 @@ static CommState* state_of(muse_ctx* ctx, void** stream_out = nullptr) {
             return muse_set_error(MUSE_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
     } while (0)
 
+// The worker: waits for an area, then  collective stream <- wait(solver done) ; all-gather ; copy ; record(gdone).
+static void comm_worker(CommState* st) {
+    (void)hipSetDevice(st->device);
+    for (;;) {
+        int area;
+        size_t cnt;
+        {
+            std::unique_lock<std::mutex> lk(st->qmu);
+            st->cv.wait(lk, [&] { return st->stop || st->q_head != st->q_tail; });
+            if (st->q_head == st->q_tail) return;  // stop requested and nothing left
+            area = st->queue[st->q_head % kAreas];
+            st->q_head += 1;
+            cnt = st->count[area];
+        }
+        {
+            std::lock_guard<std::mutex> lk(st->mu);  // RCCL calls on one communicator must not overlap
+            hipError_t e = hipStreamWaitEvent(st->cstream, st->kdone[area], 0);
+            ncclResult_t r = 0;
+            if (e == hipSuccess) {
+                if (st->direct_host) {
+                    // the collective's receive buffer IS the pinned host block (device-mapped): no copy operation follows
+                    r = g_rccl.AllGather(st->send_dev[area], st->recv_pin[area], cnt, ncclFloat64, st->comm, st->cstream);
+                } else {
+                    r = g_rccl.AllGather(st->send_dev[area], st->recv_dev[area], cnt, ncclFloat64, st->comm, st->cstream);
+                    if (r == 0)
+                        e = hipMemcpyAsync(st->recv_pin[area], st->recv_dev[area], cnt * st->nranks * sizeof(double),
+                                           hipMemcpyDeviceToHost, st->cstream);
+                }
+            }
+            if (e == hipSuccess && r == 0) e = hipEventRecord(st->gdone[area], st->cstream);
+            if ((e != hipSuccess || r != 0) && st->worker_rc == 0) {
+                st->worker_rc = r != 0 ? MUSE_ERR_RCCL : MUSE_ERR_HIP;
+                st->worker_err = r != 0 ? std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")
+                                        : std::string("collective stream: ") + hipGetErrorString(e);
+            }
+        }
+        st->enqueued[area].store(1, std::memory_order_release);
+    }
+}
+
 extern "C" {
 
 int muse_comm_unique_id(void* id_out) {
@@ -154,6 +217,8 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
         HIPCHK2(hipEventCreateWithFlags(&st->kdone[a], hipEventDisableTiming));
         HIPCHK2(hipEventCreateWithFlags(&st->gdone[a], hipEventDisableTiming));
     }
+    st->device = device;
+    st->worker = std::thread(comm_worker, st);
     *slot = st;
     return MUSE_OK;
 }
@@ -166,6 +231,12 @@ int muse_comm_destroy(muse_ctx* ctx) {
     if (rc) return rc;
     if (CommState* st = (CommState*)*slot) {
         hipSetDevice(device);
+        {
+            std::lock_guard<std::mutex> lk(st->qmu);
+            st->stop = true;
+        }
+        st->cv.notify_all();
+        if (st->worker.joinable()) st->worker.join();
         if (st->cstream) hipStreamSynchronize(st->cstream);
         if (st->comm && g_rccl.h) g_rccl.CommDestroy(st->comm);
         for (int a = 0; a < kAreas; ++a) {
@@ -197,6 +268,7 @@ int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, doub
     rc = muse_ctx_comm_buffer(ctx, (size_t)count * (size_t)(nranks + 1), &buf);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(((CommState*)*slot)->mu);
     HIPCHK2(hipMemcpyAsync(buf, send, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
     RCCLCHK(g_rccl.AllGather(buf, buf + count, (size_t)count, ncclFloat64, comm, st));
     HIPCHK2(hipMemcpyAsync(recv_out, buf + count, (size_t)count * nranks * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -217,6 +289,7 @@ int muse_allreduce_sum(muse_ctx* ctx, double* hostbuf, int64_t count) {
     rc = muse_ctx_comm_buffer(ctx, (size_t)count, &buf);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(((CommState*)*slot)->mu);
     HIPCHK2(hipMemcpyAsync(buf, hostbuf, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
     RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat64, ncclSum, ((CommState*)*slot)->comm, st));
     HIPCHK2(hipMemcpyAsync(hostbuf, buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -259,26 +332,23 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
     rc = ensure_gather_buffers(st, area, cnt);
     if (rc) return rc;
     hipStream_t ks = (hipStream_t)stream;
-    // the area's previous gather must have drained its send buffer before the solver overwrites it
-    if (st->pending[area]) HIPCHK2(hipStreamWaitEvent(ks, st->gdone[area], 0));
+    if (st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "a gather is still in flight on this result area");
+    // (the area's previous gather has been awaited -- pending is clear -- so its send buffer is free again)
     if ((size_t)n * nt < cnt)  // padding rows of a short block are zeros
         HIPCHK2(hipMemsetAsync(st->send_dev[area] + (size_t)n * nt, 0, (cnt - (size_t)n * nt) * sizeof(double), ks));
     rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area,
                                  st->send_dev[area]);
     if (rc) return rc;
     HIPCHK2(hipEventRecord(st->kdone[area], ks));
-    HIPCHK2(hipStreamWaitEvent(st->cstream, st->kdone[area], 0));
-    if (st->direct_host) {
-        // the collective's receive buffer IS the pinned host block (device-mapped): no copy operation follows
-        RCCLCHK(g_rccl.AllGather(st->send_dev[area], st->recv_pin[area], cnt, ncclFloat64, st->comm, st->cstream));
-    } else {
-        RCCLCHK(g_rccl.AllGather(st->send_dev[area], st->recv_dev[area], cnt, ncclFloat64, st->comm, st->cstream));
-        HIPCHK2(hipMemcpyAsync(st->recv_pin[area], st->recv_dev[area], cnt * st->nranks * sizeof(double),
-                               hipMemcpyDeviceToHost, st->cstream));
-    }
-    HIPCHK2(hipEventRecord(st->gdone[area], st->cstream));
     st->count[area] = cnt;
     st->pending[area] = true;
+    st->enqueued[area].store(0, std::memory_order_relaxed);
+    {   // hand the collective to the worker
+        std::lock_guard<std::mutex> lk(st->qmu);
+        st->queue[st->q_tail % kAreas] = area;
+        st->q_tail += 1;
+    }
+    st->cv.notify_one();
     return MUSE_OK;
 }
 
@@ -287,9 +357,18 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_in
     if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
     if (area < 0 || area >= kAreas) return muse_set_error(MUSE_ERR_INVALID, "bad result_area");
     if (!st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "no gather in flight on this result area");
+    while (!st->enqueued[area].load(std::memory_order_acquire)) __builtin_ia32_pause();  // the worker is microseconds behind
+    st->pending[area] = false;
+    {
+        std::lock_guard<std::mutex> lk(st->mu);
+        if (st->worker_rc) {
+            const int wrc = st->worker_rc;
+            st->worker_rc = 0;
+            return muse_set_error(wrc, st->worker_err.c_str());
+        }
+    }
     int rc = muse_wait_event(st->gdone[area]);
     if (rc) return rc;
-    st->pending[area] = false;
     if (g_all_out) memcpy(g_all_out, st->recv_pin[area], st->count[area] * st->nranks * sizeof(double));
     return muse_batch_wait(ctx, area, nullptr, info_out);  // the solver's own completion, error flag, local infos
 }
