@@ -40,6 +40,11 @@ enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4
 #define MUSE_STENCIL_U 4
 #endif
 constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil model (register budget: see tools/regs.py)
+#ifndef MUSE_STREAM_U
+#define MUSE_STREAM_U 4
+#endif
+constexpr int kStreamU = MUSE_STREAM_U;    // pairs per trip of the elementwise models' streaming passes (a pure
+                                           // performance knob: a thread visits its pairs in the same order for every U)
 
 struct BatchArgs {
     int64_t N, ld;

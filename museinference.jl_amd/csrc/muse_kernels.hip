@@ -237,19 +237,19 @@ static hipError_t launch_place(const LaunchShape& s, const BatchArgs& a, hipStre
             case P_R256x1: return launch_one<Model, PlaceResident<256, 1, false>>(s, a, st);
             case P_R512x4: return launch_one<Model, PlaceResident<512, 4, false>>(s, a, st);
             case P_R512x10: return launch_one<Model, PlaceResident<512, 10, true>>(s, a, st);
-            case P_C256: return launch_one<Model, PlaceStreaming<256, true>>(s, a, st);
+            case P_C256: return launch_one<Model, PlaceStreaming<256, true, kStreamU>>(s, a, st);
             case P_CR2: return launch_one<Model, PlaceResident<512, 5, false, true>>(s, a, st);
             case P_CR4: return launch_one<Model, PlaceResident<512, 3, false, true>>(s, a, st);
             case P_CR8: return launch_one<Model, PlaceResident<512, 2, false, true>>(s, a, st);
-            case P_S256: return launch_one<Model, PlaceStreaming<256>>(s, a, st);
-            default: return launch_one<Model, PlaceStreaming<512>>(s, a, st);
+            case P_S256: return launch_one<Model, PlaceStreaming<256, false, kStreamU>>(s, a, st);
+            default: return launch_one<Model, PlaceStreaming<512, false, kStreamU>>(s, a, st);
         }
     }
 }
 // The implicit-differentiation H runs in the streaming policy only (single workgroup, or a cluster for large N).
 template <class Model>
 static hipError_t launch_place_implicit(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
-    constexpr int U = Model::kStencil ? kStencilU : 4;
+    constexpr int U = Model::kStencil ? kStencilU : kStreamU;
     if (s.place == P_C256) return launch_one<Model, PlaceStreaming<256, true, U>, true>(s, a, st);
     return launch_one<Model, PlaceStreaming<512, false, U>, true>(s, a, st);
 }

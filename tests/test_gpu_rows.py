@@ -303,3 +303,41 @@ def test_H_column_ranges_equal_whole_jacobians(gpu, M, model, N, nth, theta, fid
     with pytest.raises((M.MuseError, ValueError)):
         prob.fd_jacobian_columns(11, 0, 5, 2, theta, step)
     prob.close()
+
+
+@pytest.mark.parametrize("split", [2, 4])
+def test_element_split_hand_offs_under_uneven_load(gpu, M, O, split):
+    """The tagged-granule exchange under load it was not tuned for: 1500 elements on clusters that each work through
+    dozens of them (every buffer parity reused hundreds of times, epochs continuing across launches), uneven work
+    (a warm restart in which two thirds of the elements converge without an iteration while the rest iterate), three
+    launches per pattern bitwise equal, spot checks against the oracle."""
+    N, nth, S = 9999, 3, 1500
+    theta = np.array([0.4, 1.1, -0.3])
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
+    prob.set_element_split(split)
+    ref = None
+    for _ in range(3):
+        g, info = prob.map_and_score_batch(5, 0, S, theta, atol=1e-6)
+        cur = (g.copy(), info.copy())
+        ref = ref or cur
+        assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
+    assert np.all(info["status"] == 0)
+    for k in (0, 749, 1499):
+        go, zo, io = O.map_and_score_batch("funnel", N, 5, k, k + 1, theta, atol=1e-6, z0_mode=0)
+        assert (info["iterations"][k], info["f_calls"][k]) == (io["iterations"][0], io["f_calls"][0])
+        np.testing.assert_allclose(g[k], go[0], rtol=1e-10)
+    # uneven: restart warm at the MAPs, but with a third of the slots overwritten by zeros (those iterate again)
+    Z = prob.get_zhat(0, S)
+    Z[::3] = 0.0
+    prob.set_zhat(0, Z)
+    ref2 = None
+    for _ in range(3):
+        prob.set_zhat(0, Z)
+        g2, info2 = prob.map_and_score_batch(5, 0, S, theta, atol=1e-6, z0_mode=M.Z0_WARM)
+        cur = (g2.copy(), info2.copy())
+        ref2 = ref2 or cur
+        assert np.array_equal(cur[0], ref2[0]) and np.array_equal(cur[1], ref2[1])
+    assert np.all(info2["iterations"][1::3] == 0) and np.all(info2["iterations"][::3] >= 1)
+    assert np.array_equal(g2[::3], g[::3])        # from zero again: the same path, the same bits
+    np.testing.assert_allclose(g2, g, rtol=1e-9)
+    prob.close()
