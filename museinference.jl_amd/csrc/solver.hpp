@@ -777,6 +777,21 @@ struct Solver {
                         g.set(2 * j + 1, i0 + 1, valid1 ? zt1 : 0.0);
                     }
                 } else {
+                    // block boundaries and sampling sd of every block in scalar registers for the loop: read through the
+                    // LDS copy of the arguments they would be re-loaded in every trip (the loop stores to LDS)
+                    int bb[MAXB];
+                    double sdl[MAXB];
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) {
+                        bb[b] = MAXB > 1 ? __builtin_amdgcn_readfirstlane(a.bnd32[b]) : 0;
+                        sdl[b] = MAXB > 1 ? uniform(sh_sd[b]) : sd0;
+                    }
+                    auto sd_of = [&](int i) {
+                        double v = sdl[0];
+#pragma unroll
+                        for (int b = 1; b < MAXB; ++b) v = (i >= bb[b]) ? sdl[b] : v;  // bnd32[b] = INT_MAX for b >= ntheta
+                        return v;
+                    };
 #pragma unroll 1
                     for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
                         // both elements of the pair unconditionally (one basic block: their Philox/Box-Muller
@@ -788,8 +803,8 @@ struct Solver {
                             store_f64x2(n2r, i0, np0.n2, np1.n2);
                         }
                         double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk_at(i0), np0.n1, np0.n2, zt0, xt0);
-                        Model::sample(sdk_at(i0 + 1), np1.n1, np1.n2, zt1, xt1);
+                        Model::sample(sd_of(i0), np0.n1, np0.n2, zt0, xt0);
+                        Model::sample(sd_of(i0 + 1), np1.n1, np1.n2, zt1, xt1);
                         const bool valid1 = i0 + 1 < (int)N;
                         x.p[i0] = xt0;
                         g.p[i0] = zt0;

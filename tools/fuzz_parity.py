@@ -21,6 +21,11 @@ while time.time() - t0 < budget:
     n = 4 if N < 20000 else 2
     seed, s0 = int(rng.integers(1, 2**40)), int(rng.integers(0, 5000))
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    split = int(rng.choice([0, 0, 2, 4, 8]))  # element split: resident clusters (N <= 10^4, elementwise) or streaming ones
+    if split and N > 512:
+        prob.set_element_split(split)
+    else:
+        split = 0
     g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=atol, z0_mode=z0)
     zh = prob.get_zhat(0, n)
     prob.close()
@@ -31,6 +36,6 @@ while time.time() - t0 < budget:
     ncase += 1
     if not ok:
         nbad += 1
-        print("MISMATCH", model, N, nth, theta.tolist(), atol, z0, seed, s0, info["iterations"], io["iterations"],
+        print("MISMATCH", "split", split, model, N, nth, theta.tolist(), atol, z0, seed, s0, info["iterations"], io["iterations"],
               info["f_calls"], io["f_calls"], info["status"], io["status"], np.abs(g - go).max(), flush=True)
 print(f"{ncase} cases, {nbad} mismatches in {time.time() - t0:.0f} s")
