@@ -314,7 +314,10 @@ def main():
         # (resident placements only: above muse_max_resident_n, and for the stencil model, the cluster size is a function
         # of N alone already; 8 never paid, tools/split_bench.py)
         splittable = model != "smooth" and 512 < N <= M.load_library().muse_max_resident_n()
-        while splittable and split < 4 and 2 * split * rows <= cus:
+        # with a collective in flight beside the solver (N > 1) the clusters fill half of the CUs at most: the RCCL kernel of
+        # the previous step and a cluster launch that needs every CU would otherwise wait for each other's workgroups
+        room = 4 if sharded else 2
+        while splittable and split < 4 and room * split * rows <= cus:
             split *= 2
     if split > 1:
         prob.set_element_split(split)
