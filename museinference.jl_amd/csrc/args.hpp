@@ -37,9 +37,10 @@ enum { BATCH_STD = 0, BATCH_FD = 1, BATCH_SINGLE = 2, BATCH_IMPLICIT = 3 };
 // kMaxResidentN / 2), selected by muse_set_element_split.
 enum PlaceId { P_S256 = 0, P_S512 = 1, P_R256x1 = 2, P_R512x4 = 3, P_R512x10 = 4, P_C256 = 5, P_CR2 = 6, P_CR4 = 7, P_CR8 = 8 };
 #ifndef MUSE_STENCIL_U
-#define MUSE_STENCIL_U 4
+#define MUSE_STENCIL_U 2
 #endif
-constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil model (register budget: see tools/regs.py)
+constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil model: 2 (no spills, 212 VGPRs; measured on smooth_1e5:
+                                           // 4.65 ms against 4.76 at 3 and 4.80 at 4, which spills 25 registers)
 #ifndef MUSE_STREAM_U
 #define MUSE_STREAM_U 4
 #endif
