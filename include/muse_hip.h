@@ -103,7 +103,7 @@ int64_t muse_max_resident_n(void);
  * of (src/muse.jl:327-333: sims or Jacobian columns); when a launch has fewer elements than the GPU has compute
  * units -- the per-GPU share of a strongly scaled map -- the remaining axis is the element itself: `split`
  * workgroups (2, 4, 8 or 16) share one element's vectors and meet in every reduction.  0 or 1 = the default
- * (a function of N alone: one workgroup up to N = 65535, clusters of 4 or 16 above).  Results are a function of
+ * (a function of N alone: one workgroup up to N = 65535, clusters of 8 or 16 above).  Results are a function of
  * (seed, sim, theta, N, model, split): for a given split they do not depend on the batch, the grid or the number of
  * GPUs, but the split changes the summation tree, i.e. the last bits (scores agree to ~1e-13 relative). */
 int muse_set_element_split(muse_ctx* ctx, int split);

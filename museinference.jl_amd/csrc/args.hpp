@@ -74,7 +74,6 @@ struct BatchArgs {
                                    // (a column range that begins inside a simulation's Jacobian)
     // cluster mode (several workgroups per problem): csize workgroups 0..csize-1 of cluster blockIdx/csize
     int csize, nclusters;
-    unsigned int* cl_counter;      // [nclusters] arrival counters (zeroed per launch)
     double* cl_part;               // [nclusters][kClusterSlotDoubles]: partial sums / maxima, or their tagged granules
     unsigned int* cl_state;        // [nclusters] epoch reached by the cluster's granule exchange (persists across launches)
     int* error_flag;               // [0] set when a bounded cluster wait expires; [1] the largest epoch reported

@@ -61,14 +61,15 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
 
 // ------------------------------------------------------------------------------------------------
 // Storage policies.
-template <int T_, bool CLUSTER = false, int U_ = 4>
+template <int T_, bool CLUSTER = false, int U_ = 4, bool COH = false>
 struct PlaceStreaming {
+    static constexpr bool kCoherent = COH;  // stencil model in a cluster: see vec.hpp, kCoherent
     static constexpr int T = T_, EPT = 0, U = U_;  // U pairs of a thread per trip of a streaming pass
     // two waves per SIMD: 2 workgroups of 256 threads (cluster mode sizes its grid from that) or 1 of 512 per CU,
     // i.e. a budget of 256 registers per lane
     static constexpr int kWavesPerEu = 2;
     static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
-    using VX = BufChunk<U_>;
+    using VX = BufChunk<U_, COH>;
     using VG = VX; using VZ = VX; using VS = VX;
     using VH = VX;
 };
@@ -79,7 +80,7 @@ struct PlaceResident {
     static_assert(!(XG_LDS && CLUSTER), "the LDS layout addresses x and g by global element index");
     static constexpr int T = T_, EPT = EPT_, U = 1;
     static constexpr int kWavesPerEu = 1;  // no lower bound beyond the launch bounds
-    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = CLUSTER;
+    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = CLUSTER, kCoherent = false;
     using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
     using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;

@@ -65,7 +65,6 @@ struct muse_ctx {
     bool prof_on = false;
     double* ncache = nullptr;            // normals cache [ncache_slots][2][ld] (muse_run, FD batches)
     int64_t ncache_slots = 0;
-    unsigned int* cl_counter = nullptr;  // cluster mode: [cl_cap] arrival counters
     double* cl_part = nullptr;           // [cl_cap][kClusterSlotDoubles]
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
@@ -102,7 +101,7 @@ static bool place_is_cluster(int pl) { return pl >= P_C256; }
 static int cluster_size(const muse_ctx* c) {
     if (c->split >= 2) return c->split;
     if (const char* e = getenv("MUSE_DEBUG_CLUSTER_SIZE")) return atoi(e);  // tuning aid
-    return c->N >= 4194304 ? 16 : (c->N >= kClusterMinN ? 4 : 1);
+    return c->N >= 4194304 ? 16 : (c->N >= kClusterMinN ? 8 : 1);  // 8: smooth_1e5 2.80 ms (4: 3.22), noise_1e6 1.56 (4: 1.61)
 }
 static bool use_cluster(const muse_ctx* c) { return c->split >= 2 || c->N >= kClusterMinN; }
 
@@ -240,11 +239,9 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         if (ncl > c->cl_cap || wrap) {
             HIPCHK(hipStreamSynchronize(c->stream));
             const int cap = ncl > c->cl_cap ? ncl : c->cl_cap;
-            if (c->cl_counter) HIPCHK(hipFree(c->cl_counter));
             if (c->cl_part) HIPCHK(hipFree(c->cl_part));
             if (c->cl_state) HIPCHK(hipFree(c->cl_state));
-            c->cl_counter = nullptr; c->cl_part = nullptr; c->cl_state = nullptr; c->cl_cap = 0;
-            HIPCHK(hipMalloc(&c->cl_counter, (size_t)cap * sizeof(unsigned int)));
+            c->cl_part = nullptr; c->cl_state = nullptr; c->cl_cap = 0;
             HIPCHK(hipMalloc(&c->cl_part, (size_t)cap * kClusterSlotDoubles * sizeof(double)));
             HIPCHK(hipMalloc(&c->cl_state, (size_t)cap * sizeof(unsigned int)));
             HIPCHK(hipMemsetAsync(c->cl_part, 0, (size_t)cap * kClusterSlotDoubles * sizeof(double), c->stream));
@@ -252,10 +249,6 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
             c->error_flag[1] = 0;
             c->cl_cap = cap;
         }
-        // the release/acquire form (stencil model) counts arrivals from zero in every launch
-        if (c->model == MUSE_MODEL_SMOOTH)
-            HIPCHK(hipMemsetAsync(c->cl_counter, 0, (size_t)ncl * sizeof(unsigned int), c->stream));
-        a.cl_counter = c->cl_counter;
         a.cl_part = c->cl_part;
         a.cl_state = c->cl_state;
     } else {
@@ -388,7 +381,7 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     muse_comm_destroy(c);
-    hipFree(c->cl_counter); hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag);
+    hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag);
     hipFree(c->ncache);
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
     hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);

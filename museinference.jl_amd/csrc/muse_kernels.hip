@@ -86,21 +86,18 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         sv.tfirst = crank * T + tid;
         sv.pstride = csize * T;
         sv.pack_blocks();
-        sv.cl_counter = a.cl_counter + cluster;
         sv.cl_part = a.cl_part + (size_t)cluster * kClusterSlotDoubles;
         sv.exch = exch;
-        if constexpr (!Model::kStencil) sv.cl_epoch = a.cl_state[cluster];  // granule tags continue across launches
+        sv.cl_epoch = a.cl_state[cluster];  // granule tags continue across launches
         for (int p = cluster; p < a.nproblems; p += a.nclusters) {
             sv.parity = 0;
             __syncthreads();
             if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);
             else sv.run(p, cl_scratch, lds_x, lds_g);
         }
-        if constexpr (!Model::kStencil) {
-            if (tid == 0 && crank == 0) {
-                a.cl_state[cluster] = sv.cl_epoch;
-                if (cluster == 0) a.error_flag[1] = (int)(sv.cl_epoch >> 1);  // the host resets the tags long before a wrap
-            }
+        if (tid == 0 && crank == 0) {
+            a.cl_state[cluster] = sv.cl_epoch;
+            if (cluster == 0) a.error_flag[1] = (int)(sv.cl_epoch >> 1);  // the host resets the tags long before a wrap
         }
     } else {
         double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
@@ -229,7 +226,7 @@ template <class Model>
 static hipError_t launch_place(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
     const int pl = s.place;
     if constexpr (Model::kStencil) {
-        if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, true, kStencilU>>(s, a, st);
+        if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, true, kStencilU, true>>(s, a, st);
         if (pl == P_S256) return launch_one<Model, PlaceStreaming<256, false, kStencilU>>(s, a, st);
         return launch_one<Model, PlaceStreaming<512, false, kStencilU>>(s, a, st);
     } else {
@@ -250,7 +247,7 @@ static hipError_t launch_place(const LaunchShape& s, const BatchArgs& a, hipStre
 template <class Model>
 static hipError_t launch_place_implicit(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
     constexpr int U = Model::kStencil ? kStencilU : kStreamU;
-    if (s.place == P_C256) return launch_one<Model, PlaceStreaming<256, true, U>, true>(s, a, st);
+    if (s.place == P_C256) return launch_one<Model, PlaceStreaming<256, true, U, Model::kStencil>, true>(s, a, st);
     return launch_one<Model, PlaceStreaming<512, false, U>, true>(s, a, st);
 }
 

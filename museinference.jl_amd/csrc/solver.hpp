@@ -35,7 +35,6 @@ struct Solver {
     int crank, csize;          // this workgroup's rank in its cluster, cluster size
     unsigned int cl_epoch;     // cluster reductions done so far in this launch
     bool cl_aborted;           // a bounded wait expired: stop waiting
-    unsigned int* cl_counter;  // this cluster's arrival counter
     double* cl_part;           // this cluster's partial slots [2][csize][8] / granules [2][csize][8][2]
     double* exch;              // LDS [kMaxCluster][8]: the epoch's values of every member (granule exchange)
 
@@ -50,72 +49,22 @@ struct Solver {
         csize = 1;
         cl_epoch = 0;
         cl_aborted = false;
-        cl_counter = nullptr;
         cl_part = nullptr;
         exch = nullptr;
     }
 
-    // Cluster all-reduce (Guideline 16 of the CDNA guide: placement-independent release/acquire).
-    // Each workgroup has reduced to workgroup-uniform values; lane 0 publishes them with write-through
-    // stores, releases at agent scope (which also makes the pass's vector stores visible to the other
-    // workgroups of the cluster -- the stencil model reads neighbours across workgroups), arrives on
-    // the cluster's monotonic counter and polls it (bounded) for this epoch; one agent-scope acquire,
-    // then every thread reads the csize partials with L1-bypassing loads and combines them in rank
-    // order.  Partial slots alternate between two buffers by epoch parity (WAR safe).
-    template <int KS, int KM>
-    __device__ __forceinline__ void cluster_allreduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
-        constexpr int K = KS + KM;
-        cl_epoch += 1;
-        gf64* slots = (gf64*)(cl_part + (size_t)(cl_epoch & 1u) * csize * 8);
-        gu32* counter = (gu32*)cl_counter;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
-        __syncthreads();
-        if (tid == 0) {
-            gf64* mine = slots + crank * 8;
-#pragma unroll
-            for (int k = 0; k < KS; ++k) __hip_atomic_store(mine + k, sv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < KM; ++k) __hip_atomic_store(mine + KS + k, mv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = cl_epoch * (unsigned)csize;
-            unsigned spins = 0;
-            // bounded (about a second): a cluster whose members are not all resident must not hang the
-            // GPU; after one expiry this workgroup never waits again and the host reports the error
-            while (!cl_aborted && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 22)) {
-                    __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    cl_aborted = true;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double acc = __hip_atomic_load(slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int c = 1; c < csize; ++c) {
-                const double v = __hip_atomic_load(slots + c * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc = k < KS ? acc + v : __builtin_fmax(acc, v);
-            }
-            if (k < KS) sv[k] = uniform(acc);
-            else mv[k - KS] = uniform(acc);
-        }
-    }
-    // Cluster all-reduce of the elementwise models.  Only these K scalars cross workgroups (every thread reads and
-    // writes its own elements of every vector, in every pass), so no fence is involved: no L2 write-back, no L1
-    // invalidate.  A value travels as two 8-byte granules {32-bit half, 32-bit tag}, each written by ONE
+    // Cluster all-reduce.  For the elementwise models only these K scalars cross workgroups (every thread reads and
+    // writes its own elements of every vector, in every pass); the stencil model's passes also read neighbours that
+    // other workgroups own, and those travel by write-through stores and cache-bypassing loads (vec.hpp: kCoherent),
+    // drained before the exchange (reduce(), pass_barrier()).  Either way no fence is involved: no L2 write-back,
+    // no L1 invalidate.  A value travels as two 8-byte granules {32-bit half, 32-bit tag}, each written by ONE
     // write-through store (MI355X_MICROARCH.md, price list row "handoff-1to1": an aligned 8-byte granule is not
     // torn, and data-tagged granules need no ordering against a separate flag).  The tag is the cluster's epoch
     // number, which keeps growing from launch to launch (BatchArgs::cl_state), so a granule is this epoch's exactly
     // when its tag says so.  Wave 0 publishes the workgroup's 2K granules with one store instruction and then sweeps
     // the cluster's csize*2K granules (one 8-byte L1-bypassing load per lane and sweep) until every tag matches; the
     // other waves get the values through LDS.  Buffers alternate by epoch parity: a workgroup reaches epoch e+2 only
-    // after every member has published e+1, i.e. after every member has consumed epoch e.  Combination in rank
-    // order, as cluster_allreduce: the two give the same bits.
+    // after every member has published e+1, i.e. after every member has consumed epoch e.  Combination in rank order.
     template <int KS, int KM>
     __device__ __forceinline__ void cluster_exchange(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
         constexpr int K = KS + KM;
@@ -174,17 +123,19 @@ struct Solver {
     // that other workgroups wrote: it needs the release/acquire form; the elementwise models exchange scalars only.
     template <int KS, int KM>
     __device__ __forceinline__ void reduce(double (&sv)[KS > 0 ? KS : 1], double (&mv)[KM > 0 ? KM : 1]) {
+        // stencil model in a cluster: this pass's (write-through) stores have left every wave before the workgroup's
+        // barrier inside block_allreduce, i.e. before wave 0 publishes the epoch the other members wait for
+        if constexpr (Place::kCluster && Model::kStencil) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         block_allreduce<T, KS, KM>(sv, mv, red, parity, tid);
-        if constexpr (Place::kCluster) {
-            if constexpr (Model::kStencil) cluster_allreduce<KS, KM>(sv, mv);
-            else cluster_exchange<KS, KM>(sv, mv);
-        }
+        if constexpr (Place::kCluster) cluster_exchange<KS, KM>(sv, mv);
     }
     // Orders this pass's vector stores before the next pass's neighbour reads (stencil model).
     __device__ __forceinline__ void pass_barrier() {
         if constexpr (Place::kCluster) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             double z1[1] = {0.0}, z2[1] = {0.0};
-            cluster_allreduce<1, 0>(z1, z2);
+            cluster_exchange<1, 0>(z1, z2);
         } else {
             __syncthreads();
         }
@@ -277,9 +228,14 @@ struct Solver {
     struct Pair {
         double a, b;
     };
-    __device__ __forceinline__ static Pair load_pair(const rsrc_t& rs, int i0) {
+    __device__ __forceinline__ static Pair load_pair(const rsrc_t& rs, int i0) {  // the thread's own pair
         Pair p;
         load_f64x2(rs, i0, p.a, p.b);
+        return p;
+    }
+    __device__ __forceinline__ static Pair load_edge(const rsrc_t& rs, int i0) {  // a pair another wave / workgroup owns
+        Pair p;
+        load_f64x2<Place::kCoherent ? kCoherent : kPlain>(rs, i0, p.a, p.b);
         return p;
     }
     static constexpr int kDppWaveShr1 = 0x138;  // lane L reads lane L-1
@@ -313,12 +269,12 @@ struct Solver {
                 const bool edge = interior[u] && (lane == 0 || lane == 63);
                 const int ie = edge ? (lane == 0 ? i0 - 2 : i0 + 2) : kOutOfRange;
                 const int ix = edge ? (lane == 0 ? i0 - 1 : i0 + 2) : kOutOfRange;
-                Pair ze = load_pair(z.rsrc, ie);
+                Pair ze = load_edge(z.rsrc, ie);
                 const double xe = x.get1(ix);
                 Pair sp{0.0, 0.0}, ztp = zp;
                 if constexpr (USE_S) {
                     sp = load_pair(s.rsrc, i0);
-                    const Pair se = load_pair(s.rsrc, ie);
+                    const Pair se = load_edge(s.rsrc, ie);
                     ztp = Pair{fma(c, sp.a, zp.a), fma(c, sp.b, zp.b)};
                     ze = Pair{fma(c, se.a, ze.a), fma(c, se.b, ze.b)};
                 }

@@ -50,15 +50,25 @@ struct RegVec {
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int off8(int i) { return (int)((unsigned)i << 3); }  // byte offset of element i (may exceed 2^31: unsigned)
+// Cache policy of a buffer access (the builtins' last argument): kPlain, or kCoherent = sc0 | sc1 -- a store that is
+// written through to the memory side (and leaves no line behind in the XCD's L2), a load that is not served from this
+// CU's L1.  Vectors whose elements OTHER workgroups read inside a launch (the stencil model's x, z, s in cluster
+// placements) are stored coherently and their foreign elements loaded coherently: together with the storing waves'
+// `s_waitcnt vmcnt(0)` before the cluster's tagged-granule exchange this makes a pass's stores visible to the other
+// members without any fence (MI355X_MICROARCH.md, "Valid forms": sc1 stores and loads on both sides).
+constexpr int kPlain = 0, kCoherent = 17;
+template <int AUX = kPlain>
 __device__ __forceinline__ double load_f64(const rsrc_t& rs, int i) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off8(i), 0, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off8(i), 0, AUX);
     return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
 }
+template <int AUX = kPlain>
 __device__ __forceinline__ void load_f64x2(const rsrc_t& rs, int i, double& d0, double& d1) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off8(i), 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off8(i), 0, AUX);
     d0 = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
     d1 = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
 }
+template <int AUX = kPlain>
 __device__ __forceinline__ void store_f64x2(const rsrc_t& rs, int i, double d0, double d1) {
     const long long b0 = __double_as_longlong(d0), b1 = __double_as_longlong(d1);
     u32x4 v;
@@ -66,7 +76,7 @@ __device__ __forceinline__ void store_f64x2(const rsrc_t& rs, int i, double d0, 
     v.y = (unsigned)(b0 >> 32);
     v.z = (unsigned)(b1 & 0xffffffffll);
     v.w = (unsigned)(b1 >> 32);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off8(i), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off8(i), 0, AUX);
 }
 // A vector in HBM, resident policy (history pairs, zhat): the element loop visits a thread's two
 // adjacent elements (jj even then jj odd) back to back, so the pair moves with ONE 16-byte buffer
@@ -99,8 +109,9 @@ struct BufVec2 {
 // prove the buffers distinct) every pair's loads waited for the previous pair's store to issue and a
 // pass paid one memory round trip per pair.  get1() is an 8-byte load at an arbitrary element (stencil
 // neighbours).
-template <int U>
+template <int U, bool COH = false>
 struct BufChunk {
+    static constexpr int kAux = COH ? kCoherent : kPlain;  // stores and foreign-element loads (get1); own pairs load plain
     rsrc_t rsrc;
     mutable double c1[U];
     double st[2 * U];
@@ -113,7 +124,7 @@ struct BufChunk {
         }
         return c1[jj >> 1];
     }
-    __device__ __forceinline__ double get1(int i) const { return load_f64(rsrc, i); }
+    __device__ __forceinline__ double get1(int i) const { return load_f64<kAux>(rsrc, i); }
     __device__ __forceinline__ void set(int jj, int, double d) { st[jj] = d; }
     __device__ __forceinline__ void clear() {}
     // the UU (<= U) pairs i0, i0 + 2*pstride, ... of the trip that started at element i0
@@ -121,7 +132,7 @@ struct BufChunk {
     __device__ __forceinline__ void flush(int i0, int pstride) {
         static_assert(UU <= U, "trip longer than the staging area");
 #pragma unroll
-        for (int u = 0; u < UU; ++u) store_f64x2(rsrc, i0 + 2 * u * pstride, st[2 * u], st[2 * u + 1]);
+        for (int u = 0; u < UU; ++u) store_f64x2<kAux>(rsrc, i0 + 2 * u * pstride, st[2 * u], st[2 * u + 1]);
     }
 };
 // flush-list entry for a vector that a pass writes only under a (workgroup-uniform) condition

@@ -23,7 +23,7 @@ HOT = [
     ("FunnelModel<4>, PlaceResident<512, 10, true>", 24),
     ("FunnelModel<1>, PlaceResident<512, 3, false, true>", 4),
     ("NoiseModel, PlaceStreaming<256, true>", 0),
-    ("SmoothModel<8>, PlaceStreaming<256, true, 2>", 0),
+    ("SmoothModel<8>, PlaceStreaming<256, true, 2, true>", 0),
 ]
 
 
