@@ -70,9 +70,11 @@ def compulsory_bytes(info, N, placement):
                 zero: 2); a kept update reads z, s, x, g and writes z, dx, dg, g, s (9; the first one has neither z
                 nor g to read: 7); the last update reads z, s, x and writes z (4; 3 from the zero start);
                 8 words per history pair used (q is read and written once per pair in this placement)
-      streaming, stencil model: sampler writes s (the true z, staged), x, z (3) and the A z pass reads s, x and
+      streaming, stencil model: sampler writes g (the true z, staged), x, z (3) and the A z pass reads g, x and
                 writes x (3); initial evaluation reads z, x, writes g, s (4); a trial reads z, s, x (3); a kept
-                update is two passes, 4 + 7 = 11; the last update 4; 8 per history pair used."""
+                update is two passes, 4 + 7 = 11; the last update 4; 8 per history pair used.
+                "stencil_lds" (clusters whose members keep the search direction in LDS): every read or write of s
+                drops out -- 3, 2, 3 + 6 = 9, 3 -- and the two-loop recursion moves 4 words per pair."""
     E = info["f_calls"].astype(np.int64)
     K = info["iterations"].astype(np.int64)
     H = info["hist_words"].astype(np.int64)
@@ -81,6 +83,9 @@ def compulsory_bytes(info, N, placement):
         words = 1 + 2 * kept + 4 * H
     elif placement == "stencil":
         words = 6 + 4 + 3 * np.maximum(E - 1, 0) + 11 * kept + 4 * (K > 0) + 8 * H
+    elif placement == "stencil_lds":  # the search direction (and the two-loop recursion's q) in LDS: one word less wherever
+        # s was read or written, 4 instead of 8 per history pair
+        words = 6 + 3 + 2 * np.maximum(E - 1, 0) + 9 * kept + 3 * (K > 0) + 4 * H
     else:
         first = (K == 1)  # the solve ended with its first line search: z stayed virtual until the last update
         trials = np.maximum(E - 2, 0)
@@ -426,8 +431,9 @@ def main():
     g, info = results[-1]
     assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
     mean_kernel_s = float(kernel_ms.mean()) * 1e-3
-    resident = model != "smooth" and N <= M.load_library().muse_max_resident_n() and args.placement != 0
-    placement = "resident" if resident else ("stencil" if model == "smooth" else "streaming")
+    pinfo = prob.placement_info()
+    placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
+                                                      if model == "smooth" else "streaming")
     comp_bytes = compulsory_bytes(info, N, placement)
     prow, why = profile_row(args.workload) if (world == 1 and split == 1) else (None, "profiles/ hold the 1-GPU, unsplit launch")
     traffic = measured_traffic(args.workload) if prow is not None else None
@@ -448,7 +454,7 @@ def main():
                 "note": "fp64-FMA issue-slot equivalents: VALU-active cycles / (1024 SIMDs x kernel time x 2.4 GHz)"}
     primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
     primary.update({
-        "kernel": "map_score_kernel", "placement": placement, "kernel_ms_mean": 1e3 * mean_kernel_s,
+        "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
         "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
         "algorithmic_bytes_d3": algorithmic_bytes(info, N),
         "hbm": hbm, "valu": valu,

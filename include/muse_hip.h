@@ -107,6 +107,11 @@ int64_t muse_max_resident_n(void);
  * (seed, sim, theta, N, model, split): for a given split they do not depend on the batch, the grid or the number of
  * GPUs, but the split changes the summation tree, i.e. the last bits (scores agree to ~1e-13 relative). */
 int muse_set_element_split(muse_ctx* ctx, int split);
+/* How the batched maps of this context run (a function of model, N, the placement and the element split): threads per
+ * workgroup, workgroups per element, whether the solver's vectors are resident in registers/LDS (else streamed from HBM),
+ * and -- stencil model in a cluster -- whether the search direction is kept in LDS.  For reports (bench.py's roofline
+ * accounts the bytes of the placement that ran); any pointer may be NULL. */
+int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element, int* resident, int* direction_in_lds);
 int muse_synchronize(muse_ctx* ctx);
 /* Device time in ms of the most recent solver launch (HIP events on the context's stream), recorded only
  * after muse_set_timing(ctx, 1): the event pair costs about 12 us of host time per launch (default: off). */

@@ -150,6 +150,7 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
 struct LaunchShape {
     int model, ntheta, place, grid;
     bool implicit;
+    bool lds_s;  // stencil model in a cluster: the search direction in LDS (vec.hpp, LdsMirror)
     size_t lds;
 };
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);

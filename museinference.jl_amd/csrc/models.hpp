@@ -61,16 +61,18 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
 
 // ------------------------------------------------------------------------------------------------
 // Storage policies.
-template <int T_, bool CLUSTER = false, int U_ = 4, bool COH = false>
+template <int T_, bool CLUSTER = false, int U_ = 4, bool COH = false, bool LDS_S = false>
 struct PlaceStreaming {
     static constexpr bool kCoherent = COH;  // stencil model in a cluster: see vec.hpp, kCoherent
+    static constexpr bool kLdsS = LDS_S;    // the search direction in LDS (vec.hpp, LdsMirror)
     static constexpr int T = T_, EPT = 0, U = U_;  // U pairs of a thread per trip of a streaming pass
     // two waves per SIMD: 2 workgroups of 256 threads (cluster mode sizes its grid from that) or 1 of 512 per CU,
     // i.e. a budget of 256 registers per lane
     static constexpr int kWavesPerEu = 2;
     static constexpr bool kResident = false, kXgLds = false, kCluster = CLUSTER;
     using VX = BufChunk<U_, COH>;
-    using VG = VX; using VZ = VX; using VS = VX;
+    using VG = VX; using VZ = VX;
+    using VS = typename std::conditional<LDS_S, LdsMirror<U_, T_>, VX>::type;
     using VH = VX;
 };
 // CLUSTER (registers only): csize workgroups share one element, thread pairs (crank*T + tid) + j*csize*T -- the
@@ -80,7 +82,7 @@ struct PlaceResident {
     static_assert(!(XG_LDS && CLUSTER), "the LDS layout addresses x and g by global element index");
     static constexpr int T = T_, EPT = EPT_, U = 1;
     static constexpr int kWavesPerEu = 1;  // no lower bound beyond the launch bounds
-    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = CLUSTER, kCoherent = false;
+    static constexpr bool kResident = true, kXgLds = XG_LDS, kCluster = CLUSTER, kCoherent = false, kLdsS = false;
     using VX = typename std::conditional<XG_LDS, LdsVec, RegVec<2 * EPT_>>::type;
     using VG = VX;
     using VZ = RegVec<2 * EPT_>; using VS = RegVec<2 * EPT_>;

@@ -98,9 +98,22 @@ static bool place_is_cluster(int pl) { return pl >= P_C256; }
 
 // Cluster size: a function of N alone (results must not depend on how many problems share a launch), unless the
 // caller asked for a split (muse_set_element_split: results then depend on (N, split), still not on the launch).
+// Stencil model in a cluster of `csize` workgroups: LDS bytes of the workgroup's own elements of the search direction
+// (vec.hpp, LdsMirror: pairs per thread rounded up to whole trips); it is kept there when two workgroups per CU fit.
+static size_t stencil_lds_s_bytes(const muse_ctx* c, int csize) {
+    const int64_t pairs = (c->ld / 2 + (int64_t)csize * 256 - 1) / ((int64_t)csize * 256);
+    const int64_t cap = (pairs + kStencilU - 1) / kStencilU * kStencilU;
+    return (size_t)cap * 256 * 16;
+}
+static bool stencil_lds_s(const muse_ctx* c, int csize) {
+    static const bool off = getenv("MUSE_DEBUG_NO_LDS_S") != nullptr;  // tuning aid
+    return !off && c->model == MUSE_MODEL_SMOOTH && csize >= 2 && stencil_lds_s_bytes(c, csize) <= 72 * 1024;
+}
 static int cluster_size(const muse_ctx* c) {
     if (c->split >= 2) return c->split;
     if (const char* e = getenv("MUSE_DEBUG_CLUSTER_SIZE")) return atoi(e);  // tuning aid
+    // stencil model: clusters of 16 where that lets the search direction live in LDS (N <= ~147 000)
+    if (c->model == MUSE_MODEL_SMOOTH && c->N >= kClusterMinN && c->N < 4194304 && stencil_lds_s(c, 16)) return 16;
     return c->N >= 4194304 ? 16 : (c->N >= kClusterMinN ? 8 : 1);  // 8: smooth_1e5 2.80 ms (4: 3.22), noise_1e6 1.56 (4: 1.61)
 }
 static bool use_cluster(const muse_ctx* c) { return c->split >= 2 || c->N >= kClusterMinN; }
@@ -133,6 +146,7 @@ static int place_wgs_per_cu(int pl) {
 static size_t place_lds(const muse_ctx* c, int pl) {
     size_t fixed = (size_t)(2 * (place_threads(pl) / 64) * 8 + 42 + kArgsDoubles) * sizeof(double);
     if (place_is_cluster(pl)) fixed += (size_t)kMaxCluster * 8 * sizeof(double);
+    if (pl == P_C256 && stencil_lds_s(c, cluster_size(c))) fixed += stencil_lds_s_bytes(c, cluster_size(c));
     if (pl == P_R512x10) fixed += (size_t)2 * (c->ld + 2) * sizeof(double);
     return fixed;
 }
@@ -280,6 +294,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     {
         LaunchShape shape;
         shape.model = c->model; shape.ntheta = c->ntheta; shape.place = pl; shape.grid = grid; shape.implicit = implicit; shape.lds = lds;
+        shape.lds_s = !implicit && pl == P_C256 && stencil_lds_s(c, a.csize);
         const hipError_t e = launch_solver(shape, a, c->stream);
         if (e != hipSuccess) rc = fail(MUSE_ERR_HIP, std::string("solver launch: ") + hipGetErrorString(e));
     }
@@ -444,6 +459,16 @@ static int check_error_flag(muse_ctx* c) {
         *c->error_flag = 0;
         return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident)");
     }
+    return MUSE_OK;
+}
+int muse_placement_info(muse_ctx* c, int* threads, int* workgroups_per_element, int* resident, int* direction_in_lds) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    const int pl = choose_place(c);
+    const int cs = place_is_cluster(pl) ? cluster_size(c) : 1;
+    if (threads) *threads = place_threads(pl);
+    if (workgroups_per_element) *workgroups_per_element = cs;
+    if (resident) *resident = (pl == P_R256x1 || pl == P_R512x4 || pl == P_R512x10 || pl >= P_CR2) ? 1 : 0;
+    if (direction_in_lds) *direction_in_lds = (pl == P_C256 && stencil_lds_s(c, cs)) ? 1 : 0;
     return MUSE_OK;
 }
 int muse_synchronize(muse_ctx* c) {

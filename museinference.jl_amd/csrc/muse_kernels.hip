@@ -226,6 +226,7 @@ template <class Model>
 static hipError_t launch_place(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
     const int pl = s.place;
     if constexpr (Model::kStencil) {
+        if (pl == P_C256 && s.lds_s) return launch_one<Model, PlaceStreaming<256, true, kStencilU, true, true>>(s, a, st);
         if (pl == P_C256) return launch_one<Model, PlaceStreaming<256, true, kStencilU, true>>(s, a, st);
         if (pl == P_S256) return launch_one<Model, PlaceStreaming<256, false, kStencilU>>(s, a, st);
         return launch_one<Model, PlaceStreaming<512, false, kStencilU>>(s, a, st);

@@ -273,7 +273,7 @@ struct Solver {
                 const double xe = x.get1(ix);
                 Pair sp{0.0, 0.0}, ztp = zp;
                 if constexpr (USE_S) {
-                    sp = load_pair(s.rsrc, i0);
+                    s.own_pair(i0, sp.a, sp.b);
                     const Pair se = load_edge(s.rsrc, ie);
                     ztp = Pair{fma(c, sp.a, zp.a), fma(c, sp.b, zp.b)};
                     ze = Pair{fma(c, se.a, ze.a), fma(c, se.b, ze.b)};
@@ -684,7 +684,8 @@ struct Solver {
         } else {
             x.bind(wg_scratch, ld);
             g.bind(wg_scratch + ld, ld);
-            s.bind(wg_scratch + 2 * ld, ld);
+            if constexpr (Place::kLdsS) s.bind(wg_scratch + 2 * ld, ld, lds_x, tfirst, pstride, tid, (int)N);
+            else s.bind(wg_scratch + 2 * ld, ld);
             zmem = d.zslot >= 0 ? a.zhat + d.zslot * ld : wg_scratch + 3 * ld;
             z.bind(zmem, ld);
             hist = wg_scratch + 4 * ld;
@@ -834,7 +835,7 @@ struct Solver {
                     if constexpr (Model::kStencil) {
                         zt = sdk(jj, i) * np.n1;
                         xt = np.n2;                           // noise now, + A z after the barrier
-                        s.set(jj, i, valid ? zt : 0.0);       // true z staged in the direction buffer
+                        g.set(jj, i, valid ? zt : 0.0);       // true z staged in the (still unused) gradient buffer
                     } else {
                         Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
                     }
@@ -845,7 +846,7 @@ struct Solver {
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
                     else if constexpr (Place::kResident) z.set(jj, i, z0src.get(jj, i));
-                }, when(Model::kStencil, s), when(KEEP_ZTRUE, ztrue), x, when(z_from_sample, z));
+                }, when(Model::kStencil, g), when(KEEP_ZTRUE, ztrue), x, when(z_from_sample, z));
                 if constexpr (!Place::kResident) {
                     if (!init_done && !z_from_sample && !z_in_place)
                         for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); }, z);
@@ -857,7 +858,7 @@ struct Solver {
                     const bool valid = i < N;
                     const int ic = valid ? i : 0;
                     const int im = ic == 0 ? (int)N - 1 : ic - 1, ip = ic == (int)N - 1 ? 0 : ic + 1;
-                    const double az = fma(0.25, s.get1(im) + s.get1(ip), 0.5 * s.get1(ic));
+                    const double az = fma(0.25, g.get1(im) + g.get1(ip), 0.5 * g.get1(ic));
                     const double xv = az + x.get(jj, i);
                     x.set(jj, i, valid ? xv : 0.0);
                 }, x);

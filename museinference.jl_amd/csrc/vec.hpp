@@ -125,6 +125,7 @@ struct BufChunk {
         return c1[jj >> 1];
     }
     __device__ __forceinline__ double get1(int i) const { return load_f64<kAux>(rsrc, i); }
+    __device__ __forceinline__ void own_pair(int i0, double& a, double& b) const { load_f64x2(rsrc, i0, a, b); }
     __device__ __forceinline__ void set(int jj, int, double d) { st[jj] = d; }
     __device__ __forceinline__ void clear() {}
     // the UU (<= U) pairs i0, i0 + 2*pstride, ... of the trip that started at element i0
@@ -133,6 +134,59 @@ struct BufChunk {
         static_assert(UU <= U, "trip longer than the staging area");
 #pragma unroll
         for (int u = 0; u < UU; ++u) store_f64x2<kAux>(rsrc, i0 + 2 * u * pstride, st[2 * u], st[2 * u + 1]);
+    }
+};
+// The search direction (and the two-loop recursion's q) of the stencil model in a cluster: the workgroup's own elements
+// live in LDS -- pair k of thread t at local slot k*T + t -- and are mirrored to the HBM vector only where somebody else
+// reads them: the pairs of the two edge lanes of every wave (the neighbouring wave's or workgroup's stencil) and the
+// pairs next to the periodic wrap (the patch path reads those element-wise).  The two-loop recursion, which reads and
+// writes this vector once per history pair, then touches HBM for the history vectors only.
+template <int U, int T>
+struct LdsMirror {
+    static constexpr int kAux = kCoherent;
+    rsrc_t rsrc;  // the HBM mirror
+    lds_double* p;
+    int tfirst, sh, tid, n;  // pstride = 1 << sh; n = N
+    mutable double c1[U];
+    double st[2 * U];
+    __device__ __forceinline__ void bind(const double* hbm, int64_t ld, double* lds, int tfirst_, int pstride, int tid_, int n_) {
+        rsrc = make_rsrc(hbm, ld * 8);
+        p = (lds_double*)lds;
+        tfirst = tfirst_;
+        sh = 31 - __builtin_clz((unsigned)pstride);
+        tid = tid_;
+        n = n_;
+    }
+    __device__ __forceinline__ int slot(int i) const { return (((((i >> 1) - tfirst) >> sh) * T) + tid) << 1; }
+    __device__ __forceinline__ double get(int jj, int i) const {
+        if ((jj & 1) == 0) {
+            const lds_double* q = p + slot(i);
+            const double d0 = q[0];
+            c1[jj >> 1] = q[1];
+            return d0;
+        }
+        return c1[jj >> 1];
+    }
+    __device__ __forceinline__ void own_pair(int i0, double& a, double& b) const {
+        const lds_double* q = p + slot(i0);
+        a = q[0];
+        b = q[1];
+    }
+    __device__ __forceinline__ double get1(int i) const { return load_f64<kCoherent>(rsrc, i); }  // a mirrored element
+    __device__ __forceinline__ void set(int jj, int, double d) { st[jj] = d; }
+    __device__ __forceinline__ void clear() {}
+    template <int UU>
+    __device__ __forceinline__ void flush(int i0, int pstride) {
+        static_assert(UU <= U, "trip longer than the staging area");
+        const int lane = tid & 63;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const int i = i0 + 2 * u * pstride;
+            lds_double* q = p + slot(i);
+            q[0] = st[2 * u];
+            q[1] = st[2 * u + 1];
+            if (lane == 0 || lane == 63 || i < 4 || i + 6 >= n) store_f64x2<kCoherent>(rsrc, i, st[2 * u], st[2 * u + 1]);
+        }
     }
 };
 // flush-list entry for a vector that a pass writes only under a (workgroup-uniform) condition

@@ -213,6 +213,13 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_set_element_split(self._ctx, int(split)))
         self.element_split = int(split)
 
+    def placement_info(self):
+        """{'threads', 'workgroups_per_element', 'resident', 'direction_in_lds'} of this problem's batched maps."""
+        v = [C.c_int() for _ in range(4)]
+        _capi.check(self._lib.muse_placement_info(self._ctx, *[C.byref(x) for x in v]))
+        return dict(threads=v[0].value, workgroups_per_element=v[1].value, resident=bool(v[2].value),
+                    direction_in_lds=bool(v[3].value))
+
     def set_stream(self, hip_stream):
         _capi.check(self._lib.muse_set_stream(self._ctx, _capi.ptr(hip_stream) if hip_stream else None))
 

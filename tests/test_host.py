@@ -274,6 +274,7 @@ def test_bench_accounting_helpers():
     assert bench.compulsory_bytes(info, 10, "resident") == 8 * 10 * (1 + 1 + (1 + 2 + 4))
     assert bench.compulsory_bytes(info[:2], 10, "streaming") == 8 * 10 * (7 + 7)
     assert bench.compulsory_bytes(info[2:], 10, "stencil") == 8 * 10 * (6 + 4 + 3 * 4 + 11 + 4 + 8)
+    assert bench.compulsory_bytes(info[2:], 10, "stencil_lds") == 8 * 10 * (6 + 3 + 2 * 4 + 9 + 3 + 4)
     assert len(bench.csrc_fingerprint()) == 16
     assert 1 <= bench.usable_cores(4) <= 4
     assert bench.measured_traffic("no_such_workload") is None
