@@ -85,11 +85,19 @@ struct Solver {
                 __hip_atomic_store(gran + crank * 16 + lane, ((unsigned long long)cl_epoch << 32) | half, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
-            const int total = csize * 16;  // granule q = rank*16 + k*2 + h; the live ones have k < K
+            // A member's granules sit in a 128-byte line of their own (16 slots; shared lines made the write-through stores
+            // of different members slower), but the sweep visits the live ones only: lane-linear index ql = rank*2K + j
+            // reads slot rank*16 + j, so that the common cases -- one value (two-loop recursion, pass barrier) or three --
+            // are one 64-lane sweep for clusters of up to 32 / 10 members.
+            // (Stencil model only: with the elementwise models the plain slot-linear sweep measured faster, 1.55 against
+            // 1.78 ms on noise_1e6, which meets in three reductions per problem; the stencil model meets twice per pass.)
+            constexpr bool kLiveOnly = Model::kStencil;
+            const int total = kLiveOnly ? csize * 2 * K : csize * 16;
             unsigned spins = 0;
             for (int q0 = 0; q0 < total; q0 += 64) {
-                const int q = q0 + lane;
-                const bool live = q < total && (q & 15) < 2 * K;
+                const int ql = q0 + lane;
+                const int q = kLiveOnly ? (ql / (2 * K)) * 16 + ql % (2 * K) : ql;
+                const bool live = ql < total && (kLiveOnly || (q & 15) < 2 * K);
                 unsigned long long gv = 0;
                 for (;;) {
                     bool ok = true;
