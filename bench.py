@@ -313,6 +313,11 @@ def main():
     # fewer elements than compute units: the element itself is the remaining parallel axis (src/muse.jl:327-333
     # chooses the longer axis; here: `split` workgroups per element).  The same split on every rank.
     cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    # The ranks of this bench share a node (the launch contract): the score blocks are exchanged host to host through the
+    # engine's shared-memory transport; MUSE_BENCH_TRANSPORT=rccl runs the device-side RCCL all-gather instead.
+    transport = os.environ.get("MUSE_BENCH_TRANSPORT", "shm")
+    if transport not in ("shm", "rccl"):
+        raise SystemExit("MUSE_BENCH_TRANSPORT must be shm or rccl")
     split = args.split
     if split < 0:
         split = 1
@@ -321,7 +326,7 @@ def main():
         splittable = model != "smooth" and 512 < N <= M.load_library().muse_max_resident_n()
         # with a collective in flight beside the solver (N > 1) the clusters fill half of the CUs at most: the RCCL kernel of
         # the previous step and a cluster launch that needs every CU would otherwise wait for each other's workgroups
-        room = 4 if sharded else 2
+        room = 4 if (sharded and transport == "rccl") else 2
         while splittable and split < 4 and room * split * rows <= cus:
             split *= 2
     if split > 1:
@@ -329,24 +334,26 @@ def main():
     gather_buf = None
     collective = None
     if sharded:
-        # Preferred: the engine's own RCCL communicator (scores stay on the device, the all-gather runs on a
-        # second stream from C).  Fallback, agreed on by all ranks: torch.distributed's all_gather.
+        # Preferred: the engine's own communicator (shm: host-to-host blocks in a shared segment; rccl: scores stay on the
+        # device, the all-gather runs on a second stream from C).  Fallback, agreed on by all ranks: torch.distributed's
+        # all_gather.
         ok = 1
         try:
-            if backend != "nccl":
-                raise RuntimeError("gloo test mode")
-            uid = [M.HipMuseProblem.comm_unique_id() if rank == 0 else None]
+            if backend != "nccl" and transport == "rccl":
+                raise RuntimeError("gloo test mode: RCCL refuses two ranks on one device")
+            uid = [M.HipMuseProblem.comm_unique_id(transport) if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             prob.comm_init(world, rank, uid[0])
         except Exception as e:  # noqa: BLE001 -- any failure means "use the fallback", on every rank
-            print(f"[bench rank {rank}] engine RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            print(f"[bench rank {rank}] engine communicator ({transport}) unavailable ({e}); using torch.distributed", file=sys.stderr)
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        collective = "rccl-capi" if int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch" else "torch"
+        collective = f"{transport}-capi" if int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch" else "torch"
         if collective == "torch":
             gather_buf = [torch.empty(rows * nth, dtype=torch.float64, device=tdev) for _ in range(world)]
 
+    capi = collective is not None and collective.endswith("-capi")
     AREAS = 4
     host_t = [0.0, 0.0]  # host seconds spent enqueueing / waiting+collecting (reported under "host_us_per_step")
 
@@ -356,7 +363,7 @@ def main():
         pending = []
         for k in range(K):
             t_enq0 = time.perf_counter()
-            if collective == "rccl-capi":
+            if capi:
                 n = prob.map_and_score_batch_gather_async(seed, sim_lo, sim_hi, theta, rows, atol=1e-2,
                                                           z0_mode=M.Z0_ZERO, result_area=k % AREAS)
             else:
@@ -373,7 +380,7 @@ def main():
 
     def finish(item, collect):
         area, n = item
-        if collective == "rccl-capi":
+        if capi:
             g_all, info = prob.batch_wait_gathered(n, rows, area)  # [world, rows, nth]: every rank holds all scores
             g = g_all[rank][:n]
         else:

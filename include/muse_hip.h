@@ -223,13 +223,25 @@ int muse_implicit_H_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64
 int muse_implicit_H_columns(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
                             const double* theta0, double atol, int cg_maxiter, double* cols_out, int32_t* cg_iters_out);
 
-/* ---- multi-GPU exchange of the per-sim accumulators (RCCL over xGMI) --------------------------- */
+/* ---- multi-GPU exchange of the per-sim accumulators -------------------------------------------- */
 /* Collectives C1-C3 of SURVEY.md §2: gather of per-rank score blocks (so that every rank reduces
  * mean/var/cov in the reference's sim order, src/muse.jl:183,188,529) and sum of per-rank H
- * accumulators (src/muse.jl:446).  One communicator per context/rank. */
+ * accumulators (src/muse.jl:446).  One communicator per context/rank.  Two transports, chosen by the id
+ * that rank 0 creates and every rank passes to muse_comm_init:
+ *   MUSE_TRANSPORT_RCCL  RCCL collectives over xGMI (any number of nodes);
+ *   MUSE_TRANSPORT_SHM   the ranks of ONE node: the blocks are kilobytes that every rank's HOST consumes
+ *                        (src/muse.jl:177-188), so each rank copies its block from its pinned result area into a
+ *                        POSIX shared-memory segment and publishes a sequence number -- no collective kernel, no
+ *                        second stream; sums are taken in rank order (bitwise the same on every rank).
+ * block_doubles: capacity per rank of one gathered block in the shared segment (0 = 16384); the synchronous
+ * collectives move longer messages in pieces, a gathered map must fit. */
 #define MUSE_UNIQUE_ID_BYTES 128
-int muse_comm_unique_id(void* id_out /* MUSE_UNIQUE_ID_BYTES, call on rank 0 and broadcast */);
+#define MUSE_TRANSPORT_RCCL 0
+#define MUSE_TRANSPORT_SHM 1
+int muse_comm_unique_id(void* id_out /* MUSE_UNIQUE_ID_BYTES, call on rank 0 and broadcast */); /* RCCL */
+int muse_comm_unique_id_ex(int transport, int64_t block_doubles, void* id_out);
 int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id);
+int muse_comm_transport(muse_ctx* ctx, int* transport_out); /* of an initialised communicator */
 int muse_comm_destroy(muse_ctx* ctx);
 /* every rank contributes count doubles (host), recv_out is [nranks][count] host */
 int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, double* recv_out);
@@ -237,10 +249,12 @@ int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, doub
 int muse_allreduce_sum(muse_ctx* ctx, double* buf, int64_t count);
 /* The sharded map body (the pmap of src/muse.jl:169-176 / :508-525 over a pool of GPUs, src/util.jl:74-83):
  * this rank's block [sim_begin, sim_end) (plus the data element where include_data) is solved exactly as
- * by muse_map_and_score_batch_async, but the scores stay on the device and the per-rank blocks are
+ * by muse_map_and_score_batch_async; RCCL transport: the scores stay on the device and the per-rank blocks are
  * all-gathered by RCCL on a stream of the communicator's own, so that the collective of batch k overlaps
- * the solver launch of batch k+1 and no host copy sits between solver and collective.  Every rank passes
- * the same rows_per_rank >= its own element count; shorter blocks are zero-padded.
+ * the solver launch of batch k+1 and no host copy sits between solver and collective; shared-memory transport:
+ * the launch is the plain one and the exchange happens inside muse_batch_wait_gathered.  Every rank passes
+ * the same rows_per_rank >= its own element count; shorter blocks are zero-padded.  Every rank makes the same
+ * sequence of gather/wait calls per result area.
  * muse_batch_wait_gathered blocks until the area's gathered block has landed: g_all_out is
  * [nranks][rows_per_rank][ntheta] host, info_out this rank's own [n] infos (may be NULL). */
 int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,

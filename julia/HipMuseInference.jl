@@ -178,10 +178,13 @@ end
 
 # One process per GPU (e.g. MPI.jl ranks or Distributed workers pinned to devices): after
 #   id = rank == 0 ? comm_unique_id() : nothing;  id = bcast(id);  comm_init(prob, nranks, rank, id)
-# every rank solves its own block of sims and receives everybody's scores through ONE RCCL all-gather on the device.
-function comm_unique_id()
+# every rank solves its own block of sims and receives everybody's scores: transport = :shm for the workers of one
+# node (blocks exchanged host to host through a shared-memory segment, no collective kernel), :rccl for ONE RCCL
+# all-gather on the device over xGMI.
+function comm_unique_id(transport::Symbol=:rccl; block_doubles=0)
     id = Vector{UInt8}(undef, 128)
-    check(ccall((:muse_comm_unique_id, libmuse_hip), Cint, (Ptr{UInt8},), id)); id
+    check(ccall((:muse_comm_unique_id_ex, libmuse_hip), Cint, (Cint, Int64, Ptr{UInt8}),
+                transport === :shm ? 1 : 0, block_doubles, id)); id
 end
 comm_init(prob::HipMuseProblem, nranks, rank, id) =
     check(ccall((:muse_comm_init, libmuse_hip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), prob.ctx, nranks, rank, id))

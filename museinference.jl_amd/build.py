@@ -4,7 +4,7 @@ The shared library is kept next to this file so that it travels with a repositor
 GPU box (it is git-ignored, not gpurun-ignored).  hipcc cross-compiles without a GPU present.
 Three translation units, each compiled to an object of its own and rebuilt only when it (or a header it
 includes) changed: muse_kernels.hip holds ALL device code (minutes: every model x placement instantiation of
-the solver kernel), muse_engine.cpp the host side and the C ABI (seconds), muse_comm.cpp the RCCL layer.
+the solver kernel), muse_engine.cpp the host side and the C ABI (seconds), muse_comm.cpp the exchange between ranks (RCCL, shared memory).
 """
 import os
 import shutil
@@ -23,11 +23,11 @@ UNITS = {
     "muse_kernels.hip": (_KERNEL_HEADERS + [_API], ["--offload-arch=gfx950", "-O3", "-ffp-contract=off"]),
     # host code: plain C++ against the HIP runtime API (no device pass)
     "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), _API], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
-    "muse_comm.cpp": ([_API], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
+    "muse_comm.cpp": ([_API, os.path.join(CSRC, "shm_gather.hpp")], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
 }
 COMMON_FLAGS = ["-std=c++17", "-fPIC", "-Wno-unused-value"]
 SOURCES = [os.path.join(CSRC, s) for s in UNITS]
-HEADERS = _KERNEL_HEADERS + [_API]
+HEADERS = _KERNEL_HEADERS + [_API, os.path.join(CSRC, "shm_gather.hpp")]
 
 
 def _stale(target, deps):
@@ -67,7 +67,7 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     tmp = lib_path + ".tmp"
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-ldl"]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-ldl", "-lrt", "-lpthread"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=CSRC)

@@ -1,10 +1,11 @@
-// muse_comm.cpp -- RCCL exchange of the per-sim accumulators (collectives C1-C3 of SURVEY.md §2).
+// muse_comm.cpp -- exchange of the per-sim accumulators between ranks (collectives C1-C3 of SURVEY.md §2).
 //
 // The reference gathers map results to the master process through Distributed.pmap
 // (src/util.jl:74-83) and reduces them there (src/muse.jl:183,188,446,529).  Here every rank owns a
 // contiguous block of sims on its own GPU and the per-rank score blocks / H accumulators are
-// exchanged with ONE small RCCL collective per outer iteration over xGMI.  Messages are <= 64 KB,
-// so the cost is collective latency, not link bandwidth.
+// exchanged once per map.  Messages are <= 64 KB, so the cost is latency, not bandwidth.  Two transports:
+// RCCL collectives over xGMI (any topology), and -- for the ranks of one node, whose hosts are the consumers
+// of the blocks -- a shared-memory segment (shm_gather.hpp) that needs no collective kernel at all.
 //
 // librccl is opened lazily (dlopen) so that libmuse_hip.so loads on hosts without a usable RCCL.
 #include <dlfcn.h>
@@ -20,6 +21,7 @@
 #include <thread>
 
 #include "../../include/muse_hip.h"
+#include "shm_gather.hpp"
 
 // Minimal slice of the public RCCL/NCCL C API (rccl.h: ncclGetUniqueId, ncclCommInitRank,
 // ncclAllGather, ncclAllReduce, ncclCommDestroy).
@@ -48,6 +50,11 @@ constexpr int kAreas = 4;  // result areas of the engine (muse_hip.h: result_are
 struct CommState {
     ncclComm_t comm = nullptr;
     int nranks = 1;
+    int rank = 0;
+    // shared-memory transport (null: RCCL).  Area kAreas of the segment carries the synchronous collectives.
+    muse_shm::Gather* shm = nullptr;
+    uint64_t seq[kAreas + 1] = {0};   // sequence number of the last exchange per area (the same on every rank)
+    size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced for the gather in flight
     hipStream_t cstream = nullptr;
     bool own_stream = true;
     bool direct_host = false;
@@ -174,6 +181,49 @@ static void comm_worker(CommState* st) {
     }
 }
 
+// The id of a shared-memory communicator: magic | capacity per block | segment name.
+struct ShmId {
+    uint64_t magic;
+    uint64_t block_doubles;
+    char name[MUSE_UNIQUE_ID_BYTES - 16];
+};
+static_assert(sizeof(ShmId) == MUSE_UNIQUE_ID_BYTES, "the id travels in the same 128 bytes as RCCL's");
+constexpr size_t kShmDefaultBlock = 16384;
+
+#define SHMCHK(st, expr, what)                                                                            \
+    do {                                                                                                  \
+        const int w_ = (expr);                                                                            \
+        if (w_ != 0)                                                                                      \
+            return muse_set_error(MUSE_ERR_RCCL, w_ == 2 ? "shared-memory transport: a peer rank failed (" what ")" \
+                                                         : "shared-memory transport: timed out waiting for the peers (" what ")"); \
+    } while (0)
+
+// Synchronous collectives over the segment's last area, in pieces of at most one block: all-gather into
+// recv [nranks][count], or (sum) the sum over ranks, taken in rank order, written back over `send`.
+static int shm_allgather(CommState* st, const double* send, size_t count, double* recv, bool sum) {
+    muse_shm::Gather& g = *st->shm;
+    const size_t B = g.block_doubles;
+    for (size_t off = 0; off < count; off += B) {
+        const size_t m = count - off < B ? count - off : B;
+        const uint64_t s = ++st->seq[kAreas];
+        SHMCHK(st, g.wait_consumed(kAreas, s - 1), "collective: previous piece");
+        memcpy(g.block(kAreas, st->rank), send + off, m * sizeof(double));
+        g.publish_ready(kAreas, s);
+        SHMCHK(st, g.wait_ready(kAreas, s), "collective");
+        if (sum) {
+            for (size_t i = 0; i < m; ++i) {
+                double acc = g.block(kAreas, 0)[i];
+                for (int q = 1; q < st->nranks; ++q) acc += g.block(kAreas, q)[i];
+                recv[off + i] = acc;
+            }
+        } else {
+            for (int q = 0; q < st->nranks; ++q) memcpy(recv + (size_t)q * count + off, g.block(kAreas, q), m * sizeof(double));
+        }
+        g.publish_consumed(kAreas, s);
+    }
+    return MUSE_OK;
+}
+
 extern "C" {
 
 int muse_comm_unique_id(void* id_out) {
@@ -185,6 +235,31 @@ int muse_comm_unique_id(void* id_out) {
     return MUSE_OK;
 }
 
+int muse_comm_unique_id_ex(int transport, int64_t block_doubles, void* id_out) {
+    if (transport == MUSE_TRANSPORT_RCCL) return muse_comm_unique_id(id_out);
+    if (transport != MUSE_TRANSPORT_SHM) return muse_set_error(MUSE_ERR_INVALID, "unknown transport");
+    if (!id_out || block_doubles < 0) return muse_set_error(MUSE_ERR_INVALID, "bad arguments");
+    static std::atomic<unsigned> counter{0};
+    ShmId id;
+    memset(&id, 0, sizeof id);
+    id.magic = muse_shm::kMagic;
+    id.block_doubles = ((block_doubles ? (size_t)block_doubles : kShmDefaultBlock) + 7) & ~(size_t)7;  // whole cache lines
+    timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    snprintf(id.name, sizeof id.name, "/muse_gather_%d_%llx_%u", (int)getpid(),
+             (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec, counter.fetch_add(1));
+    memcpy(id_out, &id, MUSE_UNIQUE_ID_BYTES);
+    return MUSE_OK;
+}
+
+int muse_comm_transport(muse_ctx* ctx, int* transport_out) {
+    CommState* st = state_of(ctx);
+    if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
+    if (!transport_out) return muse_set_error(MUSE_ERR_INVALID, "transport_out is NULL");
+    *transport_out = st->shm ? MUSE_TRANSPORT_SHM : MUSE_TRANSPORT_RCCL;
+    return MUSE_OK;
+}
+
 int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     void** slot;
     int device;
@@ -193,6 +268,27 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     if (rc) return rc;
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return muse_set_error(MUSE_ERR_INVALID, "bad communicator arguments");
     if (*slot) return muse_set_error(MUSE_ERR_INVALID, "communicator already initialised");
+    {
+        ShmId sid;
+        memcpy(&sid, id, sizeof sid);
+        if (sid.magic == muse_shm::kMagic) {
+            sid.name[sizeof sid.name - 1] = 0;
+            muse_shm::Gather* g = new muse_shm::Gather();
+            if (const char* t = getenv("MUSE_SHM_TIMEOUT_S")) g->timeout_s = atof(t) > 0 ? atof(t) : g->timeout_s;
+            std::string err;
+            if (!g->open(sid.name, nranks, rank, kAreas + 1, (size_t)sid.block_doubles, err)) {
+                delete g;
+                return muse_set_error(MUSE_ERR_RCCL, ("shared-memory transport: " + err).c_str());
+            }
+            CommState* st = new CommState();
+            st->shm = g;
+            st->nranks = nranks;
+            st->rank = rank;
+            st->device = device;
+            *slot = st;
+            return MUSE_OK;
+        }
+    }
     if (!load_rccl()) return muse_set_error(MUSE_ERR_RCCL, "librccl could not be loaded");
     HIPCHK2(hipSetDevice(device));
     ncclUniqueId uid;
@@ -202,6 +298,7 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     CommState* st = new CommState();
     st->comm = comm;
     st->nranks = nranks;
+    st->rank = rank;
     if (getenv("MUSE_COMM_ONE_STREAM")) st->cstream = (hipStream_t)stream;  // tuning aid: collectives in line with the solver
     else {
         // Highest priority: the persistent solver kernel fills every CU (LDS- and VGPR-bound, nothing can
@@ -230,6 +327,12 @@ int muse_comm_destroy(muse_ctx* ctx) {
     int rc = muse_ctx_comm_slot(ctx, &slot, &device, &stream);
     if (rc) return rc;
     if (CommState* st = (CommState*)*slot) {
+        if (st->shm) {
+            delete st->shm;
+            delete st;
+            *slot = nullptr;
+            return MUSE_OK;
+        }
         hipSetDevice(device);
         {
             std::lock_guard<std::mutex> lk(st->qmu);
@@ -262,6 +365,7 @@ int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, doub
     if (!*slot) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
     if (!send || !recv_out || count < 0) return muse_set_error(MUSE_ERR_INVALID, "bad arguments");
     if (count == 0) return MUSE_OK;
+    if (((CommState*)*slot)->shm) return shm_allgather((CommState*)*slot, send, (size_t)count, recv_out, false);
     ncclComm_t comm = ((CommState*)*slot)->comm;
     nranks = ((CommState*)*slot)->nranks;
     double* buf;
@@ -285,6 +389,7 @@ int muse_allreduce_sum(muse_ctx* ctx, double* hostbuf, int64_t count) {
     if (!*slot) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
     if (!hostbuf || count < 0) return muse_set_error(MUSE_ERR_INVALID, "bad arguments");
     if (count == 0) return MUSE_OK;
+    if (((CommState*)*slot)->shm) return shm_allgather((CommState*)*slot, hostbuf, (size_t)count, hostbuf, true);
     double* buf;
     rc = muse_ctx_comm_buffer(ctx, (size_t)count, &buf);
     if (rc) return rc;
@@ -329,10 +434,23 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
     if (sim_end < sim_begin || rows_per_rank < n || rows_per_rank < 1)
         return muse_set_error(MUSE_ERR_INVALID, "rows_per_rank must be >= this rank's element count (and >= 1)");
     const size_t cnt = (size_t)rows_per_rank * (size_t)nt;
+    if (st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "a gather is still in flight on this result area");
+    if (st->shm) {
+        // the plain launch (scores to this area's pinned block); the exchange happens in muse_batch_wait_gathered
+        if (cnt > st->shm->block_doubles)
+            return muse_set_error(MUSE_ERR_INVALID, "rows_per_rank * ntheta exceeds the block capacity the communicator's id was "
+                                                    "created with (muse_comm_unique_id_ex: block_doubles)");
+        rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, nullptr);
+        if (rc) return rc;
+        st->count[area] = cnt;
+        st->nlocal[area] = (size_t)n * nt;
+        st->seq[area] += 1;
+        st->pending[area] = true;
+        return MUSE_OK;
+    }
     rc = ensure_gather_buffers(st, area, cnt);
     if (rc) return rc;
     hipStream_t ks = (hipStream_t)stream;
-    if (st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "a gather is still in flight on this result area");
     // (the area's previous gather has been awaited -- pending is clear -- so its send buffer is free again)
     if ((size_t)n * nt < cnt)  // padding rows of a short block are zeros
         HIPCHK2(hipMemsetAsync(st->send_dev[area] + (size_t)n * nt, 0, (cnt - (size_t)n * nt) * sizeof(double), ks));
@@ -357,6 +475,27 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_in
     if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
     if (area < 0 || area >= kAreas) return muse_set_error(MUSE_ERR_INVALID, "bad result_area");
     if (!st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "no gather in flight on this result area");
+    if (st->shm) {
+        muse_shm::Gather& g = *st->shm;
+        const uint64_t s = st->seq[area];
+        const size_t cnt = st->count[area];
+        st->pending[area] = false;
+        // every rank has copied this rank's previous block of the area out (true at once in a pipelined loop)
+        SHMCHK(st, g.wait_consumed(area, s - 1), "gathered map: previous block");
+        double* mine = g.block(area, st->rank);
+        int rc = muse_batch_wait(ctx, area, mine, info_out);  // solver's completion, error flag; scores -> my block
+        if (rc) {
+            g.raise_abort();  // the peers must not wait a minute for a block that will not come
+            return rc;
+        }
+        if (st->nlocal[area] < cnt) memset(mine + st->nlocal[area], 0, (cnt - st->nlocal[area]) * sizeof(double));
+        g.publish_ready(area, s);
+        SHMCHK(st, g.wait_ready(area, s), "gathered map");
+        if (g_all_out)
+            for (int q = 0; q < st->nranks; ++q) memcpy(g_all_out + (size_t)q * cnt, g.block(area, q), cnt * sizeof(double));
+        g.publish_consumed(area, s);
+        return MUSE_OK;
+    }
     while (!st->enqueued[area].load(std::memory_order_acquire)) __builtin_ia32_pause();  // the worker is microseconds behind
     st->pending[area] = false;
     {

@@ -26,11 +26,13 @@ class ShardedMuseProblem:
 
     All attribute access other than the batched seams is forwarded to the local problem."""
 
-    def __init__(self, local, group=None, device=None, engine_comm=None):
-        """engine_comm: exchange through the engine's own RCCL communicator (muse_comm_* of the C ABI: pinned
-        host -> device -> ncclAllGather -> pinned host, no torch tensors on the path).  Default: yes when the
-        process group's backend is nccl (= RCCL) and the local problem is a HipMuseProblem; torch.distributed
-        collectives otherwise (gloo on CPU).  The unique id travels over the process group once."""
+    def __init__(self, local, group=None, device=None, engine_comm=None, transport=None):
+        """engine_comm: exchange through the engine's own communicator (muse_comm_* of the C ABI, no torch tensors on
+        the path).  transport "shm": the ranks share a node and exchange their blocks host to host through a
+        shared-memory segment; "rccl": pinned host -> device -> ncclAllGather -> pinned host.  Defaults: the engine's
+        communicator when the local problem is a HipMuseProblem and either all ranks report the same host name (shm)
+        or the process group's backend is nccl (= RCCL); torch.distributed collectives otherwise (gloo on CPU).
+        The unique id travels over the process group once."""
         import torch.distributed as dist
         self._dist = dist
         self.local = local
@@ -39,11 +41,18 @@ class ShardedMuseProblem:
         self.rank = dist.get_rank(group)
         self._device = device
         self._last_nslots = None
+        has_engine = hasattr(local, "comm_init")
+        if has_engine and transport is None and engine_comm is not False:
+            import socket
+            names = [None] * self.world
+            dist.all_gather_object(names, socket.gethostname(), group=group)
+            transport = "shm" if len(set(names)) == 1 else "rccl"
         if engine_comm is None:
-            engine_comm = dist.get_backend(group) == "nccl" and hasattr(local, "comm_init")
+            engine_comm = has_engine and (transport == "shm" or dist.get_backend(group) == "nccl")
         self.engine_comm = bool(engine_comm)
+        self.transport = transport if self.engine_comm else None
         if self.engine_comm and getattr(local, "_nranks", None) is None:
-            uid = [type(local).comm_unique_id() if self.rank == 0 else None]
+            uid = [type(local).comm_unique_id(transport or "rccl") if self.rank == 0 else None]
             dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             local.comm_init(self.world, self.rank, uid[0])
 

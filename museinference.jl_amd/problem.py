@@ -419,16 +419,28 @@ class HipMuseProblem(AbstractMuseProblem):
                                                       float(atol), int(cg_maxiter), _capi.ptr(cols), _capi.ptr(its)))
         return cols, its
 
-    # -- RCCL exchange (C1-C3 of SURVEY.md §2) through the C ABI, for hosts without torch.distributed
+    # -- exchange between ranks (C1-C3 of SURVEY.md §2) through the C ABI, for hosts without torch.distributed
+    TRANSPORTS = {"rccl": 0, "shm": 1}
+
     @staticmethod
-    def comm_unique_id():
+    def comm_unique_id(transport="rccl", block_doubles=0):
+        """Created on rank 0 and passed (by any means) to every rank's comm_init.  transport "rccl": collectives
+        over xGMI; "shm": the ranks of one node exchange their blocks through a shared-memory segment."""
         buf = (C.c_char * _capi.UNIQUE_ID_BYTES)()
-        _capi.check(_capi.load_library().muse_comm_unique_id(buf))
+        _capi.check(_capi.load_library().muse_comm_unique_id_ex(HipMuseProblem.TRANSPORTS[transport], int(block_doubles), buf))
         return bytes(buf)
 
     def comm_init(self, nranks, rank, unique_id):
-        _capi.check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), C.c_char_p(unique_id)))
+        if len(unique_id) != _capi.UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be the bytes returned by comm_unique_id")
+        buf = (C.c_char * _capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)  # (binary: not a C string)
+        _capi.check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), buf))
         self._nranks = int(nranks)
+
+    def comm_transport(self):
+        t = C.c_int(-1)
+        _capi.check(self._lib.muse_comm_transport(self._ctx, C.byref(t)))
+        return {v: k for k, v in self.TRANSPORTS.items()}[t.value]
 
     def allgather_scores(self, send):
         send = _capi.f8(send)
@@ -438,8 +450,9 @@ class HipMuseProblem(AbstractMuseProblem):
 
     def map_and_score_batch_gather_async(self, rng, sim_begin, sim_end, theta, rows_per_rank, *, include_data=False,
                                          atol=1e-2, z0_mode=_capi.Z0_ZERO, result_area=0):
-        """This rank's block of a sharded map; the score blocks of all ranks are all-gathered on the device
-        (RCCL, on the communicator's own stream).  Returns this rank's element count."""
+        """This rank's block of a sharded map; the score blocks of all ranks are all-gathered (RCCL: on the device,
+        on the communicator's own stream; shm: between the hosts, inside batch_wait_gathered).  Returns this rank's
+        element count."""
         th = self._theta(theta)
         _capi.check(self._lib.muse_map_and_score_batch_gather_async(
             self._ctx, _seed_of(rng), sim_begin, sim_end, int(bool(include_data)), _capi.ptr(th), float(atol),

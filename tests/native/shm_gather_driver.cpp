@@ -1,0 +1,59 @@
+// Test driver for museinference.jl_amd/csrc/shm_gather.hpp (the shared-memory transport's protocol, no GPU):
+//   shm_gather_driver <segment name> <nranks> <rank> <rounds> <block_doubles> [abort_at_round]
+// Every rank runs `rounds` exchanges over 4 areas in turn with rank- and round-dependent delays, fills its block with
+// a function of (rank, area, sequence number, index) and checks every block it reads.  With abort_at_round the LAST
+// rank raises the abort word instead of publishing; the others must then leave their wait with code 2 (exit 42).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../museinference.jl_amd/csrc/shm_gather.hpp"
+
+static double value(int rank, int area, uint64_t seq, size_t i) {
+    return (double)rank * 1e6 + (double)area * 1e5 + (double)(seq % 100000) + 1e-3 * (double)(i % 997);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6) return 2;
+    const char* name = argv[1];
+    const int nranks = atoi(argv[2]), rank = atoi(argv[3]), rounds = atoi(argv[4]);
+    const size_t B = (size_t)atol(argv[5]);
+    const int abort_at = argc > 6 ? atoi(argv[6]) : -1;
+    muse_shm::Gather g;
+    g.timeout_s = 20.0;
+    std::string err;
+    if (!g.open(name, nranks, rank, 4, B, err)) {
+        fprintf(stderr, "rank %d: open failed: %s\n", rank, err.c_str());
+        return 3;
+    }
+    uint64_t seq[4] = {0, 0, 0, 0};
+    unsigned lcg = 12345u + 77u * (unsigned)rank;
+    for (int k = 0; k < rounds; ++k) {
+        const int area = k % 4;
+        const uint64_t s = ++seq[area];
+        lcg = lcg * 1664525u + 1013904223u;
+        if ((lcg >> 24) % 8 == (unsigned)rank % 8) usleep((lcg >> 16) % 300);  // a different straggler every few rounds
+        int w = g.wait_consumed(area, s - 1);
+        if (w) { fprintf(stderr, "rank %d round %d: wait_consumed -> %d\n", rank, k, w); return w == 2 ? 42 : 4; }
+        if (k == abort_at && rank == nranks - 1) {
+            g.raise_abort();
+            return 43;
+        }
+        double* mine = g.block(area, rank);
+        for (size_t i = 0; i < B; ++i) mine[i] = value(rank, area, s, i);
+        g.publish_ready(area, s);
+        w = g.wait_ready(area, s);
+        if (w) { fprintf(stderr, "rank %d round %d: wait_ready -> %d\n", rank, k, w); return w == 2 ? 42 : 5; }
+        for (int q = 0; q < nranks; ++q) {
+            const double* b = g.block(area, q);
+            for (size_t i = 0; i < B; ++i)
+                if (b[i] != value(q, area, s, i)) {
+                    fprintf(stderr, "rank %d round %d: block of rank %d, word %zu: %.17g != %.17g\n", rank, k, q, i, b[i],
+                            value(q, area, s, i));
+                    return 6;
+                }
+        }
+        g.publish_consumed(area, s);
+    }
+    printf("rank %d ok %d rounds\n", rank, rounds);
+    return 0;
+}

@@ -241,6 +241,7 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank,
 x = np.load({xfile!r})
 local = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0), device=0)
 prob = M.ShardedMuseProblem(local)
+assert prob.engine_comm and prob.transport == "shm" and local.comm_transport() == "shm"   # same host: shared memory
 res = M.muse(prob, [1.0, 0.5], rng=3, nsims=21, maxsteps=4, get_covariance=True)
 with open({out!r} + str(rank), "wb") as f:
     pickle.dump(dict(theta=res.theta, J=res.J, H=res.H, Sigma=res.Sigma, gs=np.array(res.gs)), f)
@@ -250,7 +251,8 @@ dist.destroy_process_group()
 
 def test_two_ranks_on_one_gpu_match_single_process(gpu, M, O, tmp_path):
     """The sharded path on real kernels: two processes (gloo group, both on GPU 0) each solve their block of
-    the sims; every rank must reproduce the single-process result bit for bit."""
+    the sims and exchange through the engine's shared-memory transport (the default for ranks of one host); every
+    rank must reproduce the single-process result bit for bit."""
     import pickle
     import subprocess
     import sys
@@ -283,8 +285,8 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 x = np.load({xfile!r})
 local = M.HipMuseProblem(x, model="funnel", ntheta=2, prior=M.GaussianPrior(0.0, 3.0), device=0)
-prob = M.ShardedMuseProblem(local)
-assert prob.engine_comm          # nccl backend: the exchange goes through the engine's RCCL communicator
+prob = M.ShardedMuseProblem(local, transport="rccl")
+assert prob.engine_comm and local.comm_transport() == "rccl"   # the exchange goes through the engine's RCCL communicator
 res = M.muse(prob, [1.0, 0.5], rng=3, nsims=21, maxsteps=4, get_covariance=True)
 with open({out!r}, "wb") as f:
     pickle.dump(dict(theta=res.theta, J=res.J, H=res.H, Sigma=res.Sigma, gs=np.array(res.gs)), f)

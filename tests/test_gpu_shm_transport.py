@@ -1,0 +1,64 @@
+"""The shared-memory transport of the sharded map (muse_comm_unique_id_ex(MUSE_TRANSPORT_SHM), the pool seam of
+src/util.jl:74-83 for the ranks of one node) on a GPU: several processes -- all on GPU 0, the transport has no device
+side -- run the pipelined gathered map and the synchronous collectives; every rank must hold, bit for bit, what one
+process computes for the whole sim range."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
+    import museinference_jl_amd as M
+    uid = M.HipMuseProblem.comm_unique_id("shm", 4096)   # naming the segment does not touch the GPU
+    assert len(uid) == 128
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, "\n".join(logs)
+    res = [np.load(o) for o in outs]
+
+    NSIMS, N, NTH, SEED = 23, 2000, 2, 77
+    rows = -(-NSIMS // world)
+    ref = M.HipMuseProblem(None, model="funnel", ntheta=NTH, N=N)
+    for k in range(9):
+        th = np.array([0.3 * k - 1.0, 0.5 - 0.1 * k])
+        g, info = ref.map_and_score_batch(SEED, 0, NSIMS, th, atol=1e-4)
+        for r in range(world):
+            g_all = res[r][f"g{k}"]
+            assert g_all.shape == (world, rows, NTH)
+            for q in range(world):
+                lo, hi = M.block_partition(0, NSIMS, world, q)
+                assert np.array_equal(g_all[q, : hi - lo], g[lo:hi]), (k, r, q)
+                assert np.all(g_all[q, hi - lo:] == 0.0)           # padding rows of a short block
+            lo, hi = M.block_partition(0, NSIMS, world, r)
+            assert np.array_equal(res[r][f"it{k}"], info["iterations"][lo:hi])
+    ref.close()
+    big = [np.sin(np.arange(40000.0) * (q + 1)) for q in range(world)]
+    total = big[0].copy()
+    for q in range(1, world):
+        total = total + big[q]                                      # rank order: bitwise the same on every rank
+    for r in range(world):
+        assert np.array_equal(res[r]["ag"], np.stack([np.arange(5.0) + 10.0 * q for q in range(world)]))
+        assert np.array_equal(res[r]["ar"], total)
+        assert np.array_equal(res[r]["ag_big"], np.stack([b[:20001] for b in big]))
+
+
+def test_block_capacity_is_checked():
+    import museinference_jl_amd as M
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=2, N=600)
+    prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 8))
+    with pytest.raises(M.MuseError, match="capacity"):
+        prob.map_and_score_batch_gather_async(1, 0, 5, np.zeros(2), 5)      # 5 rows x 2 > 8 doubles
+    n = prob.map_and_score_batch_gather_async(1, 0, 4, np.zeros(2), 4)
+    g_all, info = prob.batch_wait_gathered(n, 4)
+    g, _ = prob.map_and_score_batch(1, 0, 4, np.zeros(2))
+    assert np.array_equal(g_all[0], g)
+    prob.close()

@@ -1,0 +1,5 @@
+import json,sys
+for line in sys.stdin:
+    if line.startswith("{"):
+        d=json.loads(line)
+        print(sys.argv[1], "value", round(d["value"]), "ms/step", round(d["ms_per_step"],4), "split", d["config"]["element_split"], d["config"]["parallelism"][-40:], "kernel_ms", round(d["roofline"]["kernel_ms_mean"],4), d["host_us_per_step"])
