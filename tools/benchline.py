@@ -1,3 +1,5 @@
+"""Reads bench.py output on stdin and prints the step time, split, transport, kernel time and host times of every JSON
+line on one line each, prefixed by argv[1] (development aid for A/B runs inside one gpurun call)."""
 import json,sys
 for line in sys.stdin:
     if line.startswith("{"):
