@@ -47,6 +47,20 @@ constexpr int kStencilU = MUSE_STENCIL_U;  // pairs per trip for the stencil mod
 constexpr int kStreamU = MUSE_STREAM_U;    // pairs per trip of the elementwise models' streaming passes (a pure
                                            // performance knob: a thread visits its pairs in the same order for every U)
 
+#ifndef MUSE_STREAM_GEN_U
+#define MUSE_STREAM_GEN_U 1
+#endif
+constexpr int kStreamGenU = MUSE_STREAM_GEN_U;  // pairs per trip of the streaming placements' sampler pass (their normals
+                                                // are drawn side by side: 2 * kStreamGenU generator chains per thread;
+                                                // noise_1e6: 1.57 ms at 1, 1.71 ms at 2)
+#ifndef MUSE_SAMPLER_PAIRS
+#define MUSE_SAMPLER_PAIRS 1
+#endif
+constexpr int kSamplerPairs = MUSE_SAMPLER_PAIRS;  // pairs drawn per trip of the LDS-resident placement's sampler (1 or 2:
+                                                   // two or four generator chains side by side per thread).  At two waves
+                                                   // per SIMD the generator is bound by SIMD throughput, not by latency:
+                                                   // measured 56.0 us (1) against 58.0 us (2) at configs[1]
+
 struct BatchArgs {
     int64_t N, ld;
     int ntheta, kind;

@@ -383,9 +383,7 @@ struct Solver {
                 mx[0] = absmax(absmax(mx[0], g0), g1);
             }, when(STORE_G, g), when(INIT_S, s));
         }
-        if (iter_stamp == 0) stamp(stamp_p, 14);
         reduce<2, 1>(sum, mx);
-        if (iter_stamp == 0) stamp(stamp_p, 15);
         f = 0.5 * (sum[0] + a.f_const);
         dphi = sum[1];
         gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
@@ -757,24 +755,47 @@ struct Solver {
                         for (int b = 1; b < MAXB; ++b) v = (i >= bb[b]) ? sdl[b] : v;  // bnd32[b] = INT_MAX for b >= ntheta
                         return v;
                     };
-#pragma unroll 1
-                    for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T) {
-                        // both elements of the pair unconditionally (one basic block: their Philox/Box-Muller
-                        // chains interleave); for odd N the last pair's second element is the pad slot, kept at 0
-                        const NormalPair np0 = normal_pair(a.seed, sim, (uint64_t)i0);
-                        const NormalPair np1 = normal_pair(a.seed, sim, (uint64_t)(i0 + 1));
-                        if (nmode == 1) {
-                            store_f64x2(n1r, i0, np0.n1, np1.n1);
-                            store_f64x2(n2r, i0, np0.n2, np1.n2);
+                    // One trip draws kSamplerPairs pairs (2 * kSamplerPairs independent Philox/Box-Muller chains in one basic
+                    // block).  At the two waves per SIMD of this placement a wave issues a VALU instruction every ~5.3 cycles
+                    // when it has four independent ones to choose from and every ~11 when each depends on the one before
+                    // (tools/clockprobe.hip): with one pair per trip the generator ran at ~9.8 cycles per instruction.
+                    auto draw = [&](auto npairs, int i0) {
+                        // both elements of a pair unconditionally; for odd N the last pair's second element is the pad
+                        // slot, kept at 0.  All 2 * P generator chains advance side by side (rng.hpp).
+                        constexpr int P = decltype(npairs)::value;
+                        uint64_t idx[2 * P];
+                        NormalPair np[2 * P];
+#pragma unroll
+                        for (int q = 0; q < P; ++q) {
+                            idx[2 * q] = (uint64_t)(i0 + 2 * T * q);
+                            idx[2 * q + 1] = (uint64_t)(i0 + 2 * T * q + 1);
                         }
-                        double zt0, xt0, zt1, xt1;
-                        Model::sample(sd_of(i0), np0.n1, np0.n2, zt0, xt0);
-                        Model::sample(sd_of(i0 + 1), np1.n1, np1.n2, zt1, xt1);
-                        const bool valid1 = i0 + 1 < (int)N;
-                        x.p[i0] = xt0;
-                        g.p[i0] = zt0;
-                        x.p[i0 + 1] = valid1 ? xt1 : 0.0;
-                        g.p[i0 + 1] = valid1 ? zt1 : 0.0;
+                        normal_pairs<2 * P>(a.seed, sim, idx, np);
+#pragma unroll
+                        for (int q = 0; q < P; ++q) {
+                            const int j0 = i0 + 2 * T * q;
+                            if (nmode == 1) {
+                                store_f64x2(n1r, j0, np[2 * q].n1, np[2 * q + 1].n1);
+                                store_f64x2(n2r, j0, np[2 * q].n2, np[2 * q + 1].n2);
+                            }
+                            double zt0, xt0, zt1, xt1;
+                            Model::sample(sd_of(j0), np[2 * q].n1, np[2 * q].n2, zt0, xt0);
+                            Model::sample(sd_of(j0 + 1), np[2 * q + 1].n1, np[2 * q + 1].n2, zt1, xt1);
+                            const bool valid1 = j0 + 1 < (int)N;
+                            x.p[j0] = xt0;
+                            g.p[j0] = zt0;
+                            x.p[j0 + 1] = valid1 ? xt1 : 0.0;
+                            g.p[j0 + 1] = valid1 ? zt1 : 0.0;
+                        }
+                    };
+#pragma unroll 1
+                    for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T * kSamplerPairs) {
+                        if constexpr (kSamplerPairs == 2) {
+                            if (i0 + 2 * T < (int)N) draw(std::integral_constant<int, 2>{}, i0);
+                            else draw(std::integral_constant<int, 1>{}, i0);
+                        } else {
+                            draw(std::integral_constant<int, 1>{}, i0);
+                        }
                     }
                 }
                 z.clear();
@@ -801,9 +822,24 @@ struct Solver {
                         // x, z, write g; read g, write s; read z, s, x of the four passes it replaces
                         const bool ztrue_start = d.z0_mode == Z0_TRUE;
                         double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
-                        for_elems<T, EPT, 1>(ld, tfirst, ps(), [&](int jj, int i) {
+                        // the normals of a trip's kGenU pairs are drawn side by side (2 * kGenU generator chains, rng.hpp)
+                        constexpr int kGenU = Place::kResident ? 1 : kStreamGenU;
+                        NormalPair npv[2 * kGenU];
+                        for_elems_pre<T, EPT, kGenU>(ld, tfirst, ps(), [&](auto ucount, int i0, int pstr) {
+                            constexpr int UU = decltype(ucount)::value;
+                            uint64_t idx[2 * UU];
+                            NormalPair got[2 * UU];
+#pragma unroll
+                            for (int u = 0; u < UU; ++u) {
+                                idx[2 * u] = (uint64_t)(i0 + 2 * u * pstr);
+                                idx[2 * u + 1] = (uint64_t)(i0 + 2 * u * pstr + 1);
+                            }
+                            normal_pairs<2 * UU>(a.seed, sim, idx, got);
+#pragma unroll
+                            for (int q = 0; q < 2 * UU; ++q) npv[q] = got[q];
+                        }, [&](int jj, int i) {
                             const bool valid = i < N;
-                            const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+                            const NormalPair np = npv[jj % (2 * kGenU)];
                             double zt, xt;
                             Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
                             zt = valid ? zt : 0.0;
@@ -1079,8 +1115,10 @@ struct Solver {
                         for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
                     }
                 }, z);
+                if (iterations == 1) stamp(p, 14);
                 if constexpr (MAXB + 1 <= 8) {
                     reduce<MAXB, 1>(acc, mx);
+                    if (iterations == 1) stamp(p, 15);
                 } else {
                     double none[1] = {0.0};
                     reduce<0, 1>(none, mx);

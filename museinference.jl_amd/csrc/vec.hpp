@@ -1,5 +1,6 @@
 // vec.hpp -- vector accessors of the two storage policies and the per-thread element loop (see muse_kernels.hip).
 #pragma once
+#include <type_traits>
 #include "args.hpp"
 
 namespace muse {
@@ -272,5 +273,47 @@ __device__ __forceinline__ void for_elems(int64_t ld, int tfirst, int pstride, F
     }
 }
 
+// The same loop with a prologue per trip: pre(integral_constant<int, UU>, i0, pstride) runs before the element bodies of
+// the UU pairs i0, i0 + 2*pstride, ... (the sampler draws the normals of all of them side by side, rng.hpp); the bodies
+// find pair u of the trip at jj % (2U) = 2u, 2u+1.
+template <int T, int EPT, int U, class P, class F, class... W>
+__device__ __forceinline__ void for_elems_pre(int64_t ld, int tfirst, int pstride, P&& pre, F&& f, W&&... written) {
+    int t = tfirst;
+    asm volatile("" : "+v"(t));
+    if constexpr (EPT > 0) {
+#pragma unroll
+        for (int j0 = 0; j0 < EPT; j0 += U) {
+            const int i0 = 2 * (t + j0 * pstride);
+            if (j0 + U <= EPT) {
+                pre(std::integral_constant<int, U>{}, i0, pstride);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    f(2 * (j0 + u), i0 + 2 * u * pstride);
+                    f(2 * (j0 + u) + 1, i0 + 2 * u * pstride + 1);
+                }
+            } else {
+                pre(std::integral_constant<int, (EPT % U) ? (EPT % U) : U>{}, i0, pstride);
+#pragma unroll
+                for (int u = 0; u < EPT % U; ++u) {
+                    f(2 * (j0 + u), i0 + 2 * u * pstride);
+                    f(2 * (j0 + u) + 1, i0 + 2 * u * pstride + 1);
+                }
+            }
+        }
+    } else {
+        const int n = (int)ld;
+#pragma unroll 1
+        for (int i0 = 2 * t; i0 < n; i0 += 2 * U * pstride) {
+            pre(std::integral_constant<int, U>{}, i0, pstride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 2 * u * pstride;
+                f(2 * u, i);
+                f(2 * u + 1, i + 1);
+            }
+            (written.template flush<U>(i0, pstride), ...);
+        }
+    }
+}
 
 }  // namespace muse

@@ -23,7 +23,14 @@ for k, nm in enumerate(names): print(f"  {nm:16s} {np.median(d[:,k]):10.0f}   ({
 print("  sample detail: start->sampler loop end", np.median(out[:,8].astype(np.int64)-st[:,0]), " ->z init end", np.median(out[:,9].astype(np.int64)-out[:,8].astype(np.int64)), " ->barrier end", np.median(st[:,1]-out[:,9].astype(np.int64)))
 o=out.astype(np.int64)
 print("  line search detail: pre-logic", np.median(o[:,10]-st[:,3]), " eval1", np.median(o[:,11]-o[:,10]), " logic1", np.median(o[:,12]-o[:,11]), " eval2", np.median(o[:,13]-o[:,12]), " post-logic", np.median(st[:,4]-o[:,13]))
-print("  first line-search evaluation: element loop", np.median(o[:,14]-o[:,10]), " reduction", np.median(o[:,15]-o[:,14]))
+print("  final update pass: element loop", np.median(o[:,14]-st[:,4]), " reduction", np.median(o[:,15]-o[:,14]), " rest", np.median(st[:,5]-o[:,15]))
 print("total per problem", np.median(st[:,7]-st[:,0]), "cycles; first start -> last end:", (st[:,7].max()-st[:,0].min()), "cycles")
+# a workgroup's next problem starts right after its previous one ended (same CU, same counter): the smallest positive
+# start - end distance of each problem to any other is the per-problem prologue/epilogue outside the stamped span
+ends = np.sort(st[:, 7]); gaps = []
+for s0 in st[:, 0]:
+    k = np.searchsorted(ends, s0) - 1
+    if k >= 0 and 0 < s0 - ends[k] < 20000: gaps.append(s0 - ends[k])
+if gaps: print("between two problems of a workgroup (end stamp -> next start stamp): median", np.median(gaps), "cycles over", len(gaps), "pairs")
 order = np.argsort(st[:,0]); 
 print("start offsets of problems (cycles, sorted) sample:", (st[order,0]-st[:,0].min())[[0,1,n//5,n//2-1,n//2,n-1]])
