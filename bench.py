@@ -318,6 +318,12 @@ def main():
     transport = os.environ.get("MUSE_BENCH_TRANSPORT", "shm")
     if transport not in ("shm", "rccl"):
         raise SystemExit("MUSE_BENCH_TRANSPORT must be shm or rccl")
+    if sharded and transport == "shm":
+        import socket
+        hosts = [None] * world
+        dist.all_gather_object(hosts, socket.gethostname())
+        if len(set(hosts)) > 1:  # not this bench's launch contract, but do not wait for the segment's time-out
+            transport = "rccl"
     split = args.split
     if split < 0:
         split = 1

@@ -91,6 +91,8 @@ struct BatchArgs {
     double* cl_part;               // [nclusters][kClusterSlotDoubles]: partial sums / maxima, or their tagged granules
     unsigned int* cl_state;        // [nclusters] epoch reached by the cluster's granule exchange (persists across launches)
     int* error_flag;               // [0] set when a bounded cluster wait expires; [1] the largest epoch reported
+    int xcd_local;                 // cluster mode: the members of a cluster are workgroups b = x (mod 8), which the dispatcher
+                                   // places on ONE XCD (round-robin over the XCDs): their exchanges stay inside it
     unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
     // Standard normals of simulation streams already drawn inside the SAME host call (muse_run's later
     // iterations re-draw every simulation at a new theta, the FD batch draws each simulation 2*ntheta times):

@@ -265,6 +265,11 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         }
         a.cl_part = c->cl_part;
         a.cl_state = c->cl_state;
+        // XCD-local clusters (muse_kernels.hip) for the elementwise models, whose members meet in scalar exchanges only:
+        // 22.2 -> 21.3 us at 64 sims split 4, noise_1e6 1.555 -> 1.52 ms.  The stencil model, whose members also stream
+        // each other's boundary elements, measured slower with all of a cluster's traffic in one XCD (2.35 -> 2.47 ms).
+        static const bool no_xcd = getenv("MUSE_DEBUG_NO_XCD_LOCAL") != nullptr;
+        a.xcd_local = (!no_xcd && ncl % 8 == 0 && c->model != MUSE_MODEL_SMOOTH) ? 1 : 0;
     } else {
         if (grid > a.nproblems) grid = a.nproblems;
         if (grid < 1) grid = 1;

@@ -78,7 +78,14 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     if constexpr (Place::kCluster) {
         // csize consecutive workgroups form a cluster that works on one problem at a time; problems are
         // dealt to clusters round-robin (every member computes the same sequence: no communication).
-        const int csize = a.csize, cluster = blockIdx.x / csize, crank = blockIdx.x % csize;
+        // XCD-local clusters: workgroup b runs on XCD b mod 8 (tools/xcdprobe.hip: 0 of 512 workgroups elsewhere), so a
+        // cluster takes its members from one residue class (cluster = (w / csize) * 8 + x, rank = w mod csize for
+        // b = 8 w + x): an agent-scope flag hand-off inside an XCD costs ~1030 shader cycles against ~1510 across XCDs
+        // (workgroup-scope accesses do not see another CU's stores at all).  Only a matter of speed: the accesses are
+        // agent-scope either way.
+        const int csize = a.csize;
+        const int cluster = a.xcd_local ? ((int)(blockIdx.x >> 3) / csize) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x / csize;
+        const int crank = a.xcd_local ? (int)(blockIdx.x >> 3) % csize : (int)blockIdx.x % csize;
         double* cl_scratch = a.scratch + (int64_t)cluster * a.scratch_stride;
         Solver<Model, Place> sv(a, tid, red, shs);
         sv.crank = crank;
