@@ -53,6 +53,12 @@ constexpr int kStreamU = MUSE_STREAM_U;    // pairs per trip of the elementwise 
 constexpr int kStreamGenU = MUSE_STREAM_GEN_U;  // pairs per trip of the streaming placements' sampler pass (their normals
                                                 // are drawn side by side: 2 * kStreamGenU generator chains per thread;
                                                 // noise_1e6: 1.57 ms at 1, 1.71 ms at 2)
+#ifndef MUSE_BG_U
+#define MUSE_BG_U 2
+#endif
+#ifndef MUSE_BG_PAIRS
+#define MUSE_BG_PAIRS 1
+#endif
 #ifndef MUSE_SAMPLER_PAIRS
 #define MUSE_SAMPLER_PAIRS 1
 #endif

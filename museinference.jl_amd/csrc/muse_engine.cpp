@@ -150,7 +150,10 @@ static size_t place_lds(const muse_ctx* c, int pl) {
     if (pl == P_R512x10) fixed += (size_t)2 * (c->ld + 2) * sizeof(double);
     return fixed;
 }
-static int64_t place_scratch_vectors(int pl) { return (pl == P_S256 || pl == P_S512 || pl == P_C256) ? 4 + 2 * kM + 1 : 2 * kM; }
+// streaming: x, g, s, z, the history, one extra vector; clusters: a second (x, s) pair for the background generator
+static int64_t place_scratch_vectors(int pl) {
+    return (pl == P_S256 || pl == P_S512) ? 4 + 2 * kM + 1 : pl == P_C256 ? 4 + 2 * kM + 1 + 2 : 2 * kM;
+}
 
 static int ensure_zhat(muse_ctx* c, int64_t slots) {
     if (slots <= c->zhat_slots) return MUSE_OK;

@@ -96,7 +96,10 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         sv.cl_part = a.cl_part + (size_t)cluster * kClusterSlotDoubles;
         sv.exch = exch;
         sv.cl_epoch = a.cl_state[cluster];  // granule tags continue across launches
-        for (int p = cluster; p < a.nproblems; p += a.nclusters) {
+        int nth = 0;
+        for (int p = cluster; p < a.nproblems; p += a.nclusters, ++nth) {
+            sv.bufsel = nth & 1;
+            sv.next_p = p + a.nclusters < a.nproblems ? p + a.nclusters : -1;
             sv.parity = 0;
             __syncthreads();
             if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);

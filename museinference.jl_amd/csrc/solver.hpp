@@ -51,6 +51,11 @@ struct Solver {
         cl_aborted = false;
         cl_part = nullptr;
         exch = nullptr;
+        gen.p = -1;
+        gen.trip = 0;
+        gen.active = false;
+        bufsel = 0;
+        next_p = -1;
     }
 
     // Cluster all-reduce.  For the elementwise models only these K scalars cross workgroups (every thread reads and
@@ -329,6 +334,110 @@ struct Solver {
         }
     }
 
+    // ---- background generator (streaming clusters of the elementwise models) --------------------------------------
+    // A streaming problem is a generator pass (VALU-bound: Philox + Box-Muller + the initial evaluation and first trial,
+    // writes x and s = -g) followed by passes that only stream (HBM-bound).  A cluster knows its next problem (problems
+    // are dealt round-robin), so the streaming passes of problem p carry the generator pass of problem p + nclusters: every
+    // trip first draws kBgPairs pairs of the next problem -- arithmetic only, placed before the trip's loads are used --
+    // and stores them with the trip's own stores, into the other (x, s) buffer pair of the cluster's scratch.  The sums
+    // of the next problem's initial evaluation accumulate in registers; whatever is left when problem p ends is
+    // drawn in the foreground.  A thread draws its pairs in the same order either way: bit-identical results.
+    static constexpr bool kBg = Place::kCluster && !Place::kResident && !Model::kStencil;
+    static constexpr int kBgPairs = MUSE_BG_PAIRS, kBgU = MUSE_BG_U;
+    struct GenState {
+        int p;         // the problem being generated (-1: none)
+        int trip;      // pairs tfirst + k*pstride, k < trip, are done
+        bool active;   // the streaming passes of the current problem still have trips of it to draw
+        uint64_t sim;
+        double sum[4], mx[2];
+    };
+    GenState gen;
+    int bufsel;        // (x, s) buffer pair of the current problem
+    int next_p;        // the cluster's next problem, -1: none
+    rsrc_t bg_xr, bg_sr;
+    double bgx[2 * kBgPairs], bgs[2 * kBgPairs];
+    __device__ __forceinline__ int gen_trips() const { return ((int)a.ld / 2 + pstride - 1) / pstride; }
+    // one pair of problem gen.p: elements i0, i0 + 1 (the arithmetic of the fused sampler pass in begin())
+    __device__ __forceinline__ void gen_pair(int i0, double* xo, double* so) {
+        const int N = (int)a.N;
+        const uint64_t idx[2] = {(uint64_t)i0, (uint64_t)(i0 + 1)};
+        NormalPair np[2];
+        normal_pairs<2>(a.seed, gen.sim, idx, np);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int i = i0 + v;
+            const bool valid = i < N;
+            double zt, xt;
+            Model::sample(sdk(v, i), np[v].n1, np[v].n2, zt, xt);
+            xt = valid ? xt : 0.0;
+            const double ivi = ivk(v, i);
+            const double gi = Model::grad(ivi, xt, 0.0, gen.sum[0]);
+            const double sd = -gi;
+            gen.sum[1] = fma(gi, sd, gen.sum[1]);
+            gen.mx[0] = absmax(gen.mx[0], gi);
+            const double zt1 = fma(1.0, sd, 0.0);
+            const double gt = Model::grad(ivi, xt, zt1, gen.sum[2]);
+            gen.sum[3] = fma(gt, sd, gen.sum[3]);
+            gen.mx[1] = absmax(gen.mx[1], gt);
+            xo[v] = xt;
+            so[v] = sd;
+        }
+    }
+    __device__ __forceinline__ void bg_draw() {  // between a trip's loads and their use: arithmetic only
+        if constexpr (kBg) {
+            if (__builtin_amdgcn_readfirstlane((int)gen.active)) {
+#pragma unroll
+                for (int q = 0; q < kBgPairs; ++q) gen_pair(2 * (tfirst + (gen.trip + q) * pstride), bgx + 2 * q, bgs + 2 * q);
+            }
+        }
+    }
+    __device__ __forceinline__ void bg_store() {  // with the trip's stores
+        if constexpr (kBg) {
+            if (__builtin_amdgcn_readfirstlane((int)gen.active)) {
+#pragma unroll
+                for (int q = 0; q < kBgPairs; ++q) {
+                    const int i0 = 2 * (tfirst + (gen.trip + q) * pstride);  // past the end: dropped by the range check
+                    store_f64x2(bg_xr, i0, bgx[2 * q], bgx[2 * q + 1]);
+                    store_f64x2(bg_sr, i0, bgs[2 * q], bgs[2 * q + 1]);
+                }
+                gen.trip += kBgPairs;
+                gen.active = gen.trip < gen_trips();
+            }
+        }
+    }
+    // The element loop of a streaming pass that carries the background generator: a trip issues the loads of the vectors
+    // the pass reads (r0, r1, r2: ReadIf entries), draws the next problem's pairs while they are in flight, runs the
+    // element bodies, and stores the trip's results and the drawn pairs together.
+    template <class R0, class R1, class R2, class F, class... W>
+    __device__ __forceinline__ void pass_elems_r(R0 r0, R1 r1, R2 r2, F&& f, W&&... written) {
+        if constexpr (kBg) {
+            int t = tfirst;
+            asm volatile("" : "+v"(t));
+            const int n = (int)a.ld, pstr = pstride;
+            constexpr int UB = kBgU < U ? kBgU : U;  // shorter trips: fewer loaded registers live across the drawing
+#pragma unroll 1
+            for (int i0 = 2 * t; i0 < n; i0 += 2 * UB * pstr) {
+                r0.template preload<UB>(i0, pstr);
+                r1.template preload<UB>(i0, pstr);
+                r2.template preload<UB>(i0, pstr);
+                bg_draw();
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = i0 + 2 * u * pstr;
+                    f(2 * u, i);
+                    f(2 * u + 1, i + 1);
+                }
+                (written.template flush<UB>(i0, pstr), ...);
+                bg_store();
+                r0.unload();
+                r1.unload();
+                r2.unload();
+            }
+        } else {
+            for_elems<T, EPT, U>(a.ld, tfirst, ps(), f, written...);
+        }
+    }
+
     // -- objective/gradient at z + c s (or at z when !USE_S).  Returns f = -logLike,
     //    dphi = grad . s and gmax = ||grad||_inf; the gradient itself is stored (into g) only when
     //    STORE_G -- a line-search trial needs just the three scalars.  One pass, one barrier.
@@ -344,6 +453,17 @@ struct Solver {
         }
         for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) { f(std::false_type{}, jj, i); }, written...);
     }
+    // ... and the same for a pass that reads z (unless it is the unwritten zero), r1 and r2, with the background generator
+    template <class R1, class R2, class F, class... W>
+    __device__ __forceinline__ void for_elems_zz_r(R1 r1, R2 r2, F&& f, W&&... written) {
+        if constexpr (!Place::kResident && !Model::kStencil) {
+            if (z_zero) {
+                pass_elems_r(reads(z, false), r1, r2, [&](int jj, int i) { f(std::true_type{}, jj, i); }, written...);
+                return;
+            }
+        }
+        pass_elems_r(reads(z), r1, r2, [&](int jj, int i) { f(std::false_type{}, jj, i); }, written...);
+    }
 
     //    INIT_S (resident policy, where s lives in registers): the pass also sets the steepest-descent
     //    direction s = -g and returns dphi = g . s, exactly as the separate pass would.
@@ -351,7 +471,7 @@ struct Solver {
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
         double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
         if constexpr (!Model::kStencil) {
-            for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) {
+            pass_elems_r(reads(z, !ZZ), reads(s, USE_S), reads(x), [&](int jj, int i) {
                 double zi = ZZ ? 0.0 : z.get(jj, i);  // ZZ: z is still the (unwritten) zero start
                 double si = 0.0;
                 if constexpr (USE_S) {
@@ -688,10 +808,20 @@ struct Solver {
                 g.bind(lds_g, ld);
             }
         } else {
-            x.bind(wg_scratch, ld);
+            // (x, s) of the cluster's elementwise problems alternate between two buffer pairs: the other one receives
+            // the next problem while this one is being solved (background generator)
+            double* xbuf = wg_scratch;
+            double* sbuf = wg_scratch + 2 * ld;
+            if constexpr (kBg) {
+                if (bufsel) {
+                    xbuf = wg_scratch + (int64_t)(4 + 2 * kM + 1) * ld;
+                    sbuf = xbuf + ld;
+                }
+            }
+            x.bind(xbuf, ld);
             g.bind(wg_scratch + ld, ld);
             if constexpr (Place::kLdsS) s.bind(wg_scratch + 2 * ld, ld, lds_x, tfirst, pstride, tid, (int)N);
-            else s.bind(wg_scratch + 2 * ld, ld);
+            else s.bind(sbuf, ld);
             zmem = d.zslot >= 0 ? a.zhat + d.zslot * ld : wg_scratch + 3 * ld;
             z.bind(zmem, ld);
             hist = wg_scratch + 4 * ld;
@@ -814,8 +944,43 @@ struct Solver {
                 // copied by a pass of its own below
                 constexpr int US = Place::kResident ? U : 1;
                 const bool z_from_sample = d.z0_mode == Z0_ZERO || d.z0_mode == Z0_TRUE;
+                if constexpr (kBg && !KEEP_ZTRUE) {
+                    if (d.z0_mode == Z0_ZERO && !d.normals_only && d.tsample < 0) {
+                        // the pass described below, through the generator state: the background generator may have drawn
+                        // part (or all) of this problem during the previous one's streaming passes
+                        if (gen.p != p) {
+                            gen.p = p;
+                            gen.trip = 0;
+                            gen.sim = sim;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) gen.sum[k] = 0.0;
+                            gen.mx[0] = gen.mx[1] = 0.0;
+                        }
+                        gen.active = false;
+                        const int ntrips = gen_trips();
+#pragma unroll 1
+                        for (; gen.trip < ntrips; ++gen.trip) {
+                            const int i0 = 2 * (tfirst + gen.trip * pstride);
+                            double xo[2], so[2];
+                            gen_pair(i0, xo, so);
+                            store_f64x2(x.rsrc, i0, xo[0], xo[1]);
+                            store_f64x2(s.rsrc, i0, so[0], so[1]);
+                        }
+                        double sum[4] = {gen.sum[0], gen.sum[1], gen.sum[2], gen.sum[3]}, mx[2] = {gen.mx[0], gen.mx[1]};
+                        reduce<4, 2>(sum, mx);
+                        init_f = 0.5 * (sum[0] + a.f_const);
+                        init_dphi = sum[1];
+                        init_gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
+                        trial_c = 1.0;
+                        trial_phi = 0.5 * (sum[2] + a.f_const);
+                        trial_dphi = sum[3];
+                        trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
+                        init_done = true;
+                        z_zero = true;
+                    }
+                }
                 if constexpr (!Model::kStencil) {  // (the LDS-resident layout has its own rolled sampler above)
-                    if (z_from_sample && !d.normals_only) {
+                    if (!init_done && z_from_sample && !d.normals_only) {
                         // sampler + initial evaluation + first line-search trial in ONE pass over values that are in
                         // registers anyway (see eval_init_with_trial for the arithmetic, which is identical): the pass
                         // writes x and s = -g only (and z when the start is the true z) -- against write x, z; read
@@ -921,6 +1086,26 @@ struct Solver {
         stamp(p, 9);
         if constexpr (Model::kStencil) pass_barrier();  // x (and the start z) complete before neighbours read them
         else __syncthreads();
+        if constexpr (kBg && !KEEP_ZTRUE) {
+            // arm the background generator with the cluster's next problem (same conditions as the foreground path above)
+            gen.active = false;
+            if (next_p >= 0 && d.tsample < 0) {
+                const ProblemDesc dn = describe(a, next_p);
+                if (dn.x_mode == X_SAMPLE && dn.z0_mode == Z0_ZERO && !dn.normals_only && dn.tsample < 0) {
+                    gen.p = next_p;
+                    gen.trip = 0;
+                    gen.sim = (uint64_t)dn.sim;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gen.sum[k] = 0.0;
+                    gen.mx[0] = gen.mx[1] = 0.0;
+                    gen.active = true;
+                    double* xb = bufsel ? wg_scratch : wg_scratch + (int64_t)(4 + 2 * kM + 1) * ld;
+                    double* sb = bufsel ? wg_scratch + 2 * ld : xb + ld;
+                    bg_xr = make_rsrc(xb, ld * 8);
+                    bg_sr = make_rsrc(sb, ld * 8);
+                }
+            }
+        }
 
         stamp(p, 1);
     }
@@ -1098,7 +1283,7 @@ struct Solver {
                 VH zout;
                 const bool store = Place::kResident && d.zslot >= 0;  // streaming: z already lives in its zhat slot
                 if (store) zout.bind(a.zhat + d.zslot * ld, ld);
-                for_elems_zz([&](auto zz, int jj, int i) {
+                for_elems_zz_r(reads(s), reads(x), [&](auto zz, int jj, int i) {
                     const double zo = decltype(zz)::value ? 0.0 : z.get(jj, i), si = s.get(jj, i);
                     const double zn = fma(alpha, si, zo);
                     z.set(jj, i, zn);

@@ -114,10 +114,12 @@ template <int U, bool COH = false>
 struct BufChunk {
     static constexpr int kAux = COH ? kCoherent : kPlain;  // stores and foreign-element loads (get1); own pairs load plain
     rsrc_t rsrc;
-    mutable double c1[U];
+    mutable double c0[U], c1[U];
+    mutable bool pl = false;  // the trip's pairs are in c0/c1 already (preload): get() issues nothing
     double st[2 * U];
     __device__ __forceinline__ void bind(const double* base, int64_t ld) { rsrc = make_rsrc(base, ld * 8); }
     __device__ __forceinline__ double get(int jj, int i) const {
+        if (pl) return (jj & 1) ? c1[jj >> 1] : c0[jj >> 1];
         if ((jj & 1) == 0) {
             double d0;
             load_f64x2(rsrc, i, d0, c1[jj >> 1]);
@@ -125,6 +127,16 @@ struct BufChunk {
         }
         return c1[jj >> 1];
     }
+    // all of a trip's loads of this vector, issued at once and ahead of anything the caller puts between them and the
+    // element bodies (the background generator's arithmetic)
+    template <int UU>
+    __device__ __forceinline__ void preload(int i0, int pstride) const {
+        static_assert(UU <= U, "trip longer than the chunk");
+#pragma unroll
+        for (int u = 0; u < UU; ++u) load_f64x2(rsrc, i0 + 2 * u * pstride, c0[u], c1[u]);
+        pl = true;
+    }
+    __device__ __forceinline__ void unload() const { pl = false; }
     __device__ __forceinline__ double get1(int i) const { return load_f64<kAux>(rsrc, i); }
     __device__ __forceinline__ void own_pair(int i0, double& a, double& b) const { load_f64x2(rsrc, i0, a, b); }
     __device__ __forceinline__ void set(int jj, int, double d) { st[jj] = d; }
@@ -202,6 +214,19 @@ struct FlushIf {
 };
 template <class V>
 __device__ __forceinline__ FlushIf<V> when(bool on, V& v) { return FlushIf<V>{v, on}; }
+// read-list entry of a pass (Solver::pass_elems_r): a vector the pass reads, under a (workgroup-uniform) condition
+template <class V>
+struct ReadIf {
+    const V& v;
+    bool on;
+    template <int UU>
+    __device__ __forceinline__ void preload(int i0, int pstride) const {
+        if (on) v.template preload<UU>(i0, pstride);
+    }
+    __device__ __forceinline__ void unload() const { v.unload(); }
+};
+template <class V>
+__device__ __forceinline__ ReadIf<V> reads(const V& v, bool on = true) { return ReadIf<V>{v, on}; }
 // A vector in LDS; p[ld], p[ld+1] is a dummy pair that holds 0.  Like BufVec2 it moves a thread's two adjacent
 // elements with one instruction (ds_read2_b64 / ds_write2_b64) and one address computation: the pair is read
 // at jj even (second half served at jj odd), a store is staged at jj even and issued at jj odd.

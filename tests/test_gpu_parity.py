@@ -192,6 +192,36 @@ def test_cluster_stencil_many_clusters_under_load(gpu, M, O):
     prob.close()
 
 
+@pytest.mark.parametrize("model,nth,theta,include_data,z0_mode", [
+    ("funnel", 3, [0.4, -0.8, 1.7], True, 0), ("noise", 1, [0.9], False, 0), ("funnel", 1, [1.2], False, 1)])
+def test_streaming_clusters_draw_the_next_problem_in_the_background(gpu, M, O, model, nth, theta, include_data, z0_mode):
+    """Streaming clusters of the elementwise models (N >= 65 536) with more problems than clusters: from its second
+    problem on a cluster finds (x, s = -g and the sums of the initial evaluation) drawn, wholly or partly, during the
+    previous problem's streaming passes, in the other buffer pair of its scratch.  The arithmetic and its order are
+    those of the foreground pass, so every problem must equal, bit for bit, the same simulation solved in a batch of
+    its own (where nothing is drawn ahead), and the oracle to the usual tolerances.  The data element (no sampling)
+    and a start from the true z (not eligible) sit in the sequence as well."""
+    N, nsims, seed = 70001, 150, 31
+    xdata = O.sample_x_z(model, N, seed, M.DATA_SIM, theta)[0] if include_data else None
+    prob = M.HipMuseProblem(xdata, model=model, ntheta=nth, N=N)
+    g, info = prob.map_and_score_batch(seed, 0, nsims, theta, include_data=include_data, atol=1e-4, z0_mode=z0_mode)
+    n = nsims + (1 if include_data else 0)
+    zh = prob.get_zhat(0, n)
+    assert np.all(info["status"] == 0)
+    off = 1 if include_data else 0
+    for sim in (0, 63, 64, 65, 127, 128, 149):          # first, second and third problem of a cluster (64 clusters of 8)
+        g1, i1 = prob.map_and_score_batch(seed, sim, sim + 1, theta, atol=1e-4, z0_mode=z0_mode)
+        z1 = prob.get_zhat(0, 1)
+        assert np.array_equal(g1[0], g[off + sim]) and np.array_equal(z1[0], zh[off + sim]), sim
+        assert i1["iterations"][0] == info["iterations"][off + sim] and i1["f_calls"][0] == info["f_calls"][off + sim]
+    for sim in (64, 149):
+        go, zo, io = O.map_and_score_batch(model, N, seed, sim, sim + 1, theta, atol=1e-4, z0_mode=z0_mode)
+        assert (info["iterations"][off + sim], info["f_calls"][off + sim]) == (io["iterations"][0], io["f_calls"][0])
+        np.testing.assert_allclose(g[off + sim], go[0], rtol=1e-10)
+        np.testing.assert_allclose(zh[off + sim], zo[0], rtol=0, atol=1e-9)
+    prob.close()
+
+
 def test_fuzz_sizes_and_models(gpu, M, O):
     """Edge sizes around every storage-policy boundary (256x1 | 512x4 | 512x10 resident, streaming, cluster),
     odd and even N, every model and several theta dimensions, against the oracle."""
