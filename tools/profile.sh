@@ -4,6 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
+rm -rf $OUT  # a stale pass must not be summarized with this one
 mkdir -p $OUT
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc_fingerprint())" > $OUT/csrc_sha16.txt
 for W in "$@"; do

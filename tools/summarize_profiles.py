@@ -37,6 +37,8 @@ for w in workloads:
     stats = glob.glob(os.path.join(PROF, "trace_" + w, "*", "*_kernel_stats.csv"))
     if not stats:
         continue
+    if len(stats) > 1:  # gpurun merges a pass into gpurun_out/: files of an earlier pass must not be mixed in
+        sys.exit(f"gpurun_out/prof/trace_{w} holds {len(stats)} passes: rm -rf gpurun_out/prof and run tools/profile.sh again")
     shutil.copy(stats[0], os.path.join(OUT, f"{tag}_{w}_kernel_stats.csv"))
     k = [r for r in csv.DictReader(open(stats[0])) if "map_score_kernel" in r["Name"]][0]
     c = {}
