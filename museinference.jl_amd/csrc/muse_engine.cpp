@@ -283,14 +283,15 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     if (rc) return rc;
     a.scratch = c->scratch;
     const size_t lds = place_lds(c, pl);
-    // Tickets: every workgroup draws tickets until it draws one past the batch, so a launch advances
-    // the counter by exactly nproblems + grid -- no per-launch memset.  Wrap-around: reset explicitly.
+    // Tickets: a workgroup's first problem is its own index, every further one a ticket (problem grid + ticket), and
+    // every workgroup draws exactly one ticket past the batch, so a launch advances the counter by exactly
+    // (nproblems - grid) + grid = nproblems (grid <= nproblems) -- no per-launch memset.  Wrap-around: reset explicitly.
     if (c->ticket_base > 0x70000000u) {
         HIPCHK(hipMemsetAsync(c->counter, 0, 16, c->stream));
         c->ticket_base = 0;
     }
     a.ticket_base = (int)c->ticket_base;
-    if (!place_is_cluster(pl)) c->ticket_base += (unsigned)a.nproblems + (unsigned)grid;  // clusters draw no tickets
+    if (!place_is_cluster(pl)) c->ticket_base += (unsigned)a.nproblems;  // clusters draw no tickets
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->prof_on && (size_t)(2 * c->prof_count + 1) < c->prof_ev.size()) {
         e0 = c->prof_ev[2 * c->prof_count];

@@ -52,6 +52,10 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     int* ticket = reinterpret_cast<int*>(shs + 40);      // [4]
     double* args_lds = shs + 42;                         // [kArgsDoubles]
     const int tid = threadIdx.x;
+#ifdef MUSE_STAMPS
+    unsigned long long t_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry)::"memory");
+#endif
     {
         typedef __attribute__((address_space(4))) const uint32_t* kernarg_ptr;
         kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -97,6 +101,9 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         sv.exch = exch;
         sv.cl_epoch = a.cl_state[cluster];  // granule tags continue across launches
         int nth = 0;
+#ifdef MUSE_STAMPS
+        if (tid == 0 && a.stamps && cluster < a.nproblems) a.stamps[(size_t)cluster * 16 + 8] = t_entry;  // kernel entry
+#endif
         for (int p = cluster; p < a.nproblems; p += a.nclusters, ++nth) {
             sv.bufsel = nth & 1;
             sv.next_p = p + a.nclusters < a.nproblems ? p + a.nclusters : -1;
@@ -105,6 +112,9 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
             if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);
             else sv.run(p, cl_scratch, lds_x, lds_g);
         }
+#ifdef MUSE_STAMPS
+        if (cluster < a.nproblems) sv.stamp(cluster + ((a.nproblems - 1 - cluster) / a.nclusters) * a.nclusters, 9);  // last instruction but the epoch store
+#endif
         if (tid == 0 && crank == 0) {
             a.cl_state[cluster] = sv.cl_epoch;
             if (cluster == 0) a.error_flag[1] = (int)(sv.cl_epoch >> 1);  // the host resets the tags long before a wrap
@@ -118,17 +128,29 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
             pk0 = s0.pk[0];
             pk1 = s0.pk[1];
         }
+        // Problems are dealt dynamically, but no workgroup waits for the dealer: the first problem is the workgroup's own
+        // index (the host launches grid <= nproblems), and the ticket of the NEXT problem (p = grid + ticket) is drawn when
+        // the current one begins -- the atomic's round trip (~1.5 k cycles, three of them per workgroup at configs[1]) is
+        // over long before its result is looked at.
+        int p = (int)blockIdx.x;
         for (;;) {
+            int next = 0;
+            if (tid == 0) next = atomicAdd(a.work_counter, 1);
+#ifdef MUSE_STAMPS
+            if (tid == 0 && a.stamps && p < (int)gridDim.x) a.stamps[(size_t)p * 16 + 8] = t_entry;  // kernel entry
+#endif
+            {
+                Solver<Model, Place> sv(a, tid, red, shs);
+                sv.pk[0] = pk0;
+                sv.pk[1] = pk1;
+                if constexpr (IMPLICIT) sv.run_implicit(p, wg_scratch, lds_x, lds_g);
+                else sv.run(p, wg_scratch, lds_x, lds_g);
+            }
             __syncthreads();
-            if (tid == 0) ticket[0] = atomicAdd(a.work_counter, 1);
+            if (tid == 0) ticket[0] = next;
             __syncthreads();
-            const int p = __builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base;
+            p = (int)gridDim.x + (__builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base);
             if (p >= a.nproblems) break;
-            Solver<Model, Place> sv(a, tid, red, shs);
-            sv.pk[0] = pk0;
-            sv.pk[1] = pk1;
-            if constexpr (IMPLICIT) sv.run_implicit(p, wg_scratch, lds_x, lds_g);
-            else sv.run(p, wg_scratch, lds_x, lds_g);
         }
     }
 }

@@ -20,6 +20,11 @@ d = np.diff(st, axis=1)
 names = ["sample/load", "eval0", "twoloop(s=-g)", "linesearch", "update", "(loop exit)", "score+zhat"]
 print("median shader cycles per phase (wave 0):")
 for k, nm in enumerate(names): print(f"  {nm:16s} {np.median(d[:,k]):10.0f}   ({np.median(d[:,k])/np.median(st[:,7]-st[:,0])*100:5.1f} %)")
+ent = o0 = out.astype(np.int64)
+first = (ent[:, 8] > 0) & (ent[:, 8] < st[:, 0]) & (st[:, 0] - ent[:, 8] < 10**7)
+if first.any(): print("  kernel entry -> first stamp of the workgroup's first problem: median", np.median(st[first, 0] - ent[first, 8]), "cycles over", int(first.sum()), "workgroups")
+last = (ent[:, 9] > st[:, 7]) & (ent[:, 9] - st[:, 7] < 10**7)
+if last.any(): print("  last stamp of the last problem -> end of the kernel's loop: median", np.median(ent[last, 9] - st[last, 7]), "cycles over", int(last.sum()))
 print("  sample detail: start->sampler loop end", np.median(out[:,8].astype(np.int64)-st[:,0]), " ->z init end", np.median(out[:,9].astype(np.int64)-out[:,8].astype(np.int64)), " ->barrier end", np.median(st[:,1]-out[:,9].astype(np.int64)))
 o=out.astype(np.int64)
 print("  line search detail: pre-logic", np.median(o[:,10]-st[:,3]), " eval1", np.median(o[:,11]-o[:,10]), " logic1", np.median(o[:,12]-o[:,11]), " eval2", np.median(o[:,13]-o[:,12]), " post-logic", np.median(st[:,4]-o[:,13]))
