@@ -174,6 +174,7 @@ struct LaunchShape {
     bool implicit;
     bool lds_s;  // stencil model in a cluster: the search direction in LDS (vec.hpp, LdsMirror)
     size_t lds;
+    void* done_event;  // hipEvent_t (or null) that the launch itself signals on completion: no separate event packet
 };
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t stream);

@@ -72,6 +72,8 @@ struct muse_ctx {
     int debug = 0;
     int split = 0;                 // muse_set_element_split: 0 = by N alone, >= 2 = workgroups per element
     unsigned int ticket_base = 0;  // value of the device ticket counter when the next launch starts
+    hipEvent_t launch_done = nullptr;  // set around launch_batch: the event this launch signals when it completes
+    bool launch_done_used = false;
     bool timing = false;           // record an event pair around every solver launch (muse_set_timing; costs ~12 us per launch)
     unsigned long long* stamps = nullptr;
     int64_t stamps_cap = 0;
@@ -304,6 +306,8 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         LaunchShape shape;
         shape.model = c->model; shape.ntheta = c->ntheta; shape.place = pl; shape.grid = grid; shape.implicit = implicit; shape.lds = lds;
         shape.lds_s = !implicit && pl == P_C256 && stencil_lds_s(c, a.csize);
+        shape.done_event = c->launch_done;
+        c->launch_done_used = c->launch_done != nullptr;
         const hipError_t e = launch_solver(shape, a, c->stream);
         if (e != hipSuccess) rc = fail(MUSE_ERR_HIP, std::string("solver launch: ") + hipGetErrorString(e));
     }
@@ -712,8 +716,18 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         a.ncache_count = (int)(sim_end - sim_begin);
         a.ncache_mode = ncache_mode;
     }
+    // the area's completion event is signalled by this launch itself; with timing events around the launch (profiling)
+    // the plain record after it keeps the order start, kernel, stop, done
+    static const bool no_ext = getenv("MUSE_DEBUG_NO_EXT_LAUNCH") != nullptr;
+    c->launch_done = (c->timing || c->prof_on || no_ext) ? nullptr : c->area_done[area];
+    c->launch_done_used = false;
     rc = launch_batch(c, a);
+    c->launch_done = nullptr;
     if (rc) return rc;
+    if (c->launch_done_used) {
+        c->res_n[area] = n;
+        return MUSE_OK;
+    }
     return enqueue_results_copy(c, area, n);
 }
 

@@ -27,6 +27,7 @@
 // muse_engine.cpp.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -247,11 +248,15 @@ namespace muse {
 template <class Model, class Place, bool IMPLICIT = false>
 static hipError_t launch_one(const LaunchShape& s, const BatchArgs& a, hipStream_t stream) {
     auto kern = map_score_kernel<Model, Place, IMPLICIT>;
-    if (s.lds > 48 * 1024) {
+    static size_t lds_allowed = 48 * 1024;  // per instantiation: the attribute is raised once, not per launch
+    if (s.lds > lds_allowed) {
         const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds);
         if (e != hipSuccess) return e;
+        lds_allowed = s.lds;
     }
-    hipLaunchKernelGGL(kern, dim3(s.grid), dim3(Place::T), s.lds, stream, a);
+    // The completion event of a result area rides on the dispatch itself (its completion signal) instead of following
+    // it as a packet of its own, which the next launch would have to wait behind.
+    hipExtLaunchKernelGGL(kern, dim3(s.grid), dim3(Place::T), s.lds, stream, nullptr, (hipEvent_t)s.done_event, 0, a);
     return hipGetLastError();
 }
 template <class Model>
