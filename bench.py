@@ -384,13 +384,23 @@ def main():
         while pending:
             finish(pending.pop(0), collect)
 
+    # result buffers of the host loop, one pair per result area (a step's results are looked at before its area comes round)
+    outs = {}
+
+    def out_for(area, n):
+        key = (area, n)
+        if key not in outs:
+            shape = (world, rows, nth) if capi else (n, nth)
+            outs[key] = (np.empty(shape), np.zeros(n, dtype=M._capi.INFO_DTYPE))
+        return outs[key]
+
     def finish(item, collect):
         area, n = item
         if capi:
-            g_all, info = prob.batch_wait_gathered(n, rows, area)  # [world, rows, nth]: every rank holds all scores
+            g_all, info = prob.batch_wait_gathered(n, rows, area, out=out_for(area, n))  # [world, rows, nth]: all ranks' scores
             g = g_all[rank][:n]
         else:
-            g, info = prob.batch_wait(n, area)
+            g, info = prob.batch_wait(n, area, out=out_for(area, n))
             if collective == "torch":
                 pad = np.zeros(rows * nth)
                 pad[: g.size] = g.reshape(-1)

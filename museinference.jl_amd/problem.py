@@ -321,9 +321,17 @@ class HipMuseProblem(AbstractMuseProblem):
                                                              int(z0_mode), int(result_area)))
         return (sim_end - sim_begin) + (1 if include_data else 0)
 
-    def batch_wait(self, n, result_area=0):
-        g = np.empty((n, self.ntheta))
-        info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+    def batch_wait(self, n, result_area=0, out=None):
+        """out: (g [n, nθ] float64, info [n] INFO_DTYPE), C-contiguous arrays to fill instead of fresh ones (a pipelined
+        host loop that waits every ~20 us reuses one pair per result area)."""
+        if out is None:
+            g = np.empty((n, self.ntheta))
+            info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+        else:
+            g, info = out
+            if g.shape != (n, self.ntheta) or info.shape != (n,) or g.dtype != np.float64 or info.dtype != _capi.INFO_DTYPE \
+                    or not (g.flags.c_contiguous and info.flags.c_contiguous):
+                raise ValueError("out must be (float64 [n, ntheta], INFO_DTYPE [n]), C-contiguous")
         _capi.check(self._lib.muse_batch_wait(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
         return g, info
 
@@ -459,10 +467,17 @@ class HipMuseProblem(AbstractMuseProblem):
             int(z0_mode), int(rows_per_rank), int(result_area)))
         return (sim_end - sim_begin) + (1 if include_data else 0)
 
-    def batch_wait_gathered(self, n, rows_per_rank, result_area=0):
-        """(g_all [nranks, rows_per_rank, nθ], this rank's info [n]) of the gather enqueued on result_area."""
-        g = np.empty((self._nranks, int(rows_per_rank), self.ntheta))
-        info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+    def batch_wait_gathered(self, n, rows_per_rank, result_area=0, out=None):
+        """(g_all [nranks, rows_per_rank, nθ], this rank's info [n]) of the gather enqueued on result_area; out: arrays
+        of those shapes to fill instead of fresh ones."""
+        if out is None:
+            g = np.empty((self._nranks, int(rows_per_rank), self.ntheta))
+            info = np.zeros(n, dtype=_capi.INFO_DTYPE)
+        else:
+            g, info = out
+            if g.shape != (self._nranks, int(rows_per_rank), self.ntheta) or info.shape != (n,) or g.dtype != np.float64 \
+                    or info.dtype != _capi.INFO_DTYPE or not (g.flags.c_contiguous and info.flags.c_contiguous):
+                raise ValueError("out must be (float64 [nranks, rows_per_rank, ntheta], INFO_DTYPE [n]), C-contiguous")
         _capi.check(self._lib.muse_batch_wait_gathered(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
         return g, info
 
