@@ -1,5 +1,5 @@
 """Long randomized parity run against the CPU oracle (development aid; the committed tests hold a fixed subset):
-random model / N / ntheta / theta / seed / atol / start mode; compares iteration and evaluation counts, status,
+random model / N / ntheta / theta / seed / atol / start mode / batch size (N >= 65 536: sometimes more problems than clusters); compares iteration and evaluation counts, status,
 scores (rtol 1e-9) and zhat (atol 1e-9).  Usage: python tools/fuzz_parity.py [seconds] [seed]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +19,8 @@ while time.time() - t0 < budget:
     atol = float(rng.choice([1e-2, 1e-4, 1e-6]))
     z0 = int(rng.choice([0, 1]))
     n = 4 if N < 20000 else 2
+    if N >= 65536 and model != "smooth" and rng.random() < 0.3:
+        n = int(rng.integers(66, 90))  # more problems than streaming clusters: the background generator draws the later ones
     seed, s0 = int(rng.integers(1, 2**40)), int(rng.integers(0, 5000))
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
     split = int(rng.choice([0, 0, 2, 4, 8]))  # element split: resident clusters (N <= 10^4, elementwise) or streaming ones
