@@ -196,6 +196,33 @@ def test_gathered_map_single_rank_matches_plain_map(gpu, M):
     p.close()
 
 
+def test_pipelined_launches_with_caller_owned_result_buffers(gpu, M):
+    """The host loop of bench.py: batches enqueued on the four result areas ahead of their waits, every wait filling
+    arrays the caller owns (`out=`).  The completion of an area is the solver dispatch's own signal; a launch that is
+    still ahead in the stream must not make an earlier area look complete, and every step equals the blocking call."""
+    N, nth, theta = 10000, 2, [0.7, -0.3]
+    p = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
+    ref = [p.map_and_score_batch(5, 100 * k, 100 * k + 300 + k, theta) for k in range(9)]
+    bufs = {}
+    pend, got = [], []
+    for k in range(9):
+        n = p.map_and_score_batch_async(5, 100 * k, 100 * k + 300 + k, theta, result_area=k % 4)
+        pend.append((k, n))
+        if len(pend) > 3:
+            kk, nn = pend.pop(0)
+            out = bufs.setdefault((kk % 4, nn), (np.empty((nn, nth)), np.zeros(nn, dtype=M._capi.INFO_DTYPE)))
+            g, info = p.batch_wait(nn, kk % 4, out=out)
+            assert g is out[0] and info is out[1]
+            got.append((g.copy(), info.copy()))
+    for kk, nn in pend:
+        got.append(p.batch_wait(nn, kk % 4))
+    for (g, info), (gr, ir) in zip(got, ref):
+        assert np.array_equal(g, gr) and np.array_equal(info, ir)
+    with pytest.raises(ValueError):
+        p.batch_wait(3, 0, out=(np.empty((3, nth + 1)), np.zeros(3, dtype=M._capi.INFO_DTYPE)))
+    p.close()
+
+
 @pytest.mark.parametrize("model,N,nth,theta", [
     ("funnel", 512, 1, [0.3]), ("funnel", 10000, 4, [1.0, 0.5, -0.5, 2.0]), ("noise", 3001, 1, [0.4]),
     ("smooth", 2000, 3, [1.0, 2.0, 0.5]), ("funnel", 70001, 2, [0.3, 0.1]), ("smooth", 66001, 2, [1.0, 2.5])])
