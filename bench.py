@@ -418,6 +418,12 @@ def main():
     # (warm, same bracket every time) until --min-seconds have been measured, so that a 20-step request is not a
     # 1.3 ms sample.  Every rank runs the same number of repetitions (rank 0 decides).
     prob.set_timing(False)
+    # The host loop must keep three launches ahead of a ~50 us kernel: a full collection of the interpreter's cyclic GC
+    # (torch alone brings more than a million tracked objects; measured 40-60 ms, once, a few hundred steps into a run)
+    # drains the pipeline.  Everything alive now is setup: collect it once and move it out of the collector's sight.
+    import gc
+    gc.collect()
+    gc.freeze()
     run_steps(args.warmup)
     barrier()
     rounds = []
@@ -434,6 +440,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         rounds.append(dt)
+        if os.environ.get('MUSE_BENCH_DEBUG_ROUNDS') and rank == 0: print(f'round {len(rounds)}: {1e6*dt/args.steps:.1f} us/step', file=sys.stderr)
         more = 1 if (sum(rounds) < args.min_seconds and len(rounds) < 100000) else 0
         if sharded:
             flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device=tdev)
