@@ -244,7 +244,7 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -261,7 +261,71 @@ def main():
                     "(e.g. 64 = one rank's share of the strongly scaled 8-GPU step, on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed muse!/get_H! rates")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(script, argv, nranks, extra_env=None, grace_s=20.0):
+    """Start `nranks` fresh processes of `script` (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, HIP_VISIBLE_DEVICES untouched), relay rank 0's JSON line to stdout and everything else to stderr, and
+    return the worst exit code.  The calling process has not touched the GPU (it never will: it only waits), so nothing
+    that has initialised HIP is ever re-executed.  This is what `python bench.py --gpus N` does when it was not started
+    by torch.distributed.run; a rank that fails takes the others down after `grace_s` seconds (they would otherwise sit
+    in a rendezvous or a collective until its time-out)."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs, lines0 = [], []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=subprocess.PIPE, text=True))
+
+    def pump(r, p):
+        for line in p.stdout:
+            if r == 0 and line.startswith("{"):
+                lines0.append(line)
+            else:  # RCCL banners and the like
+                sys.stderr.write(f"[rank {r}] {line}")
+    threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    worst, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            rc = p.poll()
+            if rc is not None and rc != 0 and t_fail is None:
+                worst, t_fail = rc, time.monotonic()
+        if t_fail is not None and time.monotonic() - t_fail > grace_s:
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            t_fail = float("inf")
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    for p in procs:
+        rc = p.returncode
+        if rc != 0 and (worst == 0 or abs(rc) > abs(worst)):
+            worst = rc
+    if worst == 0 and not lines0:
+        sys.stderr.write("[bench] rank 0 printed no result line\n")
+        worst = 1
+    if lines0:
+        sys.stdout.write(lines0[-1])
+        sys.stdout.flush()
+    return worst if worst >= 0 else 128 - worst  # a signal's number, shell style
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher (before torch or HIP is imported)
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     import torch
     import museinference_jl_amd as M
@@ -270,8 +334,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let bench.py do it: "
+                         "unset WORLD_SIZE)")
     dist = None
     sharded = world > 1 or os.environ.get("MUSE_BENCH_FORCE_DIST") == "1"  # the env var exercises the N>1 path on one GPU
     # MUSE_BENCH_BACKEND=gloo (development aid): several ranks on ONE GPU, gloo collectives on host tensors -- exercises the
@@ -310,101 +374,81 @@ def main():
         rows = nsims
         total_sims = nsims * world
     nlocal = sim_hi - sim_lo
-    # fewer elements than compute units: the element itself is the remaining parallel axis (src/muse.jl:327-333
-    # chooses the longer axis; here: `split` workgroups per element).  The same split on every rank.
     cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-    # The ranks of this bench share a node (the launch contract): the score blocks are exchanged host to host through the
-    # engine's shared-memory transport; MUSE_BENCH_TRANSPORT=rccl runs the device-side RCCL all-gather instead.
-    transport = os.environ.get("MUSE_BENCH_TRANSPORT", "shm")
-    if transport not in ("shm", "rccl"):
-        raise SystemExit("MUSE_BENCH_TRANSPORT must be shm or rccl")
-    if sharded and transport == "shm":
-        import socket
-        hosts = [None] * world
-        dist.all_gather_object(hosts, socket.gethostname())
-        if len(set(hosts)) > 1:  # not this bench's launch contract, but do not wait for the segment's time-out
-            transport = "rccl"
-    split = args.split
-    if split < 0:
-        split = 1
-        # (resident placements only: above muse_max_resident_n, and for the stencil model, the cluster size is a function
-        # of N alone already; 8 never paid, tools/split_bench.py)
-        splittable = model != "smooth" and 512 < N <= M.load_library().muse_max_resident_n()
-        # with a collective in flight beside the solver (N > 1) the clusters fill half of the CUs at most: the RCCL kernel of
-        # the previous step and a cluster launch that needs every CU would otherwise wait for each other's workgroups
-        room = 4 if (sharded and transport == "rccl") else 2
-        while splittable and split < 4 and room * split * rows <= cus:
-            split *= 2
-    if split > 1:
-        prob.set_element_split(split)
-    gather_buf = None
-    collective = None
+    # The exchange of the per-rank score blocks (N > 1).  Both transports of the engine are measured in the same run, one
+    # after the other, and both go into the line (`transports`); `value` is the better one.  "shm": the ranks of this
+    # bench share a node (the launch contract), the blocks travel host to host through the engine's shared-memory
+    # segment; "rccl": device-side RCCL all-gather over xGMI on a second stream.  MUSE_BENCH_TRANSPORT=shm|rccl: only one.
+    want = os.environ.get("MUSE_BENCH_TRANSPORT", "both")
+    if want not in ("shm", "rccl", "both"):
+        raise SystemExit("MUSE_BENCH_TRANSPORT must be shm, rccl or both")
+    transports = [None] if not sharded else (["shm", "rccl"] if want == "both" else [want])
+    same_node = True
     if sharded:
-        # Preferred: the engine's own communicator (shm: host-to-host blocks in a shared segment; rccl: scores stay on the
-        # device, the all-gather runs on a second stream from C).  Fallback, agreed on by all ranks: torch.distributed's
-        # all_gather.
-        ok = 1
-        try:
-            if backend != "nccl" and transport == "rccl":
-                raise RuntimeError("gloo test mode: RCCL refuses two ranks on one device")
-            uid = [M.HipMuseProblem.comm_unique_id(transport) if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            prob.comm_init(world, rank, uid[0])
-        except Exception as e:  # noqa: BLE001 -- any failure means "use the fallback", on every rank
-            print(f"[bench rank {rank}] engine communicator ({transport}) unavailable ({e}); using torch.distributed", file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        collective = f"{transport}-capi" if int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch" else "torch"
-        if collective == "torch":
-            gather_buf = [torch.empty(rows * nth, dtype=torch.float64, device=tdev) for _ in range(world)]
+        same_node = M.ranks_share_node(dist)
 
-    capi = collective is not None and collective.endswith("-capi")
     AREAS = 4
+    state = {"capi": False, "collective": None, "gather_buf": None, "nmaps": 1}
+    theta_rep = np.tile(np.asarray(theta, dtype=np.float64), (M._capi.MAX_MAPS, 1))
     host_t = [0.0, 0.0]  # host seconds spent enqueueing / waiting+collecting (reported under "host_us_per_step")
 
     def run_steps(K, collect=None):
         """K steps, software-pipelined: batch k is enqueued before batch k-1's results are awaited,
-        so the GPU never idles on the host; with >1 GPU the all-gather of step k-1 overlaps batch k."""
+        so the GPU never idles on the host; with >1 GPU the all-gather of step k-1 overlaps batch k.
+        With maps_per_launch = G > 1 (a rank's share of the step is smaller than the GPU) one launch carries G consecutive
+        steps -- G independent maps resident at once -- and one exchange serves all of them."""
         pending = []
-        for k in range(K):
+        capi, G = state["capi"], state["nmaps"]
+        k = j = 0
+        while k < K:
+            m = min(G, K - k)
             t_enq0 = time.perf_counter()
-            if capi:
+            if G > 1:
+                if capi:
+                    n = prob.map_and_score_multi_gather_async(seed, sim_lo, sim_hi, theta_rep[:m], rows, atol=1e-2,
+                                                              z0_mode=M.Z0_ZERO, result_area=j % AREAS)
+                else:
+                    n = prob.map_and_score_multi_async(seed, sim_lo, sim_hi, theta_rep[:m], atol=1e-2, z0_mode=M.Z0_ZERO,
+                                                       result_area=j % AREAS)
+            elif capi:
                 n = prob.map_and_score_batch_gather_async(seed, sim_lo, sim_hi, theta, rows, atol=1e-2,
-                                                          z0_mode=M.Z0_ZERO, result_area=k % AREAS)
+                                                          z0_mode=M.Z0_ZERO, result_area=j % AREAS)
             else:
                 n = prob.map_and_score_batch_async(seed, sim_lo, sim_hi, theta, atol=1e-2, z0_mode=M.Z0_ZERO,
-                                                   result_area=k % AREAS)
+                                                   result_area=j % AREAS)
             host_t[0] += time.perf_counter() - t_enq0
-            pending.append((k % AREAS, n))
+            pending.append((j % AREAS, n, m))
             if len(pending) > AREAS - 1:
                 t_w0 = time.perf_counter()
                 finish(pending.pop(0), collect)
                 host_t[1] += time.perf_counter() - t_w0
+            k += m
+            j += 1
         while pending:
             finish(pending.pop(0), collect)
 
     # result buffers of the host loop, one pair per result area (a step's results are looked at before its area comes round)
     outs = {}
 
-    def out_for(area, n):
-        key = (area, n)
+    def out_for(area, n, m):
+        key = (area, n, m, state["capi"])
         if key not in outs:
-            shape = (world, rows, nth) if capi else (n, nth)
+            shape = (world, m * rows, nth) if state["capi"] else (n, nth)
             outs[key] = (np.empty(shape), np.zeros(n, dtype=M._capi.INFO_DTYPE))
         return outs[key]
 
     def finish(item, collect):
-        area, n = item
-        if capi:
-            g_all, info = prob.batch_wait_gathered(n, rows, area, out=out_for(area, n))  # [world, rows, nth]: all ranks' scores
-            g = g_all[rank][:n]
+        area, n, m = item
+        if state["capi"]:
+            # [world, m * rows, nth]: all ranks' scores of the launch's m maps
+            g_all, info = prob.batch_wait_gathered(n, m * rows, area, out=out_for(area, n, m))
+            g = g_all[rank].reshape(m, rows, nth)[:, :nlocal]
         else:
-            g, info = prob.batch_wait(n, area, out=out_for(area, n))
-            if collective == "torch":
-                pad = np.zeros(rows * nth)
+            g, info = prob.batch_wait(n, area, out=out_for(area, n, m))
+            if state["collective"] == "torch":
+                pad = np.zeros(state["nmaps"] * rows * nth)
                 pad[: g.size] = g.reshape(-1)
-                dist.all_gather(gather_buf, torch.from_numpy(pad).to(tdev))
+                dist.all_gather(state["gather_buf"], torch.from_numpy(pad).to(tdev))
         if collect is not None:
             collect.append((g, info))
 
@@ -414,54 +458,129 @@ def main():
         torch.cuda.synchronize()
         prob.synchronize()
 
-    # timed region: EXACTLY `steps` steps between barriers, no per-launch timing events (pure throughput); repeated
-    # (warm, same bracket every time) until --min-seconds have been measured, so that a 20-step request is not a
-    # 1.3 ms sample.  Every rank runs the same number of repetitions (rank 0 decides).
-    prob.set_timing(False)
+    def setup_exchange(transport):
+        """Element split and communicator for one transport; returns (split, collective, ranks_seen) or a reason it
+        cannot run (str) -- the same answer on every rank."""
+        # fewer elements than compute units: the element itself is the remaining parallel axis (src/muse.jl:327-333
+        # chooses the longer axis; here: `split` workgroups per element).  The same split on every rank.
+        # Steps of this bench are independent maps (the get_J!-style pass), so a rank whose share of a step is smaller than
+        # its GPU keeps the GPU full with SEVERAL steps resident at once: G of them in one launch, one exchange for all
+        # (MUSE_BENCH_MAPS: 1 = one step per launch, with the element split below instead -- what a muse! iteration,
+        # whose next step depends on this one's scores, has to do).
+        G = 1
+        resident_n = model != "smooth" and N <= M.load_library().muse_max_resident_n()   # one workgroup per element and CU
+        if sharded and args.split < 0 and resident_n:
+            G = max(1, min(M._capi.MAX_MAPS, cus // max(1, nlocal))) if os.environ.get("MUSE_BENCH_MAPS") is None \
+                else max(1, min(M._capi.MAX_MAPS, int(os.environ["MUSE_BENCH_MAPS"])))
+        state["nmaps"] = G
+        split = args.split
+        if split < 0:
+            split = 1
+            # (resident placements only: above muse_max_resident_n, and for the stencil model, the cluster size is a
+            # function of N alone already; 8 never paid, tools/split_bench.py)
+            splittable = model != "smooth" and 512 < N <= M.load_library().muse_max_resident_n()
+            # with a collective in flight beside the solver (N > 1) the clusters fill half of the CUs at most: the RCCL
+            # kernel of the previous step and a cluster launch that needs every CU would otherwise wait for each other
+            room = 4 if transport == "rccl" else 2
+            while G == 1 and splittable and split < 4 and room * split * rows <= cus:
+                split *= 2
+        prob.set_element_split(split if split > 1 else 0)
+        if transport is None:
+            return split, None, 1
+        if transport == "shm" and not same_node:
+            return "the ranks do not share a node (boot id / /dev/shm probe)"
+        if transport == "rccl" and backend != "nccl":
+            return "gloo test mode: RCCL refuses two ranks on one device"
+        # Preferred: the engine's own communicator (shm: host-to-host blocks in a shared segment; rccl: scores stay on the
+        # device, the all-gather runs on a second stream from C).  Fallback, agreed on by all ranks: torch.distributed's
+        # all_gather.
+        ok, seen = 1, 0
+        try:
+            uid = [M.HipMuseProblem.comm_unique_id(transport) if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            prob.comm_init(world, rank, uid[0])
+            seen = prob.comm_ranks_seen()
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the fallback", on every rank
+            print(f"[bench rank {rank}] engine communicator ({transport}) unavailable ({e}); using torch.distributed", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_capi = int(flag.item()) == 1 and os.environ.get("MUSE_BENCH_COLLECTIVE") != "torch"
+        if not use_capi:
+            prob.comm_destroy()
+            state["gather_buf"] = [torch.empty(state["nmaps"] * rows * nth, dtype=torch.float64, device=tdev) for _ in range(world)]
+            return split, "torch", dist.get_world_size()
+        return split, f"{transport}-capi", seen
+
+    def measure(transport):
+        """Warm-up, the timed region (EXACTLY --steps steps between barriers, repeated until --min-seconds), and the
+        roofline leg (HIP events around every solver launch) for one transport."""
+        got = setup_exchange(transport)
+        if isinstance(got, str):
+            return {"skipped": got}
+        split, collective, seen = got
+        state["collective"] = collective
+        state["capi"] = collective is not None and collective.endswith("-capi")
+        prob.set_timing(False)
+        run_steps(args.warmup)
+        barrier()
+        rounds, results = [], []
+        while True:
+            results.clear()
+            host_t[0] = host_t[1] = 0.0
+            t0 = time.perf_counter()
+            run_steps(args.steps, results)
+            barrier()
+            dt = time.perf_counter() - t0
+            if sharded:
+                tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            rounds.append(dt)
+            if os.environ.get("MUSE_BENCH_DEBUG_ROUNDS") and rank == 0:
+                print(f"round {len(rounds)}: {1e6 * dt / args.steps:.1f} us/step", file=sys.stderr)
+            more = 1 if (sum(rounds) < args.min_seconds and len(rounds) < 100000) else 0
+            if sharded:  # every rank runs the same number of repetitions (rank 0 decides)
+                flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device=tdev)
+                dist.broadcast(flag, src=0)
+                more = int(flag.item())
+            if not more:
+                break
+        dt = sum(rounds) / len(rounds)
+        host_us = {"enqueue": 1e6 * host_t[0] / args.steps, "wait_and_collect": 1e6 * host_t[1] / args.steps}
+        # roofline leg: the same steps again with a HIP event pair around every solver launch, recorded on the stream the
+        # kernel is launched on
+        nprof = min(max(args.steps, 64), 256)
+        prob.profile_begin(nprof + 8)
+        run_steps(nprof)
+        barrier()
+        kernel_ms = prob.profile_end()
+        g, info = results[-1]
+        assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
+        pinfo = prob.placement_info()
+        if state["capi"]:
+            prob.comm_destroy()
+        state["capi"] = False
+        return {"dt": dt, "rounds": rounds, "host_us": host_us, "kernel_ms": kernel_ms, "info": info, "split": split,
+                "maps_per_launch": state["nmaps"],
+                "collective": collective, "ranks_seen": seen, "pinfo": pinfo, "value": total_sims * args.steps / dt}
+
     # The host loop must keep three launches ahead of a ~50 us kernel: a full collection of the interpreter's cyclic GC
     # (torch alone brings more than a million tracked objects; measured 40-60 ms, once, a few hundred steps into a run)
     # drains the pipeline.  Everything alive now is setup: collect it once and move it out of the collector's sight.
     import gc
     gc.collect()
     gc.freeze()
-    run_steps(args.warmup)
-    barrier()
-    rounds = []
-    results = []
-    while True:
-        results.clear()
-        host_t[0] = host_t[1] = 0.0
-        t0 = time.perf_counter()
-        run_steps(args.steps, results)
-        barrier()
-        dt = time.perf_counter() - t0
-        if sharded:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        rounds.append(dt)
-        if os.environ.get('MUSE_BENCH_DEBUG_ROUNDS') and rank == 0: print(f'round {len(rounds)}: {1e6*dt/args.steps:.1f} us/step', file=sys.stderr)
-        more = 1 if (sum(rounds) < args.min_seconds and len(rounds) < 100000) else 0
-        if sharded:
-            flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device=tdev)
-            dist.broadcast(flag, src=0)
-            more = int(flag.item())
-        if not more:
-            break
-    dt = sum(rounds) / len(rounds)
-    host_us = {"enqueue": 1e6 * host_t[0] / args.steps, "wait_and_collect": 1e6 * host_t[1] / args.steps}
-    # roofline leg: the same steps again with a HIP event pair around every solver launch, recorded on
-    # the stream the kernel is launched on
-    nprof = min(max(args.steps, 64), 256)
-    prob.profile_begin(nprof + 8)
-    run_steps(nprof)
-    barrier()
-    kernel_ms = prob.profile_end()
+    measured = {t: measure(t) for t in transports}
+    ran = {t: m for t, m in measured.items() if "skipped" not in m}
+    if not ran:
+        raise SystemExit(f"no transport could run: {measured}")
+    best_t = max(ran, key=lambda t: ran[t]["value"])
+    best = ran[best_t]
+    dt, rounds, host_us, kernel_ms, info, split, collective, pinfo = (best[k] for k in (
+        "dt", "rounds", "host_us", "kernel_ms", "info", "split", "collective", "pinfo"))
 
-    g, info = results[-1]
-    assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
     mean_kernel_s = float(kernel_ms.mean()) * 1e-3
-    pinfo = prob.placement_info()
     placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
                                                       if model == "smooth" else "streaming")
     comp_bytes = compulsory_bytes(info, N, placement)
@@ -514,14 +633,27 @@ def main():
         "config": {"workload": f"{args.workload}: Neal's funnel family model={model}, N={N}-dim z, {nth}-dim theta, "
                                f"nsims={total_sims} per step ({nlocal} on this rank), cold start z0=0, atol=1e-2",
                    "theta": theta, "sims_per_step_total": total_sims, "element_split": split,
+                   "pipelining": f"maps_per_launch={best['maps_per_launch']}: that many consecutive (independent) steps share one "
+                                 "launch and one exchange",
                    "parallelism": f"sims sharded over {world} GPU(s) ({scaling} scaling), one all-gather of scores per step"
                                   + (f" ({collective})" if collective else "")},
         "timed_rounds": len(rounds), "timed_seconds": sum(rounds),
         "ms_per_step_min_round": 1e3 * min(rounds) / args.steps, "ms_per_step_max_round": 1e3 * max(rounds) / args.steps,
         "roofline": primary,
-        "kernel_sims_per_s": nlocal / mean_kernel_s,
+        "kernel_sims_per_s": nlocal * best["maps_per_launch"] / mean_kernel_s,
         "host_us_per_step": host_us,
     }
+    if sharded:
+        # both exchanges of the same run, side by side: did RCCL see N ranks, and what did each cost
+        out["transport"] = best_t
+        out["transports"] = {
+            t: (m if "skipped" in m else
+                {"value": m["value"], "ms_per_step": 1e3 * m["dt"] / args.steps, "collective": m["collective"],
+                 "ranks_seen": m["ranks_seen"], "element_split": m["split"],
+                 "pipelining": f"maps_per_launch={m['maps_per_launch']}",
+                 "kernel_ms_mean": float(m["kernel_ms"].mean()), "host_us_per_step": m["host_us"],
+                 "timed_rounds": len(m["rounds"])})
+            for t, m in measured.items()}
     if rank == 0 and world == 1 and not sharded and not args.no_extra:
         out["extra"] = extra_rates(M, prob, model, N, nth, theta, nsims, seed, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

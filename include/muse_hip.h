@@ -153,6 +153,16 @@ int muse_map_and_score_batch_async(muse_ctx* ctx, uint64_t seed, int64_t sim_beg
                                    int include_data, const double* theta, double atol, int z0_mode,
                                    int result_area);
 int muse_batch_wait(muse_ctx* ctx, int result_area, double* g_out, muse_info* info_out);
+/* Several independent maps in ONE launch: `nmaps` (<= MUSE_MAX_MAPS) maps over the same elements, map m at
+ * thetas[m][0..ntheta) -- the pmap body of src/muse.jl:169-176 / :508-525 evaluated for several theta at once (the way
+ * get_H!'s finite-difference map already carries its perturbed thetas in one launch, src/muse.jl:426-432).  What it is
+ * for: a launch with fewer elements than the GPU has compute units -- one rank's share of a strongly scaled map --
+ * leaves most of the GPU idle for one problem's latency; nmaps such maps resident at once fill it.  Element e of map m
+ * is row m*n + e of the outputs (n = elements per map) and keeps its zhat at slot m*n + e.  Results are those of
+ * nmaps separate muse_map_and_score_batch_async calls, bit for bit.  muse_batch_wait returns all nmaps*n rows. */
+#define MUSE_MAX_MAPS 8
+int muse_map_and_score_multi_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
+                                   int nmaps, const double* thetas, double atol, int z0_mode, int result_area);
 /* The muse! outer loop itself (src/muse.jl:112-232) for the common case -- untransformed theta, the "sims"
  * Jacobian update H^-1_like' = Diagonal(-1 ./ var(g_sims')) (src/muse.jl:188-191), constant alpha, identity
  * `regularize`, a flat or independent-Gaussian prior (src/simple.jl:69-71) -- so that between two map launches
@@ -242,6 +252,9 @@ int muse_comm_unique_id(void* id_out /* MUSE_UNIQUE_ID_BYTES, call on rank 0 and
 int muse_comm_unique_id_ex(int transport, int64_t block_doubles, void* id_out);
 int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id);
 int muse_comm_transport(muse_ctx* ctx, int* transport_out); /* of an initialised communicator */
+/* How many ranks the initialised communicator itself counts (RCCL: ncclCommCount; shared memory: the processes that
+ * have mapped the segment) -- evidence for reports that the exchange really spans the ranks the launcher started. */
+int muse_comm_ranks_seen(muse_ctx* ctx, int* nranks_out);
 int muse_comm_destroy(muse_ctx* ctx);
 /* every rank contributes count doubles (host), recv_out is [nranks][count] host */
 int muse_allgather_scores(muse_ctx* ctx, const double* send, int64_t count, double* recv_out);
@@ -261,6 +274,11 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
                                           int include_data, const double* theta, double atol, int z0_mode,
                                           int64_t rows_per_rank, int result_area);
 int muse_batch_wait_gathered(muse_ctx* ctx, int result_area, double* g_all_out, muse_info* info_out);
+/* The sharded form of muse_map_and_score_multi_async: this rank's block of `nmaps` maps in one launch, one exchange for
+ * all of them.  The gathered block is [nranks][nmaps][rows_per_rank][ntheta]; info_out [nmaps][n]. */
+int muse_map_and_score_multi_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                                          int include_data, int nmaps, const double* thetas, double atol, int z0_mode,
+                                          int64_t rows_per_rank, int result_area);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH}
 MEM_HOST, MEM_DEVICE = 0, 1
 Z0_ZERO, Z0_TRUE, Z0_WARM = 0, 1, 2
 MAX_THETA = 8
+MAX_MAPS = 8
 UNIQUE_ID_BYTES = 128
 STATUS_NAMES = ("g_converged", "x_converged", "f_converged", "maxiter", "linesearch_failed", "nonfinite")
 STATUS_MAXITER, STATUS_NONFINITE = 3, 5
@@ -68,6 +69,8 @@ SIGNATURES = {
     "muse_map_and_score_batch": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _vp, _vp]),
     "muse_map_and_score_batch_async": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _i]),
     "muse_batch_wait": (_i, [_vp, _i, _vp, _vp]),
+    "muse_map_and_score_multi_async": (_i, [_vp, _u64, _i64, _i64, _i, _i, _vp, _d, _i, _i]),
+    "muse_map_and_score_multi_gather_async": (_i, [_vp, _u64, _i64, _i64, _i, _i, _vp, _d, _i, _i64, _i]),
     "muse_run": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_get_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
@@ -78,6 +81,7 @@ SIGNATURES = {
     "muse_comm_unique_id": (_i, [_vp]),
     "muse_comm_unique_id_ex": (_i, [_i, C.c_int64, _vp]),
     "muse_comm_transport": (_i, [_vp, C.POINTER(C.c_int)]),
+    "muse_comm_ranks_seen": (_i, [_vp, C.POINTER(C.c_int)]),
     "muse_comm_init": (_i, [_vp, _i, _i, _vp]),
     "muse_comm_destroy": (_i, [_vp]),
     "muse_allgather_scores": (_i, [_vp, _vp, _i64, _vp]),

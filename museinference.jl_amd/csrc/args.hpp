@@ -1,6 +1,7 @@
 // args.hpp -- constants, the kernel argument block and the element -> problem map of the MUSE engine (see muse_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/muse_hip.h"
@@ -24,9 +25,17 @@ constexpr double kEps = 2.220446049250313e-16;
 
 struct ThetaSet {
     double theta[kMaxTheta];
-    double sd[kMaxTheta];  // exp(theta/2), host libm
-    double iv[kMaxTheta];  // exp(-theta),  host libm
+    double sd[kMaxTheta];  // exp(theta/2)  (muse_exp: the fixed sequence of theta_math.hpp, the same bits on host and device)
+    double iv[kMaxTheta];  // exp(-theta)
 };
+// theta of a MAP problem and of its score, with the constant term of -2 logLike that goes with it
+struct MapTheta {
+    ThetaSet t;
+    double f_const;  // sum_k N_k theta_k
+    double pad_;
+};
+static_assert(sizeof(MapTheta) % 16 == 0, "copied in 4-byte words into a 16-byte aligned LDS block");
+constexpr int kMaxMaps = 8;  // independent maps (each with a theta of its own) that ONE launch can carry
 
 enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
 enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
@@ -74,12 +83,20 @@ struct BatchArgs {
     int bnd32[kMaxTheta + 1];    // the same, 32-bit (N < 2^28), for the per-element block lookup
     int pad0_;
     uint64_t seed;
-    double atol, f_const;  // f_const = sum_k N_k theta_k (constant term of -2 logLike)
+    double atol;
     int nproblems, include_data, z0_mode, store_zhat;
     int cg_maxiter;   // BATCH_IMPLICIT: IterativeSolvers.cg maxiter (reference default 100)
     int debug;        // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
     int64_t sim_begin, fid_slot, slot0;
-    ThetaSet tmap;                 // theta of the MAP problem and of the score
+    MapTheta cur;                  // theta of the MAP problem and of the score.  The LDS copy of this field is re-written at the
+                                   // start of a problem when the launch carries several maps (maps[p / n_per_map]) or takes
+                                   // theta from device memory (cur_dev)
+    const MapTheta* cur_dev;       // non-null: theta lives in device memory (written by the previous step kernel of a
+                                   // device-resident muse! loop), cur is only a placeholder
+    int nmaps, n_per_map;          // BATCH_STD: problem p is element p % n_per_map of map p / n_per_map
+    int64_t map_stride;            // score rows per map in the output block (>= n_per_map: a gathered block is padded)
+    const int* stop_flag;          // non-null and *stop_flag != 0: the launch has nothing to do (the device-resident outer loop
+                                   // has converged; the launches enqueued ahead of the host's knowledge drain as no-ops)
     const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
     const double* x_data;          // [ld]
     const double* x_given;         // BATCH_SINGLE: [ld]
@@ -109,10 +126,15 @@ struct BatchArgs {
     int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
     int imp_split;  // BATCH_IMPLICIT: elements per simulation (1: all H columns in one element; ntheta: one each)
     int64_t norm_sim0;
+    MapTheta maps[kMaxMaps];       // LAST, read from the kernarg segment only (never copied to LDS): theta of every map, nmaps > 1
 };
+constexpr size_t kArgsHeadBytes = offsetof(BatchArgs, maps);  // what the kernel keeps in LDS
+static_assert(kArgsHeadBytes % 16 == 0 && offsetof(BatchArgs, cur) % 8 == 0, "LDS copy of the argument block");
+static_assert(sizeof(BatchArgs) <= 4096, "kernarg segment");
 
 struct ProblemDesc {
     int64_t sim;
+    int64_t row;       // row of the element's score in the output block
     int nslot;         // slot of the simulation's normals in the cache, -1: none
     bool normals_only;
     int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
@@ -123,7 +145,18 @@ struct ProblemDesc {
 __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     ProblemDesc d;
     d.normals_only = false;
-    if (a.kind == BATCH_STD && p >= a.nstd) {
+    d.row = p;
+    if (a.kind == BATCH_STD && a.nmaps > 1) {  // several independent maps in one launch: slots and infos by p, scores by (map, element)
+        const int m = p / a.n_per_map, e = p - m * a.n_per_map;
+        const bool data = a.include_data && e == 0;
+        d.sim = data ? -1 : a.sim_begin + e - (a.include_data ? 1 : 0);
+        d.x_mode = (data || (a.debug & 2)) ? X_DATA : X_SAMPLE;
+        d.z0_mode = (data && a.z0_mode == Z0_TRUE) ? Z0_ZERO : a.z0_mode;
+        d.tsample = -1;
+        d.zslot = a.store_zhat ? a.slot0 + p : -1;
+        d.z0slot = a.slot0 + p;
+        d.row = (int64_t)m * a.map_stride + e;
+    } else if (a.kind == BATCH_STD && p >= a.nstd) {
         d.sim = a.norm_sim0 + (p - a.nstd);
         d.x_mode = X_SAMPLE;
         d.z0_mode = Z0_ZERO;
@@ -179,7 +212,7 @@ struct LaunchShape {
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t stream);
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t stream);
-constexpr int kArgsDoubles = (int)((sizeof(BatchArgs) + 15) / 16 * 2);  // LDS copy of the kernel arguments
+constexpr int kArgsDoubles = (int)((kArgsHeadBytes + 15) / 16 * 2);  // LDS copy of the kernel arguments (without the trailing maps[])
 
 
 }  // namespace muse

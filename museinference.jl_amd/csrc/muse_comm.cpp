@@ -37,6 +37,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;  // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -54,7 +55,8 @@ struct CommState {
     // shared-memory transport (null: RCCL).  Area kAreas of the segment carries the synchronous collectives.
     muse_shm::Gather* shm = nullptr;
     uint64_t seq[kAreas + 1] = {0};   // sequence number of the last exchange per area (the same on every rank)
-    size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced for the gather in flight
+    size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced PER MAP for the gather in flight
+    int nmaps[kAreas] = {1, 1, 1, 1}; // maps of the gather in flight (block per rank: [nmaps][rows_per_rank][ntheta])
     hipStream_t cstream = nullptr;
     bool own_stream = true;
     bool direct_host = false;
@@ -96,6 +98,7 @@ bool load_rccl() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -111,8 +114,9 @@ extern "C" {
 int muse_ctx_comm_slot(muse_ctx* ctx, void*** comm, int* device, void** stream);
 int muse_ctx_comm_buffer(muse_ctx* ctx, size_t doubles, double** buf);
 int muse_ctx_area_event(muse_ctx* ctx, int area, void** event, int* ntheta);
-int muse_internal_map_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
-                            const double* theta, double atol, int z0_mode, int area, double* scores_dev);
+int muse_internal_map_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data, int nmaps,
+                            const double* thetas, double atol, int z0_mode, int area, int64_t map_stride, double* scores_dev);
+int muse_ctx_set_comm_reserve(muse_ctx* ctx, int cus);
 int muse_set_error(int code, const char* msg);
 int muse_wait_event(void* event);
 }
@@ -260,6 +264,20 @@ int muse_comm_transport(muse_ctx* ctx, int* transport_out) {
     return MUSE_OK;
 }
 
+int muse_comm_ranks_seen(muse_ctx* ctx, int* nranks_out) {
+    CommState* st = state_of(ctx);
+    if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
+    if (!nranks_out) return muse_set_error(MUSE_ERR_INVALID, "nranks_out is NULL");
+    if (st->shm) {
+        *nranks_out = st->shm->attached();
+        return MUSE_OK;
+    }
+    if (!g_rccl.CommCount) return muse_set_error(MUSE_ERR_RCCL, "librccl has no ncclCommCount");
+    std::lock_guard<std::mutex> lk(st->mu);
+    RCCLCHK(g_rccl.CommCount(st->comm, nranks_out));
+    return MUSE_OK;
+}
+
 int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     void** slot;
     int device;
@@ -317,6 +335,7 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     st->device = device;
     st->worker = std::thread(comm_worker, st);
     *slot = st;
+    muse_ctx_set_comm_reserve(ctx, 16);  // the all-gather kernel of step k runs beside the (cluster) solver launch of step k+1
     return MUSE_OK;
 }
 
@@ -334,6 +353,7 @@ int muse_comm_destroy(muse_ctx* ctx) {
             return MUSE_OK;
         }
         hipSetDevice(device);
+        muse_ctx_set_comm_reserve(ctx, 0);
         {
             std::lock_guard<std::mutex> lk(st->qmu);
             st->stop = true;
@@ -420,8 +440,8 @@ static int ensure_gather_buffers(CommState* st, int area, size_t doubles_per_ran
     return MUSE_OK;
 }
 
-int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
-                                          int include_data, const double* theta, double atol, int z0_mode,
+int muse_map_and_score_multi_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                                          int include_data, int nmaps, const double* thetas, double atol, int z0_mode,
                                           int64_t rows_per_rank, int area) {
     void* stream = nullptr;
     CommState* st = state_of(ctx, &stream);
@@ -433,17 +453,20 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
     const int64_t n = (sim_end - sim_begin) + (include_data ? 1 : 0);
     if (sim_end < sim_begin || rows_per_rank < n || rows_per_rank < 1)
         return muse_set_error(MUSE_ERR_INVALID, "rows_per_rank must be >= this rank's element count (and >= 1)");
-    const size_t cnt = (size_t)rows_per_rank * (size_t)nt;
+    if (nmaps < 1) return muse_set_error(MUSE_ERR_INVALID, "nmaps must be >= 1");
+    const size_t cnt = (size_t)nmaps * (size_t)rows_per_rank * (size_t)nt;   // block per rank: [nmaps][rows_per_rank][ntheta]
     if (st->pending[area]) return muse_set_error(MUSE_ERR_INVALID, "a gather is still in flight on this result area");
     if (st->shm) {
         // the plain launch (scores to this area's pinned block); the exchange happens in muse_batch_wait_gathered
         if (cnt > st->shm->block_doubles)
-            return muse_set_error(MUSE_ERR_INVALID, "rows_per_rank * ntheta exceeds the block capacity the communicator's id was "
+            return muse_set_error(MUSE_ERR_INVALID, "nmaps * rows_per_rank * ntheta exceeds the block capacity the communicator's id was "
                                                     "created with (muse_comm_unique_id_ex: block_doubles)");
-        rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, nullptr);
+        rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, nmaps, thetas, atol, z0_mode, area, rows_per_rank,
+                                     nullptr);
         if (rc) return rc;
         st->count[area] = cnt;
         st->nlocal[area] = (size_t)n * nt;
+        st->nmaps[area] = nmaps;
         st->seq[area] += 1;
         st->pending[area] = true;
         return MUSE_OK;
@@ -452,9 +475,9 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
     if (rc) return rc;
     hipStream_t ks = (hipStream_t)stream;
     // (the area's previous gather has been awaited -- pending is clear -- so its send buffer is free again)
-    if ((size_t)n * nt < cnt)  // padding rows of a short block are zeros
-        HIPCHK2(hipMemsetAsync(st->send_dev[area] + (size_t)n * nt, 0, (cnt - (size_t)n * nt) * sizeof(double), ks));
-    rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area,
+    if (n < rows_per_rank)  // padding rows of a short block are zeros
+        HIPCHK2(hipMemsetAsync(st->send_dev[area], 0, cnt * sizeof(double), ks));
+    rc = muse_internal_map_async(ctx, seed, sim_begin, sim_end, include_data, nmaps, thetas, atol, z0_mode, area, rows_per_rank,
                                  st->send_dev[area]);
     if (rc) return rc;
     HIPCHK2(hipEventRecord(st->kdone[area], ks));
@@ -468,6 +491,13 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
     }
     st->cv.notify_one();
     return MUSE_OK;
+}
+
+int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,
+                                          int include_data, const double* theta, double atol, int z0_mode,
+                                          int64_t rows_per_rank, int area) {
+    return muse_map_and_score_multi_gather_async(ctx, seed, sim_begin, sim_end, include_data, 1, theta, atol, z0_mode,
+                                                 rows_per_rank, area);
 }
 
 int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_info* info_out) {
@@ -488,7 +518,12 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_in
             g.raise_abort();  // the peers must not wait a minute for a block that will not come
             return rc;
         }
-        if (st->nlocal[area] < cnt) memset(mine + st->nlocal[area], 0, (cnt - st->nlocal[area]) * sizeof(double));
+        {   // padding rows of a short block (after every map's own rows) are zeros
+            const size_t per_map = cnt / (size_t)st->nmaps[area];
+            if (st->nlocal[area] < per_map)
+                for (int m = 0; m < st->nmaps[area]; ++m)
+                    memset(mine + (size_t)m * per_map + st->nlocal[area], 0, (per_map - st->nlocal[area]) * sizeof(double));
+        }
         g.publish_ready(area, s);
         SHMCHK(st, g.wait_ready(area, s), "gathered map");
         if (g_all_out)
@@ -496,7 +531,17 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_in
         g.publish_consumed(area, s);
         return MUSE_OK;
     }
-    while (!st->enqueued[area].load(std::memory_order_acquire)) __builtin_ia32_pause();  // the worker is microseconds behind
+    {   // the worker is microseconds behind; bounded all the same (a worker that has died must not hang the caller)
+        const double t0 = muse_shm::now_s();
+        unsigned spins = 0;
+        while (!st->enqueued[area].load(std::memory_order_acquire)) {
+            MUSE_CPU_RELAX();
+            if ((++spins & 0xfff) == 0 && muse_shm::now_s() - t0 > 30.0) {
+                st->pending[area] = false;
+                return muse_set_error(MUSE_ERR_RCCL, "the communicator's worker thread did not enqueue the gather within 30 s");
+            }
+        }
+    }
     st->pending[area] = false;
     {
         std::lock_guard<std::mutex> lk(st->mu);

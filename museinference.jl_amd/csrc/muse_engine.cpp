@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -21,6 +22,13 @@
 // ================================================================================================
 using namespace muse;
 
+#if defined(__x86_64__) || defined(__i386__)
+#define MUSE_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define MUSE_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define MUSE_CPU_RELAX() std::this_thread::yield()
+#endif
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -54,7 +62,10 @@ struct muse_ctx {
     double* scores_pin[kResultAreas] = {nullptr};
     muse_info* info_pin[kResultAreas] = {nullptr};
     int64_t res_cap[kResultAreas] = {0};
-    int64_t res_n[kResultAreas] = {0};
+    int64_t res_n[kResultAreas] = {0};     // infos (elements) of the area's last launch
+    int64_t res_rows[kResultAreas] = {0};  // score rows of it (>= res_n: a gathered multi-map block is padded per map)
+    bool area_inflight[kResultAreas] = {false};  // launched, not yet waited for
+    bool area_failed[kResultAreas] = {false};    // was in flight when a cluster wait expired (check_error_flag)
     double* small_dev = nullptr;  // 16 doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr, last0 = nullptr, last1 = nullptr;
     bool ev_valid = false;
@@ -77,6 +88,7 @@ struct muse_ctx {
     bool timing = false;           // record an event pair around every solver launch (muse_set_timing; costs ~12 us per launch)
     unsigned long long* stamps = nullptr;
     int64_t stamps_cap = 0;
+    int comm_reserve_cus = 0;  // compute units left to a device-side collective that runs beside the solver (muse_comm.cpp)
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
     double* comm_buf = nullptr;
     size_t comm_buf_doubles = 0;
@@ -238,12 +250,21 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.x_data = c->x_data;
     if (!a.zhat) a.zhat = c->zhat;
     a.work_counter = c->counter;
+    if (a.nmaps <= 1) {
+        a.nmaps = 1;
+        a.n_per_map = a.nproblems;
+        a.map_stride = a.nproblems;
+    }
     a.debug = c->debug;
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     const bool implicit = a.kind == BATCH_IMPLICIT;
     const int pl = implicit ? (use_cluster(c) ? P_C256 : P_S512) : choose_place(c);
     int grid = c->num_cus * place_wgs_per_cu(pl);
     a.csize = 1;
+    // cluster placements need every member resident at once: a device-side collective of the previous step (RCCL transport:
+    // its kernel holds compute units on a high-priority stream until the slowest peer arrives) keeps a share of the GPU
+    if (place_is_cluster(pl) && c->comm_reserve_cus > 0 && c->num_cus > 2 * c->comm_reserve_cus)
+        grid = (c->num_cus - c->comm_reserve_cus) * place_wgs_per_cu(pl);
     a.nclusters = 0;
     if (place_is_cluster(pl)) {
         // every workgroup of a cluster must be resident at once (they wait for each other): the grid is sized from
@@ -385,6 +406,11 @@ int muse_ctx_comm_slot(muse_ctx* c, void*** comm, int* device, void** stream) {
     *stream = (void*)c->stream;
     return MUSE_OK;
 }
+int muse_ctx_set_comm_reserve(muse_ctx* c, int cus) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    c->comm_reserve_cus = cus > 0 ? cus : 0;
+    return MUSE_OK;
+}
 int muse_ctx_area_event(muse_ctx* c, int area, void** event, int* ntheta) {
     if (!c || area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
     *event = (void*)c->area_done[area];
@@ -465,12 +491,29 @@ int muse_set_element_split(muse_ctx* c, int split) {
     c->split = split == 1 ? 0 : split;
     return MUSE_OK;
 }
-// A bounded cluster wait that expired inside a solver kernel leaves the pinned error word set; every entry point
-// that has synchronised with the launch reports (and clears) it instead of returning the launch's garbage.
+// A bounded cluster wait that expired inside a solver kernel leaves the pinned error word set; every entry point that has
+// synchronised with a launch reports it instead of returning the launch's garbage.  Recovery: the members that gave up went
+// on with garbage reductions, so their control flow -- and their epoch counters -- diverged from their cluster's; only rank
+// 0's epoch is saved, and granules tagged ahead of it are still lying in cl_part, where a later launch could take one for
+// the current epoch's value.  So: drain the stream, start the cluster state over (tags and epochs from zero, as after the
+// 32-bit wrap), and mark every result area whose launch was in flight as failed -- each of their waits reports the error
+// once -- before the flag is cleared.
 static int check_error_flag(muse_ctx* c) {
     if (*c->error_flag) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->cl_part && c->cl_cap > 0) {
+            (void)hipMemsetAsync(c->cl_part, 0, (size_t)c->cl_cap * kClusterSlotDoubles * sizeof(double), c->stream);
+            (void)hipMemsetAsync(c->cl_state, 0, (size_t)c->cl_cap * sizeof(unsigned int), c->stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
+        for (int r = 0; r < kResultAreas; ++r) {
+            if (c->area_inflight[r]) c->area_failed[r] = true;
+            c->area_inflight[r] = false;
+        }
+        c->error_flag[1] = 0;
         *c->error_flag = 0;
-        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident)");
+        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident); "
+                                  "the cluster state was reset, result areas in flight are marked failed");
     }
     return MUSE_OK;
 }
@@ -559,8 +602,9 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
         a.bnd[k] = c->bnd[k];
         a.bnd32[k] = k < c->ntheta ? (int)c->bnd[k] : 0x7fffffff;
     }
-    make_thetaset(c, theta, a.tmap);
-    a.f_const = theta_const(c, theta);
+    make_thetaset(c, theta, a.cur.t);
+    a.cur.f_const = theta_const(c, theta);
+    a.nmaps = 1;
     a.fid_slot = -1;
     a.nstd = 0x7fffffff;  // no normals-only elements
 }
@@ -670,51 +714,68 @@ int muse_zhat_at_theta(muse_ctx* c, const double* x, const double* z0, const dou
     return MUSE_OK;
 }
 
-// The batched map with the scores directed at `scores_dev` (any device-accessible buffer of n*ntheta
-// doubles; NULL = the area's pinned host block).  muse_comm.cpp points it at the send buffer of the
-// RCCL all-gather so that the scores never visit the host between the solver and the collective.
+// The batched map: `nmaps` independent maps over the same elements, each with a theta of its own (thetas [nmaps][ntheta]), in
+// ONE launch.  Scores go to `scores_dev` (any device-accessible buffer; NULL = the area's pinned host block -- muse_comm.cpp
+// points it at the send buffer of the RCCL all-gather so that the scores never visit the host between the solver and the
+// collective), map m's rows at m * map_stride (>= the element count: a gathered block is padded to rows_per_rank).
+struct MapOpts {
+    int nmaps = 1;
+    int64_t map_stride = 0;   // 0: the element count
+    double* scores_dev = nullptr;
+    int ncache_mode = 0;      // 1: the batch also stores the normals of its simulations; 2: it loads them (same seed and range
+                              // as the storing batch of the same host call).  Silently 0 where the cache does not apply.
+    const MapTheta* theta_dev = nullptr;  // theta from device memory (device-resident muse! loop); thetas is then only a placeholder
+    const int* stop_flag = nullptr;
+};
 static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
-                          const double* theta, double atol, int z0_mode, int area, double* scores_dev, int ncache_mode);
-int muse_internal_map_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
-                            const double* theta, double atol, int z0_mode, int area, double* scores_dev) {
-    return map_async_impl(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, scores_dev, 0);
-}
-// ncache_mode 1: the batch also stores the normals of its simulations; 2: it loads them (same seed and range as the
-// storing batch of the same host call).  Silently 0 where the cache does not apply.
-static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
-                          const double* theta, double atol, int z0_mode, int area, double* scores_dev, int ncache_mode) {
+                          const double* thetas, double atol, int z0_mode, int area, const MapOpts& o) {
     int rc = check_ctx(c);
     if (rc) return rc;
-    if (!theta) return fail(MUSE_ERR_INVALID, "theta is NULL");
+    if (!thetas) return fail(MUSE_ERR_INVALID, "theta is NULL");
     if (sim_end < sim_begin || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad sim range");
     if (z0_mode < MUSE_Z0_ZERO || z0_mode > MUSE_Z0_WARM) return fail(MUSE_ERR_INVALID, "bad z0_mode");
     if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
+    if (o.nmaps < 1 || o.nmaps > kMaxMaps) return fail(MUSE_ERR_INVALID, "nmaps must be in [1, MUSE_MAX_MAPS]");
     if (include_data && !c->has_data) return fail(MUSE_ERR_NODATA, "include_data set but muse_set_data was not called");
     const int64_t n = (sim_end - sim_begin) + (include_data ? 1 : 0);
-    if (n == 0) { c->res_n[area] = 0; return MUSE_OK; }
-    if (n > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
-    rc = ensure_zhat(c, n);
+    const int64_t stride = o.map_stride > 0 ? o.map_stride : n;
+    if (stride < n) return fail(MUSE_ERR_INVALID, "map_stride smaller than the element count");
+    c->area_failed[area] = false;
+    if (n == 0) { c->res_n[area] = 0; c->res_rows[area] = 0; return MUSE_OK; }
+    const int64_t total = n * o.nmaps, rows = stride * o.nmaps;
+    if (total > 0x7fffffff || rows > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
+    rc = ensure_zhat(c, total);
     if (rc) return rc;
-    rc = ensure_results(c, area, n);
+    rc = ensure_results(c, area, rows);
     if (rc) return rc;
     BatchArgs a;
-    base_args(c, a, theta);
+    base_args(c, a, thetas);
     a.kind = BATCH_STD;
     a.seed = seed;
     a.atol = atol;
-    a.nproblems = (int)n;
+    a.nproblems = (int)total;
     a.include_data = include_data ? 1 : 0;
     a.z0_mode = z0_mode;
     a.store_zhat = 1;
     a.sim_begin = sim_begin;
     a.slot0 = 0;
-    a.scores = scores_dev ? scores_dev : c->scores_dev[area];
+    a.scores = o.scores_dev ? o.scores_dev : c->scores_dev[area];
     a.info = c->info_dev[area];
-    if (ncache_mode != 0 && sim_end > sim_begin && ensure_ncache(c, sim_end - sim_begin)) {
+    a.nmaps = o.nmaps;
+    a.n_per_map = (int)n;
+    a.map_stride = stride;
+    a.cur_dev = o.theta_dev;
+    a.stop_flag = o.stop_flag;
+    if (o.nmaps > 1)
+        for (int m = 0; m < o.nmaps; ++m) {
+            make_thetaset(c, thetas + (size_t)m * c->ntheta, a.maps[m].t);
+            a.maps[m].f_const = theta_const(c, thetas + (size_t)m * c->ntheta);
+        }
+    if (o.ncache_mode != 0 && o.nmaps == 1 && sim_end > sim_begin && ensure_ncache(c, sim_end - sim_begin)) {
         a.ncache = c->ncache;
         a.ncache_sim0 = sim_begin;
         a.ncache_count = (int)(sim_end - sim_begin);
-        a.ncache_mode = ncache_mode;
+        a.ncache_mode = o.ncache_mode;
     }
     // the area's completion event is signalled by this launch itself; with timing events around the launch (profiling)
     // the plain record after it keeps the order start, kernel, stop, done
@@ -724,16 +785,32 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     rc = launch_batch(c, a);
     c->launch_done = nullptr;
     if (rc) return rc;
+    c->area_inflight[area] = true;
+    c->res_rows[area] = rows;
     if (c->launch_done_used) {
-        c->res_n[area] = n;
+        c->res_n[area] = total;
         return MUSE_OK;
     }
-    return enqueue_results_copy(c, area, n);
+    return enqueue_results_copy(c, area, total);
+}
+int muse_internal_map_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data, int nmaps,
+                            const double* thetas, double atol, int z0_mode, int area, int64_t map_stride, double* scores_dev) {
+    MapOpts o;
+    o.nmaps = nmaps;
+    o.map_stride = map_stride;
+    o.scores_dev = scores_dev;
+    return map_async_impl(c, seed, sim_begin, sim_end, include_data, thetas, atol, z0_mode, area, o);
 }
 
 int muse_map_and_score_batch_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
                                    const double* theta, double atol, int z0_mode, int area) {
-    return muse_internal_map_async(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, nullptr);
+    return map_async_impl(c, seed, sim_begin, sim_end, include_data, theta, atol, z0_mode, area, MapOpts());
+}
+int muse_map_and_score_multi_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data, int nmaps,
+                                   const double* thetas, double atol, int z0_mode, int area) {
+    MapOpts o;
+    o.nmaps = nmaps;
+    return map_async_impl(c, seed, sim_begin, sim_end, include_data, thetas, atol, z0_mode, area, o);
 }
 
 // Wait for an event by polling its signal (hipEventQuery) before falling back to the runtime's blocking
@@ -745,7 +822,7 @@ int muse_wait_event(void* event) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return MUSE_OK;
         if (e != hipErrorNotReady) return fail(MUSE_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
-        __builtin_ia32_pause();
+        MUSE_CPU_RELAX();
     }
     HIPCHK(hipEventSynchronize(ev));
     return MUSE_OK;
@@ -757,10 +834,15 @@ int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {
     if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
     rc = muse_wait_event(c->area_done[area]);  // this area only: later launches keep running
     if (rc) return rc;
+    c->area_inflight[area] = false;
     rc = check_error_flag(c);
     if (rc) return rc;
-    const int64_t n = c->res_n[area];
-    if (g_out && n) memcpy(g_out, c->scores_pin[area], (size_t)n * c->ntheta * sizeof(double));
+    if (c->area_failed[area]) {  // its launch ran beside (or behind) one whose cluster wait expired: its results are not trusted
+        c->area_failed[area] = false;
+        return fail(MUSE_ERR_HIP, "this result area was in flight when a cluster wait expired inside a solver kernel");
+    }
+    const int64_t n = c->res_n[area], rows = c->res_rows[area];
+    if (g_out && rows) memcpy(g_out, c->scores_pin[area], (size_t)rows * c->ntheta * sizeof(double));
     if (info_out && n) memcpy(info_out, c->info_pin[area], (size_t)n * sizeof(muse_info));
     return MUSE_OK;
 }
@@ -838,7 +920,9 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
         const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
         // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
         // standard normals, the later ones load them instead of running the generator again
-        rc = map_async_impl(c, seed, 0, S, 1, theta, o->atol, z0_mode, 0, nullptr, i == 1 ? 1 : 2);
+        MapOpts mo;
+        mo.ncache_mode = i == 1 ? 1 : 2;
+        rc = map_async_impl(c, seed, 0, S, 1, theta, o->atol, z0_mode, 0, mo);
         if (rc) return rc;
         rc = muse_batch_wait(c, 0, g.data(), info.data());
         if (rc) return rc;

@@ -42,6 +42,29 @@ namespace muse {
 // parameter: hipcc materialises a by-value aggregate in scratch as soon as any select/phi of two
 // field addresses is formed, and every access then becomes a scratch access.  LDS loads at uniform
 // addresses are uniform values, so control flow on them stays scalar.
+typedef __attribute__((address_space(4))) const uint32_t* kernarg_ptr;
+// theta of problem p into the LDS copy of the arguments (BatchArgs::cur): from device memory (cur_dev: the theta the previous
+// step kernel of a device-resident muse! loop left there), or -- a launch that carries several maps -- from the map's entry of
+// maps[], read straight from the kernarg segment.  Workgroup-uniform; a no-op (no barrier) for the plain launch.
+__device__ __forceinline__ void load_problem_theta(const BatchArgs& a, double* args_lds, int p, int tid) {
+    if (a.nmaps > 1 || a.cur_dev) {
+        __syncthreads();  // every thread is done with the previous problem's theta
+        asm volatile("" : "+v"(tid));  // (else the source address is formed at the kernel's entry and held -- spilled -- across it)
+        if (tid < (int)(sizeof(MapTheta) / 4)) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(args_lds) + offsetof(BatchArgs, cur) / 4;
+            uint32_t v;
+            if (a.cur_dev) {
+                v = reinterpret_cast<const uint32_t*>(a.cur_dev)[tid];
+            } else {
+                kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                v = kp[(offsetof(BatchArgs, maps) + (size_t)(p / a.n_per_map) * sizeof(MapTheta)) / 4 + tid];
+            }
+            dst[tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
 template <class Model, class Place, bool IMPLICIT = false>
 __global__ void __launch_bounds__(Place::T) __attribute__((amdgpu_waves_per_eu(Place::kWavesPerEu)))
 map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
@@ -58,13 +81,18 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry)::"memory");
 #endif
     {
-        typedef __attribute__((address_space(4))) const uint32_t* kernarg_ptr;
         kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         uint32_t* dst = reinterpret_cast<uint32_t*>(args_lds);
-        for (int w = tid; w < (int)(sizeof(BatchArgs) / 4); w += T) dst[w] = kp[w];
+        for (int w = tid; w < (int)(kArgsHeadBytes / 4); w += T) dst[w] = kp[w];  // (not the trailing maps[]: see load_problem_theta)
     }
     __syncthreads();
     const BatchArgs& a = *reinterpret_cast<const BatchArgs*>(args_lds);
+    if (a.stop_flag && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(a.stop_flag)) != 0) {
+        // the device-resident outer loop has converged: this launch was enqueued ahead of the host's knowledge and drains as
+        // a no-op.  The ticket counter still advances by exactly nproblems (muse_engine.cpp, launch_batch).
+        if (!Place::kCluster && blockIdx.x == 0 && tid == 0) atomicAdd(a.work_counter, a.nproblems);
+        return;
+    }
     double* exch = args_lds + kArgsDoubles;   // cluster placements: [kMaxCluster][8] values of the epoch's exchange
     double* lds_x = exch + (Place::kCluster ? kMaxCluster * 8 : 0);  // [ld + 2]: elements, dummy slot (index ld), pad
     double* lds_g = lds_x + a.ld + 2;         // [ld + 2]
@@ -110,6 +138,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
             sv.next_p = p + a.nclusters < a.nproblems ? p + a.nclusters : -1;
             sv.parity = 0;
             __syncthreads();
+            load_problem_theta(a, args_lds, p, tid);
             if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);
             else sv.run(p, cl_scratch, lds_x, lds_g);
         }
@@ -140,6 +169,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
 #ifdef MUSE_STAMPS
             if (tid == 0 && a.stamps && p < (int)gridDim.x) a.stamps[(size_t)p * 16 + 8] = t_entry;  // kernel entry
 #endif
+            load_problem_theta(a, args_lds, p, tid);
             {
                 Solver<Model, Place> sv(a, tid, red, shs);
                 sv.pk[0] = pk0;
@@ -165,7 +195,7 @@ __global__ void __launch_bounds__(256) sample_kernel(BatchArgs a, uint64_t sim, 
     const int64_t N = a.N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = a.ntheta > 1 ? block_of(a, i) : 0;
-        const double sdk = a.tmap.sd[k];
+        const double sdk = a.cur.t.sd[k];
         const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
         if (MODEL == MUSE_MODEL_NOISE) {
             z[i] = np.n1;
@@ -208,7 +238,7 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     // vectors are padded to the even length ld with a zero pad element (phantom zero, see for_elems)
     for_elems<T, 0, 1>(a.ld, tid, T, [&](int, int i) {
         const int k = MAXB > 1 ? block_of(a, i) : 0;
-        const double ivk = a.tmap.iv[k];
+        const double ivk = a.cur.t.iv[k];
         double gi;
         if constexpr (Model::kStencil) {
             const bool valid = i < Ni;
@@ -232,9 +262,9 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     block_allreduce<T, 2, 0>(sum, mx, red, parity, tid);
     block_allreduce<T, MAXB, 0>(acc, mx, red, parity, tid);
     if (tid == 0) {
-        out[0] = -(0.5 * (sum[0] + a.f_const));
+        out[0] = -(0.5 * (sum[0] + a.cur.f_const));
         for (int b = 0; b < MAXB; ++b)
-            if (b < a.ntheta) out[1 + b] = 0.5 * (a.tmap.iv[b] * acc[b] - (double)(a.bnd[b + 1] - a.bnd[b]));
+            if (b < a.ntheta) out[1 + b] = 0.5 * (a.cur.t.iv[b] * acc[b] - (double)(a.bnd[b + 1] - a.bnd[b]));
     }
 }
 

@@ -30,6 +30,16 @@
 #include <atomic>
 #include <string>
 
+#ifndef MUSE_CPU_RELAX  // a polite spin on every host the library builds on
+#if defined(__x86_64__) || defined(__i386__)
+#define MUSE_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define MUSE_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define MUSE_CPU_RELAX() sched_yield()
+#endif
+#endif
+
 namespace muse_shm {
 
 constexpr uint64_t kMagic = 0x314d48534553554dull;  // "MUSESHM1"
@@ -146,6 +156,7 @@ public:
     double* block(int area, int r) const { return data_ + ((size_t)area * nranks + r) * block_doubles; }
     void raise_abort() { if (hdr_) hdr_->abort.store(1, std::memory_order_release); }
     bool aborted() const { return hdr_ && hdr_->abort.load(std::memory_order_acquire) != 0; }
+    int attached() const { return hdr_ ? (int)hdr_->attached.load(std::memory_order_acquire) : 0; }  // ranks that mapped the segment
 
     // 0 ok, 1 timeout, 2 aborted by a peer
     int wait_consumed(int area, uint64_t seq) const { return wait_all(area, seq, false); }
@@ -166,7 +177,7 @@ private:
             const std::atomic<uint64_t>& w = ready ? line(area, q).ready : line(area, q).consumed;
             unsigned spins = 0;
             while (w.load(std::memory_order_acquire) < seq) {
-                __builtin_ia32_pause();
+                MUSE_CPU_RELAX();
                 if ((++spins & 0x3ff) == 0) {  // every ~1024 polls: abort word, clock, and let an oversubscribed host run the peer
                     if (hdr_->abort.load(std::memory_order_acquire)) return 2;
                     const double t = now_s();

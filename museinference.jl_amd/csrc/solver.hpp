@@ -77,7 +77,8 @@ struct Solver {
         cl_epoch += 1;
         gu64* gran = (gu64*)cl_part + (size_t)(cl_epoch & 1u) * (kMaxCluster * 16);
         if (tid < 64) {
-            const int lane = tid;
+            int lane = tid;
+            asm volatile("" : "+v"(lane));  // (else the lane masks below -- one set per K -- are computed at the kernel's entry and kept in spilled SGPRs)
             if (lane < 2 * K) {  // granule (value k = lane >> 1, half h = lane & 1) of this workgroup
                 double v = 0.0;
 #pragma unroll
@@ -99,6 +100,7 @@ struct Solver {
             constexpr bool kLiveOnly = Model::kStencil;
             const int total = kLiveOnly ? csize * 2 * K : csize * 16;
             unsigned spins = 0;
+            unsigned long long t_wait0 = 0;
             for (int q0 = 0; q0 < total; q0 += 64) {
                 const int ql = q0 + lane;
                 const int q = kLiveOnly ? (ql / (2 * K)) * 16 + ql % (2 * K) : ql;
@@ -111,10 +113,17 @@ struct Solver {
                         ok = (unsigned)(gv >> 32) == cl_epoch;
                     }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || cl_aborted) break;
-                    // bounded (about a second): members that are not all resident must not hang the GPU
-                    if (++spins > (1u << 21)) {
-                        __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        cl_aborted = true;
+                    // bounded by TIME (s_memtime: the 100 MHz reference clock, looked at every 1024 sweeps): members that are
+                    // not all resident must not hang the GPU, and a peer that is merely late (a collective kernel beside the
+                    // launch, a pre-empted wave) must not be taken for one -- 4 seconds
+                    if ((++spins & 0x3ffu) == 0) {
+                        unsigned long long now;
+                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                        if (t_wait0 == 0) t_wait0 = now;
+                        else if (now - t_wait0 > 400000000ull) {
+                            __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            cl_aborted = true;
+                        }
                     }
                 }
                 if (live) reinterpret_cast<unsigned*>(exch)[q] = (unsigned)(gv & 0xffffffffull);
@@ -183,12 +192,19 @@ struct Solver {
     unsigned pk[2];
     __device__ __forceinline__ int blk(int jj, int i) const {
         if constexpr (MAXB == 1) return 0;
-        else if constexpr (Place::kResident) return (int)((pk[jj / 10] >> (3 * (jj % 10))) & 7u);
+        else if constexpr (Place::kResident) {
+            // (laundered: the extraction and everything derived from it -- the lane masks k == b of the score sums, 20 slots x
+            // MAXB of them, the LDS addresses of the per-block coefficients -- is otherwise hoisted to the kernel's entry, held
+            // across the persistent loop and spilled: 172 SGPRs and 21 VGPRs for FunnelModel<4>, 353 / 33 for <8>)
+            unsigned w = pk[jj / 10];
+            asm volatile("" : "+v"(w));
+            return (int)((w >> (3 * (jj % 10))) & 7u);
+        }
         else return block_of<MAXB>(a, i);
     }
     __device__ __forceinline__ double ivk(int jj, int i) const {
         if constexpr (MAXB == 1) return iv0;
-        else return a.tmap.iv[blk(jj, i)];
+        else return a.cur.t.iv[blk(jj, i)];
     }
     __device__ __forceinline__ double sdk(int jj, int i) const {
         if constexpr (MAXB == 1) return sd0;
@@ -504,7 +520,7 @@ struct Solver {
             }, when(STORE_G, g), when(INIT_S, s));
         }
         reduce<2, 1>(sum, mx);
-        f = 0.5 * (sum[0] + a.f_const);
+        f = 0.5 * (sum[0] + a.cur.f_const);
         dphi = sum[1];
         gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
         f_calls += 1;
@@ -537,12 +553,12 @@ struct Solver {
             mx[1] = absmax(mx[1], gt);
         }, s);
         reduce<4, 2>(sum, mx);
-        f = 0.5 * (sum[0] + a.f_const);
+        f = 0.5 * (sum[0] + a.cur.f_const);
         dphi = sum[1];
         gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
         f_calls += 1;
         trial_c = c0;
-        trial_phi = 0.5 * (sum[2] + a.f_const);
+        trial_phi = 0.5 * (sum[2] + a.cur.f_const);
         trial_dphi = sum[3];
         trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
         have_trial = true;
@@ -792,11 +808,11 @@ struct Solver {
         z_zero = false;
         have_trial = false;
         stamp(p, 0);
-        iv0 = a.tmap.iv[0];
-        sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.tmap.sd[0];
+        iv0 = a.cur.t.iv[0];
+        sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.cur.t.sd[0];
         if constexpr (MAXB > 1) {
             // FD batches sample at a theta that differs from the MAP theta
-            if (tid < MAXB) sh_sd[tid] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tid] : a.tmap.sd[tid];
+            if (tid < MAXB) sh_sd[tid] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tid] : a.cur.t.sd[tid];
             __syncthreads();
         }
         // bind storage
@@ -870,26 +886,22 @@ struct Solver {
                         g.set(2 * j + 1, i0 + 1, valid1 ? zt1 : 0.0);
                     }
                 } else {
-                    // block boundaries and sampling sd of every block in scalar registers for the loop: read through the
-                    // LDS copy of the arguments they would be re-loaded in every trip (the loop stores to LDS)
-                    int bb[MAXB];
-                    double sdl[MAXB];
-#pragma unroll
-                    for (int b = 0; b < MAXB; ++b) {
-                        bb[b] = MAXB > 1 ? __builtin_amdgcn_readfirstlane(a.bnd32[b]) : 0;
-                        sdl[b] = MAXB > 1 ? uniform(sh_sd[b]) : sd0;
-                    }
-                    auto sd_of = [&](int i) {
-                        double v = sdl[0];
-#pragma unroll
-                        for (int b = 1; b < MAXB; ++b) v = (i >= bb[b]) ? sdl[b] : v;  // bnd32[b] = INT_MAX for b >= ntheta
-                        return v;
+                    // sampling sd of the element in (run-time) slot jj: the slot's packed block index selects the value in LDS.
+                    // (A select chain over per-block scalars -- boundaries and sd values in SGPRs -- was turned into a
+                    // lane-indexed table in SCRATCH by the compiler: a scratch load per element in the generator loop.)
+                    auto sd_of = [&](int jj) {
+                        if constexpr (MAXB == 1) return sd0;
+                        else {
+                            const unsigned w = jj >= 10 ? pk[1] : pk[0];
+                            const int sh = 3 * (jj >= 10 ? jj - 10 : jj);
+                            return sh_sd[(w >> sh) & 7u];
+                        }
                     };
                     // One trip draws kSamplerPairs pairs (2 * kSamplerPairs independent Philox/Box-Muller chains in one basic
                     // block).  At the two waves per SIMD of this placement a wave issues a VALU instruction every ~5.3 cycles
                     // when it has four independent ones to choose from and every ~11 when each depends on the one before
                     // (tools/clockprobe.hip): with one pair per trip the generator ran at ~9.8 cycles per instruction.
-                    auto draw = [&](auto npairs, int i0) {
+                    auto draw = [&](auto npairs, int i0, int j) {
                         // both elements of a pair unconditionally; for odd N the last pair's second element is the pad
                         // slot, kept at 0.  All 2 * P generator chains advance side by side (rng.hpp).
                         constexpr int P = decltype(npairs)::value;
@@ -909,8 +921,8 @@ struct Solver {
                                 store_f64x2(n2r, j0, np[2 * q].n2, np[2 * q + 1].n2);
                             }
                             double zt0, xt0, zt1, xt1;
-                            Model::sample(sd_of(j0), np[2 * q].n1, np[2 * q].n2, zt0, xt0);
-                            Model::sample(sd_of(j0 + 1), np[2 * q + 1].n1, np[2 * q + 1].n2, zt1, xt1);
+                            Model::sample(sd_of(2 * (j + q)), np[2 * q].n1, np[2 * q].n2, zt0, xt0);
+                            Model::sample(sd_of(2 * (j + q) + 1), np[2 * q + 1].n1, np[2 * q + 1].n2, zt1, xt1);
                             const bool valid1 = j0 + 1 < (int)N;
                             x.p[j0] = xt0;
                             g.p[j0] = zt0;
@@ -918,13 +930,16 @@ struct Solver {
                             g.p[j0 + 1] = valid1 ? zt1 : 0.0;
                         }
                     };
+                    int j = 0;  // the pair's slot: pair j of this thread is elements i0, i0 + 1 with i0 = 2 (tid + j T)
+                    int tl = tid;
+                    asm volatile("" : "+v"(tl));  // (else the first Philox round's product with tid is held -- spilled -- across the kernel)
 #pragma unroll 1
-                    for (int i0 = 2 * tid; i0 < (int)N; i0 += 2 * T * kSamplerPairs) {
+                    for (int i0 = 2 * tl; i0 < (int)N; i0 += 2 * T * kSamplerPairs, j += kSamplerPairs) {
                         if constexpr (kSamplerPairs == 2) {
-                            if (i0 + 2 * T < (int)N) draw(std::integral_constant<int, 2>{}, i0);
-                            else draw(std::integral_constant<int, 1>{}, i0);
+                            if (i0 + 2 * T < (int)N) draw(std::integral_constant<int, 2>{}, i0, j);
+                            else draw(std::integral_constant<int, 1>{}, i0, j);
                         } else {
-                            draw(std::integral_constant<int, 1>{}, i0);
+                            draw(std::integral_constant<int, 1>{}, i0, j);
                         }
                     }
                 }
@@ -968,11 +983,11 @@ struct Solver {
                         }
                         double sum[4] = {gen.sum[0], gen.sum[1], gen.sum[2], gen.sum[3]}, mx[2] = {gen.mx[0], gen.mx[1]};
                         reduce<4, 2>(sum, mx);
-                        init_f = 0.5 * (sum[0] + a.f_const);
+                        init_f = 0.5 * (sum[0] + a.cur.f_const);
                         init_dphi = sum[1];
                         init_gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
                         trial_c = 1.0;
-                        trial_phi = 0.5 * (sum[2] + a.f_const);
+                        trial_phi = 0.5 * (sum[2] + a.cur.f_const);
                         trial_dphi = sum[3];
                         trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
                         init_done = true;
@@ -1025,11 +1040,11 @@ struct Solver {
                             mx[1] = absmax(mx[1], gt);
                         }, when(KEEP_ZTRUE, ztrue), x, s, when(Place::kResident || ztrue_start, z));
                         reduce<4, 2>(sum, mx);
-                        init_f = 0.5 * (sum[0] + a.f_const);
+                        init_f = 0.5 * (sum[0] + a.cur.f_const);
                         init_dphi = sum[1];
                         init_gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
                         trial_c = 1.0;
-                        trial_phi = 0.5 * (sum[2] + a.f_const);
+                        trial_phi = 0.5 * (sum[2] + a.cur.f_const);
                         trial_dphi = sum[3];
                         trial_gmax = nan_if(sum[2] != sum[2] || sum[3] != sum[3], mx[1]);
                         init_done = true;
@@ -1621,8 +1636,8 @@ struct Solver {
                 for (int b = 1; b < MAXB; ++b) mine = (tl == b) ? acc[b] : mine;
                 const double cnt = (double)(a.bnd32[tl < a.ntheta - 1 ? tl + 1 : 0] - a.bnd32[tl]);
                 const double cnt_last = (double)((int)a.N - a.bnd32[tl]);  // bnd32[ntheta] is a sentinel, not N
-                a.scores[(int64_t)p * a.ntheta + tl] =
-                    0.5 * (a.tmap.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
+                a.scores[d.row * a.ntheta + tl] =
+                    0.5 * (a.cur.t.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
             }
             if (tid == 0 && crank == 0) {
                 muse_info inf;

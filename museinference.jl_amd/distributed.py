@@ -8,9 +8,52 @@ after which every rank holds all scores in the reference's sim order and does th
 so a result is bitwise independent of the number of GPUs.  Collectives go through torch.distributed
 (backend "nccl" = RCCL over xGMI on GPUs; "gloo" on CPU for the multi-process tests).
 """
+import os
+import sys
+import time
+
 import numpy as np
 
 from . import _capi
+
+
+def ranks_share_node(dist, group=None):
+    """True when every rank of the group runs under ONE kernel and sees ONE /dev/shm, which is what the engine's
+    shared-memory transport needs.  Host names do not say that: containers on different nodes often share one, and
+    containers on one node may have private /dev/shm mounts.  Rank 0 writes its boot id
+    (/proc/sys/kernel/random/boot_id) into a probe file under /dev/shm; a rank agrees when it finds the file and
+    its own boot id in it.  Collective over the group: the same answer on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    token = [None]
+    if rank == 0 and boot:
+        name = f"/dev/shm/muse_probe_{os.getpid()}_{time.time_ns():x}"
+        try:
+            fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+            os.write(fd, boot.encode())
+            os.close(fd)
+            token[0] = name
+        except OSError:
+            token[0] = None
+    dist.broadcast_object_list(token, src=src, group=group)
+    ok = False
+    if token[0] is not None and boot:
+        try:
+            ok = open(token[0]).read().strip() == boot
+        except OSError:
+            ok = False
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(ok), group=group)  # also the barrier before the probe file goes away
+    if rank == 0 and token[0] is not None:
+        try:
+            os.unlink(token[0])
+        except OSError:
+            pass
+    return all(oks)
 
 
 def block_partition(begin, end, world, rank):
@@ -29,10 +72,11 @@ class ShardedMuseProblem:
     def __init__(self, local, group=None, device=None, engine_comm=None, transport=None):
         """engine_comm: exchange through the engine's own communicator (muse_comm_* of the C ABI, no torch tensors on
         the path).  transport "shm": the ranks share a node and exchange their blocks host to host through a
-        shared-memory segment; "rccl": pinned host -> device -> ncclAllGather -> pinned host.  Defaults: the engine's
-        communicator when the local problem is a HipMuseProblem and either all ranks report the same host name (shm)
-        or the process group's backend is nccl (= RCCL); torch.distributed collectives otherwise (gloo on CPU).
-        The unique id travels over the process group once."""
+        shared-memory segment; "rccl": pinned host -> device -> ncclAllGather -> pinned host.  Defaults, when the local
+        problem is a HipMuseProblem: "shm" if the ranks share a node (ranks_share_node: one boot id, one /dev/shm), else
+        "rccl" if the process group's backend is nccl (= RCCL); a transport that fails to come up on ANY rank is given
+        up by ALL ranks together and the next one is tried; torch.distributed collectives otherwise (gloo on CPU).
+        The unique id travels over the process group once.  `transport` reports what is in use (None: torch)."""
         import torch.distributed as dist
         self._dist = dist
         self.local = local
@@ -41,20 +85,56 @@ class ShardedMuseProblem:
         self.rank = dist.get_rank(group)
         self._device = device
         self._last_nslots = None
+        self._last_had_data = False
         has_engine = hasattr(local, "comm_init")
-        if has_engine and transport is None and engine_comm is not False:
-            import socket
-            names = [None] * self.world
-            dist.all_gather_object(names, socket.gethostname(), group=group)
-            transport = "shm" if len(set(names)) == 1 else "rccl"
-        if engine_comm is None:
-            engine_comm = has_engine and (transport == "shm" or dist.get_backend(group) == "nccl")
-        self.engine_comm = bool(engine_comm)
-        self.transport = transport if self.engine_comm else None
-        if self.engine_comm and getattr(local, "_nranks", None) is None:
-            uid = [type(local).comm_unique_id(transport or "rccl") if self.rank == 0 else None]
-            dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            local.comm_init(self.world, self.rank, uid[0])
+        nccl = dist.get_backend(group) == "nccl"
+        self.engine_comm = False
+        self.transport = None
+        if not has_engine or engine_comm is False:
+            return
+        if getattr(local, "_nranks", None) is not None:  # the caller initialised the local communicator itself
+            self.engine_comm = True
+            self.transport = local.comm_transport()
+            return
+        # Transports to try, in order; an explicit request is tried alone (then torch.distributed).  Whether one works
+        # is a COLLECTIVE decision: every rank reports, and all ranks move on to the next candidate together when any
+        # of them failed -- a rank must never sit in a segment's or a communicator's time-out alone.
+        if transport is not None:
+            candidates = [transport]
+        else:
+            candidates = (["shm"] if ranks_share_node(dist, group) else []) + (["rccl"] if nccl else [])
+        if engine_comm is None and not candidates:
+            return
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        for cand in candidates:
+            ok, why = True, ""
+            uid = [None]
+            if self.rank == 0:
+                try:
+                    uid[0] = type(local).comm_unique_id(cand)
+                except Exception as e:  # noqa: BLE001
+                    why = str(e)
+            dist.broadcast_object_list(uid, src=src, group=group)
+            if uid[0] is None:
+                ok = False
+            else:
+                try:
+                    local.comm_init(self.world, self.rank, uid[0])
+                except Exception as e:  # noqa: BLE001
+                    ok, why = False, str(e)
+            oks = [None] * self.world
+            dist.all_gather_object(oks, ok, group=group)
+            if all(oks):
+                self.engine_comm = True
+                self.transport = cand
+                return
+            if ok:  # this rank was fine, a peer was not: give the communicator back
+                local.comm_destroy()
+            if self.rank == 0:
+                print(f"[museinference] engine communicator '{cand}' unavailable on {oks.count(False)} rank(s)"
+                      + (f" ({why})" if why else "") + "; trying the next transport", file=sys.stderr)
+        if engine_comm is True and transport is not None:
+            raise RuntimeError(f"engine communicator '{transport}' could not be initialised on every rank")
 
     def __getattr__(self, name):
         return getattr(self.local, name)
@@ -98,8 +178,8 @@ class ShardedMuseProblem:
                             z0_mode=_capi.Z0_ZERO):
         lo, hi = block_partition(sim_begin, sim_end, self.world, self.rank)
         data_here = include_data and self.rank == 0
-        if include_data:
-            self._last_nslots = (sim_end - sim_begin) + 1
+        self._last_nslots = (sim_end - sim_begin) + (1 if include_data else 0)
+        self._last_had_data = bool(include_data)
         g, info = self.local.map_and_score_batch(rng, lo, hi, theta, include_data=data_here, atol=atol,
                                                  z0_mode=z0_mode)
         counts = []
@@ -184,21 +264,26 @@ class ShardedMuseProblem:
 
     # -- resident MAPs.  Slots follow the element order of the LAST map: [data] + sims, the data element and the first
     #    block on rank 0, every rank's block in its local slots from 0 (rank 0: after the data element).
-    def _slot_owner(self, nslots):
-        """(rank, local slot) of every global slot 0..nslots-1 for a map of nslots elements that included the data."""
-        nsims = nslots - 1
-        owners = [(0, 0)]
+    def _slot_owner(self, nslots, had_data=True):
+        """(rank, local slot) of every global slot 0..nslots-1 of a map of nslots elements: [data] + sims."""
+        if nslots is None:
+            raise ValueError("no sharded map has run on this problem yet (and no set_zhat): pass nslots, the element "
+                             "count of the map whose MAPs are meant")
+        d = 1 if had_data else 0
+        nsims = nslots - d
+        owners = [(0, 0)] if had_data else []
         for r in range(self.world):
             lo, hi = block_partition(0, nsims, self.world, r)
-            owners += [(r, (s - lo) + (1 if r == 0 else 0)) for s in range(lo, hi)]
+            owners += [(r, (s - lo) + (d if r == 0 else 0)) for s in range(lo, hi)]
         return owners
 
     def get_zhat(self, slot_begin, slot_end, nslots=None):
         """MAPs of global slots [slot_begin, slot_end) of the last (nsims+1)-element muse! map, gathered from the owning
         ranks (save_MAPs, src/muse.jl:139-143,219).  nslots = nsims + 1 of that map (default: what the last sharded
         map_and_score_batch with include_data used)."""
+        had_data = self._last_had_data if nslots is None else True
         nslots = self._last_nslots if nslots is None else nslots
-        owners = self._slot_owner(nslots)[slot_begin:slot_end]
+        owners = self._slot_owner(nslots, had_data)[slot_begin:slot_end]
         mine = [ls for (r, ls) in owners if r == self.rank]
         rows = np.zeros((len(mine), self.local.N))
         for k, ls in enumerate(mine):
@@ -212,6 +297,7 @@ class ShardedMuseProblem:
         zs = np.atleast_2d(np.asarray(zs, dtype=np.float64))
         nslots = slot_begin + zs.shape[0] if nslots is None else nslots
         self._last_nslots = nslots
+        self._last_had_data = True
         for k, (r, ls) in enumerate(self._slot_owner(nslots)[slot_begin:slot_begin + zs.shape[0]]):
             if r == self.rank:
                 self.local.set_zhat(ls, zs[k:k + 1])

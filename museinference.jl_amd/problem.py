@@ -321,6 +321,19 @@ class HipMuseProblem(AbstractMuseProblem):
                                                              int(z0_mode), int(result_area)))
         return (sim_end - sim_begin) + (1 if include_data else 0)
 
+    def map_and_score_multi_async(self, rng, sim_begin, sim_end, thetas, *, include_data=False, atol=1e-2,
+                                  z0_mode=_capi.Z0_ZERO, result_area=0):
+        """Several independent maps over the same elements in ONE launch, map m at thetas[m] (muse_map_and_score_multi_async
+        of the C ABI: a launch with fewer elements than compute units leaves the GPU idle for one problem's latency;
+        several such maps resident at once fill it).  Returns the total row count nmaps * n for batch_wait."""
+        th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(-1, self.ntheta))
+        if not 1 <= th.shape[0] <= _capi.MAX_MAPS:
+            raise ValueError(f"1 <= nmaps <= {_capi.MAX_MAPS}")
+        _capi.check(self._lib.muse_map_and_score_multi_async(self._ctx, _seed_of(rng), sim_begin, sim_end,
+                                                             int(bool(include_data)), th.shape[0], _capi.ptr(th), float(atol),
+                                                             int(z0_mode), int(result_area)))
+        return th.shape[0] * ((sim_end - sim_begin) + (1 if include_data else 0))
+
     def batch_wait(self, n, result_area=0, out=None):
         """out: (g [n, nθ] float64, info [n] INFO_DTYPE), C-contiguous arrays to fill instead of fresh ones (a pipelined
         host loop that waits every ~20 us reuses one pair per result area)."""
@@ -445,6 +458,17 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), buf))
         self._nranks = int(nranks)
 
+    def comm_destroy(self):
+        """Tear the communicator down (a context may then be given another one, e.g. the other transport)."""
+        _capi.check(self._lib.muse_comm_destroy(self._ctx))
+        self._nranks = None
+
+    def comm_ranks_seen(self):
+        """Ranks the communicator itself counts (ncclCommCount / processes attached to the shared segment)."""
+        n = C.c_int(-1)
+        _capi.check(self._lib.muse_comm_ranks_seen(self._ctx, C.byref(n)))
+        return n.value
+
     def comm_transport(self):
         t = C.c_int(-1)
         _capi.check(self._lib.muse_comm_transport(self._ctx, C.byref(t)))
@@ -466,6 +490,17 @@ class HipMuseProblem(AbstractMuseProblem):
             self._ctx, _seed_of(rng), sim_begin, sim_end, int(bool(include_data)), _capi.ptr(th), float(atol),
             int(z0_mode), int(rows_per_rank), int(result_area)))
         return (sim_end - sim_begin) + (1 if include_data else 0)
+
+    def map_and_score_multi_gather_async(self, rng, sim_begin, sim_end, thetas, rows_per_rank, *, include_data=False,
+                                         atol=1e-2, z0_mode=_capi.Z0_ZERO, result_area=0):
+        """The sharded form of map_and_score_multi_async: this rank's block of nmaps maps in one launch and ONE exchange
+        for all of them; batch_wait_gathered(nmaps * n, nmaps * rows_per_rank, area) then returns
+        g_all [nranks, nmaps * rows_per_rank, nθ] (map m of rank q: rows m*rows_per_rank ...) and info [nmaps * n]."""
+        th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(-1, self.ntheta))
+        _capi.check(self._lib.muse_map_and_score_multi_gather_async(
+            self._ctx, _seed_of(rng), sim_begin, sim_end, int(bool(include_data)), th.shape[0], _capi.ptr(th), float(atol),
+            int(z0_mode), int(rows_per_rank), int(result_area)))
+        return th.shape[0] * ((sim_end - sim_begin) + (1 if include_data else 0))
 
     def batch_wait_gathered(self, n, rows_per_rank, result_area=0, out=None):
         """(g_all [nranks, rows_per_rank, nθ], this rank's info [n]) of the gather enqueued on result_area; out: arrays

@@ -21,7 +21,14 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 x, _ = O.sample_x_z("funnel", 256, 5, M.DATA_SIM, [0.0, 0.0])
 local = OracleBatchedProblem(x, "funnel", 2, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+assert M.ranks_share_node(dist) is True          # one kernel, one /dev/shm: what the shared-memory transport needs
 prob = M.ShardedMuseProblem(local)
+assert prob.engine_comm is False and prob.transport is None     # the oracle stand-in has no engine communicator: torch collectives
+try:
+    M.ShardedMuseProblem(local).get_zhat(0, 1)
+    raise SystemExit("get_zhat before any sharded map must raise")
+except ValueError as e:
+    assert "nslots" in str(e)
 res = M.muse(prob, [1.0, 0.5], rng=3, nsims=13, maxsteps=4, get_covariance=True)
 g, info = prob.map_and_score_batch(3, 2, 9, [0.1, 0.2], include_data=True)
 Hi, its = prob.implicit_H_batch(3, 0, 5, [0.1, 0.2])

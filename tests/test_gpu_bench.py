@@ -1,0 +1,50 @@
+"""bench.py end to end on a GPU, through its own launcher: `python bench.py --gpus 2` (the driver's command) with the
+gloo development backend -- two ranks sharing GPU 0, the engine's shared-memory transport between them (RCCL refuses two
+ranks on one device and is reported as skipped) -- and the one-rank N > 1 path with both transports in one line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "4", "--min-seconds", "0",
+         "--no-cpu-baseline", "--no-extra"]
+
+
+def run(extra, env):
+    e = dict(os.environ, **env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run(BENCH + extra, env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_self_launch_gloo(gpu):
+    d = run(["--gpus", "2"], {"MUSE_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["sims_per_step_total"] == 512
+    assert d["transport"] == "shm"
+    shm, rccl = d["transports"]["shm"], d["transports"]["rccl"]
+    assert shm["collective"] == "shm-capi" and shm["ranks_seen"] == 2
+    assert "skipped" in rccl
+    assert d["value"] > 0 and abs(d["value"] - 512 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
+
+
+def test_bench_forced_dist_reports_both_transports(gpu):
+    d = run(["--nsims", "64"], {"MUSE_BENCH_FORCE_DIST": "1"})
+    assert d["n_gpus"] == 1 and set(d["transports"]) == {"shm", "rccl"}
+    for t in ("shm", "rccl"):
+        m = d["transports"][t]
+        assert m["collective"] == f"{t}-capi" and m["ranks_seen"] == 1, m
+    assert d["transport"] in ("shm", "rccl") and d["value"] == max(m["value"] for m in d["transports"].values())
+
+
+def test_bench_default_line_is_the_single_gpu_workload(gpu):
+    d = run([], {})
+    assert d["n_gpus"] == 1 and "transports" not in d and d["config"]["element_split"] == 1
+    assert d["roofline"]["placement"] == "resident" and d["dtype"] == "f64"

@@ -384,3 +384,60 @@ def test_native_outer_loop_options(gpu, M, O):
     np.testing.assert_allclose(r1.theta, r2.theta, rtol=1e-12)
     assert len(r1.history) == len(r2.history) >= 2
     prob.close()
+
+
+# ---- several independent maps in one launch (muse_map_and_score_multi_async) ---------------------------------------
+@pytest.mark.parametrize("model,N,nth,include_data", [("funnel", 10000, 1, False), ("funnel", 3000, 4, True),
+                                                       ("noise", 700, 1, False), ("smooth", 900, 3, True)])
+def test_multi_map_launch_equals_separate_maps(gpu, M, model, N, nth, include_data):
+    """nmaps maps over the same elements, each with its own theta, in ONE launch (a rank's share of a strongly scaled map
+    is smaller than the GPU: several maps resident at once fill it) give, bit for bit, what nmaps separate launches
+    give: scores, solver infos and the resident MAPs (map m, element e at slot m*n + e)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(N)
+    prob = M.HipMuseProblem(x, model=model, ntheta=nth)
+    ref = M.HipMuseProblem(x, model=model, ntheta=nth)
+    nmaps, nsims = 3, 11
+    thetas = rng.uniform(-0.5, 1.0, size=(nmaps, nth))
+    n = nsims + (1 if include_data else 0)
+    tot = prob.map_and_score_multi_async(7, 2, 2 + nsims, thetas, include_data=include_data, atol=1e-3, result_area=1)
+    assert tot == nmaps * n
+    g, info = prob.batch_wait(tot, 1)
+    Z = prob.get_zhat(0, tot)
+    for m in range(nmaps):
+        gm, im = ref.map_and_score_batch(7, 2, 2 + nsims, thetas[m], include_data=include_data, atol=1e-3)
+        assert np.array_equal(g[m * n:(m + 1) * n], gm), m
+        assert np.array_equal(info[m * n:(m + 1) * n], im), m
+        assert np.array_equal(Z[m * n:(m + 1) * n], ref.get_zhat(0, n)), m
+    # a plain launch afterwards is unaffected by the multi-map launch before it
+    g1, i1 = prob.map_and_score_batch(7, 2, 2 + nsims, thetas[1], include_data=include_data, atol=1e-3)
+    gm, im = ref.map_and_score_batch(7, 2, 2 + nsims, thetas[1], include_data=include_data, atol=1e-3)
+    assert np.array_equal(g1, gm) and np.array_equal(i1, im)
+    with pytest.raises(M.MuseError):
+        prob.map_and_score_multi_async(7, 0, 4, np.zeros((9, nth)))     # more than MUSE_MAX_MAPS
+    prob.close()
+    ref.close()
+
+
+def test_multi_map_with_element_split_and_gather_padding(gpu, M):
+    """The same through the gathered entry (shared-memory transport, one rank) with padding rows between the maps'
+    blocks, and with an element split (register-resident clusters) under the multi-map launch."""
+    N, nth, nsims, nmaps, rows = 10000, 2, 5, 4, 8
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
+    ref = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
+    thetas = np.array([[0.1 * m, 0.3 - 0.2 * m] for m in range(nmaps)])
+    prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm"))
+    for split in (0, 4):
+        prob.set_element_split(split)
+        ref.set_element_split(split)
+        tot = prob.map_and_score_multi_gather_async(3, 0, nsims, thetas, rows, result_area=2)
+        g_all, info = prob.batch_wait_gathered(tot, nmaps * rows, 2)
+        assert g_all.shape == (1, nmaps * rows, nth)
+        blk = g_all[0].reshape(nmaps, rows, nth)
+        for m in range(nmaps):
+            gm, im = ref.map_and_score_batch(3, 0, nsims, thetas[m])
+            assert np.array_equal(blk[m, :nsims], gm), (split, m)
+            assert np.all(blk[m, nsims:] == 0.0)
+            assert np.array_equal(info[m * nsims:(m + 1) * nsims], im)
+    prob.close()
+    ref.close()
