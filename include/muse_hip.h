@@ -122,6 +122,9 @@ int muse_set_timing(muse_ctx* ctx, int enabled);
  * per-launch durations in ms.  The reference only keeps wall-clock deltas (src/muse.jl:161,210,232). */
 int muse_profile_begin(muse_ctx* ctx, int max_launches);
 int muse_profile_end(muse_ctx* ctx, float* ms_out, int cap, int* count);
+/* Shader clock (Hz) during the last launch profiled between begin and end: workgroup 0 of such a launch stamps the
+ * shader-cycle counter and the constant 100 MHz counter at its entry and exit (no stamp executes otherwise). */
+int muse_profile_clock_hz(muse_ctx* ctx, double* hz_out);
 
 /* ---- per-simulation operators (the AbstractMuseProblem interface, src/interface.jl:4-186) ----- */
 /* sample_x_z(prob, rng, theta) -> (;x, z)                       src/interface.jl:92-99, src/simple.jl:95 */
@@ -190,6 +193,14 @@ typedef struct muse_run_options {
 #define MUSE_RUN_HIST(ntheta) (7 * (ntheta) + (ntheta) * (ntheta) + 1)
 int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
              double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
+/* The same loop, same arguments, same results bit for bit, with NO host round trip between two maps: after every map
+ * launch a one-workgroup step kernel forms the reductions, the prior terms, H^-1_post', the Newton-Raphson step, the
+ * history record and the convergence test on the device and leaves the next theta in device memory, where the next map
+ * launch reads it; the host enqueues (map, step) pairs a few iterations ahead and watches completion events.  Launches
+ * enqueued past the end of the loop find a stop flag set and drain as no-ops.  (exp(theta/2), exp(-theta) are a fixed
+ * sequence of IEEE operations on host and device for this reason.)  nsims * ntheta <= 7600. */
+int muse_run_device(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
+                    double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 
 /* Resident MAP state: read back / restore zhat of slots [slot_begin, slot_end) ([n][N], row-major).
  * Serves save_MAPs (src/muse.jl:139-143,219) and checkpoint/resume (src/muse.jl:134-135,234). */

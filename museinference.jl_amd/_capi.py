@@ -62,6 +62,7 @@ SIGNATURES = {
     "muse_set_timing": (_i, [_vp, _i]),
     "muse_profile_begin": (_i, [_vp, _i]),
     "muse_profile_end": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
+    "muse_profile_clock_hz": (_i, [_vp, C.POINTER(_d)]),
     "muse_sample_x_z": (_i, [_vp, _u64, _i64, _vp, _vp, _vp, _i]),
     "muse_logLike_and_grad_z": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_d), _vp, _i]),
     "muse_grad_theta": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "muse_map_and_score_multi_async": (_i, [_vp, _u64, _i64, _i64, _i, _i, _vp, _d, _i, _i]),
     "muse_map_and_score_multi_gather_async": (_i, [_vp, _u64, _i64, _i64, _i, _i, _vp, _d, _i, _i64, _i]),
     "muse_run": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
+    "muse_run_device": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_get_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_fd_jacobian_batch": (_i, [_vp, _u64, _i64, _i64, _vp, _vp, _d, _i, _i64, _vp, _vp]),

@@ -15,14 +15,16 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmuse_hip.so")
 OBJ_DIR = os.path.join(_HERE, "build")
 _API = os.path.join(_HERE, "..", "include", "muse_hip.h")
-_KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "solver.hpp")]
+_KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "solver.hpp", "step.hpp")]
 # source -> (headers it depends on, extra flags)
 # -ffp-contract=off: the sampler's log/sincos sequences and the model gradients are defined in terms
 # of individually rounded IEEE operations (bit-equal to a host evaluation of the same sequence).
 UNITS = {
     "muse_kernels.hip": (_KERNEL_HEADERS + [_API], ["--offload-arch=gfx950", "-O3", "-ffp-contract=off"]),
     # host code: plain C++ against the HIP runtime API (no device pass)
-    "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), _API], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
+    # (-ffp-contract=off here too: step.hpp's algebra must round on the host exactly as in the step kernel)
+    "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), _API],
+                        ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
     "muse_comm.cpp": ([_API, os.path.join(CSRC, "shm_gather.hpp")], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
 }
 COMMON_FLAGS = ["-std=c++17", "-fPIC", "-Wno-unused-value"]

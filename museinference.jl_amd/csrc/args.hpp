@@ -116,6 +116,8 @@ struct BatchArgs {
     int* error_flag;               // [0] set when a bounded cluster wait expires; [1] the largest epoch reported
     int xcd_local;                 // cluster mode: the members of a cluster are workgroups b = x (mod 8), which the dispatcher
                                    // places on ONE XCD (round-robin over the XCDs): their exchanges stay inside it
+    unsigned long long* clock_out; // non-null (bench.py's roofline leg only): workgroup 0 stores {s_memtime, s_memrealtime} at its
+                                   // entry ([0], [1]) and exit ([2], [3]): shader clock = d(memtime) / d(memrealtime) x 100 MHz
     unsigned long long* stamps;    // diagnostic build (-DMUSE_STAMPS) only: [nproblems][16] shader-clock stamps
     // Standard normals of simulation streams already drawn inside the SAME host call (muse_run's later
     // iterations re-draw every simulation at a new theta, the FD batch draws each simulation 2*ntheta times):
@@ -126,7 +128,7 @@ struct BatchArgs {
     int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
     int imp_split;  // BATCH_IMPLICIT: elements per simulation (1: all H columns in one element; ntheta: one each)
     int64_t norm_sim0;
-    MapTheta maps[kMaxMaps];       // LAST, read from the kernarg segment only (never copied to LDS): theta of every map, nmaps > 1
+    alignas(16) MapTheta maps[kMaxMaps];  // LAST, read from the kernarg segment only (never copied to LDS): theta of every map, nmaps > 1
 };
 constexpr size_t kArgsHeadBytes = offsetof(BatchArgs, maps);  // what the kernel keeps in LDS
 static_assert(kArgsHeadBytes % 16 == 0 && offsetof(BatchArgs, cur) % 8 == 0, "LDS copy of the argument block");
@@ -201,6 +203,33 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
 }
 #endif  // __HIPCC__
 
+// what the step needs to know beside the scores (the plain option set of muse_run, include/muse_hip.h)
+struct StepParams {
+    int ntheta, nsims;
+    int prior_kind;  // 0 flat, 1 independent Gaussian
+    int pad_;
+    double alpha, theta_rtol;
+    double prior_mean[kMaxTheta], prior_sigma[kMaxTheta];
+};
+// Arguments of the step kernel of the device-resident muse! loop (muse_kernels.hip: muse_step_kernel): iteration `iter`'s
+// scores -> its history record, the next theta (for the next map launch: BatchArgs::cur_dev) and the stop flag.
+struct StepArgs {
+    StepParams sp;
+    int iter, maxsteps;              // 1-based iteration this step closes
+    int64_t bnd[kMaxTheta + 1];
+    const double* scores;            // device [nsims + 1][ntheta]: the map's scores, data element first
+    const muse_info* info;           // device [nsims + 1]
+    MapTheta* theta_dev;             // in: theta of this iteration's map; out: the next iterate
+    double* prev_rec;                // device [MUSE_RUN_HIST]: the previous record (in), this one (out)
+    double* hist_out;                // pinned [maxsteps][MUSE_RUN_HIST]
+    double* gsims_out;               // pinned [maxsteps][nsims][ntheta]
+    muse_info* info_out;             // pinned [maxsteps][nsims + 1]
+    double* theta_out;               // pinned [ntheta]: the iterate after the last executed step
+    int* stop_flag;                  // device: set when the loop has ended (converged, or failed)
+    int* status;                     // pinned: [0] iterations executed, [1] STEP_* error, [2] converged
+    unsigned long long* tprev;       // device: s_memrealtime (100 MHz) at the end of the previous step / the start of the run
+};
+
 // launch shims of muse_kernels.hip (the only translation unit that holds device code)
 struct LaunchShape {
     int model, ntheta, place, grid;
@@ -212,6 +241,8 @@ struct LaunchShape {
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t stream);
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t stream);
+hipError_t launch_step(const StepArgs& s, hipStream_t stream, void* done_event);
+hipError_t launch_time_stamp(unsigned long long* out, int* stop_flag, hipStream_t stream);
 constexpr int kArgsDoubles = (int)((kArgsHeadBytes + 15) / 16 * 2);  // LDS copy of the kernel arguments (without the trailing maps[])
 
 

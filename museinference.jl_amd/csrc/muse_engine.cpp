@@ -16,6 +16,7 @@
 
 #include "../../include/muse_hip.h"
 #include "args.hpp"
+#include "step.hpp"
 
 // ================================================================================================
 // Host side: context, workspace, launches, C ABI.
@@ -88,24 +89,24 @@ struct muse_ctx {
     bool timing = false;           // record an event pair around every solver launch (muse_set_timing; costs ~12 us per launch)
     unsigned long long* stamps = nullptr;
     int64_t stamps_cap = 0;
+    unsigned long long* clock_pin = nullptr;  // pinned [4]: {s_memtime, s_memrealtime} at entry and exit of workgroup 0 (profiling launches)
+    struct RunBuffers* run = nullptr;  // buffers of the device-resident muse! loop (muse_run_device)
     int comm_reserve_cus = 0;  // compute units left to a device-side collective that runs beside the solver (muse_comm.cpp)
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
     double* comm_buf = nullptr;
     size_t comm_buf_doubles = 0;
 };
 
+// exp(theta/2), exp(-theta) and the constant term: step.hpp's fixed sequences (the device-resident loop forms the same bits)
 static void make_thetaset(const muse_ctx* c, const double* theta, ThetaSet& t) {
-    memset(&t, 0, sizeof(t));
-    for (int k = 0; k < c->ntheta; ++k) {
-        t.theta[k] = theta[k];
-        t.sd[k] = exp(0.5 * theta[k]);
-        t.iv[k] = exp(-theta[k]);
-    }
+    MapTheta m;
+    make_map_theta(c->ntheta, c->bnd, theta, m);
+    t = m.t;
 }
 static double theta_const(const muse_ctx* c, const double* theta) {
-    double cst = 0.0;
-    for (int k = 0; k < c->ntheta; ++k) cst += (double)(c->bnd[k + 1] - c->bnd[k]) * theta[k];
-    return cst;
+    MapTheta m;
+    make_map_theta(c->ntheta, c->bnd, theta, m);
+    return m.f_const;
 }
 
 static bool place_is_cluster(int pl) { return pl >= P_C256; }
@@ -257,6 +258,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     }
     a.debug = c->debug;
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
+    a.clock_out = c->prof_on ? c->clock_pin : nullptr;  // roofline leg only
     const bool implicit = a.kind == BATCH_IMPLICIT;
     const int pl = implicit ? (use_cluster(c) ? P_C256 : P_S512) : choose_place(c);
     int grid = c->num_cus * place_wgs_per_cu(pl);
@@ -381,6 +383,8 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     HIPCHK(hipMemset(c->counter, 0, 16));
     HIPCHK(hipHostMalloc(&c->error_flag, 64, hipHostMallocDefault));
     c->error_flag[0] = c->error_flag[1] = 0;
+    HIPCHK(hipHostMalloc(&c->clock_pin, 64, hipHostMallocDefault));
+    memset(c->clock_pin, 0, 64);
     HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&c->tsample_dev, 2 * kMaxTheta * sizeof(ThetaSet)));
@@ -396,6 +400,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
 }
 
 int muse_comm_destroy(muse_ctx* ctx);
+static void free_run_buffers(muse_ctx* c);
 
 // accessors for muse_comm.cpp (the context layout is private to this file)
 int muse_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
@@ -435,7 +440,8 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     muse_comm_destroy(c);
-    hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag);
+    free_run_buffers(c);
+    hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag); hipHostFree(c->clock_pin);
     hipFree(c->ncache);
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
     hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
@@ -593,6 +599,17 @@ int muse_profile_end(muse_ctx* c, float* ms_out, int cap, int* count) {
     return MUSE_OK;
 }
 
+int muse_profile_clock_hz(muse_ctx* c, double* hz_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!hz_out) return fail(MUSE_ERR_INVALID, "hz_out is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const unsigned long long* t = c->clock_pin;
+    if (t[3] <= t[1] || t[2] <= t[0]) return fail(MUSE_ERR_INVALID, "no profiled launch has run (muse_profile_begin ... end)");
+    *hz_out = (double)(t[2] - t[0]) / (double)(t[3] - t[1]) * 1e8;  // s_memrealtime ticks at a constant 100 MHz
+    return MUSE_OK;
+}
+
 static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     memset(&a, 0, sizeof(a));
     a.N = c->N;
@@ -726,6 +743,8 @@ struct MapOpts {
                               // as the storing batch of the same host call).  Silently 0 where the cache does not apply.
     const MapTheta* theta_dev = nullptr;  // theta from device memory (device-resident muse! loop); thetas is then only a placeholder
     const int* stop_flag = nullptr;
+    muse_info* info_dev = nullptr;        // solver infos to a device buffer (NULL: the area's pinned block)
+    bool no_event = false;                // the caller watches a later kernel's completion instead of this launch's
 };
 static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
                           const double* thetas, double atol, int z0_mode, int area, const MapOpts& o) {
@@ -760,7 +779,7 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     a.sim_begin = sim_begin;
     a.slot0 = 0;
     a.scores = o.scores_dev ? o.scores_dev : c->scores_dev[area];
-    a.info = c->info_dev[area];
+    a.info = o.info_dev ? o.info_dev : c->info_dev[area];
     a.nmaps = o.nmaps;
     a.n_per_map = (int)n;
     a.map_stride = stride;
@@ -780,14 +799,14 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     // the area's completion event is signalled by this launch itself; with timing events around the launch (profiling)
     // the plain record after it keeps the order start, kernel, stop, done
     static const bool no_ext = getenv("MUSE_DEBUG_NO_EXT_LAUNCH") != nullptr;
-    c->launch_done = (c->timing || c->prof_on || no_ext) ? nullptr : c->area_done[area];
+    c->launch_done = (c->timing || c->prof_on || no_ext || o.no_event) ? nullptr : c->area_done[area];
     c->launch_done_used = false;
     rc = launch_batch(c, a);
     c->launch_done = nullptr;
     if (rc) return rc;
     c->area_inflight[area] = true;
     c->res_rows[area] = rows;
-    if (c->launch_done_used) {
+    if (c->launch_done_used || o.no_event) {
         c->res_n[area] = total;
         return MUSE_OK;
     }
@@ -854,47 +873,50 @@ int muse_map_and_score_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int6
     return muse_batch_wait(c, 0, g_out, info_out);
 }
 
-// ---- the muse! outer loop in native host code (see muse_hip.h) ----------------------------------------
-// inverse of a small dense matrix (n <= MUSE_MAX_THETA) by Gauss-Jordan with partial pivoting; false if singular
-static bool small_inverse(int n, const double* A, double* inv) {
-    double M[kMaxTheta][2 * kMaxTheta];
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            M[i][j] = A[i * n + j];
-            M[i][n + j] = i == j ? 1.0 : 0.0;
-        }
-    for (int col = 0; col < n; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < n; ++r)
-            if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
-        if (!(fabs(M[piv][col]) > 0.0)) return false;
-        if (piv != col)
-            for (int j = 0; j < 2 * n; ++j) std::swap(M[piv][j], M[col][j]);
-        const double d = M[col][col];
-        for (int j = 0; j < 2 * n; ++j) M[col][j] /= d;
-        for (int r = 0; r < n; ++r) {
-            if (r == col) continue;
-            const double f = M[r][col];
-            if (f != 0.0)
-                for (int j = 0; j < 2 * n; ++j) M[r][j] -= f * M[col][j];
-        }
-    }
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) inv[i * n + j] = M[i][n + j];
-    return true;
-}
-
-int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
-             double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+// ---- the muse! outer loop in native code (see muse_hip.h) -------------------------------------------------
+static int check_run_args(muse_ctx* c, const double* theta0, const muse_run_options* o, int32_t* niter_out, double* theta_out,
+                          double* hist_out, double* gsims_out) {
     if (!theta0 || !o || !niter_out || !theta_out || !hist_out || !gsims_out) return fail(MUSE_ERR_INVALID, "NULL argument");
     if (o->nsims < 2 || o->maxsteps < 1) return fail(MUSE_ERR_INVALID, "muse_run needs nsims >= 2 and maxsteps >= 1");
     if (o->prior_kind != 0 && o->prior_kind != 1) return fail(MUSE_ERR_INVALID, "prior_kind must be 0 (flat) or 1 (Gaussian)");
     if (!c->has_data) return fail(MUSE_ERR_NODATA, "muse_run needs the observed data (muse_set_data)");
+    return MUSE_OK;
+}
+static void step_params(const muse_ctx* c, const muse_run_options* o, StepParams& sp) {
+    memset(&sp, 0, sizeof sp);
+    sp.ntheta = c->ntheta;
+    sp.nsims = o->nsims;
+    sp.prior_kind = o->prior_kind;
+    sp.alpha = o->alpha;
+    sp.theta_rtol = o->theta_rtol;
+    for (int k = 0; k < c->ntheta; ++k) {
+        sp.prior_mean[k] = o->prior_mean[k];
+        sp.prior_sigma[k] = o->prior_sigma[k];
+    }
+}
+static int step_error(int err) {
+    switch (err) {
+        case STEP_SINGULAR_LIKE: return fail(MUSE_ERR_INVALID, "muse_run: singular H^-1_like (zero score variance)");
+        case STEP_SINGULAR_POST: return fail(MUSE_ERR_INVALID, "muse_run: singular posterior Hessian");
+        case STEP_DOMAIN:
+            // sqrt of a negative argument is a DomainError in the reference (an H^-1_post' that is not negative definite)
+            return fail(MUSE_ERR_INVALID, "muse_run: DomainError in the convergence test: dtheta' H^-1_post' dtheta > 0 (H^-1_post' is not negative definite)");
+        default: return MUSE_OK;
+    }
+}
+
+// The loop with the algebra on the host: launch, wait, step (step.hpp), launch again.
+int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
+             double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    rc = check_run_args(c, theta0, o, niter_out, theta_out, hist_out, gsims_out);
+    if (rc) return rc;
     const int nt = c->ntheta, S = o->nsims;
     const int64_t H = MUSE_RUN_HIST(nt);
-    double theta[kMaxTheta], gprior[kMaxTheta], hprior[kMaxTheta];
+    StepParams sp;
+    step_params(c, o, sp);
+    double theta[kMaxTheta], theta_next[kMaxTheta], mean[kMaxTheta], var[kMaxTheta];
     for (int k = 0; k < nt; ++k) theta[k] = theta0[k];
     std::vector<double> g((size_t)(S + 1) * nt);
     std::vector<muse_info> info((size_t)S + 1);
@@ -902,20 +924,10 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
     for (int i = 1; i <= o->maxsteps; ++i) {
         const double t_start = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(
                                    std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-9;
-        if (i > 2) {  // convergence on the last two records (src/muse.jl:163-166)
-            const double* h1 = hist_out + (int64_t)(i - 2) * H;  // record i-1
-            const double* h0 = hist_out + (int64_t)(i - 3) * H;  // record i-2
-            const double* Hp = h1 + 7 * nt;
-            double q = 0.0;
-            for (int a_ = 0; a_ < nt; ++a_) {
-                double row = 0.0;
-                for (int b = 0; b < nt; ++b) row += Hp[a_ * nt + b] * (h1[b] - h0[b]);
-                q += (h1[a_] - h0[a_]) * row;
-            }
-            // sqrt of a negative argument is a DomainError in the reference (an H^-1_post' that is not negative
-            // definite); a NaN compares false and the loop goes on
-            if (-q < 0.0) return fail(MUSE_ERR_INVALID, "muse_run: DomainError in the convergence test: dtheta' H^-1_post' dtheta > 0 (H^-1_post' is not negative definite)");
-            if (sqrt(-q) < o->theta_rtol) break;
+        if (i > 2) {  // convergence on the last two records (src/muse.jl:163-166); a NaN compares false and the loop goes on
+            const int cv = step_converged(nt, hist_out + (int64_t)(i - 2) * H, hist_out + (int64_t)(i - 3) * H, o->theta_rtol);
+            if (cv < 0) return step_error(STEP_DOMAIN);
+            if (cv > 0) break;
         }
         const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
         // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
@@ -930,45 +942,10 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
         double* gs = gsims_out + (int64_t)(i - 1) * S * nt;
         memcpy(gs, g.data() + nt, (size_t)S * nt * sizeof(double));
         if (info_out) memcpy(info_out + (int64_t)(i - 1) * (S + 1), info.data(), ((size_t)S + 1) * sizeof(muse_info));
-        double Hlike[kMaxTheta * kMaxTheta], Hinv_like_inv[kMaxTheta * kMaxTheta], Hpost[kMaxTheta * kMaxTheta];
-        for (int k = 0; k < nt; ++k) {
-            double m = 0.0;
-            for (int s = 0; s < S; ++s) m += gs[(int64_t)s * nt + k];
-            m /= S;
-            double v = 0.0;
-            for (int s = 0; s < S; ++s) {
-                const double dlt = gs[(int64_t)s * nt + k] - m;
-                v += dlt * dlt;
-            }
-            v /= (S - 1);  // corrected (src/muse.jl:188)
-            if (o->prior_kind == 1) {
-                const double sg2 = o->prior_sigma[k] * o->prior_sigma[k];
-                gprior[k] = -(theta[k] - o->prior_mean[k]) / sg2;
-                hprior[k] = -1.0 / sg2;
-            } else {
-                gprior[k] = 0.0;
-                hprior[k] = 0.0;
-            }
-            h[k] = theta[k];
-            h[nt + k] = g[k];                    // g_like_dat
-            h[2 * nt + k] = g[k] - m;            // g_like  = g_dat - mean(g_sims)
-            h[3 * nt + k] = gprior[k];
-            h[4 * nt + k] = h[2 * nt + k] + gprior[k];  // g_post
-            h[5 * nt + k] = -1.0 / v;            // diag H^-1_like
-            h[6 * nt + k] = hprior[k];
-        }
-        // H^-1_post = inv(inv(H^-1_like) + H_prior): both diagonal here, kept general through the dense inverse
-        for (int a_ = 0; a_ < nt * nt; ++a_) Hlike[a_] = 0.0;
-        for (int k = 0; k < nt; ++k) Hlike[k * nt + k] = h[5 * nt + k];
-        if (!small_inverse(nt, Hlike, Hinv_like_inv)) return fail(MUSE_ERR_INVALID, "muse_run: singular H^-1_like (zero score variance)");
-        for (int k = 0; k < nt; ++k) Hinv_like_inv[k * nt + k] += hprior[k];
-        if (!small_inverse(nt, Hinv_like_inv, Hpost)) return fail(MUSE_ERR_INVALID, "muse_run: singular posterior Hessian");
-        for (int a_ = 0; a_ < nt * nt; ++a_) h[7 * nt + a_] = Hpost[a_];
-        for (int a_ = 0; a_ < nt; ++a_) {  // Newton-Raphson step (src/muse.jl:224)
-            double stp = 0.0;
-            for (int b = 0; b < nt; ++b) stp += Hpost[a_ * nt + b] * h[4 * nt + b];
-            theta[a_] = h[a_] - o->alpha * stp;
-        }
+        for (int k = 0; k < nt; ++k) step_moments(k, nt, S, gs, mean[k], var[k]);
+        const int err = step_record(sp, theta, g.data(), mean, var, h, theta_next);
+        if (err != STEP_OK) return step_error(err);
+        for (int k = 0; k < nt; ++k) theta[k] = theta_next[k];
         const double t_end = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(
                                  std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-9;
         h[7 * nt + nt * nt] = t_end - t_start;
@@ -976,6 +953,155 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
     }
     *niter_out = n;
     for (int k = 0; k < nt; ++k) theta_out[k] = theta[k];
+    return MUSE_OK;
+}
+
+// The same loop with NO host round trip between two maps: after every map a one-workgroup step kernel (muse_kernels.hip,
+// muse_step_kernel: step.hpp's arithmetic, the same bits as the loop above) turns the scores into the history record and
+// the next theta, which the next map launch reads from device memory (BatchArgs::cur_dev); the host only enqueues
+// (map, step) pairs a few iterations ahead and watches the steps' completion events; launches enqueued past the end of
+// the loop find the stop flag set and drain as no-ops.
+struct RunBuffers {
+    // device
+    MapTheta* theta_dev = nullptr;
+    double* prev_rec = nullptr;
+    int* stop_flag = nullptr;
+    unsigned long long* tprev = nullptr;
+    double* scores = nullptr;
+    muse_info* info = nullptr;
+    int64_t elems = 0;
+    // pinned
+    double* hist = nullptr;
+    double* gsims = nullptr;
+    muse_info* infos = nullptr;
+    double* theta_out = nullptr;
+    int* status = nullptr;
+    int64_t cap_steps = 0, cap_sims = 0;
+    hipEvent_t done[8] = {nullptr};
+};
+static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S) {
+    if (!c->run) c->run = new RunBuffers();
+    RunBuffers& r = *c->run;
+    const int nt = c->ntheta;
+    if (!r.theta_dev) {
+        HIPCHK(hipMalloc(&r.theta_dev, sizeof(MapTheta)));
+        HIPCHK(hipMalloc(&r.prev_rec, MUSE_RUN_HIST(kMaxTheta) * sizeof(double)));
+        HIPCHK(hipMalloc(&r.stop_flag, 64));
+        HIPCHK(hipMalloc(&r.tprev, 64));
+        HIPCHK(hipHostMalloc(&r.theta_out, kMaxTheta * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&r.status, 64, hipHostMallocDefault));
+        for (int k = 0; k < 8; ++k) HIPCHK(hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
+    }
+    if (S + 1 > r.elems) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (r.scores) HIPCHK(hipFree(r.scores));
+        if (r.info) HIPCHK(hipFree(r.info));
+        r.scores = nullptr; r.info = nullptr; r.elems = 0;
+        HIPCHK(hipMalloc(&r.scores, (size_t)(S + 1) * nt * sizeof(double)));
+        HIPCHK(hipMalloc(&r.info, (size_t)(S + 1) * sizeof(muse_info)));
+        r.elems = S + 1;
+    }
+    if (maxsteps > r.cap_steps || S > r.cap_sims) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (r.hist) HIPCHK(hipHostFree(r.hist));
+        if (r.gsims) HIPCHK(hipHostFree(r.gsims));
+        if (r.infos) HIPCHK(hipHostFree(r.infos));
+        r.hist = nullptr; r.gsims = nullptr; r.infos = nullptr; r.cap_steps = r.cap_sims = 0;
+        const int64_t ms = maxsteps > r.cap_steps ? maxsteps : r.cap_steps, ss = S > r.cap_sims ? S : r.cap_sims;
+        HIPCHK(hipHostMalloc(&r.hist, (size_t)ms * MUSE_RUN_HIST(kMaxTheta) * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&r.gsims, (size_t)ms * ss * nt * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&r.infos, (size_t)ms * (ss + 1) * sizeof(muse_info), hipHostMallocDefault));
+        r.cap_steps = ms;
+        r.cap_sims = ss;
+    }
+    return MUSE_OK;
+}
+static void free_run_buffers(muse_ctx* c) {
+    if (!c->run) return;
+    RunBuffers& r = *c->run;
+    hipFree(r.theta_dev); hipFree(r.prev_rec); hipFree(r.stop_flag); hipFree(r.tprev); hipFree(r.scores); hipFree(r.info);
+    hipHostFree(r.hist); hipHostFree(r.gsims); hipHostFree(r.infos); hipHostFree(r.theta_out); hipHostFree(r.status);
+    for (int k = 0; k < 8; ++k)
+        if (r.done[k]) hipEventDestroy(r.done[k]);
+    delete c->run;
+    c->run = nullptr;
+}
+
+int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
+                    double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    rc = check_run_args(c, theta0, o, niter_out, theta_out, hist_out, gsims_out);
+    if (rc) return rc;
+    const int nt = c->ntheta, S = o->nsims, maxsteps = o->maxsteps;
+    const int64_t H = MUSE_RUN_HIST(nt);
+    if ((size_t)S * nt * sizeof(double) + 256 > 60 * 1024)  // the step kernel keeps the simulation scores in LDS
+        return fail(MUSE_ERR_INVALID, "muse_run_device: nsims * ntheta too large for the step kernel (use muse_run)");
+    rc = ensure_run_buffers(c, maxsteps, S);
+    if (rc) return rc;
+    RunBuffers& r = *c->run;
+    MapTheta m0;
+    make_map_theta(nt, c->bnd, theta0, m0);
+    HIPCHK(hipMemcpyAsync(r.theta_dev, &m0, sizeof m0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // (m0 is on this stack frame)
+    r.status[0] = r.status[1] = r.status[2] = 0;
+    for (int k = 0; k < nt; ++k) r.theta_out[k] = theta0[k];
+    HIPCHK(launch_time_stamp(r.tprev, r.stop_flag, c->stream));
+    StepArgs sa;
+    memset(&sa, 0, sizeof sa);
+    step_params(c, o, sa.sp);
+    sa.maxsteps = maxsteps;
+    for (int k = 0; k <= kMaxTheta; ++k) sa.bnd[k] = c->bnd[k];
+    sa.scores = r.scores;
+    sa.info = r.info;
+    sa.theta_dev = r.theta_dev;
+    sa.prev_rec = r.prev_rec;
+    sa.hist_out = r.hist;
+    sa.gsims_out = r.gsims;
+    sa.info_out = info_out ? r.infos : nullptr;
+    sa.theta_out = r.theta_out;
+    sa.stop_flag = r.stop_flag;
+    sa.status = r.status;
+    sa.tprev = r.tprev;
+    // how far the host runs ahead of the device: deep enough that the device never waits for a launch (a pair takes the
+    // host ~15 us to enqueue, the device ~60 us to run), shallow enough that few no-op pairs follow the end of the loop
+    constexpr int kAhead = 3, kRing = 8;
+    int enq = 0, done = 0;
+    bool stopped = false;
+    while (true) {
+        while (!stopped && enq < maxsteps && enq - done < kAhead) {
+            const int i = enq + 1;
+            MapOpts mo;
+            mo.ncache_mode = i == 1 ? 1 : 2;
+            mo.theta_dev = r.theta_dev;
+            mo.stop_flag = r.stop_flag;
+            mo.scores_dev = r.scores;
+            mo.info_dev = r.info;
+            mo.no_event = true;
+            const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
+            rc = map_async_impl(c, seed, 0, S, 1, theta0 /* placeholder: theta comes from the device */, o->atol, z0_mode, 0, mo);
+            if (rc) return rc;
+            sa.iter = i;
+            HIPCHK(launch_step(sa, c->stream, r.done[enq % kRing]));
+            enq += 1;
+        }
+        if (done == enq) break;
+        rc = muse_wait_event(r.done[done % kRing]);
+        if (rc) return rc;
+        done += 1;
+        if (r.status[1] != 0 || r.status[2] != 0 || r.status[0] < done) stopped = true;  // failed, converged, or a no-op step
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->area_inflight[0] = false;
+    rc = check_error_flag(c);
+    if (rc) return rc;
+    if (r.status[1] != 0) return step_error(r.status[1]);
+    const int n = r.status[0];
+    *niter_out = n;
+    for (int k = 0; k < nt; ++k) theta_out[k] = r.theta_out[k];
+    memcpy(hist_out, r.hist, (size_t)n * H * sizeof(double));
+    memcpy(gsims_out, r.gsims, (size_t)n * S * nt * sizeof(double));
+    if (info_out) memcpy(info_out, r.infos, (size_t)n * (S + 1) * sizeof(muse_info));
     return MUSE_OK;
 }
 

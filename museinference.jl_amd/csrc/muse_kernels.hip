@@ -34,6 +34,7 @@
 
 #include "../../include/muse_hip.h"
 #include "solver.hpp"
+#include "step.hpp"
 
 namespace muse {
 
@@ -96,6 +97,18 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     double* exch = args_lds + kArgsDoubles;   // cluster placements: [kMaxCluster][8] values of the epoch's exchange
     double* lds_x = exch + (Place::kCluster ? kMaxCluster * 8 : 0);  // [ld + 2]: elements, dummy slot (index ld), pad
     double* lds_g = lds_x + a.ld + 2;         // [ld + 2]
+    // (only when asked for: no stamp executes in a timed launch.  Every lane of wave 0 stores the same scalars: the condition
+    // lives in a scalar register, where a per-lane `tid == 0` would keep a vector register alive to the kernel's last line)
+    const bool wave0 = (__builtin_amdgcn_readfirstlane(tid) >> 6) == 0;
+    auto clock_stamp = [&](int k) {
+        if (a.clock_out && blockIdx.x == 0 && wave0) {
+            unsigned long long t0, t1;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(t1)::"memory");
+            a.clock_out[2 * k] = t0;
+            a.clock_out[2 * k + 1] = t1;
+        }
+    };
+    clock_stamp(0);
     if constexpr (Place::kXgLds) {
         if (tid == 0) {  // the dummy slot and the pad element (N odd) hold 0 for the kernel's lifetime
             lds_x[a.ld] = 0.0;
@@ -145,6 +158,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
 #ifdef MUSE_STAMPS
         if (cluster < a.nproblems) sv.stamp(cluster + ((a.nproblems - 1 - cluster) / a.nclusters) * a.nclusters, 9);  // last instruction but the epoch store
 #endif
+        clock_stamp(1);
         if (tid == 0 && crank == 0) {
             a.cl_state[cluster] = sv.cl_epoch;
             if (cluster == 0) a.error_flag[1] = (int)(sv.cl_epoch >> 1);  // the host resets the tags long before a wrap
@@ -183,6 +197,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
             p = (int)gridDim.x + (__builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base);
             if (p >= a.nproblems) break;
         }
+        clock_stamp(1);
     }
 }
 
@@ -268,6 +283,70 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The device-resident muse! loop (muse_run_device, muse_engine.cpp): between two map launches this ONE workgroup does
+// what the host loop does between them -- the reductions over the simulation scores, the prior terms, H^-1_post, the
+// Newton-Raphson step, the history record, the convergence test (src/muse.jl:163-166,177-232; the arithmetic is
+// step.hpp's, shared with the host loop, so the two trajectories are the same bits) -- and leaves the next theta in
+// device memory for the next map launch, so that no host round trip sits between two maps.  Component k's sequential
+// sums run in lane k; the dense part (nθ <= 8) in lane 0.
+__global__ void __launch_bounds__(256) muse_step_kernel(StepArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, nt = s.sp.ntheta, S = s.sp.nsims;
+    if (*reinterpret_cast<const volatile int*>(s.stop_flag) != 0) return;   // the loop ended before this step
+    double* gs = reinterpret_cast<double*>(smem);      // [S][nt] simulation scores
+    double* small = gs + (size_t)S * nt;               // g_dat [8], mean [8], var [8]
+    const int64_t H = MUSE_RUN_HIST(nt);
+    double* gs_out = s.gsims_out + (int64_t)(s.iter - 1) * S * nt;
+    for (int w = tid; w < (S + 1) * nt; w += 256) {
+        const double v = s.scores[w];
+        if (w < nt) small[w] = v;
+        else {
+            gs[w - nt] = v;
+            gs_out[w - nt] = v;
+        }
+    }
+    if (s.info_out)
+        for (int w = tid; w < S + 1; w += 256) s.info_out[(int64_t)(s.iter - 1) * (S + 1) + w] = s.info[w];
+    __syncthreads();
+    if (tid < nt) step_moments(tid, nt, S, gs, small[8 + tid], small[16 + tid]);
+    __syncthreads();
+    if (tid == 0) {
+        double theta[kMaxTheta], theta_next[kMaxTheta], rec[MUSE_RUN_HIST(kMaxTheta)];
+        for (int k = 0; k < nt; ++k) theta[k] = s.theta_dev->t.theta[k];
+        int err = step_record(s.sp, theta, small, small + 8, small + 16, rec, theta_next);
+        int converged = 0;
+        if (err == STEP_OK) {
+            unsigned long long now;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            rec[7 * nt + nt * nt] = (double)(now - *s.tprev) * 1e-8;   // seconds of this iteration
+            *s.tprev = now;
+            double* h = s.hist_out + (int64_t)(s.iter - 1) * H;
+            for (int64_t k = 0; k < H; ++k) h[k] = rec[k];
+            // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
+            if (s.iter >= 2 && s.iter < s.maxsteps) {
+                const int c = step_converged(nt, rec, s.prev_rec, s.sp.theta_rtol);
+                if (c < 0) err = STEP_DOMAIN;
+                converged = c > 0;
+            }
+            for (int64_t k = 0; k < H; ++k) s.prev_rec[k] = rec[k];
+            make_map_theta(nt, s.bnd, theta_next, *s.theta_dev);
+            for (int k = 0; k < nt; ++k) s.theta_out[k] = theta_next[k];
+        }
+        if (err != STEP_OK || converged || s.iter == s.maxsteps) *s.stop_flag = 1;
+        s.status[0] = err == STEP_OK ? s.iter : s.iter - 1;
+        s.status[1] = err;
+        s.status[2] = converged;
+    }
+}
+// the start of the run on the 100 MHz counter (the first iteration's time is measured from here); also clears the stop flag
+__global__ void muse_time_stamp_kernel(unsigned long long* out, int* stop_flag) {
+    unsigned long long now;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    *out = now;
+    *stop_flag = 0;
+}
+
 }  // namespace muse
 
 // ================================================================================================
@@ -345,6 +424,22 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
            : nt <= 4 ? launch_place<SmoothModel<4>>(s, a, st)
                      : launch_place<SmoothModel<kMaxTheta>>(s, a, st);
 #endif
+}
+
+hipError_t launch_step(const StepArgs& s, hipStream_t st, void* done_event) {
+    const size_t lds = ((size_t)s.sp.nsims * s.sp.ntheta + 24) * sizeof(double);
+    static size_t lds_allowed = 48 * 1024;
+    if (lds > lds_allowed) {
+        const hipError_t e = hipFuncSetAttribute((const void*)muse_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_allowed = lds;
+    }
+    hipExtLaunchKernelGGL(muse_step_kernel, dim3(1), dim3(256), lds, st, nullptr, (hipEvent_t)done_event, 0, s);
+    return hipGetLastError();
+}
+hipError_t launch_time_stamp(unsigned long long* out, int* stop_flag, hipStream_t st) {
+    hipLaunchKernelGGL(muse_time_stamp_kernel, dim3(1), dim3(1), 0, st, out, stop_flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t st) {

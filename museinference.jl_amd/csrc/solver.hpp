@@ -113,12 +113,12 @@ struct Solver {
                         ok = (unsigned)(gv >> 32) == cl_epoch;
                     }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || cl_aborted) break;
-                    // bounded by TIME (s_memtime: the 100 MHz reference clock, looked at every 1024 sweeps): members that are
-                    // not all resident must not hang the GPU, and a peer that is merely late (a collective kernel beside the
-                    // launch, a pre-empted wave) must not be taken for one -- 4 seconds
+                    // bounded by TIME (s_memrealtime: the constant 100 MHz counter, looked at every 1024 sweeps): members that
+                    // are not all resident must not hang the GPU, and a peer that is merely late (a collective kernel beside
+                    // the launch, a pre-empted wave) must not be taken for one -- 4 seconds
                     if ((++spins & 0x3ffu) == 0) {
                         unsigned long long now;
-                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
                         if (t_wait0 == 0) t_wait0 = now;
                         else if (now - t_wait0 > 400000000ull) {
                             __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1,0 +1,170 @@
+// step.hpp -- the scalar algebra between two maps of the muse! outer loop (src/muse.jl:163-166, 177-232), written ONCE for
+// the host (muse_run's loop in muse_engine.cpp) and for the device (the step kernel of the device-resident loop in
+// muse_kernels.hip): the same statements in the same order, compiled without floating-point contraction on both sides,
+// every operation an IEEE +, -, *, / or sqrt -- so the two loops produce the same bits.  Also muse_exp, the exponential
+// behind ThetaSet::sd / ::iv: a fixed fdlibm-style sequence instead of the host's libm, for the same reason (the device
+// loop forms the next theta's exp(theta/2), exp(-theta) itself).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "args.hpp"
+
+#if defined(__HIPCC__)
+#define MUSE_HD __host__ __device__ inline
+#else
+#define MUSE_HD inline
+#endif
+
+namespace muse {
+
+// exp(x) after fdlibm's e_exp.c: x = k ln2 + r, |r| <= ln2/2; exp(r) = 1 - ((lo - r c / (2 - c)) - hi) with
+// c = r - r^2 (P1 + r^2 (P2 + ...)); scaled by 2^k through the exponent field.  < 1 ulp.  Plain * and + only.
+MUSE_HD double muse_exp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return INFINITY;
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const int k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double dk = (double)k;
+    const double hi = x - dk * ln2HI, lo = dk * ln2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    // y in [0.70, 1.42]; y * 2^k in one exact step where 2^k is a normal number, in two otherwise
+    union { uint64_t u; double d; } s;
+    if (k >= -1021 && k <= 1023) {
+        s.u = (uint64_t)(k + 1023) << 52;
+        return y * s.d;
+    }
+    if (k > 1023) {
+        s.u = (uint64_t)(k - 1 + 1023) << 52;
+        return (y * 2.0) * s.d;
+    }
+    s.u = (uint64_t)(k + 1000 + 1023) << 52;  // k >= -1075: a normal number
+    return (y * s.d) * 9.33263618503218878990e-302;  // 2^-1000
+}
+
+MUSE_HD void make_map_theta(int ntheta, const int64_t* bnd, const double* theta, MapTheta& m) {
+    for (int k = 0; k < kMaxTheta; ++k) m.t.theta[k] = m.t.sd[k] = m.t.iv[k] = 0.0;
+    double cst = 0.0;
+    for (int k = 0; k < ntheta; ++k) {
+        m.t.theta[k] = theta[k];
+        m.t.sd[k] = muse_exp(0.5 * theta[k]);
+        m.t.iv[k] = muse_exp(-theta[k]);
+        cst += (double)(bnd[k + 1] - bnd[k]) * theta[k];
+    }
+    m.f_const = cst;
+    m.pad_ = 0.0;
+}
+
+// inverse of a small dense matrix (n <= kMaxTheta) by Gauss-Jordan with partial pivoting; false if singular
+MUSE_HD bool small_inverse(int n, const double* A, double* inv) {
+    double M[kMaxTheta][2 * kMaxTheta];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            M[i][j] = A[i * n + j];
+            M[i][n + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < n; ++r)
+            if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+        if (!(fabs(M[piv][col]) > 0.0)) return false;
+        if (piv != col)
+            for (int j = 0; j < 2 * n; ++j) {
+                const double tmp = M[piv][j];
+                M[piv][j] = M[col][j];
+                M[col][j] = tmp;
+            }
+        const double d = M[col][col];
+        for (int j = 0; j < 2 * n; ++j) M[col][j] /= d;
+        for (int r = 0; r < n; ++r) {
+            if (r == col) continue;
+            const double f = M[r][col];
+            if (f != 0.0)
+                for (int j = 0; j < 2 * n; ++j) M[r][j] -= f * M[col][j];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) inv[i * n + j] = M[i][n + j];
+    return true;
+}
+
+enum { STEP_OK = 0, STEP_SINGULAR_LIKE = 1, STEP_SINGULAR_POST = 2, STEP_DOMAIN = 3 };
+
+// mean and corrected variance of component k of the S simulation scores gs[s * ntheta + k] (src/muse.jl:183,188):
+// sequential sums in simulation order.
+MUSE_HD void step_moments(int k, int ntheta, int S, const double* gs, double& mean, double& var) {
+    double m = 0.0;
+    for (int s = 0; s < S; ++s) m += gs[(int64_t)s * ntheta + k];
+    m /= S;
+    double v = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double dlt = gs[(int64_t)s * ntheta + k] - m;
+        v += dlt * dlt;
+    }
+    v /= (S - 1);  // corrected (src/muse.jl:188)
+    mean = m;
+    var = v;
+}
+
+// One record of the history and the next iterate, from theta (where the map ran), the data element's score g_dat and the
+// moments of the simulation scores: h = [theta, g_like_dat, g_like, g_prior, g_post, diag H^-1_like, diag H_prior]
+// (ntheta each), H^-1_post (ntheta x ntheta); theta_next = theta - alpha H^-1_post g_post (src/muse.jl:183-208,224).
+MUSE_HD int step_record(const StepParams& sp, const double* theta, const double* g_dat, const double* mean, const double* var,
+                        double* h, double* theta_next) {
+    const int nt = sp.ntheta;
+    double gprior[kMaxTheta], hprior[kMaxTheta];
+    double Hlike[kMaxTheta * kMaxTheta], Hinv_like_inv[kMaxTheta * kMaxTheta], Hpost[kMaxTheta * kMaxTheta];
+    for (int k = 0; k < nt; ++k) {
+        if (sp.prior_kind == 1) {
+            const double sg2 = sp.prior_sigma[k] * sp.prior_sigma[k];
+            gprior[k] = -(theta[k] - sp.prior_mean[k]) / sg2;
+            hprior[k] = -1.0 / sg2;
+        } else {
+            gprior[k] = 0.0;
+            hprior[k] = 0.0;
+        }
+        h[k] = theta[k];
+        h[nt + k] = g_dat[k];                       // g_like_dat
+        h[2 * nt + k] = g_dat[k] - mean[k];         // g_like  = g_dat - mean(g_sims)
+        h[3 * nt + k] = gprior[k];
+        h[4 * nt + k] = h[2 * nt + k] + gprior[k];  // g_post
+        h[5 * nt + k] = -1.0 / var[k];              // diag H^-1_like
+        h[6 * nt + k] = hprior[k];
+    }
+    // H^-1_post = inv(inv(H^-1_like) + H_prior): both diagonal here, kept general through the dense inverse
+    for (int a_ = 0; a_ < nt * nt; ++a_) Hlike[a_] = 0.0;
+    for (int k = 0; k < nt; ++k) Hlike[k * nt + k] = h[5 * nt + k];
+    if (!small_inverse(nt, Hlike, Hinv_like_inv)) return STEP_SINGULAR_LIKE;
+    for (int k = 0; k < nt; ++k) Hinv_like_inv[k * nt + k] += hprior[k];
+    if (!small_inverse(nt, Hinv_like_inv, Hpost)) return STEP_SINGULAR_POST;
+    for (int a_ = 0; a_ < nt * nt; ++a_) h[7 * nt + a_] = Hpost[a_];
+    for (int a_ = 0; a_ < nt; ++a_) {  // Newton-Raphson step (src/muse.jl:224)
+        double stp = 0.0;
+        for (int b = 0; b < nt; ++b) stp += Hpost[a_ * nt + b] * h[4 * nt + b];
+        theta_next[a_] = h[a_] - sp.alpha * stp;
+    }
+    return STEP_OK;
+}
+
+// The convergence test at the top of an iteration i > 2 on the last two records h1 (newer) and h0 (src/muse.jl:163-166):
+// 1 converged, 0 go on, -1 DomainError (sqrt of a negative number: H^-1_post' is not negative definite).
+MUSE_HD int step_converged(int nt, const double* h1, const double* h0, double theta_rtol) {
+    const double* Hp = h1 + 7 * nt;
+    double q = 0.0;
+    for (int a_ = 0; a_ < nt; ++a_) {
+        double row = 0.0;
+        for (int b = 0; b < nt; ++b) row += Hp[a_ * nt + b] * (h1[b] - h0[b]);
+        q += (h1[a_] - h0[a_]) * row;
+    }
+    if (-q < 0.0) return -1;  // a NaN compares false and the loop goes on
+    return sqrt(-q) < theta_rtol ? 1 : 0;
+}
+
+}  // namespace muse

@@ -245,6 +245,12 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_profile_end(self._ctx, buf, self._prof_cap, C.byref(n)))
         return np.array(buf[: min(n.value, self._prof_cap)], dtype=np.float64)
 
+    def profile_clock_hz(self):
+        """Shader clock during the last launch profiled between profile_begin and profile_end (in-kernel counters)."""
+        hz = C.c_double()
+        _capi.check(self._lib.muse_profile_clock_hz(self._ctx, C.byref(hz)))
+        return hz.value
+
     # -- prior (SimpleMuseProblem forwards to the user's function, src/simple.jl:93)
     def logPrior_theta(self, theta, theta_space=UnTransformedθ):
         return self.prior.logpdf(np.asarray(theta, dtype=np.float64))
@@ -358,9 +364,11 @@ class HipMuseProblem(AbstractMuseProblem):
                     np.broadcast_to(np.asarray(self.prior.sigma, dtype=np.float64), (self.ntheta,)).copy())
         return None
 
-    def run_muse(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False):
-        """The muse! outer loop in the library's native host code (muse_run, include/muse_hip.h): returns
-        (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1])."""
+    def run_muse(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False, device_loop=None):
+        """The muse! outer loop in the library's native code (muse_run / muse_run_device, include/muse_hip.h): returns
+        (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]).  device_loop: the per-iteration algebra in a
+        step kernel on the GPU, no host round trip between two maps (default where it applies: nsims * nθ <= 7600);
+        False: the algebra on the host.  The same results bit for bit."""
         kind, mean, sigma = self.native_prior()
         o = _capi.RunOptions()
         o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)
@@ -374,8 +382,11 @@ class HipMuseProblem(AbstractMuseProblem):
         info = np.zeros((maxsteps, nsims + 1), dtype=_capi.INFO_DTYPE)
         theta = np.zeros(self.ntheta)
         n = C.c_int32()
-        _capi.check(self._lib.muse_run(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
-                                       _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
+        if device_loop is None:
+            device_loop = nsims * self.ntheta <= 7600
+        fn = self._lib.muse_run_device if device_loop else self._lib.muse_run
+        _capi.check(fn(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
+                       _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
         return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
 
     def get_zhat(self, slot_begin, slot_end):

@@ -212,6 +212,36 @@ static inline double mo_Az(const double* z, int64_t i, int64_t N) { /* periodic 
 
 
 /* sum_i theta_k(i) = sum_k N_k theta_k, N_k = size of block k */
+/* exp(theta/2) and exp(-theta) of the models.  The engine does not call a libm here: its device-resident muse! loop forms
+ * the next theta's exponentials on the GPU, and host and device have to agree to the bit, so the engine defines exp as
+ * one fixed sequence of IEEE operations -- fdlibm's e_exp.c: x = k ln2 + r with |r| <= ln2/2 (k = trunc(x / ln2 +- 1/2),
+ * r = (x - k ln2_hi) - k ln2_lo), exp(r) = 1 - ((lo - r c / (2 - c)) - hi) with c = r - r^2 P(r^2) (Remez, degree 5 in
+ * r^2), result scaled by 2^k.  Restated here from that published algorithm (not from the engine's source); the sampler
+ * parity tests are bit-exact, so the two sides must evaluate the same sequence. */
+static double mo_exp(double x) {
+    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10,
+                        INV_LN2 = 1.44269504088896338700e+00;
+    static const double P[5] = {1.66666666666666019037e-01, -2.77777777770155933842e-03, 6.61375632143793436117e-05,
+                                -1.65339022054652515390e-06, 4.13813679705723846039e-08};
+    if (isnan(x)) return x;
+    if (x > 7.09782712893383973096e+02) return INFINITY;
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    int k = (int)(INV_LN2 * x + (x < 0.0 ? -0.5 : 0.5)); /* conversion truncates toward zero */
+    double hi = x - (double)k * LN2_HI;
+    double lo = (double)k * LN2_LO;
+    double r = hi - lo;
+    double r2 = r * r;
+    double poly = P[4];
+    for (int j = 3; j >= 0; --j) poly = P[j] + r2 * poly;
+    double c = r - r2 * poly;
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    if (k >= -1021 && k <= 1023) return y * ldexp(1.0, k);      /* 2^k is a normal number: one exact scaling */
+    if (k > 1023) return (y * 2.0) * ldexp(1.0, k - 1);
+    return (y * ldexp(1.0, k + 1000)) * ldexp(1.0, -1000);       /* towards the subnormal range in two steps */
+}
+
+double mo_expd(double x) { return mo_exp(x); } /* for tests/test_oracle.py */
+
 static double mo_theta_const(int64_t N, int ntheta, const double* theta) {
     double cst = 0.0;
     for (int k = 0; k < ntheta; ++k) {
@@ -225,7 +255,7 @@ static double mo_theta_const(int64_t N, int ntheta, const double* theta) {
 void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim, const double* theta,
                    double* x, double* z) {
     double sd[64];
-    for (int k = 0; k < ntheta; ++k) sd[k] = exp(0.5 * theta[k]);
+    for (int k = 0; k < ntheta; ++k) sd[k] = mo_exp(0.5 * theta[k]);
     if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) {
             double n1, n2;
@@ -256,7 +286,7 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
 double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, const double* z,
                           const double* theta, double* G) {
     double iv[64];
-    for (int k = 0; k < ntheta; ++k) iv[k] = exp(-theta[k]);
+    for (int k = 0; k < ntheta; ++k) iv[k] = mo_exp(-theta[k]);
     double acc = 0.0, cst = 0.0;
     if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) {
@@ -307,7 +337,7 @@ void mo_grad_theta(int model, int64_t N, int ntheta, const double* x, const doub
             double r = x[i] - z[i];
             acc += r * r;
         }
-        out[0] = 0.5 * (exp(-theta[0]) * acc - (double)N);
+        out[0] = 0.5 * (mo_exp(-theta[0]) * acc - (double)N);
         return;
     }
     double acc[64];
@@ -318,7 +348,7 @@ void mo_grad_theta(int model, int64_t N, int ntheta, const double* x, const doub
         acc[k] += z[i] * z[i];
         cnt[k] += 1;
     }
-    for (int k = 0; k < ntheta; ++k) out[k] = 0.5 * (exp(-theta[k]) * acc[k] - (double)cnt[k]);
+    for (int k = 0; k < ntheta; ++k) out[k] = 0.5 * (mo_exp(-theta[k]) * acc[k] - (double)cnt[k]);
 }
 
 /* ---------------------------------------------------------------- objective wrapper with
@@ -817,7 +847,7 @@ int mo_implicit_H(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, 
     double *b = (double*)malloc(nb), *v = (double*)malloc(nb), *r = (double*)malloc(nb), *pp = (double*)malloc(nb);
     double *Ap = (double*)malloc(nb), *tmp = (double*)malloc(nb);
     double iv[64];
-    for (int k = 0; k < ntheta; ++k) iv[k] = exp(-theta0[k]);
+    for (int k = 0; k < ntheta; ++k) iv[k] = mo_exp(-theta0[k]);
     mo_sample_x_z(model, N, ntheta, seed, (uint64_t)sim, theta0, x, zt);
     mo_zhat_at_theta(model, N, ntheta, x, z0, theta0, atol, zh, NULL);
     for (int j = 0; j < ntheta; ++j) {

@@ -56,6 +56,8 @@ def lib():
         _lib.mo_negloglike_grad.restype = C.c_double
         _lib.mo_logLike_and_grad_z.restype = C.c_double
         _lib.mo_num_threads.restype = C.c_int
+        _lib.mo_expd.restype = C.c_double
+        _lib.mo_expd.argtypes = [C.c_double]
     return _lib
 
 
@@ -65,6 +67,11 @@ def _p(a):
 
 def _f8(a):
     return np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64)))
+
+
+def exp_fixed(x):
+    """The fixed-sequence exponential behind the models' exp(theta/2), exp(-theta) (muse_oracle.c, mo_exp)."""
+    return float(lib().mo_expd(float(x)))
 
 
 def philox4x32_10(ctr, key):

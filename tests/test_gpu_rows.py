@@ -128,6 +128,66 @@ def test_native_muse_run_matches_independent_restatement(gpu, M):
     prob.close()
 
 
+@pytest.mark.parametrize("model,N,nth,nsims,maxsteps,rtol", [
+    ("funnel", 10000, 1, 512, 50, 1e-1), ("funnel", 10000, 1, 64, 6, 0.0), ("funnel", 3000, 4, 100, 50, 1e-1),
+    ("noise", 5000, 1, 33, 50, 1e-1), ("smooth", 2000, 3, 17, 9, 1e-2), ("funnel", 512, 8, 40, 12, 1e-3)])
+def test_device_resident_muse_loop_equals_host_loop(gpu, M, O, model, N, nth, nsims, maxsteps, rtol):
+    """muse_run_device -- the per-iteration algebra (means, corrected variances, prior terms, H^-1_post', Newton step,
+    convergence test: src/muse.jl:163-166,177-232) in a step kernel on the GPU, the next theta read by the next map from
+    device memory, no host round trip between two maps -- against muse_run, the same loop with the algebra on the host:
+    the same number of iterations and the same bits in every history record, score, solver info and in the result."""
+    xdata, _ = O.sample_x_z(model, N, 3, M.DATA_SIM, np.zeros(nth))
+    prior = M.GaussianPrior(0.0, 3.0) if nth != 4 else None
+    prob = M.HipMuseProblem(xdata, model=model, ntheta=nth, prior=prior)
+    th0 = np.linspace(1.0, 0.3, nth)
+    outs = []
+    for dev in (False, True, True):
+        n, theta, hist, gs, info = prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7,
+                                                 device_loop=dev)
+        outs.append((n, theta, hist, gs, info))
+    n0, theta0, hist0, gs0, info0 = outs[0]
+    assert 2 <= n0 <= maxsteps
+    for n, theta, hist, gs, info in outs[1:]:
+        assert n == n0
+        assert np.array_equal(theta, theta0)
+        assert np.array_equal(hist[:, :-1], hist0[:, :-1])       # (last column: the iteration's wall time)
+        assert np.all(hist[:, -1] > 0) and np.all(hist[:, -1] < 1.0)
+        assert np.array_equal(gs, gs0) and np.array_equal(info, info0)
+    # and through the driver: muse() takes the device loop by default
+    res = M.muse(prob, th0, rng=11, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, alpha=0.7)
+    assert len(res.history) == n0 and np.array_equal(res.theta, theta0)
+    # a z0 warm start (first map from the resident MAPs) and the host's knowledge lagging behind the device's stop
+    n1, t1, h1, g1, i1 = prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7, z0_warm=True,
+                                       device_loop=False)
+    prob.run_muse(11, th0, nsims=nsims, maxsteps=2, theta_rtol=rtol, atol=1e-2, alpha=0.7)   # leaves other MAPs behind
+    prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7, device_loop=False)
+    n2, t2, h2, g2, i2 = prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7, z0_warm=True,
+                                       device_loop=True)
+    assert n2 == n1 and np.array_equal(t2, t1) and np.array_equal(h2[:, :-1], h1[:, :-1]) and np.array_equal(i2, i1)
+    # a map after the loop is unaffected by the loop's device-side theta and stop flag
+    g, _ = prob.map_and_score_batch(11, 0, 5, th0)
+    ref = M.HipMuseProblem(xdata, model=model, ntheta=nth, prior=prior)
+    gr, _ = ref.map_and_score_batch(11, 0, 5, th0)
+    assert np.array_equal(g, gr)
+    prob.close()
+    ref.close()
+
+
+def test_device_loop_reports_errors_like_the_host_loop(gpu, M):
+    """A step that cannot be taken ends both loops with the same error: a NaN theta makes every score NaN, the score
+    variance NaN and H^-1_like' singular (the device loop's step kernel raises its stop flag, the launches already
+    enqueued drain as no-ops)."""
+    prob = M.HipMuseProblem(np.linspace(-1, 1, 600), model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    for dev in (False, True):
+        with pytest.raises(M.MuseError, match="singular"):
+            prob.run_muse(1, [np.nan], nsims=8, maxsteps=5, theta_rtol=0.1, atol=1e-2, alpha=0.7, device_loop=dev)
+    g, _ = prob.map_and_score_batch(1, 0, 4, [0.5])              # the context is usable afterwards
+    assert np.all(np.isfinite(g))
+    n, theta, hist, gs, info = prob.run_muse(1, [0.5], nsims=8, maxsteps=5, theta_rtol=0.1, atol=1e-2, alpha=0.7)
+    assert n >= 2 and np.all(np.isfinite(theta))
+    prob.close()
+
+
 # ---- row f3: checkpoint / resume / save_MAPs on the HIP path ---------------------------------------------
 def test_checkpoint_resume_and_saved_maps_on_hip(gpu, M, O, tmp_path):
     N = 3000
@@ -209,10 +269,10 @@ def test_element_split_vs_oracle_and_invariances(gpu, M, O, model, N, nth, theta
     g, info = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
     zh = prob.get_zhat(0, 25)
     go, zo, io = O.map_and_score_batch(model, N, 42, 0, 24, theta, atol=1e-2, x_data=xdata, z0_mode=0)
-    same = (info["iterations"] == io["iterations"]) & (info["f_calls"] == io["f_calls"])
-    assert same.mean() >= 0.9 and np.array_equal(info["status"], io["status"])
-    np.testing.assert_allclose(g[same], go[same], rtol=1e-10)
-    np.testing.assert_allclose(zh[same], zo[same], rtol=0, atol=1e-9)
+    # elements on the oracle's L-BFGS path: scores rtol 1e-10, MAPs 1e-9; an element that left it (the split changes the
+    # summation tree; long stencil solves only) is still BOUNDED: both sides converged, |dz| <= 2 atol / lambda_min
+    same = assert_same_path_or_close(info, io, zh, zo, g, go, model, theta, 1e-2, f"split {split}")
+    assert same.mean() >= 0.9
     g2, info2 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
     assert np.array_equal(g, g2) and np.array_equal(info, info2) and np.array_equal(zh, prob.get_zhat(0, 25))
     same0 = (info["iterations"] == i0["iterations"]) & (info["f_calls"] == i0["f_calls"])

@@ -51,7 +51,7 @@ def test_normals_accuracy_against_numpy(O):
 def test_funnel_closed_forms(O, theta, N):
     x, z = O.sample_x_z("funnel", N, 0, 5, theta)
     n1, n2 = O.normals(0, 5, N)
-    np.testing.assert_array_equal(z, np.exp(0.5 * theta) * n1)
+    np.testing.assert_array_equal(z, O.exp_fixed(0.5 * theta) * n1)   # (the models' exp is a fixed sequence, within 1 ulp of libm)
     np.testing.assert_array_equal(x, z + n2)
     for z0 in (np.zeros(N), z):
         zh, info = O.zhat_at_theta("funnel", x, z0, theta, 1e-2)
@@ -177,7 +177,26 @@ def test_implicit_diff_H_closed_form_and_fd(O):
     assert its[0] == 1  # isotropic Hessian: CG converges in one step
     for model, t in [("noise", [0.4]), ("funnel", [0.3, -0.2]), ("smooth", [1.0, 2.0, 0.5])]:
         _, zfid, _ = O.map_and_score_batch(model, 600, 5, 2, 3, t, atol=1e-12, z0_mode=0)
-        Hfd = O.fd_jacobian(model, 600, 5, 2, t, [1e-5] * len(t), zfid[0], atol=1e-13)
+        # (step 1e-3: truncation error 1.6e-7 relative; at 1e-5 the stencil model's difference quotient amplifies the
+        #  ~1e-9 noise an L-BFGS solve stops with -- x/f convergence before 1e-13 -- to a few 1e-6)
+        Hfd = O.fd_jacobian(model, 600, 5, 2, t, [1e-3] * len(t), zfid[0], atol=1e-13)
         Him, its = O.implicit_H(model, 600, 5, 2, t, atol=1e-12)
         np.testing.assert_allclose(Him, Hfd, rtol=1e-6, atol=1e-6 * np.abs(Hfd).max())
     assert its.max() > 5   # the smooth model needs real CG iterations
+
+
+def test_fixed_sequence_exp_is_within_one_ulp(O):
+    """exp(theta/2), exp(-theta) are a fixed fdlibm-style sequence (so that the device-resident muse! loop and the host form
+    the same bits): check it against libm over the whole range, the special values and the scaling paths."""
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-30, 30, 4000), rng.uniform(-745, 709, 2000), [0.0, -0.0, 1.0, -1.0, 0.5, 1e-300, -1e-300,
+                         709.782712893384, 709.78271289338409, -708.3964185322641, -744.0, -745.13321910194, 1e-17, -1e-17,
+                         0.34657359027997264, -0.34657359027997264]])
+    for x in xs:
+        got, want = O.exp_fixed(x), float(np.exp(x))
+        if want == 0.0 or not np.isfinite(want):
+            assert got == want or abs(got - want) <= 5e-324, x
+        else:
+            assert abs(got - want) <= 1.0 * np.spacing(want), (x, got, want)
+    assert O.exp_fixed(710.0) == np.inf and O.exp_fixed(-746.0) == 0.0 and np.isnan(O.exp_fixed(np.nan))
+    assert O.exp_fixed(0.0) == 1.0

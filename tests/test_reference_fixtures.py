@@ -56,3 +56,34 @@ def test_oracle_against_reference_outputs(O):
                                 atol=float(d["run_atol"]))
     np.testing.assert_allclose(np.array(J), r["run_J"], rtol=1e-6)
     np.testing.assert_allclose(np.array(H), r["run_H"], rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(OUTPUTS), reason="tests/golden/reference_outputs.npz absent: run "
+                    "julia/make_reference_fixtures.jl where Julia and MuseInference.jl are installed")
+def test_hip_against_reference_outputs(gpu, M):
+    """The same comparison for the PRODUCT path: libmuse_hip's ẑ_at_θ (counts, ẑ, minimum, score) and a whole
+    muse()/get_J!/get_H! run on HipMuseProblem against what the reference package produced from the same inputs (the
+    normals injected into the reference are the engine's own Philox streams, bit for bit: test_sampler_bit_exact).  The
+    day someone runs the Julia script, parity against the real package goes green (or red) in one step."""
+    d, r = np.load(INPUTS), np.load(OUTPUTS)
+    for c in range(int(d["ncases"])):
+        model, th, atol = MODELS[int(d[f"case{c}_model"])], d[f"case{c}_theta"], float(d[f"case{c}_atol"])
+        prob = M.HipMuseProblem(d[f"case{c}_x"], model=model, ntheta=th.size)
+        zh, info = prob.zhat_at_theta(d[f"case{c}_x"], d[f"case{c}_z0"], th, atol)
+        it, fc = int(r[f"case{c}_counts"][0]), int(r[f"case{c}_counts"][1])
+        assert (info["iterations"], info["f_calls"]) == (it, fc), f"case {c}: HIP {info['iterations'], info['f_calls']} vs Optim {it, fc}"
+        np.testing.assert_allclose(zh, r[f"case{c}_zhat"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(-info["f_min"], -r[f"case{c}_fmin"][0], rtol=1e-10)
+        np.testing.assert_allclose(prob.grad_theta_logLike(d[f"case{c}_x"], zh, th), r[f"case{c}_score"], rtol=1e-8)
+        prob.close()
+    prob = M.HipMuseProblem(d["run_x"], model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, float(d["run_prior_sigma"])))
+    res = M.muse(prob, list(d["run_theta0"]), rng=int(d["run_seed"]), nsims=int(d["run_nsims"]), maxsteps=int(d["run_maxsteps"]),
+                 theta_rtol=float(d["run_theta_rtol"]), grad_z_logLike_atol=float(d["run_atol"]), alpha=float(d["run_alpha"]),
+                 get_covariance=True)
+    np.testing.assert_allclose(np.array([h["θ"] for h in res.history]), r["run_thetas"], rtol=1e-7)
+    np.testing.assert_allclose(res.theta, r["run_theta"], rtol=1e-6)
+    np.testing.assert_allclose(np.array(res.gs), r["run_gs"], rtol=1e-7)
+    np.testing.assert_allclose(res.J, np.atleast_2d(r["run_J"]), rtol=1e-6)
+    np.testing.assert_allclose(res.H, np.atleast_2d(r["run_H"]), rtol=1e-4)
+    prob.close()
