@@ -198,7 +198,7 @@ int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_
  * history record and the convergence test on the device and leaves the next theta in device memory, where the next map
  * launch reads it; the host enqueues (map, step) pairs a few iterations ahead and watches completion events.  Launches
  * enqueued past the end of the loop find a stop flag set and drain as no-ops.  (exp(theta/2), exp(-theta) are a fixed
- * sequence of IEEE operations on host and device for this reason.)  nsims * ntheta <= 7600. */
+ * sequence of IEEE operations on host and device for this reason.)  nsims * ntheta <= 18000. */
 int muse_run_device(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
                     double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 

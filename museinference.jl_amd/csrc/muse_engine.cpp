@@ -916,6 +916,7 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
     const int64_t H = MUSE_RUN_HIST(nt);
     StepParams sp;
     step_params(c, o, sp);
+    StepWork work;
     double theta[kMaxTheta], theta_next[kMaxTheta], mean[kMaxTheta], var[kMaxTheta];
     for (int k = 0; k < nt; ++k) theta[k] = theta0[k];
     std::vector<double> g((size_t)(S + 1) * nt);
@@ -943,7 +944,7 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
         memcpy(gs, g.data() + nt, (size_t)S * nt * sizeof(double));
         if (info_out) memcpy(info_out + (int64_t)(i - 1) * (S + 1), info.data(), ((size_t)S + 1) * sizeof(muse_info));
         for (int k = 0; k < nt; ++k) step_moments(k, nt, S, gs, mean[k], var[k]);
-        const int err = step_record(sp, theta, g.data(), mean, var, h, theta_next);
+        const int err = step_record(sp, theta, g.data(), mean, var, h, theta_next, work);
         if (err != STEP_OK) return step_error(err);
         for (int k = 0; k < nt; ++k) theta[k] = theta_next[k];
         const double t_end = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -1035,7 +1036,7 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     if (rc) return rc;
     const int nt = c->ntheta, S = o->nsims, maxsteps = o->maxsteps;
     const int64_t H = MUSE_RUN_HIST(nt);
-    if ((size_t)S * nt * sizeof(double) + 256 > 60 * 1024)  // the step kernel keeps the simulation scores in LDS
+    if ((size_t)S * nt > 18000)  // the step kernel keeps the simulation scores in LDS (144 KB of the 160)
         return fail(MUSE_ERR_INVALID, "muse_run_device: nsims * ntheta too large for the step kernel (use muse_run)");
     rc = ensure_run_buffers(c, maxsteps, S);
     if (rc) return rc;

@@ -311,32 +311,44 @@ __global__ void __launch_bounds__(256) muse_step_kernel(StepArgs s) {
     __syncthreads();
     if (tid < nt) step_moments(tid, nt, S, gs, small[8 + tid], small[16 + tid]);
     __syncthreads();
+    // the dense part in ONE lane, every array it indexes at run time in LDS (StepWork)
+    StepWork& w = *reinterpret_cast<StepWork*>(small + 24);
+    int* flags = reinterpret_cast<int*>(small + 24 + sizeof(StepWork) / 8);  // [0] err, [1] converged
     if (tid == 0) {
-        double theta[kMaxTheta], theta_next[kMaxTheta], rec[MUSE_RUN_HIST(kMaxTheta)];
-        for (int k = 0; k < nt; ++k) theta[k] = s.theta_dev->t.theta[k];
-        int err = step_record(s.sp, theta, small, small + 8, small + 16, rec, theta_next);
+        for (int k = 0; k < nt; ++k) w.theta[k] = s.theta_dev->t.theta[k];
+        int err = step_record(s.sp, w.theta, small, small + 8, small + 16, w.rec, w.theta_next, w);
         int converged = 0;
         if (err == STEP_OK) {
             unsigned long long now;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            rec[7 * nt + nt * nt] = (double)(now - *s.tprev) * 1e-8;   // seconds of this iteration
+            w.rec[7 * nt + nt * nt] = (double)(now - *s.tprev) * 1e-8;   // seconds of this iteration
             *s.tprev = now;
-            double* h = s.hist_out + (int64_t)(s.iter - 1) * H;
-            for (int64_t k = 0; k < H; ++k) h[k] = rec[k];
             // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
             if (s.iter >= 2 && s.iter < s.maxsteps) {
-                const int c = step_converged(nt, rec, s.prev_rec, s.sp.theta_rtol);
+                const int c = step_converged(nt, w.rec, s.prev_rec, s.sp.theta_rtol);
                 if (c < 0) err = STEP_DOMAIN;
                 converged = c > 0;
             }
-            for (int64_t k = 0; k < H; ++k) s.prev_rec[k] = rec[k];
-            make_map_theta(nt, s.bnd, theta_next, *s.theta_dev);
-            for (int k = 0; k < nt; ++k) s.theta_out[k] = theta_next[k];
+            make_map_theta(nt, s.bnd, w.theta_next, *s.theta_dev);
         }
         if (err != STEP_OK || converged || s.iter == s.maxsteps) *s.stop_flag = 1;
+        flags[0] = err;
+        flags[1] = converged;
+    }
+    __syncthreads();
+    const int err = flags[0];
+    if (err == STEP_OK) {   // the record to the host (pinned) and to device memory (the next step's h0), by all lanes
+        double* h = s.hist_out + (int64_t)(s.iter - 1) * H;
+        for (int k = tid; k < (int)H; k += 256) {
+            h[k] = w.rec[k];
+            s.prev_rec[k] = w.rec[k];
+        }
+        if (tid < nt) s.theta_out[tid] = w.theta_next[tid];
+    }
+    if (tid == 0) {
         s.status[0] = err == STEP_OK ? s.iter : s.iter - 1;
         s.status[1] = err;
-        s.status[2] = converged;
+        s.status[2] = flags[1];
     }
 }
 // the start of the run on the 100 MHz counter (the first iteration's time is measured from here); also clears the stop flag
@@ -427,7 +439,7 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
 }
 
 hipError_t launch_step(const StepArgs& s, hipStream_t st, void* done_event) {
-    const size_t lds = ((size_t)s.sp.nsims * s.sp.ntheta + 24) * sizeof(double);
+    const size_t lds = ((size_t)s.sp.nsims * s.sp.ntheta + 24) * sizeof(double) + sizeof(StepWork) + 64;
     static size_t lds_allowed = 48 * 1024;
     if (lds > lds_allowed) {
         const hipError_t e = hipFuncSetAttribute((const void*)muse_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

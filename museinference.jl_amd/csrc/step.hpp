@@ -62,9 +62,19 @@ MUSE_HD void make_map_theta(int ntheta, const int64_t* bnd, const double* theta,
     m.pad_ = 0.0;
 }
 
-// inverse of a small dense matrix (n <= kMaxTheta) by Gauss-Jordan with partial pivoting; false if singular
-MUSE_HD bool small_inverse(int n, const double* A, double* inv) {
+// Work space of one step.  The caller places it: on the device in LDS -- a lane's local arrays indexed at run time live in
+// scratch memory (HBM), and the dependent chains of a one-lane Gauss-Jordan then pay a memory round trip per access
+// (measured: 50 us per step that way) -- on the host on the stack.
+struct StepWork {
     double M[kMaxTheta][2 * kMaxTheta];
+    double gprior[kMaxTheta], hprior[kMaxTheta];
+    double Hlike[kMaxTheta * kMaxTheta], Hinv_like_inv[kMaxTheta * kMaxTheta], Hpost[kMaxTheta * kMaxTheta];
+    double rec[7 * kMaxTheta + kMaxTheta * kMaxTheta + 1];
+    double theta[kMaxTheta], theta_next[kMaxTheta];
+};
+
+// inverse of a small dense matrix (n <= kMaxTheta) by Gauss-Jordan with partial pivoting; false if singular
+MUSE_HD bool small_inverse(int n, const double* A, double* inv, double (*M)[2 * kMaxTheta]) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             M[i][j] = A[i * n + j];
@@ -117,10 +127,13 @@ MUSE_HD void step_moments(int k, int ntheta, int S, const double* gs, double& me
 // moments of the simulation scores: h = [theta, g_like_dat, g_like, g_prior, g_post, diag H^-1_like, diag H_prior]
 // (ntheta each), H^-1_post (ntheta x ntheta); theta_next = theta - alpha H^-1_post g_post (src/muse.jl:183-208,224).
 MUSE_HD int step_record(const StepParams& sp, const double* theta, const double* g_dat, const double* mean, const double* var,
-                        double* h, double* theta_next) {
+                        double* h, double* theta_next, StepWork& w) {
     const int nt = sp.ntheta;
-    double gprior[kMaxTheta], hprior[kMaxTheta];
-    double Hlike[kMaxTheta * kMaxTheta], Hinv_like_inv[kMaxTheta * kMaxTheta], Hpost[kMaxTheta * kMaxTheta];
+    double* gprior = w.gprior;
+    double* hprior = w.hprior;
+    double* Hlike = w.Hlike;
+    double* Hinv_like_inv = w.Hinv_like_inv;
+    double* Hpost = w.Hpost;
     for (int k = 0; k < nt; ++k) {
         if (sp.prior_kind == 1) {
             const double sg2 = sp.prior_sigma[k] * sp.prior_sigma[k];
@@ -141,9 +154,9 @@ MUSE_HD int step_record(const StepParams& sp, const double* theta, const double*
     // H^-1_post = inv(inv(H^-1_like) + H_prior): both diagonal here, kept general through the dense inverse
     for (int a_ = 0; a_ < nt * nt; ++a_) Hlike[a_] = 0.0;
     for (int k = 0; k < nt; ++k) Hlike[k * nt + k] = h[5 * nt + k];
-    if (!small_inverse(nt, Hlike, Hinv_like_inv)) return STEP_SINGULAR_LIKE;
+    if (!small_inverse(nt, Hlike, Hinv_like_inv, w.M)) return STEP_SINGULAR_LIKE;
     for (int k = 0; k < nt; ++k) Hinv_like_inv[k * nt + k] += hprior[k];
-    if (!small_inverse(nt, Hinv_like_inv, Hpost)) return STEP_SINGULAR_POST;
+    if (!small_inverse(nt, Hinv_like_inv, Hpost, w.M)) return STEP_SINGULAR_POST;
     for (int a_ = 0; a_ < nt * nt; ++a_) h[7 * nt + a_] = Hpost[a_];
     for (int a_ = 0; a_ < nt; ++a_) {  // Newton-Raphson step (src/muse.jl:224)
         double stp = 0.0;

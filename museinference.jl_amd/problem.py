@@ -367,7 +367,7 @@ class HipMuseProblem(AbstractMuseProblem):
     def run_muse(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False, device_loop=None):
         """The muse! outer loop in the library's native code (muse_run / muse_run_device, include/muse_hip.h): returns
         (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]).  device_loop: the per-iteration algebra in a
-        step kernel on the GPU, no host round trip between two maps (default where it applies: nsims * nθ <= 7600);
+        step kernel on the GPU, no host round trip between two maps (default where it applies: nsims * nθ <= 18000);
         False: the algebra on the host.  The same results bit for bit."""
         kind, mean, sigma = self.native_prior()
         o = _capi.RunOptions()
@@ -383,7 +383,7 @@ class HipMuseProblem(AbstractMuseProblem):
         theta = np.zeros(self.ntheta)
         n = C.c_int32()
         if device_loop is None:
-            device_loop = nsims * self.ntheta <= 7600
+            device_loop = nsims * self.ntheta <= 18000
         fn = self._lib.muse_run_device if device_loop else self._lib.muse_run
         _capi.check(fn(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
                        _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))

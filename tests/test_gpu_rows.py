@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from test_gpu_parity import assert_same_path_or_close
 from test_host import LogNormalVariancePrior, check_outer_variants
 
 pytestmark = pytest.mark.gpu

@@ -1,0 +1,18 @@
+"""Wall time per outer iteration of the native muse! loops (muse_run: algebra on the host; muse_run_device: step kernel on
+the GPU, no host round trip between maps) at configs[1]'s shape: python tools/runloop_bench.py [N] [nsims] [ntheta]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import museinference_jl_amd as M
+N, nsims, nth = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (10000, 512, 1)
+xdata, _ = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N).sample_x_z(M.SimRng(0, M.DATA_SIM), [0.0] * nth)
+prob = M.HipMuseProblem(xdata, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+for dev in (False, True, False, True):
+    best = 1e9
+    for rep in range(5):
+        t0 = time.perf_counter()
+        n, theta, hist, gs, info = prob.run_muse(0, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7,
+                                                 device_loop=dev)
+        best = min(best, (time.perf_counter() - t0) / n)
+    print(f"N={N} nsims={nsims} ntheta={nth} device_loop={dev}: {1e6 * best:.1f} us per outer iteration ({n} iterations), "
+          f"device-side iteration time {1e6 * float(np.median(hist[5:, -1])):.1f} us", flush=True)
