@@ -47,7 +47,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 78.6    # fp64 vector peak: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def algorithmic_bytes(info, N):
@@ -93,6 +93,34 @@ def compulsory_bytes(info, N, placement):
                          2 + 2 * np.minimum(trials, 1) + 3 * np.maximum(trials - 1, 0) + 7 + 9 * np.maximum(kept - 1, 0)
                          + 4 * (K > 0) + 8 * H)
     return int(8 * N * words.sum())
+
+
+# ---- algorithmic VALU work of the resident placements (the vectors never leave the chip: the bound is instruction issue) ----
+# Operation counts per ELEMENT, read off the source (csrc/rng.hpp, models.hpp, solver.hpp), not off the compiler's output:
+#   sampler (one Philox4x32-10 call -> two uniforms -> Box-Muller pair -> the model's (z, x)):
+#     Philox: 10 rounds x 2 32x32->64 multiplies, 10 x 4 xors;  bits -> uniforms: 4 alignbit, 5 fp64;
+#     log_unit: 29 fp64 (8 of them the IEEE division f/(2+f)) + 8 integer ops on the exponent/mantissa words;
+#     sqrt_normal 10 + 1 (the factor -2);  sincospi_02: 29 fp64 + 8 integer/select;  Box-Muller products 2;  Model::sample 2
+#   evaluation passes (funnel/noise gradient: 5 fp64; + g.s fma, |g| max):
+#     sampler-fused initial evaluation AND first trial 14;  every further line-search trial 8;
+#     last update pass (z += alpha s, step norm, score term) 5;  a kept update pass (K > 1) 14
+# Issue cost per wave-instruction on one SIMD, measured by tools/clockprobe.hip with all CUs busy: fp64 4.4
+# cycles (nominal 4: 16 lanes/clk), v_mad_u64_u32 4.75, 32-bit integer / select 2.7.
+ALG_OPS = {"sampler_fp64": 5 + 29 + 11 + 29 + 2 + 2, "sampler_mul64": 20, "sampler_int32": 40 + 4 + 8 + 8,
+           "init_fp64": 14, "trial_fp64": 8, "last_fp64": 5, "kept_fp64": 14}
+ISSUE_CYCLES = {"fp64": 4.4, "mul64": 4.75, "int32": 2.7}
+
+
+def algorithmic_valu(info, N, clock_hz):
+    """(issue cycles per launch summed over the SIMDs, fp64 ops per launch) that the solves of `info` need by the counts
+    above: cold start from zero(z), E = f_calls evaluations, K = iterations."""
+    E = info["f_calls"].astype(np.float64)
+    K = info["iterations"].astype(np.float64)
+    fp64 = ALG_OPS["sampler_fp64"] + ALG_OPS["init_fp64"] + ALG_OPS["trial_fp64"] * np.maximum(E - 2, 0) \
+        + ALG_OPS["last_fp64"] * (K > 0) + ALG_OPS["kept_fp64"] * np.maximum(K - 1, 0)
+    cyc = fp64 * ISSUE_CYCLES["fp64"] + ALG_OPS["sampler_mul64"] * ISSUE_CYCLES["mul64"] + ALG_OPS["sampler_int32"] * ISSUE_CYCLES["int32"]
+    elems = float(N)
+    return float(cyc.sum() * elems / 64.0), float(fp64.sum() * elems)
 
 
 def csrc_fingerprint():
@@ -235,12 +263,38 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     t0 = time.perf_counter()
     res30 = M.muse(prob, [1.0] * nth, rng=seed, nsims=nsims, maxsteps=30, theta_rtol=1e-12)
     dt30 = time.perf_counter() - t0
+    # the native loops alone (no Python between the iterations, no history records built): algebra on the host / in a step kernel
+    loops = {}
+    for name, dev in (("host_loop", False), ("device_loop", True)):
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            n30 = prob.run_muse(seed, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=dev)[0]
+            best = min(best, (time.perf_counter() - t0) / max(1, n30))
+        loops[name] = 1e6 * best
     out["muse_run"] = {"wall_s": dt, "outer_iterations": len(res.history), "theta": [float(t) for t in res.theta],
                        "sigma": [float(t) for t in np.sqrt(np.diag(np.atleast_2d(res.Sigma)))],
-                       "us_per_outer_iteration_30": 1e6 * dt30 / max(1, len(res30.history)),
+                       "us_per_outer_iteration_30": loops["host_loop"],
+                       "us_per_outer_iteration_30_device_loop": loops["device_loop"],
+                       "us_per_outer_iteration_30_with_python_history": 1e6 * dt30 / max(1, len(res30.history)),
                        "note": "muse(prob, theta0=1; nsims, get_covariance=True): outer iterations (native muse_run) + get_J! + get_H!, "
-                               "host algebra included; us_per_outer_iteration_30 from a 30-iteration run"}
+                               "host algebra included; us_per_outer_iteration_30: wall of a 30-iteration muse_run (the library's loop: "
+                               "launch, wait, algebra on the host) per iteration; ..._device_loop: muse_run_device (step kernel, theta "
+                               "from device memory); ..._with_python_history: through muse(), which also builds the 30 history records"}
     prob.close()
+    # the get_H! finite-difference map at configs[3]'s OWN shape: funnel, N = 10^4, 4 theta blocks, 512 sims ->
+    # 1 fiducial + 512 x 4 x 2 perturbed MAP+score problems (src/muse.jl:407-446); last, on a context of its own
+    p4 = M.HipMuseProblem(None, model="funnel", ntheta=4, N=10000, device=device)
+    th4, st4 = [1.0] * 4, [0.05] * 4
+    p4.fd_jacobian_batch(seed, 0, 512, th4, st4)
+    best = float("inf")
+    for _ in range(5):
+        t0 = time.perf_counter()
+        p4.fd_jacobian_batch(seed, 0, 512, th4, st4)
+        best = min(best, time.perf_counter() - t0)
+    out["get_H_fd_configs3"] = {"maps_per_s": (1 + 2 * 4 * 512) / best, "ms_per_call": 1e3 * best, "nsims": 512, "ntheta": 4,
+                                "maps_per_call": 1 + 2 * 4 * 512}
+    p4.close()
     return out
 
 
@@ -470,7 +524,8 @@ def main():
         G = 1
         resident_n = model != "smooth" and N <= M.load_library().muse_max_resident_n()   # one workgroup per element and CU
         if sharded and args.split < 0 and resident_n:
-            G = max(1, min(M._capi.MAX_MAPS, cus // max(1, nlocal))) if os.environ.get("MUSE_BENCH_MAPS") is None \
+            # as many maps as make the launch the shape of the 1-GPU step: two problems per compute unit
+            G = max(1, min(M._capi.MAX_MAPS, (2 * cus) // max(1, nlocal))) if os.environ.get("MUSE_BENCH_MAPS") is None \
                 else max(1, min(M._capi.MAX_MAPS, int(os.environ["MUSE_BENCH_MAPS"])))
         state["nmaps"] = G
         split = args.split
@@ -555,6 +610,10 @@ def main():
         run_steps(nprof)
         barrier()
         kernel_ms = prob.profile_end()
+        try:
+            clock_hz = prob.profile_clock_hz()   # in-kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz of a profiled launch
+        except M.MuseError:
+            clock_hz = None
         g, info = results[-1]
         assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
         pinfo = prob.placement_info()
@@ -563,7 +622,8 @@ def main():
         state["capi"] = False
         return {"dt": dt, "rounds": rounds, "host_us": host_us, "kernel_ms": kernel_ms, "info": info, "split": split,
                 "maps_per_launch": state["nmaps"],
-                "collective": collective, "ranks_seen": seen, "pinfo": pinfo, "value": total_sims * args.steps / dt}
+                "collective": collective, "ranks_seen": seen, "pinfo": pinfo, "value": total_sims * args.steps / dt,
+                "clock_hz": clock_hz, "launches": -(-args.steps // state["nmaps"])}
 
     # The host loop must keep three launches ahead of a ~50 us kernel: a full collection of the interpreter's cyclic GC
     # (torch alone brings more than a million tracked objects; measured 40-60 ms, once, a few hundred steps into a run)
@@ -590,17 +650,34 @@ def main():
            "frac": comp_bytes / mean_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
            "compulsory_bytes_per_launch": comp_bytes,
            "traffic_GBps": None if traffic is None else traffic / mean_kernel_s / 1e9}
+    # The kernel time a fraction is quoted against: the event pair around a launch costs the kernel ~3 us (it cannot overlap
+    # the next launch's start), so a launch cannot have taken longer than the pipelined step it is part of.
+    launch_s = min(mean_kernel_s, dt / best["launches"]) if world == 1 else mean_kernel_s
+    clock_hz = best["clock_hz"] or CLOCK_HZ
     valu = None
-    if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
-        # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
-        # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
-        # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
-        busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
-        fr = busy / (N_SIMD * mean_kernel_s * CLOCK_HZ)
-        valu = {"bound": "valu", "achieved": fr * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fr,
-                "traffic": traffic, "valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
-                "clock_hz_assumed": CLOCK_HZ,
-                "note": "fp64-FMA issue-slot equivalents: VALU-active cycles / (1024 SIMDs x kernel time x 2.4 GHz)"}
+    if placement == "resident":
+        alg_cycles, alg_fp64 = algorithmic_valu(info, N, clock_hz)
+        alg = {"fp64_ops_per_launch": alg_fp64, "issue_cycles_per_launch": alg_cycles,
+               "frac_of_issue_peak": alg_cycles / (N_SIMD * launch_s * clock_hz),
+               "fp64_TFLOPs_fma_equiv": 2.0 * alg_fp64 / launch_s / 1e12,
+               "ops_per_element": ALG_OPS, "issue_cycles_per_wave_instruction": ISSUE_CYCLES,
+               "note": "work / peak: operation counts per element from the source (bench.py: ALG_OPS) x the measured issue cost "
+                       "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
+                       "many instructions the compiled kernel spends on them"}
+        valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,
+                "clock_hz": clock_hz, "clock_source": "in-kernel s_memtime / s_memrealtime" if best["clock_hz"] else "assumed",
+                "launch_s_used": launch_s}
+        if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
+            # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
+            # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
+            # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
+            busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
+            valu["utilisation"] = {"valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
+                                   "frac": busy / (N_SIMD * launch_s * clock_hz),
+                                   "note": "VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (1024 SIMDs x launch "
+                                           "time x measured clock): how busy the kernel's OWN instruction stream keeps the SIMDs "
+                                           "(round 2 quoted this figure, against an assumed 2.4 GHz, as the roofline fraction)"}
     primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
     primary.update({
         "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
@@ -610,7 +687,10 @@ def main():
         "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
         "profile_note": why,
         "note": ("resident placement: z, s, x, g never leave registers/LDS, the HBM leg only carries zhat out (and the "
-                 "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes)"
+                 "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes). "
+                 "frac = algorithmic work / issue peak (valu.algorithmic); valu.utilisation is how busy the compiled kernel keeps "
+                 "the SIMDs.  BASELINE.json's '>= 40 % of the HBM roofline' can be neither met nor missed by this placement: it "
+                 "moves 1 word per element where SURVEY 8.d3's accounting assumes 22 (hbm.frac is that one word / 8 TB/s)"
                  if placement == "resident" else
                  "streaming placement: achieved = compulsory bytes of the passes the solves made / kernel time"),
         "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),

@@ -154,13 +154,13 @@ def test_device_resident_muse_loop_equals_host_loop(gpu, M, O, model, N, nth, ns
         assert np.array_equal(hist[:, :-1], hist0[:, :-1])       # (last column: the iteration's wall time)
         assert np.all(hist[:, -1] > 0) and np.all(hist[:, -1] < 1.0)
         assert np.array_equal(gs, gs0) and np.array_equal(info, info0)
-    # and through the driver: muse() takes the device loop by default
+    # and through the driver (which takes the host loop)
     res = M.muse(prob, th0, rng=11, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, alpha=0.7)
     assert len(res.history) == n0 and np.array_equal(res.theta, theta0)
     # a z0 warm start (first map from the resident MAPs) and the host's knowledge lagging behind the device's stop
     n1, t1, h1, g1, i1 = prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7, z0_warm=True,
                                        device_loop=False)
-    prob.run_muse(11, th0, nsims=nsims, maxsteps=2, theta_rtol=rtol, atol=1e-2, alpha=0.7)   # leaves other MAPs behind
+    prob.run_muse(11, th0, nsims=nsims, maxsteps=2, theta_rtol=rtol, atol=1e-2, alpha=0.7, device_loop=True)   # leaves other MAPs behind
     prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7, device_loop=False)
     n2, t2, h2, g2, i2 = prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7, z0_warm=True,
                                        device_loop=True)

@@ -2,6 +2,7 @@
 # rocprofv3 evidence for profiles/: kernel trace + stats, then HBM counters in separate --pmc passes
 # (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no --pmc together with traces).
 cd /tmp && export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?tools/profile.sh runs on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT  # a stale pass must not be summarized with this one
