@@ -247,3 +247,37 @@ def test_fuzz_sizes_and_models(gpu, M, O):
             xo, zz = O.sample_x_z(model, N, seed, s0, theta)
             assert np.array_equal(x, xo) and np.array_equal(z, zz), ctx
             prob.close()
+
+
+def test_fuzz_offpath_cases(gpu, M, O):
+    """The 64 cases on which round 2's randomized runs (tools/fuzz_parity.py, 301 433 cases) found the HIP path and the
+    oracle apart -- different iteration / evaluation counts, or scores apart by more than 1e-9 with equal counts: all the
+    stencil model at N <= 140 with 25-53 L-BFGS iterations, where tree-ordered and sequential sums differ by O(sqrt(N) eps)
+    per dot product and a long, ill-conditioned solve amplifies that.  Iteration-count parity is empirical (DESIGN.md §4);
+    what must hold regardless: both sides converge (same status), stop within a few iterations of each other, and their
+    MAPs agree to the solve's own tolerance, |dz|_inf <= 2 atol / lambda_min (lambda_min = e^-max(theta): the stencil's
+    A^T A is singular at the Nyquist mode), the scores to the bound that implies."""
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_offpath.json")))["cases"]
+    assert len(cases) == 64
+    worst = 0.0
+    for c in cases:
+        th = np.array(c["theta"])
+        prob = M.HipMuseProblem(None, model=c["model"], ntheta=c["ntheta"], N=c["N"])
+        if c["split"]:
+            prob.set_element_split(c["split"])
+        n = c["nsims"]
+        g, info = prob.map_and_score_batch(c["seed"], c["sim0"], c["sim0"] + n, th, atol=c["atol"], z0_mode=c["z0_mode"])
+        zh = prob.get_zhat(0, n)
+        prob.close()
+        go, zo, io = O.map_and_score_batch(c["model"], c["N"], c["seed"], c["sim0"], c["sim0"] + n, th, atol=c["atol"],
+                                           z0_mode=c["z0_mode"])
+        assert np.array_equal(info["status"], io["status"]) and np.all(info["status"] == 0), c
+        assert np.abs(info["iterations"] - io["iterations"]).max() <= 4, (c, info["iterations"], io["iterations"])
+        lam = float(np.exp(-np.max(th))) if c["model"] == "smooth" else 1.0
+        bound = 2 * c["atol"] / lam
+        dz = np.abs(zh - zo).max()
+        assert dz <= bound, (c, dz, bound)
+        worst = max(worst, dz / bound)
+        np.testing.assert_allclose(g, go, rtol=0, atol=bound * np.sqrt(c["N"]) * (1 + np.abs(zo).max()), err_msg=str(c))
+    assert worst < 1.0

@@ -28,7 +28,14 @@ while time.time() - t0 < budget:
         prob.set_element_split(split)
     else:
         split = 0
-    g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=atol, z0_mode=z0)
+    nmaps = int(rng.choice([1, 1, 1, 2, 3]))  # several maps in one launch: map 0 is compared, the others carry other thetas
+    if nmaps > 1:
+        thetas = np.vstack([theta] + [rng.uniform(-1.5, 2.5, size=nth) for _ in range(nmaps - 1)])
+        tot = prob.map_and_score_multi_async(seed, s0, s0 + n, thetas, atol=atol, z0_mode=z0, result_area=2)
+        g, info = prob.batch_wait(tot, 2)
+        g, info = g[:n], info[:n]
+    else:
+        g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=atol, z0_mode=z0)
     zh = prob.get_zhat(0, n)
     prob.close()
     go, zo, io = O.map_and_score_batch(model, N, seed, s0, s0 + n, theta, atol=atol, z0_mode=z0, nthreads=8)
@@ -38,6 +45,6 @@ while time.time() - t0 < budget:
     ncase += 1
     if not ok:
         nbad += 1
-        print("MISMATCH", "split", split, model, N, nth, theta.tolist(), atol, z0, seed, s0, info["iterations"], io["iterations"],
+        print("MISMATCH", "nmaps", nmaps, "split", split, model, N, nth, theta.tolist(), atol, z0, seed, s0, info["iterations"], io["iterations"],
               info["f_calls"], io["f_calls"], info["status"], io["status"], np.abs(g - go).max(), flush=True)
 print(f"{ncase} cases, {nbad} mismatches in {time.time() - t0:.0f} s")
