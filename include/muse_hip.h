@@ -230,6 +230,18 @@ int muse_fd_jacobian_columns(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, in
                              const double* theta0, const double* step, double atol, int fid_mode, int64_t fid_sim,
                              double* cols_out, muse_info* info_out);
 
+/* The raw values behind any finite-difference method (FiniteDifferences' fdm(f, x[, step]) evaluates f on x + step*grid,
+ * src/util.jl:9-27): for the units [col_begin, col_end) of the same list and `ngrid` grid points each,
+ *   f(eps) = grad_theta( x(theta0 + eps e_j; the sim's randoms), zhat(x; theta0, start zfid), theta0 )
+ * at eps = offsets[.][g].  offsets is [ntheta][ngrid] -- one row per column j, shared by the simulations -- or, with
+ * offsets_per_unit, [n][ngrid], one row per unit (an adaptive step is estimated per simulation and column).  An offset
+ * of 0 evaluates at theta0 itself.  f_out [n][ngrid][ntheta] host, info_out [n][ngrid] (may be NULL).  The host combines
+ * the values with the method's coefficients: central_fdm(p, 1) for any p, and the step estimation that get_H! runs when
+ * neither `step` nor result.gs exist (src/muse.jl:300,411-413). */
+int muse_fd_values_columns(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
+                           const double* theta0, int ngrid, const double* offsets, int offsets_per_unit, double atol,
+                           int fid_mode, int64_t fid_sim, double* f_out, muse_info* info_out);
+
 /* The get_H! implicit-differentiation branch (src/muse.jl:335-405) for sims sim_begin..sim_end-1:
  *   H = H1 - dFdtheta^T A^{-1} dFdtheta1, A = Hessian_z logLike at (x, zhat, theta0), A^{-1} by conjugate
  *   gradients (IterativeSolvers.cg defaults: x0 = 0, reltol sqrt(eps), maxiter = cg_maxiter, reference 100);

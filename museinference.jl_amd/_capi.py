@@ -80,6 +80,7 @@ SIGNATURES = {
     "muse_implicit_H_batch": (_i, [_vp, _u64, _i64, _i64, _vp, _d, _i, _vp, _vp]),
     "muse_fd_jacobian_columns": (_i, [_vp, _u64, _i64, _i64, _i64, _vp, _vp, _d, _i, _i64, _vp, _vp]),
     "muse_implicit_H_columns": (_i, [_vp, _u64, _i64, _i64, _i64, _vp, _d, _i, _vp, _vp]),
+    "muse_fd_values_columns": (_i, [_vp, _u64, _i64, _i64, _i64, _vp, _i, _vp, _i, _d, _i, _i64, _vp, _vp]),
     "muse_comm_unique_id": (_i, [_vp]),
     "muse_comm_unique_id_ex": (_i, [_i, C.c_int64, _vp]),
     "muse_comm_transport": (_i, [_vp, C.POINTER(C.c_int)]),

@@ -28,6 +28,9 @@ struct ThetaSet {
     double sd[kMaxTheta];  // exp(theta/2)  (muse_exp: the fixed sequence of theta_math.hpp, the same bits on host and device)
     double iv[kMaxTheta];  // exp(-theta)
 };
+struct SampleSd {
+    double sd[kMaxTheta];  // exp(theta/2) of a theta simulations are DRAWN at (it differs from the MAP's theta in get_H!'s maps)
+};
 // theta of a MAP problem and of its score, with the constant term of -2 logLike that goes with it
 struct MapTheta {
     ThetaSet t;
@@ -97,7 +100,9 @@ struct BatchArgs {
     int64_t map_stride;            // score rows per map in the output block (>= n_per_map: a gathered block is padded)
     const int* stop_flag;          // non-null and *stop_flag != 0: the launch has nothing to do (the device-resident outer loop
                                    // has converged; the launches enqueued ahead of the host's knowledge drain as no-ops)
-    const ThetaSet* tsample;       // FD: [2*ntheta] sampling thetas (plus, minus per column); else null
+    const SampleSd* tsample;       // FD: exp(theta/2) of the sampling thetas, [fd_grid * ntheta] (column j, grid point g at
+                                   // j * fd_grid + g; shared by the simulations) or, fd_per_problem, one entry per problem
+    int fd_grid, fd_per_problem;   // BATCH_FD: grid points per (simulation, column) unit (central_fdm(3,1): +step, -step = 2)
     const double* x_data;          // [ld]
     const double* x_given;         // BATCH_SINGLE: [ld]
     double* zhat;                  // [slots][ld]
@@ -175,11 +180,11 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.zslot = a.store_zhat ? a.slot0 + p : -1;
         d.z0slot = a.slot0 + p;
     } else if (a.kind == BATCH_FD) {
-        const int per = 2 * a.ntheta, pp = p + a.p0;
+        const int per = a.fd_grid * a.ntheta, pp = p + a.p0;
         d.sim = a.sim_begin + pp / per;
         d.x_mode = X_SAMPLE;
         d.z0_mode = Z0_COPY;
-        d.tsample = pp % per;
+        d.tsample = a.fd_per_problem ? p : pp % per;
         d.zslot = -1;
         d.z0slot = a.fid_slot >= 0 ? a.fid_slot : a.slot0 + pp / per;
     } else if (a.kind == BATCH_IMPLICIT) {

@@ -55,8 +55,9 @@ struct muse_ctx {
     size_t scratch_doubles = 0;
     int* counter = nullptr;
     double* tmp = nullptr;  // 3 vectors for the per-sim operator entry points
-    ThetaSet* tsample_dev = nullptr;
-    ThetaSet* tsample_pin = nullptr;
+    SampleSd* tsample_dev = nullptr;   // sampling thetas of a finite-difference map (grown on demand)
+    SampleSd* tsample_pin = nullptr;
+    size_t tsample_cap = 0;
     // result areas: device + pinned host, each [cap] scores and infos
     double* scores_dev[kResultAreas] = {nullptr};
     muse_info* info_dev[kResultAreas] = {nullptr};
@@ -387,8 +388,6 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     memset(c->clock_pin, 0, 64);
     HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
-    HIPCHK(hipMalloc(&c->tsample_dev, 2 * kMaxTheta * sizeof(ThetaSet)));
-    HIPCHK(hipHostMalloc(&c->tsample_pin, 2 * kMaxTheta * sizeof(ThetaSet), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     for (int r = 0; r < kResultAreas; ++r) HIPCHK(hipEventCreateWithFlags(&c->area_done[r], hipEventDisableTiming));
@@ -444,7 +443,7 @@ int muse_ctx_destroy(muse_ctx* c) {
     hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag); hipHostFree(c->clock_pin);
     hipFree(c->ncache);
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
-    hipFree(c->small_dev); hipFree(c->tsample_dev); hipHostFree(c->tsample_pin);
+    hipFree(c->small_dev); if (c->tsample_dev) hipFree(c->tsample_dev); if (c->tsample_pin) hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
     for (int r = 0; r < kResultAreas; ++r) {
         hipHostFree(c->scores_pin[r]);
@@ -1129,31 +1128,51 @@ int muse_set_zhat(muse_ctx* c, int64_t b, int64_t e, const double* in, int mem) 
     return MUSE_OK;
 }
 
-// Columns [e_begin, e_end) of the list (sim_begin, column 0), (sim_begin, column 1), ... : element e is column
-// e % ntheta of the finite-difference Jacobian of simulation sim_begin + e / ntheta.  cols_out [e_end-e_begin][ntheta]
-// (cols[e][i] = d g_i / d theta_j), info_out [e_end-e_begin][2] (plus, minus).
-static int fd_columns_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t e_begin, int64_t e_end, const double* theta0,
-                           const double* step, double atol, int fid_mode, int64_t fid_sim, double* cols_out,
-                           muse_info* info_out) {
+static int ensure_tsample(muse_ctx* c, size_t entries) {
+    if (entries <= c->tsample_cap) return MUSE_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->tsample_dev) HIPCHK(hipFree(c->tsample_dev));
+    if (c->tsample_pin) HIPCHK(hipHostFree(c->tsample_pin));
+    c->tsample_dev = nullptr; c->tsample_pin = nullptr; c->tsample_cap = 0;
+    const size_t cap = entries + entries / 2 + 16;
+    HIPCHK(hipMalloc(&c->tsample_dev, cap * sizeof(SampleSd)));
+    HIPCHK(hipHostMalloc(&c->tsample_pin, cap * sizeof(SampleSd), hipHostMallocDefault));
+    c->tsample_cap = cap;
+    return MUSE_OK;
+}
+
+// The finite-difference map of get_H! (src/muse.jl:426-442) in raw form: for the units (simulation, column) e in
+// [e_begin, e_end) of the list (sim_begin, column 0), (sim_begin, column 1), ... -- unit e is column j = e % ntheta of
+// simulation sim_begin + e / ntheta -- and G grid points each, the function
+//   f(eps) = grad_theta( x(theta0 + eps e_j; the sim's randoms), zhat(x; theta0, start zfid), theta0 )
+// at eps = offsets[.][g]: offsets [ntheta][G] shared by the simulations (per_unit false) or [ne][G], one row per unit
+// (FiniteDifferences' adaptive step is estimated per call, i.e. per simulation and column).  f_out [ne][G][ntheta],
+// info_out [ne][G].  An offset of 0 is allowed (the fiducial theta itself, same randoms).
+static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t e_begin, int64_t e_end, const double* theta0,
+                          int G, const double* offsets, bool per_unit, double atol, int fid_mode, int64_t fid_sim, double* f_out,
+                          muse_info* info_out) {
     const int nt = c->ntheta;
     const int64_t ne = e_end - e_begin;
     if (ne == 0) return MUSE_OK;
-    const int64_t n = ne * 2;
+    if (G < 1 || G > 64) return fail(MUSE_ERR_INVALID, "grid points per column must be in [1, 64]");
+    const int64_t n = ne * G;
     if (n > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
-    for (int j = 0; j < nt; ++j)
-        if (!(step[j] != 0.0) || !isfinite(step[j])) return fail(MUSE_ERR_INVALID, "step must be finite and non-zero");
+    for (int64_t k = 0; k < (per_unit ? ne : nt) * G; ++k)
+        if (!isfinite(offsets[k])) return fail(MUSE_ERR_INVALID, "finite-difference offsets must be finite");
     const int64_t s_lo = sim_begin + e_begin / nt, s_hi = sim_begin + (e_end - 1) / nt + 1;  // simulations touched
     const int64_t nsims = s_hi - s_lo;
     // 1. fiducial MAPs at theta0 from zero(z) (src/muse.jl:417-423)
     const int64_t nfid = fid_mode == 0 ? 1 : nsims;
     int rc = ensure_zhat(c, nfid);
     if (rc) return rc;
-    // every simulation is drawn 2*ntheta times (same randoms, perturbed theta; src/muse.jl:426-432): its standard
+    // every simulation is drawn G*ntheta times (same randoms, perturbed theta; src/muse.jl:426-432): its standard
     // normals are generated once -- by its own fiducial problem (fid_mode 1) or by a normals-only element of the
     // fiducial launch (fid_mode 0) -- and loaded by the perturbed problems
     const bool cached = ensure_ncache(c, nsims);
     const int64_t nprep = nfid + ((cached && fid_mode == 0) ? nsims : 0);
     rc = ensure_results(c, 1, n > nprep ? n : nprep);
+    if (rc) return rc;
+    rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G));
     if (rc) return rc;
     {
         BatchArgs a;
@@ -1180,17 +1199,26 @@ static int fd_columns_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         rc = launch_batch(c, a);
         if (rc) return rc;
     }
-    // 2. the perturbed simulations (plus, minus per column), MAP and score at theta0
-    std::vector<double> th(nt);
-    for (int j = 0; j < nt; ++j) {
-        for (int s = 0; s < 2; ++s) {
+    // 2. the perturbed simulations, MAP and score at theta0
+    {
+        std::vector<double> th(nt);
+        auto fill = [&](int64_t entry, int j, double off) {
             for (int k = 0; k < nt; ++k) th[k] = theta0[k];
-            th[j] = theta0[j] + (s == 0 ? step[j] : -step[j]);
-            make_thetaset(c, th.data(), c->tsample_pin[2 * j + s]);
+            th[j] = theta0[j] + off;
+            MapTheta m;
+            make_map_theta(nt, c->bnd, th.data(), m);
+            memcpy(c->tsample_pin[entry].sd, m.t.sd, sizeof(SampleSd));
+        };
+        if (per_unit) {
+            for (int64_t e = 0; e < ne; ++e)
+                for (int g = 0; g < G; ++g) fill(e * G + g, (int)((e_begin + e) % nt), offsets[e * G + g]);
+        } else {
+            for (int j = 0; j < nt; ++j)
+                for (int g = 0; g < G; ++g) fill((int64_t)j * G + g, j, offsets[(int64_t)j * G + g]);
         }
     }
-    HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)2 * nt * sizeof(ThetaSet), hipMemcpyHostToDevice,
-                          c->stream));
+    HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)(per_unit ? n : (int64_t)nt * G) * sizeof(SampleSd),
+                          hipMemcpyHostToDevice, c->stream));
     {
         BatchArgs a;
         base_args(c, a, theta0);
@@ -1199,7 +1227,9 @@ static int fd_columns_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
         a.atol = atol;
         a.nproblems = (int)n;
         a.sim_begin = s_lo;
-        a.p0 = (int)(2 * (e_begin - (s_lo - sim_begin) * nt));  // the range may begin inside s_lo's Jacobian
+        a.fd_grid = G;
+        a.fd_per_problem = per_unit ? 1 : 0;
+        a.p0 = (int)(G * (e_begin - (s_lo - sim_begin) * nt));  // the range may begin inside s_lo's Jacobian
         a.fid_slot = fid_mode == 0 ? 0 : -1;
         a.slot0 = 0;
         a.tsample = c->tsample_dev;
@@ -1219,16 +1249,48 @@ static int fd_columns_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = check_error_flag(c);
     if (rc) return rc;
+    if (f_out) memcpy(f_out, c->scores_pin[1], (size_t)n * nt * sizeof(double));
+    if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
+    return MUSE_OK;
+}
+
+// central_fdm(3,1) with an explicit step: grid (-1, 0, 1), coefficients (-1/2, 0, 1/2) (src/muse.jl:300, src/util.jl:13);
+// the centre point has coefficient 0 and is not evaluated.  cols_out [e_end-e_begin][ntheta] (cols[e][i] = d g_i / d theta_j),
+// info_out [e_end-e_begin][2] (plus, minus).
+static int fd_columns_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t e_begin, int64_t e_end, const double* theta0,
+                           const double* step, double atol, int fid_mode, int64_t fid_sim, double* cols_out,
+                           muse_info* info_out) {
+    const int nt = c->ntheta;
+    const int64_t ne = e_end - e_begin;
+    if (ne == 0) return MUSE_OK;
+    std::vector<double> off((size_t)2 * nt);
+    for (int j = 0; j < nt; ++j) {
+        if (!(step[j] != 0.0) || !isfinite(step[j])) return fail(MUSE_ERR_INVALID, "step must be finite and non-zero");
+        off[2 * j] = step[j];
+        off[2 * j + 1] = -step[j];
+    }
+    int rc = fd_values_impl(c, seed, sim_begin, e_begin, e_end, theta0, 2, off.data(), false, atol, fid_mode, fid_sim, nullptr, info_out);
+    if (rc) return rc;
     const double* g = c->scores_pin[1];
     for (int64_t e = 0; e < ne; ++e) {
         const int j = (int)((e_begin + e) % nt);
         const double* gp = g + (e * 2 + 0) * nt;
         const double* gm = g + (e * 2 + 1) * nt;
-        // central_fdm(3,1): grid (-1, 0, 1), coefficients (-1/2, 0, 1/2) (src/muse.jl:300, src/util.jl:13)
         for (int i = 0; i < nt; ++i) cols_out[e * nt + i] = (-0.5 * gm[i] + 0.5 * gp[i]) / step[j];
     }
-    if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
     return MUSE_OK;
+}
+
+int muse_fd_values_columns(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,
+                           const double* theta0, int ngrid, const double* offsets, int offsets_per_unit, double atol,
+                           int fid_mode, int64_t fid_sim, double* f_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !offsets || !f_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (col_end < col_begin || col_begin < 0 || sim_begin < 0) return fail(MUSE_ERR_INVALID, "bad column range");
+    if (fid_mode != 0 && fid_mode != 1) return fail(MUSE_ERR_INVALID, "fid_mode must be 0 or 1");
+    return fd_values_impl(c, seed, sim_begin, col_begin, col_end, theta0, ngrid, offsets, offsets_per_unit != 0, atol, fid_mode,
+                          fid_sim, f_out, info_out);
 }
 
 int muse_fd_jacobian_columns(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t col_begin, int64_t col_end,

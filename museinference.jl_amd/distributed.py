@@ -232,6 +232,29 @@ class ShardedMuseProblem:
         iall = self._rows_to_info(allrows[:, nth * nth:].reshape(n * nth * 2, ninfo)).reshape(n, nth, 2)
         return np.ascontiguousarray(Hall), iall
 
+    def fd_values_columns(self, rng, sim_begin, col_begin, col_end, theta0, offsets, *, per_unit=False, atol=1e-2, fid_mode=0,
+                          fid_sim=None):
+        """The raw finite-difference values (any central_fdm(p, 1), estimated steps): the (sim, column) units are cut into
+        contiguous blocks, one per rank, every rank ends up with all of them.  (F [n, G, nθ], info [n, G])"""
+        from .problem import MASTER_SIM
+        fid_sim = MASTER_SIM if fid_sim is None else fid_sim
+        nth = np.atleast_1d(theta0).size
+        ninfo = len(_capi.INFO_DTYPE.names)
+        off = np.asarray(offsets, dtype=np.float64)
+        G = off.shape[1]
+        lo, hi = block_partition(col_begin, col_end, self.world, self.rank)
+        if hi > lo:
+            F, info = self.local.fd_values_columns(rng, sim_begin, lo, hi, theta0, off[lo - col_begin:hi - col_begin] if per_unit else off,
+                                                   per_unit=per_unit, atol=atol, fid_mode=fid_mode, fid_sim=fid_sim)
+        else:
+            F, info = np.zeros((0, G, nth)), np.zeros((0, G), dtype=_capi.INFO_DTYPE)
+        counts = [h - l for l, h in (block_partition(col_begin, col_end, self.world, r) for r in range(self.world))]
+        rows = np.concatenate([F.reshape(hi - lo, G * nth), self._info_to_rows(info).reshape(hi - lo, G * ninfo)], axis=1)
+        allrows = self._allgather_rows(rows, counts)
+        n = col_end - col_begin
+        return (np.ascontiguousarray(allrows[:, :G * nth].reshape(n, G, nth)),
+                self._rows_to_info(allrows[:, G * nth:].reshape(n * G, ninfo)).reshape(n, G))
+
     def implicit_H_batch(self, rng, sim_begin, sim_end, theta0, *, atol=1e-1, cg_maxiter=100):
         """get_H! implicit-differentiation branch (src/muse.jl:335-405), the (sim, column) units shared like the
         finite-difference ones."""

@@ -18,6 +18,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _capi
+from .fdm import as_fdm
 from .problem import MASTER_SIM, SimRng, UnTransformedθ, Transformedθ, split_rng
 
 
@@ -82,6 +83,19 @@ def _default_rng():
     return int(np.random.SeedSequence().entropy & ((1 << 63) - 1))
 
 
+_warned_ignored = set()
+
+
+def _note_ignored(**kw):
+    """`pool` / `progress` exist for signature parity with the reference (src/muse.jl:124-125,305-306,492-493) and do
+    nothing here (the map is one GPU launch; there is no progress bar): say so once instead of silently."""
+    for name, val in kw.items():
+        if val not in (None, False) and name not in _warned_ignored:
+            _warned_ignored.add(name)
+            warnings.warn(f"`{name}` is accepted for signature parity with MuseInference.jl and ignored: the map over "
+                          "simulations is one batched GPU launch", RuntimeWarning, stacklevel=3)
+
+
 def _has_batch(prob):
     return hasattr(prob, "map_and_score_batch")
 
@@ -127,6 +141,7 @@ def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rt
     `rng` is the master seed; it is stored, never advanced (src/muse.jl:134, src/util.jl:87-92).
     `pool` is accepted for signature parity and ignored: the batch is one GPU launch.
     """
+    _note_ignored(pool=pool, progress=progress)
     result.rng = rng = int(_something(rng, result.rng, _default_rng()))
     # `native`: run the whole outer loop in the library's host code (muse_run of the C ABI) when the options are
     # the plain ones it implements -- a fresh run, "sims" Jacobian update, constant alpha, identity regularize,
@@ -286,6 +301,7 @@ def get_J_(result, prob, theta0=None, *, z0=None, grad_z_logLike_atol=1e-2, rng=
     """get_J!(result, prob, θ₀; ...)   (src/muse.jl:484-532).  J = var(gs) / corrected sample covariance
     (SimpleCovariance(corrected=true), src/muse.jl:495,529); only nsims - length(result.gs) new sims are
     run, continuing the same streams (src/muse.jl:499-506)."""
+    _note_ignored(pool=pool, progress=progress)
     rng = int(_something(rng, result.rng, _default_rng()))
     theta0 = prob.standardize_theta(_something(theta0, result.theta))
     existing = len(result.gs)
@@ -326,14 +342,18 @@ def get_H_(result, prob, theta0=None, *, fdm="central_fdm(3,1)", grad_z_logLike_
            implicit_diff=False, implicit_diff_H1_is_zero=False, implicit_diff_cg_kwargs=None, fid_mode=0):
     """get_H!(result, prob, θ₀; ...) finite-difference branch   (src/muse.jl:296-333, 407-450).
 
-    step defaults to 0.1 ./ std(result.gs) (src/muse.jl:411-413).  fid_mode 0 reproduces the reference's
+    fdm: "central_fdm(p,1)" or a fdm.FiniteDifferenceMethod (reference default central_fdm(3,1), src/muse.jl:300).
+    step defaults to 0.1 ./ std(result.gs) (src/muse.jl:411-413); with neither a step nor result.gs the method estimates
+    its own step per simulation and column, as FiniteDifferences does (fdm.py).  fid_mode 0 reproduces the reference's
     fiducial warm start (every FD MAP starts from the MAP of the one simulation drawn from the un-split
     master stream, src/muse.jl:417-423); fid_mode 1 uses each sim's own fiducial MAP.
     """
+    _note_ignored(pool=pool, progress=progress)
     if implicit_diff:
         return _get_H_implicit(result, prob, theta0, rng, nsims, implicit_diff_cg_kwargs, skip_errors)
-    if fdm != "central_fdm(3,1)":
-        raise NotImplementedError("only central_fdm(3,1), the reference default (src/muse.jl:300), is built")
+    method = as_fdm(fdm)
+    if method.q != 1:
+        raise ValueError("get_H! differentiates once: fdm must be a first-derivative method (central_fdm(p, 1))")
     rng = int(_something(rng, result.rng, _default_rng()))
     theta0 = prob.standardize_theta(_something(theta0, result.theta))
     existing = len(result.Hs)
@@ -343,25 +363,60 @@ def get_H_(result, prob, theta0=None, *, fdm="central_fdm(3,1)", grad_z_logLike_
     t0 = time.perf_counter()
     if step is None and len(result.gs) > 0:
         step = 0.1 / np.std(np.array(result.gs), axis=0, ddof=1)
-    if step is None:
-        raise NotImplementedError("FiniteDifferences' adaptive step (no result.gs and no step) is not built; "
-                                  "run get_J_ first or pass step")
-    step = np.broadcast_to(np.atleast_1d(np.asarray(step, dtype=np.float64)), theta0.shape).copy()
+    if step is not None:
+        step = np.broadcast_to(np.atleast_1d(np.asarray(step, dtype=np.float64)), theta0.shape).copy()
     # split_rng(rng, nsims_remaining): streams 0 .. remaining-1 (src/muse.jl:323)
     Hs = None
     if _has_batch(prob) and z0 is None:
         try:
-            Hs, info = prob.fd_jacobian_batch(rng, 0, remaining, theta0, step, atol=grad_z_logLike_atol,
-                                              fid_mode=fid_mode, fid_sim=MASTER_SIM)
+            if step is not None and method.grid == [-1, 0, 1]:   # the reference default with an explicit step: one entry
+                Hs, info = prob.fd_jacobian_batch(rng, 0, remaining, theta0, step, atol=grad_z_logLike_atol,
+                                                  fid_mode=fid_mode, fid_sim=MASTER_SIM)
+            elif hasattr(prob, "fd_values_columns"):
+                Hs, info = _fd_batched(prob, rng, remaining, theta0, method, step, grad_z_logLike_atol, fid_mode)
+            else:
+                raise NotImplementedError
             Hs, _ = _apply_skip_errors(Hs, info, skip_errors, "get_H!")
         except NotImplementedError:
             Hs = None
     if Hs is None:
-        Hs = _fd_serial(prob, rng, remaining, theta0, step, grad_z_logLike_atol, z0, fid_mode)
+        Hs = _fd_serial(prob, rng, remaining, theta0, method, step, grad_z_logLike_atol, z0, fid_mode)
     result.Hs = list(result.Hs) + list(Hs)
     result.H = np.mean(np.array(result.Hs), axis=0)
     result.time += time.perf_counter() - t0
     return finalize_result_(result, prob)
+
+
+def _fd_batched(prob, rng, nsims, theta0, m, step, atol, fid_mode):
+    """get_H!'s finite-difference map for any central_fdm(p, 1), with an explicit step or -- neither `step` nor result.gs --
+    FiniteDifferences' own step estimation (src/muse.jl:300,411-413; src/util.jl:13: fdm(f, 0) without a step), through the
+    engine's raw-value seam: every grid point of every (simulation, column) unit is one MAP + score problem of ONE launch.
+    The step is estimated per fdm call, i.e. per simulation and column, from the method's bound estimator (order p + 2)
+    evaluated at ITS default step."""
+    nth = theta0.size
+    n = nsims * nth
+    kw = dict(atol=atol, fid_mode=fid_mode, fid_sim=MASTER_SIM)
+    grid = np.array(m.grid, dtype=np.float64)
+    infos = []
+    if step is not None:
+        nz = np.flatnonzero(m.coefs != 0.0)                     # a point with coefficient 0 is not evaluated
+        F, info = prob.fd_values_columns(rng, 0, 0, n, theta0, step[:, None] * grid[None, nz], **kw)
+        cols = np.tensordot(F, m.coefs[nz], axes=(1, 0)) / np.tile(step, nsims)[:, None] ** m.q
+        infos.append(info)
+    else:
+        est = m.bound_estimator
+        if est is None or est.bound_estimator is not None:
+            raise NotImplementedError("batched step estimation is built for adapt = 1")
+        step_e = est.estimate_step(None)
+        Fe, info_e = prob.fd_values_columns(rng, 0, 0, n, theta0, np.tile(step_e * np.array(est.grid, dtype=np.float64), (nth, 1)), **kw)
+        steps = np.array([m.step_from_magnitudes(*est.magnitudes_from_values(Fe[u], step_e)) for u in range(n)])
+        F, info = prob.fd_values_columns(rng, 0, 0, n, theta0, steps[:, None] * grid[None, :], per_unit=True, **kw)
+        cols = np.tensordot(F, m.coefs, axes=(1, 0)) / steps[:, None] ** m.q
+        infos += [info_e, info]
+    # the per-sim Jacobian is the hcat of its columns (src/util.jl:25): Hs[s][i][j] = cols[s*nθ + j][i]
+    Hs = np.ascontiguousarray(cols.reshape(nsims, nth, nth).transpose(0, 2, 1))
+    info = np.concatenate([i.reshape(nsims, -1) for i in infos], axis=1)
+    return Hs, info
 
 
 def _get_H_implicit(result, prob, theta0, rng, nsims, cg_kwargs, skip_errors):
@@ -385,7 +440,8 @@ def _get_H_implicit(result, prob, theta0, rng, nsims, cg_kwargs, skip_errors):
     return finalize_result_(result, prob)
 
 
-def _fd_serial(prob, rng, nsims, theta0, step, atol, z0, fid_mode):
+def _fd_serial(prob, rng, nsims, theta0, m, step, atol, z0, fid_mode):
+    """The same map element by element through the per-simulation operators (pjacobian, src/util.jl:9-27)."""
     nth = theta0.size
     Hs = []
     zfid_master = None
@@ -398,14 +454,16 @@ def _fd_serial(prob, rng, nsims, theta0, step, atol, z0, fid_mode):
         zfid = zfid_master
         H = np.empty((nth, nth))
         for j in range(nth):
-            gpm = []
-            for sgn in (+1.0, -1.0):
+            def f(eps, j=j, s=s, zfid=zfid):
                 th = theta0.copy()
-                th[j] = theta0[j] + sgn * step[j]
+                th[j] = theta0[j] + eps
                 x, _ = prob.sample_x_z(SimRng(rng, s), th)
                 zh, _ = prob.zhat_at_theta(x, zfid, theta0, atol)
-                gpm.append(np.atleast_1d(prob.grad_theta_logLike(x, zh, theta0, UnTransformedθ)))
-            H[:, j] = (-0.5 * gpm[1] + 0.5 * gpm[0]) / step[j]
+                return np.atleast_1d(prob.grad_theta_logLike(x, zh, theta0, UnTransformedθ))
+            if step is not None and m.grid == [-1, 0, 1]:
+                H[:, j] = (-0.5 * f(-step[j]) + 0.5 * f(step[j])) / step[j]
+            else:
+                H[:, j] = m(f, 0.0, None if step is None else step[j])
         Hs.append(H)
     return Hs
 

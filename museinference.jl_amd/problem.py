@@ -442,6 +442,25 @@ class HipMuseProblem(AbstractMuseProblem):
                                                        _capi.ptr(cols), _capi.ptr(info)))
         return cols, info
 
+    def fd_values_columns(self, rng, sim_begin, col_begin, col_end, theta0, offsets, *, per_unit=False, atol=1e-2, fid_mode=0,
+                          fid_sim=MASTER_SIM):
+        """The raw values of get_H!'s finite-difference map (muse_fd_values_columns): for units (sim, column) [col_begin,
+        col_end) of the list and G grid points each, the score at theta0 of the simulation drawn at theta0 + offset e_j.
+        offsets [nθ, G] (row j for column j, shared by the sims) or, per_unit, [n, G] (one row per unit).  Returns
+        (F [n, G, nθ], info [n, G])."""
+        th = self._theta(theta0)
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.float64))
+        n = col_end - col_begin
+        if off.ndim != 2 or off.shape[0] != (n if per_unit else self.ntheta):
+            raise ValueError("offsets must be [ntheta, G], or [n_units, G] with per_unit")
+        G = off.shape[1]
+        F = np.empty((n, G, self.ntheta))
+        info = np.zeros((n, G), dtype=_capi.INFO_DTYPE)
+        _capi.check(self._lib.muse_fd_values_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th), G,
+                                                     _capi.ptr(off), int(per_unit), float(atol), int(fid_mode), int(fid_sim),
+                                                     _capi.ptr(F), _capi.ptr(info)))
+        return F, info
+
     def implicit_H_columns(self, rng, sim_begin, col_begin, col_end, theta0, *, atol=1e-1, cg_maxiter=100):
         """The same column range for the implicit-differentiation H: (cols [n, nθ], cg iteration counts [n])."""
         th = self._theta(theta0)

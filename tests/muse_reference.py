@@ -173,3 +173,82 @@ def finalize(H, J, prior_hess_u):
     S_inv = _matmul(_matmul(_transpose(H), _inv(J)), H)
     S_inv = [[S_inv[a][b] - prior_hess_u[a][b] for b in range(nt)] for a in range(nt)]
     return S_inv, _inv(S_inv)
+
+
+# ---- FiniteDifferences.jl: central_fdm(p, q) and the estimated step (reference: fdm at src/muse.jl:300, applied at
+#      src/util.jl:13 as fdm(f, 0[, step])).  The package is not vendored in the reference (Project.toml:40, compat
+#      0.12.20) and cannot run here: restated from its published algorithm AS RECALLED -- coefficients from the
+#      Vandermonde system solved in exact rationals; step = argmin of  C1 h^-q + C2 h^(p-q),  C1 = eps(|f|) * sum|c| * factor,
+#      C2 = |f^(p)| * sum|c g^p| / p!,  |f^(p)| and |f| from one evaluation of central_fdm(p + 2, p) at ITS default step
+#      (|f^(p)| taken as `condition` = 10, error eps(Float64)), maxima over three neighbourhood estimates (the same values
+#      with the grid shifted by -1, 0, +1); steps capped at 1000 x the default step. ------------------------------------
+def fdm_central_grid(p):
+    half = p // 2
+    return list(range(-half, half + 1)) if p % 2 else [g for g in range(-half, half + 1) if g != 0]
+
+
+def fdm_coefs(grid, q):
+    from fractions import Fraction
+    p = len(grid)
+    rows = [[Fraction(g) ** i for g in grid] for i in range(p)]
+    rhs = [Fraction(math.factorial(q) if i == q else 0) for i in range(p)]
+    for c in range(p):                                   # Gauss-Jordan on exact rationals
+        r = c
+        while rows[r][c] == 0:
+            r += 1
+        rows[c], rows[r], rhs[c], rhs[r] = rows[r], rows[c], rhs[r], rhs[c]
+        piv = rows[c][c]
+        rows[c] = [v / piv for v in rows[c]]
+        rhs[c] = rhs[c] / piv
+        for k in range(p):
+            if k != c and rows[k][c] != 0:
+                fac = rows[k][c]
+                rows[k] = [a - fac * b for a, b in zip(rows[k], rows[c])]
+                rhs[k] = rhs[k] - fac * rhs[c]
+    return [float(v) for v in rhs]
+
+
+def _fdm_mults(grid, q):
+    c = fdm_coefs(grid, q)
+    p = len(grid)
+    return c, sum(abs(ci * g ** p) for ci, g in zip(c, grid)) / math.factorial(p), sum(abs(ci) for ci in c)
+
+
+def _fdm_step(p, q, grad_mult, err_mult, grad_magnitude, f_error, factor=1.0):
+    c1 = f_error * err_mult * factor
+    c2 = grad_magnitude * grad_mult
+    return (q / (p - q) * (c1 / c2)) ** (1.0 / p)
+
+
+def fdm_default_step(p, q, condition=10.0):
+    _, gm, em = _fdm_mults(fdm_central_grid(p), q)
+    return _fdm_step(p, q, gm, em, condition, 2.220446049250313e-16)
+
+
+def fdm_estimate_step(f, p, q, x=0.0):
+    """Step of central_fdm(p, q; adapt = 1) for f (float -> list of floats) at x."""
+    pe, qe = p + 2, p                                    # the bound estimator: central_fdm(p + 2, p), not adapted
+    ge = fdm_central_grid(pe)
+    he = min(fdm_default_step(pe, qe), 1000.0 * fdm_default_step(pe, qe))
+    vals = [list(f(x + he * g)) for g in ge]
+    grad_mag = 0.0
+    for shift in (-1, 0, 1):
+        cs = fdm_coefs([g + shift for g in ge], qe)
+        for k in range(len(vals[0])):
+            grad_mag = max(grad_mag, abs(math.fsum(c * v[k] for c, v in zip(cs, vals)) / he ** qe))
+    f_mag = max(abs(v) for row in vals for v in row)
+    _, gm, em = _fdm_mults(fdm_central_grid(p), q)
+    if grad_mag == 0.0 or f_mag == 0.0:
+        h = fdm_default_step(p, q)
+    else:
+        h = _fdm_step(p, q, gm, em, grad_mag, math.ulp(f_mag))
+    return min(h, 1000.0 * fdm_default_step(p, q))
+
+
+def fdm_apply(f, p, q, x=0.0, step=None):
+    """fdm(f, x[, step]) for central_fdm(p, q): sum_g c_g f(x + h g) / h^q, every grid point evaluated."""
+    grid = fdm_central_grid(p)
+    h = fdm_estimate_step(f, p, q, x) if step is None else step
+    c = fdm_coefs(grid, q)
+    vals = [list(f(x + h * g)) for g in grid]
+    return [math.fsum(ci * v[k] for ci, v in zip(c, vals)) / h ** q for k in range(len(vals[0]))]

@@ -91,6 +91,34 @@ class OracleBatchedProblem(OracleMuseProblem):
         cols = Hs.transpose(0, 2, 1).reshape(-1, nth)[col_begin - (s_lo - sim_begin) * nth:][: col_end - col_begin]
         return np.ascontiguousarray(cols), np.zeros((col_end - col_begin, 2), dtype=M._capi.INFO_DTYPE)
 
+    def fd_values_columns(self, rng, sim_begin, col_begin, col_end, theta0, offsets, *, per_unit=False, atol=1e-2, fid_mode=0,
+                          fid_sim=M.MASTER_SIM):
+        """The raw finite-difference values on the oracle, unit by unit: score at theta0 of the simulation drawn at
+        theta0 + offset e_j, MAP at theta0 from the fiducial MAP (src/muse.jl:426-432)."""
+        seed = rng.seed if isinstance(rng, M.SimRng) else int(rng)
+        th = np.atleast_1d(np.asarray(theta0, dtype=np.float64))
+        nth, off = th.size, np.asarray(offsets, dtype=np.float64)
+        n, G = col_end - col_begin, off.shape[1]
+        F = np.empty((n, G, nth))
+        info = np.zeros((n, G), dtype=M._capi.INFO_DTYPE)
+        zfids = {}
+        for u in range(n):
+            e = col_begin + u
+            s, j = sim_begin + e // nth, e % nth
+            fid = fid_sim if fid_mode == 0 else s
+            if fid not in zfids:
+                zfids[fid] = O.map_and_score_batch(self.model, self.N, seed, fid, fid + 1, th, atol=atol, z0_mode=0)[1][0]
+            for g in range(G):
+                t = th.copy()
+                t[j] = th[j] + off[u if per_unit else j, g]
+                x, _ = O.sample_x_z(self.model, self.N, seed, s, t)
+                zh, inf = O.zhat_at_theta(self.model, x, zfids[fid], th, atol)
+                F[u, g] = O.grad_theta(self.model, x, zh, th)
+                for k in inf:
+                    info[u, g][k] = inf[k]
+        self.fd_maps_done = getattr(self, "fd_maps_done", 0) + n * G
+        return F, info
+
     def implicit_H_columns(self, rng, sim_begin, col_begin, col_end, theta0, *, atol=1e-1, cg_maxiter=100):
         nth = np.atleast_1d(theta0).size
         s_lo, s_hi = sim_begin + col_begin // nth, sim_begin + (col_end - 1) // nth + 1

@@ -441,3 +441,69 @@ def test_multi_map_with_element_split_and_gather_padding(gpu, M):
             assert np.array_equal(info[m * nsims:(m + 1) * nsims], im)
     prob.close()
     ref.close()
+
+
+# ---- get_H! with any central_fdm(p, 1) and with FiniteDifferences' estimated step (muse_fd_values_columns) -----------
+@pytest.mark.parametrize("model,N,nth", [("funnel", 3000, 3), ("funnel", 10000, 4), ("noise", 900, 1), ("smooth", 700, 2)])
+def test_fd_values_columns_vs_oracle(gpu, M, O, model, N, nth):
+    """The raw values of get_H!'s finite-difference map for arbitrary grids: offsets shared by the simulations and one row
+    per (simulation, column) unit, a column range that begins and ends inside a simulation's Jacobian, an offset of zero,
+    both fiducial modes -- against the oracle's per-simulation operators, and the central_fdm(3,1) entry rebuilt from them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_problem import OracleBatchedProblem
+    rng = np.random.default_rng(2)
+    th0 = rng.uniform(-0.3, 0.8, size=nth)
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    orc = OracleBatchedProblem(None, model, nth, N=N, nthreads=1)
+    nsims, G, atol = 3, 5, 1e-6
+    lo, hi = 1, nsims * nth - (1 if nth > 1 else 0)
+    for fid_mode in (0, 1):
+        shared = rng.uniform(-0.05, 0.05, size=(nth, G))
+        shared[:, 2] = 0.0
+        F, info = prob.fd_values_columns(9, 4, lo, hi, th0, shared, atol=atol, fid_mode=fid_mode)
+        Fo, io = orc.fd_values_columns(9, 4, lo, hi, th0, shared, atol=atol, fid_mode=fid_mode)
+        assert F.shape == (hi - lo, G, nth) and np.array_equal(info["status"], io["status"])
+        np.testing.assert_allclose(F, Fo, rtol=1e-8, atol=1e-8 * np.abs(Fo).max())
+        per = rng.uniform(-0.05, 0.05, size=(hi - lo, G))
+        F2, _ = prob.fd_values_columns(9, 4, lo, hi, th0, per, per_unit=True, atol=atol, fid_mode=fid_mode)
+        Fo2, _ = orc.fd_values_columns(9, 4, lo, hi, th0, per, per_unit=True, atol=atol, fid_mode=fid_mode)
+        np.testing.assert_allclose(F2, Fo2, rtol=1e-8, atol=1e-8 * np.abs(Fo2).max())
+        # the explicit-step central_fdm(3,1) entry is the same map
+        step = np.full(nth, 0.03)
+        cols, _ = prob.fd_jacobian_columns(9, 4, lo, hi, th0, step, atol=atol, fid_mode=fid_mode)
+        Fpm, _ = prob.fd_values_columns(9, 4, lo, hi, th0, np.stack([step, -step], axis=1), atol=atol, fid_mode=fid_mode)
+        want = (-0.5 * Fpm[:, 1] + 0.5 * Fpm[:, 0]) / step[(lo + np.arange(hi - lo)) % nth][:, None]
+        assert np.array_equal(cols, want)
+    with pytest.raises(ValueError):
+        prob.fd_values_columns(9, 0, 0, nth, th0, np.zeros((nth + 1, 2)))
+    prob.close()
+
+
+def test_get_H_other_orders_and_estimated_step_on_hip(gpu, M, O):
+    """get_H! on HipMuseProblem with fdm = central_fdm(5,1) (explicit step) and with neither step nor result.gs (the
+    method estimates its step per simulation and column: src/muse.jl:300,411-413 on a fresh MuseResult) against the same
+    driver on the oracle; and a sharded-style column range through the driver's batched path."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_problem import OracleBatchedProblem
+    N, nth = 2000, 2
+    x, _ = O.sample_x_z("funnel", N, 4, M.DATA_SIM, np.zeros(nth))
+    th0 = np.array([0.5, -0.2])
+    hip = M.HipMuseProblem(x, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+    orc = OracleBatchedProblem(x, "funnel", nth, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+    for fdm, step, rtol in [("central_fdm(5,1)", [0.05, 0.03], 1e-7), ("central_fdm(2,1)", [0.02, 0.02], 1e-7),
+                            ("central_fdm(3,1)", None, 2e-3), ("central_fdm(5,1)", None, 2e-3)]:
+        rh, ro = M.MuseResult(theta=th0.copy()), M.MuseResult(theta=th0.copy())
+        M.get_H_(rh, hip, rng=8, nsims=3, fdm=fdm, step=step, grad_z_logLike_atol=1e-10)
+        M.get_H_(ro, orc, rng=8, nsims=3, fdm=fdm, step=step, grad_z_logLike_atol=1e-10)
+        np.testing.assert_allclose(np.array(rh.Hs), np.array(ro.Hs), rtol=rtol, atol=rtol * np.abs(np.array(ro.Hs)).max())
+    # closed form of the Gaussian model's H (estimated step, tight MAP): 1/2 e^-theta sigma^2 sum x z per block
+    r = M.MuseResult(theta=th0.copy())
+    M.get_H_(r, hip, rng=8, nsims=4, fdm="central_fdm(5,1)", grad_z_logLike_atol=1e-12)
+    for s in range(4):
+        xs, zs = hip.sample_x_z(M.SimRng(8, s), th0)
+        sig = 1 / (1 + np.exp(-th0))
+        want = [0.5 * np.exp(-th0[k]) * sig[k] ** 2 * np.sum((xs * zs)[N // 2 * k:N // 2 * (k + 1)]) for k in range(nth)]
+        np.testing.assert_allclose(np.diag(r.Hs[s]), want, rtol=1e-4)
+    hip.close()

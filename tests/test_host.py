@@ -1,5 +1,6 @@
 """Host drivers (muse_, get_J_, get_H_, finalize_result_) on CPU, driven through the oracle-backed
 problem: reference semantics of src/muse.jl restated in SURVEY.md Appendix A."""
+import math
 import os
 
 import numpy as np
@@ -292,3 +293,87 @@ def test_native_path_selection(M, O, funnel512):
     with pytest.raises(ValueError):
         M.muse(prob, [1.0], rng=0, nsims=8, maxsteps=2, native=True)
     assert M.HipMuseProblem.supports_native_muse and not getattr(M.ShardedMuseProblem, "supports_native_muse", False)
+
+
+# ---- finite-difference methods of get_H! (fdm.py against the independent restatement in muse_reference.py) ----------
+def test_fdm_coefficients_known_answers(M):
+    from museinference_jl_amd.fdm import central_fdm
+    import muse_reference as R
+    known = {(2, 1): [-0.5, 0.5], (3, 1): [-0.5, 0.0, 0.5], (3, 2): [1.0, -2.0, 1.0],
+             (5, 1): [1 / 12, -2 / 3, 0.0, 2 / 3, -1 / 12], (5, 3): [-0.5, 1.0, 0.0, -1.0, 0.5],
+             (4, 1): [1 / 12, -2 / 3, 2 / 3, -1 / 12], (7, 1): [-1 / 60, 3 / 20, -3 / 4, 0.0, 3 / 4, -3 / 20, 1 / 60]}
+    for (p, q), want in known.items():
+        m = central_fdm(p, q)
+        np.testing.assert_allclose(m.coefs, want, rtol=1e-15, atol=0)
+        assert m.grid == R.fdm_central_grid(p) and list(m.coefs) == R.fdm_coefs(m.grid, q)
+    m = central_fdm(3, 1)
+    assert m.f_error_mult == 1.0 and abs(m.grad_magnitude_mult - 1 / 6) < 1e-16
+    assert m.bound_estimator.grid == [-2, -1, 0, 1, 2] and m.bound_estimator.q == 3 and m.bound_estimator.bound_estimator is None
+    with pytest.raises(ValueError):
+        central_fdm(2, 2)
+
+
+def test_fdm_estimated_step_and_derivatives_match_the_restatement(M):
+    from museinference_jl_amd.fdm import central_fdm, as_fdm
+    import muse_reference as R
+    f = lambda t: [math.sin(3 * t) + 0.1 * t * t, math.exp(0.5 * t)]
+    for p in (2, 3, 4, 5, 7):
+        m = central_fdm(p, 1)
+        fv = lambda offs: np.array([f(0.3 + o) for o in offs])
+        h, hr = m.estimate_step(fv, 0.3), R.fdm_estimate_step(f, p, 1, 0.3)
+        assert abs(h - hr) <= 1e-6 * hr, (p, h, hr)     # (the |f^(p)| estimate is a cancelling sum: its last digits depend on the summation order)
+        assert 1e-10 < h < 1.0
+        d, dr = m(f, 0.3), R.fdm_apply(f, p, 1, 0.3)
+        np.testing.assert_allclose(d, dr, rtol=1e-9)
+        np.testing.assert_allclose(d, [3 * math.cos(0.9) + 0.06, 0.5 * math.exp(0.15)], rtol=1e-5 if p <= 3 else 1e-8)
+        np.testing.assert_allclose(m(f, 0.3, 1e-3), R.fdm_apply(f, p, 1, 0.3, 1e-3), rtol=1e-12)
+    assert as_fdm("central_fdm(5, 1)").grid == [-2, -1, 0, 1, 2]
+    # a constant function: the magnitudes vanish and the default step is taken
+    assert central_fdm(3, 1).estimate_step(lambda offs: np.zeros((len(offs), 1))) == central_fdm(3, 1).default_step()
+
+
+def test_get_H_other_orders_and_estimated_step(M, O, funnel512):
+    """get_H! with fdm = central_fdm(5,1) and an explicit step, and with NEITHER a step nor result.gs (FiniteDifferences'
+    own step estimation, src/muse.jl:300,411-413 -- a reachable reference path: get_H! on a fresh MuseResult): the batched
+    seam (every grid point of every (sim, column) unit one problem of one launch) against the element-by-element path and
+    against the independent restatement (muse_reference.fdm_apply on the oracle's per-simulation operators)."""
+    import muse_reference as R
+    from oracle_problem import OracleBatchedProblem, OracleMuseProblem
+    x, _ = O.sample_x_z("funnel", 96, 9, M.DATA_SIM, [0.0, 0.0])
+    th0, atol, nsims, seed = np.array([0.4, -0.3]), 1e-9, 2, 5
+    mk = lambda cls, **kw: cls(x, "funnel", 2, prior=M.GaussianPrior(0.0, 3.0), **kw)
+
+    def restated(p, step):
+        zfid = O.map_and_score_batch("funnel", 96, seed, M.MASTER_SIM, M.MASTER_SIM + 1, th0, atol=atol, z0_mode=0)[1][0]
+        Hs = []
+        for s in range(nsims):
+            cols = []
+            for j in range(2):
+                def f(eps):
+                    t = th0.copy()
+                    t[j] += eps
+                    xs, _ = O.sample_x_z("funnel", 96, seed, s, t)
+                    zh, _ = O.zhat_at_theta("funnel", xs, zfid, th0, atol)
+                    return list(O.grad_theta("funnel", xs, zh, th0))
+                cols.append(R.fdm_apply(f, p, 1, 0.0, None if step is None else step[j]))
+            Hs.append(np.array(cols).T)
+        return np.array(Hs)
+
+    for p, step in [(5, np.array([0.05, 0.02])), (3, None), (5, None), (2, np.array([0.01, 0.01]))]:
+        res = {}
+        for name, prob in (("batched", mk(OracleBatchedProblem, nthreads=1)), ("serial", mk(OracleMuseProblem, batched=False))):
+            r = M.MuseResult(theta=th0.copy())
+            M.get_H_(r, prob, rng=seed, nsims=nsims, fdm=f"central_fdm({p},1)", step=step, grad_z_logLike_atol=atol)
+            res[name] = np.array(r.Hs)
+        want = restated(p, step)
+        np.testing.assert_allclose(res["batched"], want, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(res["serial"], want, rtol=1e-9, atol=1e-9)
+    # closed form: H_sim = 1/2 e^-theta sigma(theta)^2 sum x z per block (Gaussian model), the estimated step is accurate enough
+    r = M.MuseResult(theta=th0.copy())
+    M.get_H_(r, mk(OracleBatchedProblem, nthreads=1), rng=seed, nsims=1, fdm="central_fdm(5,1)", grad_z_logLike_atol=1e-12)
+    xs, zs = O.sample_x_z("funnel", 96, seed, 0, th0)
+    sig = 1 / (1 + np.exp(-th0))
+    want = [0.5 * np.exp(-th0[k]) * sig[k] ** 2 * np.sum((xs * zs)[48 * k:48 * (k + 1)]) for k in range(2)]
+    np.testing.assert_allclose(np.diag(r.Hs[0]), want, rtol=1e-5)
+    with pytest.raises(ValueError):
+        M.get_H_(M.MuseResult(theta=th0.copy()), mk(OracleBatchedProblem), rng=seed, nsims=1, fdm="central_fdm(3,2)")

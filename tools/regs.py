@@ -28,7 +28,7 @@ HOT = [
     ("FunnelModel<4>, PlaceResident<512, 3, false, true>", 16),
     ("FunnelModel<8>, PlaceResident<512, 10, true>", 16),
     ("FunnelModel<1>, PlaceResident<512, 3, false, true>", 6),
-    ("NoiseModel, PlaceStreaming<256, true>", 8),   # the background generator's sums across a pass: once per pass, not per trip
+    ("NoiseModel, PlaceStreaming<256, true>", 12),   # the background generator's sums across a pass: once per pass, not per trip
     ("SmoothModel<8>, PlaceStreaming<256, true, 2, true, true>", 0),   # configs[4]: clusters with the direction in LDS
 ]
 
