@@ -209,11 +209,47 @@ function get_J!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=res
     finalize_result!(result, prob)
 end
 
+# Several independent maps (one θ each) in ONE launch: muse_map_and_score_multi_async -- what keeps a GPU full when one
+# map's share of the sims is smaller than the GPU (bench.py --gpus N).  thetas: nθ × nmaps.
+function map_and_score_multi(prob::HipMuseProblem, seed::Integer, sims::UnitRange, thetas::AbstractMatrix;
+                             include_data=false, atol=1e-2, z0_mode=0, area=0)
+    nmaps = size(thetas, 2)
+    n = length(sims) + (include_data ? 1 : 0)
+    check(ccall((:muse_map_and_score_multi_async, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Cint, Cint, Ptr{Float64}, Float64, Cint, Cint),
+                prob.ctx, seed, first(sims), last(sims) + 1, include_data, nmaps, Matrix{Float64}(thetas), atol, z0_mode, area))
+    g = Array{Float64}(undef, prob.nθ, n, nmaps)                  # column-major [nθ, element, map] = C's [map][element][nθ]
+    check(ccall((:muse_batch_wait, libmuse_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Cvoid}), prob.ctx, area, g, C_NULL))
+    g
+end
+
+# The values fdm(f, 0[, step]) asks for in pjacobian (src/util.jl:9-27), every grid point of every (sim, column) unit one
+# problem of one launch: offsets is G × nθ (one column of offsets per θ component, shared by the sims).
+function fd_values(prob::HipMuseProblem, seed::Integer, nsims::Integer, θ₀, offsets::AbstractMatrix; atol=1e-2)
+    G = size(offsets, 1)
+    F = Array{Float64}(undef, prob.nθ, G, prob.nθ, nsims)         # [i, grid point, column j, sim]
+    check(ccall((:muse_fd_values_columns, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Float64, Cint, Int64, Ptr{Float64}, Ptr{Cvoid}),
+                prob.ctx, seed, 0, 0, nsims * prob.nθ, θ₀, G, Matrix{Float64}(offsets), 0, atol, 0, (1 << 62) - 1, F, C_NULL))
+    F
+end
+
 function get_H!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=result.rng, nsims=10, step=nothing,
-                ∇z_logLike_atol=1e-2, kwargs...)
+                fdm=central_fdm(3,1), ∇z_logLike_atol=1e-2, kwargs...)
     θ₀ = standardizeθ(prob, something(θ₀, result.θ))
     remaining = nsims - length(result.Hs)
     remaining <= 0 && return
+    if !(step === nothing && isempty(result.gs)) && fdm.grid != [-1, 0, 1]
+        # another central_fdm(p, 1) with an explicit step: its non-zero-coefficient grid points through fd_values
+        step = collect(Float64, something(step, 0.1 ./ std(result.gs)))
+        nz = findall(!iszero, fdm.coefs)
+        F = fd_values(prob, UInt64(rng), remaining, θ₀, [fdm.grid[g] * step[j] for g in nz, j in 1:prob.nθ]; atol=∇z_logLike_atol)
+        append!(result.Hs, [hcat((sum(fdm.coefs[nz[g]] .* F[:, g, j, s] for g in eachindex(nz)) ./ step[j] for j in 1:prob.nθ)...) for s in 1:remaining])
+        result.H = mean(result.Hs)
+        return finalize_result!(result, prob)
+    end
+    # (neither step nor result.gs: FiniteDifferences estimates the step per call; the Python host does that through the same
+    #  entry point with offsets per (sim, column) unit -- museinference.jl_amd/fdm.py, muse.py:_fd_batched)
     step = something(step, 0.1 ./ std(result.gs))         # src/muse.jl:411-413
     Hs = Array{Float64}(undef, prob.nθ, prob.nθ, remaining)
     check(ccall((:muse_fd_jacobian_batch, libmuse_hip), Cint,
