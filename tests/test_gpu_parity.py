@@ -258,6 +258,7 @@ def test_fuzz_offpath_cases(gpu, M, O):
     MAPs agree to the solve's own tolerance, |dz|_inf <= 2 atol / lambda_min (lambda_min = e^-max(theta): the stencil's
     A^T A is singular at the Nyquist mode), the scores to the bound that implies."""
     import json
+    import os
     cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_offpath.json")))["cases"]
     assert len(cases) == 64
     worst = 0.0
