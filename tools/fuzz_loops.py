@@ -1,0 +1,76 @@
+"""Randomized checks of the round-3 paths on a GPU (development aid; the committed tests hold fixed cases):
+  * muse_run_device against muse_run: the same number of iterations and the same bits (history, scores, infos, theta);
+  * several maps in one launch against separate launches (bitwise);
+  * muse_fd_values_columns against the oracle's per-simulation operators (rtol 1e-7).
+Usage: python tools/fuzz_loops.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import museinference_jl_amd as M
+from oracle import oracle as O
+from oracle_problem import OracleBatchedProblem
+O.build()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+n = {"loop": 0, "multi": 0, "fd": 0}
+bad = 0
+while time.time() - t0 < budget:
+    model = str(rng.choice(["funnel", "noise", "smooth"]))
+    N = int(rng.choice([int(rng.integers(8, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)), int(rng.integers(10000, 30000))]))
+    nth = 1 if model == "noise" else min(N, int(rng.choice([1, 2, 3, 4, 8])))
+    seed = int(rng.integers(1, 2**40))
+    kind = str(rng.choice(["loop", "multi", "fd"]))
+    x = rng.standard_normal(N) * 1.3
+    prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0) if rng.random() < 0.7 else None)
+    ok, why = True, ""
+    try:
+        if kind == "loop":
+            nsims = int(rng.integers(2, 200)) if N < 5000 else int(rng.integers(2, 64))
+            th0 = rng.uniform(-0.5, 1.5, size=nth)
+            kw = dict(nsims=nsims, maxsteps=int(rng.integers(1, 12)), theta_rtol=float(rng.choice([0.0, 1e-2, 1e-1, 1.0])),
+                      atol=float(rng.choice([1e-2, 1e-4])), alpha=float(rng.uniform(0.3, 1.0)), z0_warm=bool(rng.random() < 0.2))
+            a = prob.run_muse(seed, th0, device_loop=False, **kw)
+            b = prob.run_muse(seed, th0, device_loop=True, **kw)
+            ok = (a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2][:, :-1], b[2][:, :-1], equal_nan=True)
+                  and np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[4], b[4]))
+            why = f"{kw} n {a[0]} {b[0]}"
+        elif kind == "multi":
+            nmaps, nsims, incl = int(rng.integers(2, 9)), int(rng.integers(1, 40)) if N < 20000 else 3, bool(rng.random() < 0.5)
+            split = int(rng.choice([0, 0, 2, 4]))
+            if split and N > 512:
+                prob.set_element_split(split)
+            thetas = rng.uniform(-1.0, 2.0, size=(nmaps, nth))
+            atol, z0 = float(rng.choice([1e-2, 1e-5])), int(rng.choice([0, 1]))
+            tot = prob.map_and_score_multi_async(seed, 3, 3 + nsims, thetas, include_data=incl, atol=atol, z0_mode=z0, result_area=1)
+            g, info = prob.batch_wait(tot, 1)
+            per = tot // nmaps
+            for m in range(nmaps):
+                gm, im = prob.map_and_score_batch(seed, 3, 3 + nsims, thetas[m], include_data=incl, atol=atol, z0_mode=z0)
+                ok = ok and np.array_equal(g[m * per:(m + 1) * per], gm, equal_nan=True) and np.array_equal(info[m * per:(m + 1) * per], im)
+            why = f"nmaps {nmaps} nsims {nsims} data {incl} split {split}"
+        else:
+            if N > 3000:
+                prob.close()
+                continue
+            G, nsims = int(rng.integers(1, 7)), int(rng.integers(1, 4))
+            th0 = rng.uniform(-0.3, 1.0, size=nth)
+            lo = int(rng.integers(0, nth))
+            hi = int(rng.integers(lo + 1, nsims * nth + 1))
+            per_unit = bool(rng.random() < 0.5)
+            off = rng.uniform(-0.05, 0.05, size=((hi - lo) if per_unit else nth, G))
+            fid = int(rng.choice([0, 1]))
+            F, info = prob.fd_values_columns(seed, 2, lo, hi, th0, off, per_unit=per_unit, atol=1e-6, fid_mode=fid)
+            orc = OracleBatchedProblem(x, model, nth, nthreads=1)
+            Fo, io = orc.fd_values_columns(seed, 2, lo, hi, th0, off, per_unit=per_unit, atol=1e-6, fid_mode=fid)
+            ok = np.allclose(F, Fo, rtol=1e-7, atol=1e-7 * max(1.0, np.abs(Fo).max())) and np.array_equal(info["status"], io["status"])
+            why = f"G {G} cols [{lo},{hi}) per_unit {per_unit} fid {fid} maxdiff {np.abs(F - Fo).max():.2e}"
+    except M.MuseError as e:
+        ok, why = False, f"MuseError {e}"
+    n[kind] += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH", kind, model, N, nth, seed, why, flush=True)
+    prob.close()
+print(f"{n} cases, {bad} mismatches in {time.time() - t0:.0f} s")
