@@ -90,3 +90,76 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert np.array_equal(got[r]["theta2"], r2.theta)
         assert np.array_equal(got[r]["zdat"], r2.history[-1]["ẑ_dat"])
         assert np.array_equal(got[r]["zsims"], np.array(r2.history[-1]["ẑ_sims"]))
+
+
+FALLBACK_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch.distributed as dist
+import museinference_jl_amd as M
+from oracle import oracle as O
+from oracle_problem import OracleBatchedProblem
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+
+class FlakyEngineProblem(OracleBatchedProblem):
+    # a local problem that HAS an engine communicator, which comes up on rank 0 and fails on rank 1
+    log = []
+
+    @staticmethod
+    def comm_unique_id(transport="rccl", block_doubles=0):
+        return bytes(128)
+
+    def comm_init(self, nranks, rank_, uid):
+        self.log.append(("init", rank_))
+        if rank_ == 1:
+            raise RuntimeError("segment not visible on this rank")
+        self._nranks = nranks
+
+    def comm_destroy(self):
+        self.log.append(("destroy",))
+        self._nranks = None
+
+    def allgather_scores(self, send):
+        raise AssertionError("the engine communicator must not be used after the ranks agreed it failed")
+
+
+x, _ = O.sample_x_z("funnel", 128, 5, M.DATA_SIM, [0.0])
+local = FlakyEngineProblem(x, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+prob = M.ShardedMuseProblem(local)          # candidates: shm (the ranks share this node); it fails on rank 1 -> all fall back
+assert prob.engine_comm is False and prob.transport is None, (prob.engine_comm, prob.transport)
+assert ("destroy",) in local.log if rank == 0 else ("destroy",) not in local.log     # rank 0 gave its communicator back
+g, info = prob.map_and_score_batch(3, 0, 7, [0.4], include_data=True)              # torch.distributed collectives
+try:
+    M.ShardedMuseProblem(FlakyEngineProblem(x, "funnel", 1, nthreads=1), engine_comm=True, transport="shm")
+    raise SystemExit("an explicitly requested transport that fails must raise on every rank")
+except RuntimeError as e:
+    assert "could not be initialised" in str(e)
+with open({out!r} + str(rank), "wb") as f:
+    pickle.dump(dict(g=g), f)
+dist.destroy_process_group()
+"""
+
+
+def test_engine_transport_failure_is_a_collective_decision(tmp_path):
+    """a transport that fails to come up on ONE rank (a /dev/shm the rank cannot see, a communicator that times
+    out) must not leave the other ranks waiting or the run dead: every rank reports, all of them give the transport up
+    together and move on (here: to torch.distributed collectives), and the sharded map still equals the single-process one."""
+    import museinference_jl_amd as M
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_problem import OracleBatchedProblem
+    out = str(tmp_path / "res")
+    port = 31500 + os.getpid() % 2000
+    script = tmp_path / "worker.py"
+    script.write_text(FALLBACK_WORKER.format(root=ROOT, port=port, out=out))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                                                     OMP_NUM_THREADS="1")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    x, _ = O.sample_x_z("funnel", 128, 5, M.DATA_SIM, [0.0])
+    single = OracleBatchedProblem(x, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+    gref, _ = single.map_and_score_batch(3, 0, 7, [0.4], include_data=True)
+    for r in range(2):
+        assert np.array_equal(pickle.load(open(out + str(r), "rb"))["g"], gref)
