@@ -416,6 +416,10 @@ def main():
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=local_rank)
     if args.placement >= 0:
         prob.set_placement(args.placement)
+    # consecutive steps on alternating lanes (streams): a launch starts on the compute units the previous one has left
+    lanes = int(os.environ.get("MUSE_BENCH_LANES", "1"))
+    if lanes > 1:
+        prob.set_concurrency(lanes)
     scaling = args.scaling or ("strong" if world > 1 else "weak")
     if scaling == "strong":
         # the step's nsims sims are shared by the ranks: contiguous blocks (the reference's pmap over a worker pool
@@ -631,109 +635,136 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    measured = {t: measure(t) for t in transports}
-    ran = {t: m for t, m in measured.items() if "skipped" not in m}
-    if not ran:
-        raise SystemExit(f"no transport could run: {measured}")
-    best_t = max(ran, key=lambda t: ran[t]["value"])
-    best = ran[best_t]
-    dt, rounds, host_us, kernel_ms, info, split, collective, pinfo = (best[k] for k in (
-        "dt", "rounds", "host_us", "kernel_ms", "info", "split", "collective", "pinfo"))
+    def build_line(measured):
+        """The result line from what has been measured (all transports, or -- from the watchdog -- the ones that finished)."""
+        ran = {t: m for t, m in measured.items() if "skipped" not in m}
+        if not ran:
+            raise SystemExit(f"no transport could run: {measured}")
+        best_t = max(ran, key=lambda t: ran[t]["value"])
+        best = ran[best_t]
+        dt, rounds, host_us, kernel_ms, info, split, collective, pinfo = (best[k] for k in (
+            "dt", "rounds", "host_us", "kernel_ms", "info", "split", "collective", "pinfo"))
 
-    mean_kernel_s = float(kernel_ms.mean()) * 1e-3
-    placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
-                                                      if model == "smooth" else "streaming")
-    comp_bytes = compulsory_bytes(info, N, placement)
-    prow, why = profile_row(args.workload) if (world == 1 and split == 1) else (None, "profiles/ hold the 1-GPU, unsplit launch")
-    traffic = measured_traffic(args.workload) if prow is not None else None
-    hbm = {"bound": "hbm", "achieved": comp_bytes / mean_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": comp_bytes / mean_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-           "compulsory_bytes_per_launch": comp_bytes,
-           "traffic_GBps": None if traffic is None else traffic / mean_kernel_s / 1e9}
-    # The kernel time a fraction is quoted against: the event pair around a launch costs the kernel ~3 us (it cannot overlap
-    # the next launch's start), so a launch cannot have taken longer than the pipelined step it is part of.
-    launch_s = min(mean_kernel_s, dt / best["launches"]) if world == 1 else mean_kernel_s
-    clock_hz = best["clock_hz"] or CLOCK_HZ
-    valu = None
-    if placement == "resident":
-        alg_cycles, alg_fp64 = algorithmic_valu(info, N, clock_hz)
-        alg = {"fp64_ops_per_launch": alg_fp64, "issue_cycles_per_launch": alg_cycles,
-               "frac_of_issue_peak": alg_cycles / (N_SIMD * launch_s * clock_hz),
-               "fp64_TFLOPs_fma_equiv": 2.0 * alg_fp64 / launch_s / 1e12,
-               "ops_per_element": ALG_OPS, "issue_cycles_per_wave_instruction": ISSUE_CYCLES,
-               "note": "work / peak: operation counts per element from the source (bench.py: ALG_OPS) x the measured issue cost "
-                       "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
-                       "many instructions the compiled kernel spends on them"}
-        valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,
-                "clock_hz": clock_hz, "clock_source": "in-kernel s_memtime / s_memrealtime" if best["clock_hz"] else "assumed",
-                "launch_s_used": launch_s}
-        if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
-            # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
-            # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
-            # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
-            busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
-            valu["utilisation"] = {"valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
-                                   "frac": busy / (N_SIMD * launch_s * clock_hz),
-                                   "note": "VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (1024 SIMDs x launch "
-                                           "time x measured clock): how busy the kernel's OWN instruction stream keeps the SIMDs "
-                                           "(round 2 quoted this figure, against an assumed 2.4 GHz, as the roofline fraction)"}
-    primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
-    primary.update({
-        "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
-        "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
-        "algorithmic_bytes_d3": algorithmic_bytes(info, N),
-        "hbm": hbm, "valu": valu,
-        "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
-        "profile_note": why,
-        "note": ("resident placement: z, s, x, g never leave registers/LDS, the HBM leg only carries zhat out (and the "
-                 "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes). "
-                 "frac = algorithmic work / issue peak (valu.algorithmic); valu.utilisation is how busy the compiled kernel keeps "
-                 "the SIMDs.  BASELINE.json's '>= 40 % of the HBM roofline' can be neither met nor missed by this placement: it "
-                 "moves 1 word per element where SURVEY 8.d3's accounting assumes 22 (hbm.frac is that one word / 8 TB/s)"
-                 if placement == "resident" else
-                 "streaming placement: achieved = compulsory bytes of the passes the solves made / kernel time"),
-        "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
-                    "hist_pairs_mean": float(info["hist_words"].mean())},
-    })
+        mean_kernel_s = float(kernel_ms.mean()) * 1e-3
+        placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
+                                                          if model == "smooth" else "streaming")
+        comp_bytes = compulsory_bytes(info, N, placement)
+        prow, why = profile_row(args.workload) if (world == 1 and split == 1) else (None, "profiles/ hold the 1-GPU, unsplit launch")
+        traffic = measured_traffic(args.workload) if prow is not None else None
+        hbm = {"bound": "hbm", "achieved": comp_bytes / mean_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": comp_bytes / mean_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+               "compulsory_bytes_per_launch": comp_bytes,
+               "traffic_GBps": None if traffic is None else traffic / mean_kernel_s / 1e9}
+        # The kernel time a fraction is quoted against: the event pair around a launch costs the kernel ~3 us (it cannot overlap
+        # the next launch's start), so a launch cannot have taken longer than the pipelined step it is part of.
+        launch_s = min(mean_kernel_s, dt / best["launches"]) if world == 1 else mean_kernel_s
+        clock_hz = best["clock_hz"] or CLOCK_HZ
+        valu = None
+        if placement == "resident":
+            alg_cycles, alg_fp64 = algorithmic_valu(info, N, clock_hz)
+            alg = {"fp64_ops_per_launch": alg_fp64, "issue_cycles_per_launch": alg_cycles,
+                   "frac_of_issue_peak": alg_cycles / (N_SIMD * launch_s * clock_hz),
+                   "fp64_TFLOPs_fma_equiv": 2.0 * alg_fp64 / launch_s / 1e12,
+                   "ops_per_element": ALG_OPS, "issue_cycles_per_wave_instruction": ISSUE_CYCLES,
+                   "note": "work / peak: operation counts per element from the source (bench.py: ALG_OPS) x the measured issue cost "
+                           "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
+                           "many instructions the compiled kernel spends on them"}
+            valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,
+                    "clock_hz": clock_hz, "clock_source": "in-kernel s_memtime / s_memrealtime" if best["clock_hz"] else "assumed",
+                    "launch_s_used": launch_s}
+            if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
+                # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
+                # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
+                # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
+                busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
+                valu["utilisation"] = {"valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
+                                       "frac": busy / (N_SIMD * launch_s * clock_hz),
+                                       "note": "VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (1024 SIMDs x launch "
+                                               "time x measured clock): how busy the kernel's OWN instruction stream keeps the SIMDs "
+                                               "(round 2 quoted this figure, against an assumed 2.4 GHz, as the roofline fraction)"}
+        primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
+        primary.update({
+            "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
+            "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
+            "algorithmic_bytes_d3": algorithmic_bytes(info, N),
+            "hbm": hbm, "valu": valu,
+            "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
+            "profile_note": why,
+            "note": ("resident placement: z, s, x, g never leave registers/LDS, the HBM leg only carries zhat out (and the "
+                     "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes). "
+                     "frac = algorithmic work / issue peak (valu.algorithmic); valu.utilisation is how busy the compiled kernel keeps "
+                     "the SIMDs.  BASELINE.json's '>= 40 % of the HBM roofline' can be neither met nor missed by this placement: it "
+                     "moves 1 word per element where SURVEY 8.d3's accounting assumes 22 (hbm.frac is that one word / 8 TB/s)"
+                     if placement == "resident" else
+                     "streaming placement: achieved = compulsory bytes of the passes the solves made / kernel time"),
+            "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
+                        "hist_pairs_mean": float(info["hist_words"].mean())},
+        })
 
-    out = {
-        "metric": "MC sims/sec (MAP+score)",
-        "value": total_sims * args.steps / dt,
-        "unit": "sims/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True,
-        "scaling": scaling,
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload}: Neal's funnel family model={model}, N={N}-dim z, {nth}-dim theta, "
-                               f"nsims={total_sims} per step ({nlocal} on this rank), cold start z0=0, atol=1e-2",
-                   "theta": theta, "sims_per_step_total": total_sims, "element_split": split,
-                   "pipelining": f"maps_per_launch={best['maps_per_launch']}: that many consecutive (independent) steps share one "
-                                 "launch and one exchange",
-                   "parallelism": f"sims sharded over {world} GPU(s) ({scaling} scaling), one all-gather of scores per step"
-                                  + (f" ({collective})" if collective else "")},
-        "timed_rounds": len(rounds), "timed_seconds": sum(rounds),
-        "ms_per_step_min_round": 1e3 * min(rounds) / args.steps, "ms_per_step_max_round": 1e3 * max(rounds) / args.steps,
-        "roofline": primary,
-        "kernel_sims_per_s": nlocal * best["maps_per_launch"] / mean_kernel_s,
-        "host_us_per_step": host_us,
-    }
-    if sharded:
-        # both exchanges of the same run, side by side: did RCCL see N ranks, and what did each cost
-        out["transport"] = best_t
-        out["transports"] = {
-            t: (m if "skipped" in m else
-                {"value": m["value"], "ms_per_step": 1e3 * m["dt"] / args.steps, "collective": m["collective"],
-                 "ranks_seen": m["ranks_seen"], "element_split": m["split"],
-                 "pipelining": f"maps_per_launch={m['maps_per_launch']}",
-                 "kernel_ms_mean": float(m["kernel_ms"].mean()), "host_us_per_step": m["host_us"],
-                 "timed_rounds": len(m["rounds"])})
-            for t, m in measured.items()}
+        out = {
+            "metric": "MC sims/sec (MAP+score)",
+            "value": total_sims * args.steps / dt,
+            "unit": "sims/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": scaling,
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: Neal's funnel family model={model}, N={N}-dim z, {nth}-dim theta, "
+                                   f"nsims={total_sims} per step ({nlocal} on this rank), cold start z0=0, atol=1e-2",
+                       "theta": theta, "sims_per_step_total": total_sims, "element_split": split,
+                       "pipelining": f"maps_per_launch={best['maps_per_launch']}: that many consecutive (independent) steps share one "
+                                     "launch and one exchange",
+                       "parallelism": f"sims sharded over {world} GPU(s) ({scaling} scaling), one all-gather of scores per step"
+                                      + (f" ({collective})" if collective else "")},
+            "timed_rounds": len(rounds), "timed_seconds": sum(rounds),
+            "ms_per_step_min_round": 1e3 * min(rounds) / args.steps, "ms_per_step_max_round": 1e3 * max(rounds) / args.steps,
+            "roofline": primary,
+            "kernel_sims_per_s": nlocal * best["maps_per_launch"] / mean_kernel_s,
+            "host_us_per_step": host_us,
+        }
+        if sharded:
+            # both exchanges of the same run, side by side: did RCCL see N ranks, and what did each cost
+            out["transport"] = best_t
+            out["transports"] = {
+                t: (m if "skipped" in m else
+                    {"value": m["value"], "ms_per_step": 1e3 * m["dt"] / args.steps, "collective": m["collective"],
+                     "ranks_seen": m["ranks_seen"], "element_split": m["split"],
+                     "pipelining": f"maps_per_launch={m['maps_per_launch']}",
+                     "kernel_ms_mean": float(m["kernel_ms"].mean()), "host_us_per_step": m["host_us"],
+                     "timed_rounds": len(m["rounds"])})
+                for t, m in measured.items()}
+        return out
+
+    # A transport whose collective never completes (RCCL over a broken link, a peer that died) must not cost the line: every
+    # rank arms a watchdog for the transports after the first; when it fires, rank 0 prints the line of what finished -- the
+    # hung transport marked failed -- and every rank leaves (os._exit: the main thread is inside a C call).
+    import threading
+    measured = {}
+    deadline = float(os.environ.get("MUSE_BENCH_TRANSPORT_DEADLINE_S", "240"))
+    for idx, t in enumerate(transports):
+        timer = None
+        if idx > 0:
+            def fire(t=t):
+                print(f"[bench rank {rank}] transport {t} did not finish within {deadline:.0f} s: reporting without it", file=sys.stderr)
+                if rank == 0:
+                    line = build_line(dict(measured, **{t: {"skipped": f"did not finish within {deadline:.0f} s (watchdog)"}}))
+                    sys.stdout.write(json.dumps(line) + "\n")
+                    sys.stdout.flush()
+                os._exit(0)
+            timer = threading.Timer(deadline, fire)
+            timer.daemon = True
+            timer.start()
+        measured[t] = measure(t)
+        if timer is not None:
+            timer.cancel()
+    out = build_line(measured)
+    best_t = out.get("transport")
     if rank == 0 and world == 1 and not sharded and not args.no_extra:
         out["extra"] = extra_rates(M, prob, model, N, nth, theta, nsims, seed, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -112,6 +112,13 @@ int muse_set_element_split(muse_ctx* ctx, int split);
  * and -- stencil model in a cluster -- whether the search direction is kept in LDS.  For reports (bench.py's roofline
  * accounts the bytes of the placement that ran); any pointer may be NULL. */
 int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element, int* resident, int* direction_in_lds);
+/* Concurrency of the batched maps: with n > 1 result area r runs on lane r mod n -- a stream, a workgroup scratch, a
+ * ticket counter and a cluster state of its own -- so that consecutive launches (enqueued on different result areas) overlap:
+ * a launch starts on the compute units the previous one has already left instead of behind its last workgroup and a
+ * launch gap.  Results are unchanged.  Maps in flight at once share the resident zhat slots, so a map that warm-starts
+ * (MUSE_Z0_WARM), the muse_run loops, the finite-difference / implicit maps and the RCCL gather stay on lane 0.  n in
+ * [1, 4]; 1 (default) = one launch after the other. */
+int muse_set_concurrency(muse_ctx* ctx, int nlanes);
 int muse_synchronize(muse_ctx* ctx);
 /* Device time in ms of the most recent solver launch (HIP events on the context's stream), recorded only
  * after muse_set_timing(ctx, 1): the event pair costs about 12 us of host time per launch (default: off). */

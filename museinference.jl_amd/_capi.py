@@ -57,6 +57,7 @@ SIGNATURES = {
     "muse_max_resident_n": (_i64, []),
     "muse_set_element_split": (_i, [_vp, _i]),
     "muse_placement_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "muse_set_concurrency": (_i, [_vp, _i]),
     "muse_synchronize": (_i, [_vp]),
     "muse_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "muse_set_timing": (_i, [_vp, _i]),

@@ -42,7 +42,29 @@ static int fail(int code, const std::string& msg) {
             return fail(MUSE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
+// What a solver launch owns exclusively while it runs.  A context has one set of these per LANE; the lane a call uses is
+// swapped into the context's own fields of the same names (use_lane), so that the launch code below is written once.
+// One lane (the default): launches of a context run one after the other on its stream.  muse_set_concurrency(ctx, n):
+// result area r runs on lane r mod n -- a stream, a workgroup scratch, a ticket counter and a cluster state of its own --
+// so that a launch can start on the compute units the previous one has already left, instead of behind its last workgroup
+// and a launch gap.
+constexpr int kMaxLanes = 4;
+struct LaneState {
+    hipStream_t stream = nullptr;
+    double* scratch = nullptr;
+    size_t scratch_doubles = 0;
+    int* counter = nullptr;
+    unsigned int ticket_base = 0;
+    double* cl_part = nullptr;
+    unsigned int* cl_state = nullptr;
+    int cl_cap = 0;
+    int* error_flag = nullptr;
+    bool ready = false;
+};
+
 struct muse_ctx {
+    LaneState lanes[kMaxLanes];   // lanes[cur_lane] is stale while that lane is swapped in
+    int nlanes = 1, cur_lane = 0;
     int model = 0, ntheta = 1, device = 0, placement = -1, num_cus = 0;
     int64_t N = 0, ld = 0;
     int64_t bnd[kMaxTheta + 1] = {0};
@@ -178,6 +200,8 @@ static int ensure_zhat(muse_ctx* c, int64_t slots) {
         return fail(MUSE_ERR_ALLOC, "hipMalloc(zhat) failed");
     HIPCHK(hipMemsetAsync(nz, 0, (size_t)slots * c->ld * sizeof(double), c->stream));
     if (c->zhat) {
+        for (int l = 0; l < kMaxLanes; ++l)   // launches of other lanes may still be writing the old slots
+            if (l != c->cur_lane && c->lanes[l].ready) HIPCHK(hipStreamSynchronize(c->lanes[l].stream));
         HIPCHK(hipMemcpyAsync(nz, c->zhat, (size_t)c->zhat_slots * c->ld * sizeof(double), hipMemcpyDeviceToDevice,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -268,6 +292,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     // its kernel holds compute units on a high-priority stream until the slowest peer arrives) keeps a share of the GPU
     if (place_is_cluster(pl) && c->comm_reserve_cus > 0 && c->num_cus > 2 * c->comm_reserve_cus)
         grid = (c->num_cus - c->comm_reserve_cus) * place_wgs_per_cu(pl);
+    if (place_is_cluster(pl) && c->nlanes > 1) grid /= c->nlanes;   // ... and so do the launches of the other lanes
     a.nclusters = 0;
     if (place_is_cluster(pl)) {
         // every workgroup of a cluster must be resident at once (they wait for each other): the grid is sized from
@@ -343,6 +368,41 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         c->ev_valid = true;
     }
     return MUSE_OK;
+}
+
+// Swap lane `l` into the context's launch-state fields (and the current one back into its slot); a lane's stream, ticket
+// counter and error word are created on first use.
+static int use_lane(muse_ctx* c, int l) {
+    if (l == c->cur_lane) return MUSE_OK;
+    LaneState& out = c->lanes[c->cur_lane];
+    out.stream = c->stream; out.scratch = c->scratch; out.scratch_doubles = c->scratch_doubles; out.counter = c->counter;
+    out.ticket_base = c->ticket_base; out.cl_part = c->cl_part; out.cl_state = c->cl_state; out.cl_cap = c->cl_cap;
+    out.error_flag = c->error_flag; out.ready = true;
+    LaneState& in = c->lanes[l];
+    if (!in.ready) {
+        HIPCHK(hipStreamCreateWithFlags(&in.stream, hipStreamNonBlocking));
+        HIPCHK(hipMalloc(&in.counter, 16));
+        HIPCHK(hipMemset(in.counter, 0, 16));
+        HIPCHK(hipHostMalloc(&in.error_flag, 64, hipHostMallocDefault));
+        in.error_flag[0] = in.error_flag[1] = 0;
+        in.ready = true;
+    }
+    c->stream = in.stream; c->scratch = in.scratch; c->scratch_doubles = in.scratch_doubles; c->counter = in.counter;
+    c->ticket_base = in.ticket_base; c->cl_part = in.cl_part; c->cl_state = in.cl_state; c->cl_cap = in.cl_cap;
+    c->error_flag = in.error_flag;
+    c->cur_lane = l;
+    return MUSE_OK;
+}
+template <class F>
+static int for_each_lane(muse_ctx* c, F&& f) {   // f() with every lane that exists swapped in; lane 0 afterwards
+    int rc = MUSE_OK;
+    for (int l = 0; l < kMaxLanes && rc == MUSE_OK; ++l) {
+        if (l != c->cur_lane && !c->lanes[l].ready) continue;
+        rc = use_lane(c, l);
+        if (rc == MUSE_OK) rc = f();
+    }
+    const int rc0 = use_lane(c, 0);
+    return rc ? rc : rc0;
 }
 
 extern "C" {
@@ -437,7 +497,13 @@ int muse_ctx_comm_buffer(muse_ctx* c, size_t doubles, double** buf) {
 int muse_ctx_destroy(muse_ctx* c) {
     if (!c) return MUSE_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)for_each_lane(c, [&]() { hipStreamSynchronize(c->stream); return MUSE_OK; });
+    for (int l = 1; l < kMaxLanes; ++l) {   // lane 0's resources are the context's own fields now (freed below)
+        LaneState& ln = c->lanes[l];
+        if (!ln.ready) continue;
+        hipFree(ln.scratch); hipFree(ln.counter); hipFree(ln.cl_part); hipFree(ln.cl_state); hipHostFree(ln.error_flag);
+        hipStreamDestroy(ln.stream);
+    }
     muse_comm_destroy(c);
     free_run_buffers(c);
     hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag); hipHostFree(c->clock_pin);
@@ -459,7 +525,7 @@ int muse_ctx_destroy(muse_ctx* c) {
 static int check_ctx(muse_ctx* c) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    return MUSE_OK;
+    return use_lane(c, 0);   // every entry point works on lane 0 unless it says otherwise (map_async_impl)
 }
 static hipMemcpyKind in_kind(int mem) { return mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; }
 static hipMemcpyKind out_kind(int mem) { return mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost; }
@@ -504,23 +570,27 @@ int muse_set_element_split(muse_ctx* c, int split) {
 // 32-bit wrap), and mark every result area whose launch was in flight as failed -- each of their waits reports the error
 // once -- before the flag is cleared.
 static int check_error_flag(muse_ctx* c) {
-    if (*c->error_flag) {
+    bool any = *c->error_flag != 0;
+    for (int l = 0; l < kMaxLanes; ++l)
+        if (l != c->cur_lane && c->lanes[l].ready && c->lanes[l].error_flag[0]) any = true;
+    if (!any) return MUSE_OK;
+    (void)for_each_lane(c, [&]() -> int {
         (void)hipStreamSynchronize(c->stream);
         if (c->cl_part && c->cl_cap > 0) {
             (void)hipMemsetAsync(c->cl_part, 0, (size_t)c->cl_cap * kClusterSlotDoubles * sizeof(double), c->stream);
             (void)hipMemsetAsync(c->cl_state, 0, (size_t)c->cl_cap * sizeof(unsigned int), c->stream);
             (void)hipStreamSynchronize(c->stream);
         }
-        for (int r = 0; r < kResultAreas; ++r) {
-            if (c->area_inflight[r]) c->area_failed[r] = true;
-            c->area_inflight[r] = false;
-        }
         c->error_flag[1] = 0;
-        *c->error_flag = 0;
-        return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident); "
-                                  "the cluster state was reset, result areas in flight are marked failed");
+        c->error_flag[0] = 0;
+        return MUSE_OK;
+    });
+    for (int r = 0; r < kResultAreas; ++r) {
+        if (c->area_inflight[r]) c->area_failed[r] = true;
+        c->area_inflight[r] = false;
     }
-    return MUSE_OK;
+    return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident); "
+                              "the cluster state was reset, result areas in flight are marked failed");
 }
 int muse_placement_info(muse_ctx* c, int* threads, int* workgroups_per_element, int* resident, int* direction_in_lds) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
@@ -535,7 +605,16 @@ int muse_placement_info(muse_ctx* c, int* threads, int* workgroups_per_element, 
 int muse_synchronize(muse_ctx* c) {
     int rc = check_ctx(c);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    return for_each_lane(c, [&]() -> int {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return MUSE_OK;
+    });
+}
+int muse_set_concurrency(muse_ctx* c, int nlanes) {
+    int rc = muse_synchronize(c);
+    if (rc) return rc;
+    if (nlanes < 1 || nlanes > kMaxLanes) return fail(MUSE_ERR_INVALID, "concurrency must be in [1, 4]");
+    c->nlanes = nlanes;
     return MUSE_OK;
 }
 int muse_last_kernel_ms(muse_ctx* c, float* ms) {
@@ -590,7 +669,11 @@ int muse_profile_end(muse_ctx* c, float* ms_out, int cap, int* count) {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!count) return fail(MUSE_ERR_INVALID, "count is NULL");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = for_each_lane(c, [&]() -> int {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return MUSE_OK;
+    });
+    if (rc) return rc;
     c->prof_on = false;
     *count = c->prof_count;
     for (int k = 0; k < c->prof_count && k < cap && ms_out; ++k)
@@ -744,6 +827,7 @@ struct MapOpts {
     const int* stop_flag = nullptr;
     muse_info* info_dev = nullptr;        // solver infos to a device buffer (NULL: the area's pinned block)
     bool no_event = false;                // the caller watches a later kernel's completion instead of this launch's
+    bool lanes_ok = true;                 // the launch may run on the result area's lane (muse_set_concurrency)
 };
 static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
                           const double* thetas, double atol, int z0_mode, int area, const MapOpts& o) {
@@ -760,6 +844,12 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     if (stride < n) return fail(MUSE_ERR_INVALID, "map_stride smaller than the element count");
     c->area_failed[area] = false;
     if (n == 0) { c->res_n[area] = 0; c->res_rows[area] = 0; return MUSE_OK; }
+    // the area's lane (muse_set_concurrency).  Maps in flight at once share the resident zhat slots: lanes are for maps that
+    // do not warm-start from them; a device-side collective, whose stream order is tied to lane 0's, keeps everything there
+    if (c->nlanes > 1 && o.lanes_ok && z0_mode != MUSE_Z0_WARM) {
+        rc = use_lane(c, area % c->nlanes);
+        if (rc) return rc;
+    }
     const int64_t total = n * o.nmaps, rows = stride * o.nmaps;
     if (total > 0x7fffffff || rows > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
     rc = ensure_zhat(c, total);
@@ -817,6 +907,7 @@ int muse_internal_map_async(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64
     o.nmaps = nmaps;
     o.map_stride = map_stride;
     o.scores_dev = scores_dev;
+    o.lanes_ok = scores_dev == nullptr;   // RCCL transport: the collective stream waits on an event of lane 0's stream
     return map_async_impl(c, seed, sim_begin, sim_end, include_data, thetas, atol, z0_mode, area, o);
 }
 
@@ -934,6 +1025,7 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
         // standard normals, the later ones load them instead of running the generator again
         MapOpts mo;
         mo.ncache_mode = i == 1 ? 1 : 2;
+        mo.lanes_ok = false;
         rc = map_async_impl(c, seed, 0, S, 1, theta, o->atol, z0_mode, 0, mo);
         if (rc) return rc;
         rc = muse_batch_wait(c, 0, g.data(), info.data());
@@ -1078,6 +1170,7 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
             mo.scores_dev = r.scores;
             mo.info_dev = r.info;
             mo.no_event = true;
+            mo.lanes_ok = false;
             const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
             rc = map_async_impl(c, seed, 0, S, 1, theta0 /* placeholder: theta comes from the device */, o->atol, z0_mode, 0, mo);
             if (rc) return rc;

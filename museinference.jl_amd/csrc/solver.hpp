@@ -1104,7 +1104,10 @@ struct Solver {
         if constexpr (kBg && !KEEP_ZTRUE) {
             // arm the background generator with the cluster's next problem (same conditions as the foreground path above)
             gen.active = false;
-            if (next_p >= 0 && d.tsample < 0) {
+            // (a launch that carries several maps: only a next problem of the SAME map -- the pairs are drawn and evaluated
+            //  with the theta that is in LDS now; the first problem of another map is drawn in the foreground)
+            const bool same_map = a.nmaps <= 1 || next_p / a.n_per_map == p / a.n_per_map;
+            if (next_p >= 0 && d.tsample < 0 && same_map) {
                 const ProblemDesc dn = describe(a, next_p);
                 if (dn.x_mode == X_SAMPLE && dn.z0_mode == Z0_ZERO && !dn.normals_only && dn.tsample < 0) {
                     gen.p = next_p;

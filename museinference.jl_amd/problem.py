@@ -213,6 +213,11 @@ class HipMuseProblem(AbstractMuseProblem):
         _capi.check(self._lib.muse_set_element_split(self._ctx, int(split)))
         self.element_split = int(split)
 
+    def set_concurrency(self, nlanes):
+        """Result area r runs on lane r mod nlanes (a stream, scratch and ticket counter of its own): consecutive launches on
+        different areas overlap instead of queueing behind each other's last workgroup.  Results are unchanged."""
+        _capi.check(self._lib.muse_set_concurrency(self._ctx, int(nlanes)))
+
     def placement_info(self):
         """{'threads', 'workgroups_per_element', 'resident', 'direction_in_lds'} of this problem's batched maps."""
         v = [C.c_int() for _ in range(4)]

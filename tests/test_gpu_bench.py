@@ -48,3 +48,11 @@ def test_bench_default_line_is_the_single_gpu_workload(gpu):
     d = run([], {})
     assert d["n_gpus"] == 1 and "transports" not in d and d["config"]["element_split"] == 1
     assert d["roofline"]["placement"] == "resident" and d["dtype"] == "f64"
+
+
+def test_bench_watchdog_reports_without_a_transport_that_hangs(gpu):
+    """A second transport that does not finish in time (here: a deadline of a millisecond) must not cost the line: the ranks
+    report what the first transport measured and mark the other one."""
+    d = run(["--nsims", "64"], {"MUSE_BENCH_FORCE_DIST": "1", "MUSE_BENCH_TRANSPORT_DEADLINE_S": "0.001"})
+    assert d["transport"] == "shm" and "watchdog" in d["transports"]["rccl"]["skipped"]
+    assert d["transports"]["shm"]["ranks_seen"] == 1 and d["value"] == d["transports"]["shm"]["value"]

@@ -419,6 +419,23 @@ def test_multi_map_launch_equals_separate_maps(gpu, M, model, N, nth, include_da
     ref.close()
 
 
+def test_multi_map_launch_with_streaming_clusters(gpu, M):
+    """Found by tools/fuzz_loops.py: streaming clusters (N > 10^4 with an element split, or N >= 65 536) draw the NEXT
+    problem of a cluster during the current one's streaming passes -- with the theta that is in LDS; when a launch carries
+    several maps the next problem may belong to another map and must then be drawn in the foreground."""
+    for model, N, split, nmaps, nsims in [("noise", 19449, 4, 8, 34), ("funnel", 19730, 4, 8, 36), ("funnel", 70000, 0, 3, 40)]:
+        prob = M.HipMuseProblem(None, model=model, ntheta=1, N=N)
+        if split:
+            prob.set_element_split(split)
+        thetas = np.linspace(-0.8, 1.7, nmaps).reshape(nmaps, 1)
+        tot = prob.map_and_score_multi_async(123, 3, 3 + nsims, thetas, atol=1e-2, result_area=1)
+        g, info = prob.batch_wait(tot, 1)
+        for m in range(nmaps):
+            gm, im = prob.map_and_score_batch(123, 3, 3 + nsims, thetas[m], atol=1e-2)
+            assert np.array_equal(g[m * nsims:(m + 1) * nsims], gm) and np.array_equal(info[m * nsims:(m + 1) * nsims], im), (model, N, m)
+        prob.close()
+
+
 def test_multi_map_with_element_split_and_gather_padding(gpu, M):
     """The same through the gathered entry (shared-memory transport, one rank) with padding rows between the maps'
     blocks, and with an element split (register-resident clusters) under the multi-map launch."""
@@ -507,3 +524,40 @@ def test_get_H_other_orders_and_estimated_step_on_hip(gpu, M, O):
         want = [0.5 * np.exp(-th0[k]) * sig[k] ** 2 * np.sum((xs * zs)[N // 2 * k:N // 2 * (k + 1)]) for k in range(nth)]
         np.testing.assert_allclose(np.diag(r.Hs[s]), want, rtol=1e-4)
     hip.close()
+
+
+@pytest.mark.parametrize("model,N,nth,split", [("funnel", 10000, 1, 0), ("funnel", 10000, 4, 4), ("noise", 70000, 1, 0),
+                                                ("smooth", 3000, 2, 0), ("funnel", 400, 2, 0)])
+def test_concurrent_lanes_give_the_same_results(gpu, M, model, N, nth, split):
+    """muse_set_concurrency: result area r on lane r mod n (a stream, scratch, ticket counter and cluster state of its
+    own), consecutive launches overlapping on the GPU -- the same bits as one launch after the other, for every
+    placement kind (resident, split clusters, streaming clusters, streaming), different maps in flight at once."""
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    ref = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    if split:
+        prob.set_element_split(split)
+        ref.set_element_split(split)
+    rng = np.random.default_rng(1)
+    nel = 40 if N <= 10000 else 5
+    thetas = [rng.uniform(-0.5, 1.0, size=nth) for _ in range(10)]
+    want = [ref.map_and_score_batch(5, k, k + nel, th, atol=1e-3) for k, th in enumerate(thetas)]
+    for lanes in (2, 4, 1):
+        prob.set_concurrency(lanes)
+        pend, got = [], {}
+        for k, th in enumerate(thetas):
+            n = prob.map_and_score_batch_async(5, k, k + nel, th, atol=1e-3, result_area=k % 4)
+            pend.append((k, n))
+            if len(pend) > 3:
+                kk, nn = pend.pop(0)
+                got[kk] = prob.batch_wait(nn, kk % 4)
+        for kk, nn in pend:
+            got[kk] = prob.batch_wait(nn, kk % 4)
+        for k in range(len(thetas)):
+            assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1]), (lanes, k)
+    # a warm start and the native loop stay on lane 0 and see the MAPs of the last map
+    prob.set_concurrency(2)
+    g1, _ = prob.map_and_score_batch(5, 0, nel, thetas[0], atol=1e-3)
+    g2, i2 = prob.map_and_score_batch(5, 0, nel, thetas[0], atol=1e-3, z0_mode=M.Z0_WARM)
+    assert np.all(i2["iterations"] == 0) and np.array_equal(g1, g2)
+    prob.close()
+    ref.close()

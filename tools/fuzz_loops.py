@@ -31,11 +31,20 @@ while time.time() - t0 < budget:
             th0 = rng.uniform(-0.5, 1.5, size=nth)
             kw = dict(nsims=nsims, maxsteps=int(rng.integers(1, 12)), theta_rtol=float(rng.choice([0.0, 1e-2, 1e-1, 1.0])),
                       atol=float(rng.choice([1e-2, 1e-4])), alpha=float(rng.uniform(0.3, 1.0)), z0_warm=bool(rng.random() < 0.2))
-            a = prob.run_muse(seed, th0, device_loop=False, **kw)
-            b = prob.run_muse(seed, th0, device_loop=True, **kw)
-            ok = (a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2][:, :-1], b[2][:, :-1], equal_nan=True)
-                  and np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[4], b[4]))
-            why = f"{kw} n {a[0]} {b[0]}"
+            def run(dev):
+                if kw["z0_warm"]:   # the same resident MAPs under both loops: those of a cold map at th0
+                    prob.map_and_score_batch(seed, 0, nsims, th0, include_data=True, atol=kw["atol"])
+                try:
+                    return prob.run_muse(seed, th0, device_loop=dev, **kw)
+                except M.MuseError as e:
+                    return str(e)
+            a, b = run(False), run(True)
+            if isinstance(a, str) or isinstance(b, str):
+                ok = a == b   # the same error from both loops
+            else:
+                ok = (a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2][:, :-1], b[2][:, :-1], equal_nan=True)
+                      and np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[4], b[4]))
+            why = f"{kw} {a if isinstance(a, str) else a[0]} {b if isinstance(b, str) else b[0]}"
         elif kind == "multi":
             nmaps, nsims, incl = int(rng.integers(2, 9)), int(rng.integers(1, 40)) if N < 20000 else 3, bool(rng.random() < 0.5)
             split = int(rng.choice([0, 0, 2, 4]))
