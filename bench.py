@@ -417,7 +417,10 @@ def main():
     if args.placement >= 0:
         prob.set_placement(args.placement)
     # consecutive steps on alternating lanes (streams): a launch starts on the compute units the previous one has left
-    lanes = int(os.environ.get("MUSE_BENCH_LANES", "1"))
+    # (measured, one GPU: funnel_1e4 50.2 -> 46.1 us per step, funnel4_1e4 59.7 -> 54.0, noise_1e6 1.377 -> 1.268 ms -- the
+    # HBM-only tail of one launch runs beside the generator-only head of the next; the stencil model's 16-member clusters, whose
+    # launches would have to share the compute units, lose 4 %: one lane)
+    lanes = int(os.environ.get("MUSE_BENCH_LANES", "1" if model == "smooth" else "2"))
     if lanes > 1:
         prob.set_concurrency(lanes)
     scaling = args.scaling or ("strong" if world > 1 else "weak")
@@ -651,13 +654,15 @@ def main():
         comp_bytes = compulsory_bytes(info, N, placement)
         prow, why = profile_row(args.workload) if (world == 1 and split == 1) else (None, "profiles/ hold the 1-GPU, unsplit launch")
         traffic = measured_traffic(args.workload) if prow is not None else None
-        hbm = {"bound": "hbm", "achieved": comp_bytes / mean_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": comp_bytes / mean_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-               "compulsory_bytes_per_launch": comp_bytes,
-               "traffic_GBps": None if traffic is None else traffic / mean_kernel_s / 1e9}
-        # The kernel time a fraction is quoted against: the event pair around a launch costs the kernel ~3 us (it cannot overlap
-        # the next launch's start), so a launch cannot have taken longer than the pipelined step it is part of.
+        # The time a launch is charged with: its own duration between HIP events, unless the pipelined step is shorter --
+        # the event pair costs a launch ~3 us (it cannot overlap the next launch's start), and with two lanes a launch's own
+        # duration (events and rocprofv3 agree on it: kernel_ms_mean) includes waiting for the compute units the launch
+        # before it still holds, while launches complete once per step.
         launch_s = min(mean_kernel_s, dt / best["launches"]) if world == 1 else mean_kernel_s
+        hbm = {"bound": "hbm", "achieved": comp_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": comp_bytes / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+               "compulsory_bytes_per_launch": comp_bytes, "launch_s_used": launch_s,
+               "traffic_GBps": None if traffic is None else traffic / launch_s / 1e9}
         clock_hz = best["clock_hz"] or CLOCK_HZ
         valu = None
         if placement == "resident":
@@ -686,6 +691,7 @@ def main():
         primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
         primary.update({
             "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
+            "lanes": lanes, "ms_per_launch_pipelined": 1e3 * dt / best["launches"],
             "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
             "algorithmic_bytes_d3": algorithmic_bytes(info, N),
             "hbm": hbm, "valu": valu,

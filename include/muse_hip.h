@@ -115,9 +115,10 @@ int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element
 /* Concurrency of the batched maps: with n > 1 result area r runs on lane r mod n -- a stream, a workgroup scratch, a
  * ticket counter and a cluster state of its own -- so that consecutive launches (enqueued on different result areas) overlap:
  * a launch starts on the compute units the previous one has already left instead of behind its last workgroup and a
- * launch gap.  Results are unchanged.  Maps in flight at once share the resident zhat slots, so a map that warm-starts
- * (MUSE_Z0_WARM), the muse_run loops, the finite-difference / implicit maps and the RCCL gather stay on lane 0.  n in
- * [1, 4]; 1 (default) = one launch after the other. */
+ * launch gap.  Results are unchanged.  A lane keeps resident zhat slots of its own (a streaming solve works in its
+ * slot); muse_get_zhat / muse_set_zhat and warm starts (MUSE_Z0_WARM) address lane 0's, and a map that warm-starts, the
+ * muse_run loops, the finite-difference / implicit maps and the RCCL gather run on lane 0.  n in [1, 4]; 1 (default) =
+ * one launch after the other. */
 int muse_set_concurrency(muse_ctx* ctx, int nlanes);
 int muse_synchronize(muse_ctx* ctx);
 /* Device time in ms of the most recent solver launch (HIP events on the context's stream), recorded only

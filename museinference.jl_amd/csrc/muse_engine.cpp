@@ -59,6 +59,8 @@ struct LaneState {
     unsigned int* cl_state = nullptr;
     int cl_cap = 0;
     int* error_flag = nullptr;
+    double* zhat = nullptr;        // the lane's resident MAP slots: a streaming solve works IN its slot, so maps in flight at once
+    int64_t zhat_slots = 0;        // cannot share them
     bool ready = false;
 };
 
@@ -200,8 +202,6 @@ static int ensure_zhat(muse_ctx* c, int64_t slots) {
         return fail(MUSE_ERR_ALLOC, "hipMalloc(zhat) failed");
     HIPCHK(hipMemsetAsync(nz, 0, (size_t)slots * c->ld * sizeof(double), c->stream));
     if (c->zhat) {
-        for (int l = 0; l < kMaxLanes; ++l)   // launches of other lanes may still be writing the old slots
-            if (l != c->cur_lane && c->lanes[l].ready) HIPCHK(hipStreamSynchronize(c->lanes[l].stream));
         HIPCHK(hipMemcpyAsync(nz, c->zhat, (size_t)c->zhat_slots * c->ld * sizeof(double), hipMemcpyDeviceToDevice,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -377,7 +377,7 @@ static int use_lane(muse_ctx* c, int l) {
     LaneState& out = c->lanes[c->cur_lane];
     out.stream = c->stream; out.scratch = c->scratch; out.scratch_doubles = c->scratch_doubles; out.counter = c->counter;
     out.ticket_base = c->ticket_base; out.cl_part = c->cl_part; out.cl_state = c->cl_state; out.cl_cap = c->cl_cap;
-    out.error_flag = c->error_flag; out.ready = true;
+    out.error_flag = c->error_flag; out.zhat = c->zhat; out.zhat_slots = c->zhat_slots; out.ready = true;
     LaneState& in = c->lanes[l];
     if (!in.ready) {
         HIPCHK(hipStreamCreateWithFlags(&in.stream, hipStreamNonBlocking));
@@ -390,6 +390,8 @@ static int use_lane(muse_ctx* c, int l) {
     c->stream = in.stream; c->scratch = in.scratch; c->scratch_doubles = in.scratch_doubles; c->counter = in.counter;
     c->ticket_base = in.ticket_base; c->cl_part = in.cl_part; c->cl_state = in.cl_state; c->cl_cap = in.cl_cap;
     c->error_flag = in.error_flag;
+    c->zhat = in.zhat;
+    c->zhat_slots = in.zhat_slots;
     c->cur_lane = l;
     return MUSE_OK;
 }
@@ -502,6 +504,7 @@ int muse_ctx_destroy(muse_ctx* c) {
         LaneState& ln = c->lanes[l];
         if (!ln.ready) continue;
         hipFree(ln.scratch); hipFree(ln.counter); hipFree(ln.cl_part); hipFree(ln.cl_state); hipHostFree(ln.error_flag);
+        hipFree(ln.zhat);
         hipStreamDestroy(ln.stream);
     }
     muse_comm_destroy(c);
@@ -844,8 +847,9 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     if (stride < n) return fail(MUSE_ERR_INVALID, "map_stride smaller than the element count");
     c->area_failed[area] = false;
     if (n == 0) { c->res_n[area] = 0; c->res_rows[area] = 0; return MUSE_OK; }
-    // the area's lane (muse_set_concurrency).  Maps in flight at once share the resident zhat slots: lanes are for maps that
-    // do not warm-start from them; a device-side collective, whose stream order is tied to lane 0's, keeps everything there
+    // the area's lane (muse_set_concurrency).  A lane has resident zhat slots of its own (a streaming solve works in its
+    // slot): a warm start, which means "from the MAPs muse_get_zhat / the last plain map left", stays on lane 0; so does a
+    // map whose scores feed a device-side collective (its stream order is tied to lane 0's)
     if (c->nlanes > 1 && o.lanes_ok && z0_mode != MUSE_Z0_WARM) {
         rc = use_lane(c, area % c->nlanes);
         if (rc) return rc;
