@@ -14,14 +14,14 @@ O.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
-n = {"loop": 0, "multi": 0, "fd": 0}
+n = {"loop": 0, "multi": 0, "fd": 0, "lanes": 0}
 bad = 0
 while time.time() - t0 < budget:
     model = str(rng.choice(["funnel", "noise", "smooth"]))
     N = int(rng.choice([int(rng.integers(8, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)), int(rng.integers(10000, 30000))]))
     nth = 1 if model == "noise" else min(N, int(rng.choice([1, 2, 3, 4, 8])))
     seed = int(rng.integers(1, 2**40))
-    kind = str(rng.choice(["loop", "multi", "fd"]))
+    kind = str(rng.choice(["loop", "multi", "fd", "lanes"]))
     x = rng.standard_normal(N) * 1.3
     prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0) if rng.random() < 0.7 else None)
     ok, why = True, ""
@@ -59,6 +59,25 @@ while time.time() - t0 < budget:
                 gm, im = prob.map_and_score_batch(seed, 3, 3 + nsims, thetas[m], include_data=incl, atol=atol, z0_mode=z0)
                 ok = ok and np.array_equal(g[m * per:(m + 1) * per], gm, equal_nan=True) and np.array_equal(info[m * per:(m + 1) * per], im)
             why = f"nmaps {nmaps} nsims {nsims} data {incl} split {split}"
+        elif kind == "lanes":
+            # a pipelined sequence of different maps over the result areas with 2-4 lanes against one launch after the other
+            nel, nl = (int(rng.integers(1, 60)) if N < 20000 else 3), int(rng.integers(2, 5))
+            split = int(rng.choice([0, 0, 2, 4]))
+            if split and N > 512:
+                prob.set_element_split(split)
+            maps = [(int(rng.integers(0, 50)), rng.uniform(-1.0, 2.0, size=nth), int(rng.choice([0, 1]))) for _ in range(7)]
+            want = [prob.map_and_score_batch(seed, s0, s0 + nel, th, atol=1e-3, z0_mode=z0) for s0, th, z0 in maps]
+            prob.set_concurrency(nl)
+            pend, got = [], {}
+            for k, (s0, th, z0) in enumerate(maps):
+                pend.append((k, prob.map_and_score_batch_async(seed, s0, s0 + nel, th, atol=1e-3, z0_mode=z0, result_area=k % 4)))
+                if len(pend) > 3:
+                    kk, nn = pend.pop(0)
+                    got[kk] = prob.batch_wait(nn, kk % 4)
+            for kk, nn in pend:
+                got[kk] = prob.batch_wait(nn, kk % 4)
+            ok = all(np.array_equal(got[k][0], want[k][0], equal_nan=True) and np.array_equal(got[k][1], want[k][1]) for k in range(len(maps)))
+            why = f"lanes {nl} nel {nel} split {split}"
         else:
             if N > 3000:
                 prob.close()
