@@ -6,19 +6,24 @@ batch, sample (x, z) ~ P(x, z | θ), find the latent MAP ẑ by L-BFGS/HagerZhan
 ẑ₀ = 0 to ||∇z||∞ <= 1e-2, and evaluate the score ∇θ logP(x, ẑ | θ) -- the get_J!/muse! map body of
 the reference (src/muse.jl:169-176, :508-525), one launch per batch.  Workload at N=1 GPU:
 BASELINE.json configs[1], Neal's funnel, 10^4-dim z, 1-dim θ (θ = 1), nsims = 512, fp64, synthetic
-(Philox) data.  With --gpus N the map is sharded over the ranks and the per-rank score blocks are exchanged with
-one all-gather per step (RCCL): --scaling strong (the default for N > 1; BASELINE.json's north star) keeps the
-512 sims of the step and gives every rank a contiguous block of 512/N of them, each element split over
-min(8, CUs / elements) workgroups; --scaling weak gives every rank its own 512-sim block of a 512*N-sim map.
+(Philox) data.  `python bench.py --gpus N` starts its own N ranks (one per GPU; under torch.distributed.run the ranks are
+used as they come).  With N > 1 the map is sharded over the ranks and the per-rank score blocks are exchanged once per launch
+-- both transports of the engine are measured in the same run (shared memory between the ranks of a node; RCCL all-gather)
+and reported side by side with the ranks each communicator counts: --scaling strong (the default for N > 1; BASELINE.json's
+north star) keeps the 512 sims of the step and gives every rank a contiguous block of 512/N of them; the steps are
+independent maps, so a rank whose share is smaller than its GPU carries several consecutive steps in ONE launch
+(maps_per_launch; MUSE_BENCH_MAPS=1: one step per launch, each element split over 2/4 workgroups instead, which is what a
+dependent map -- a muse! iteration -- has to do); --scaling weak gives every rank its own 512-sim block of a 512*N-sim map.
+Consecutive launches alternate over two lanes (streams with scratch and MAP slots of their own: MUSE_BENCH_LANES).
 
 Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
-  roofline      the solver kernel against the bound that actually binds it, from its mean launch duration measured
-                live (HIP events on the launch stream): "hbm" -- compulsory HBM bytes of the placement the launch
-                used / duration against the 8 TB/s peak -- for the streaming placements; "valu" -- the kernel's
-                VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (SIMDs x duration x clock),
-                quoted in fp64-FMA-slot TFLOP/s against the 78.6 TFLOP/s vector peak -- for the register/LDS
-                resident placements, whose vectors never leave the chip.  Both objects are always present
-                (`roofline.hbm`, `roofline.valu`); SURVEY 8.d3's accounting figure is kept as
+  roofline      the solver kernel against the bound that actually binds it, per launch: "hbm" -- compulsory HBM bytes of the
+                placement the launch used / launch time against the 8 TB/s peak -- for the streaming placements; "valu" --
+                ALGORITHMIC work (operation counts per element from the source x the measured issue cost of each kind) /
+                (SIMDs x launch time x the clock measured inside the kernel) for the register/LDS resident placements, whose
+                vectors never leave the chip, with the VALU-active-counter utilisation (rocprofv3, profiles/) beside it.
+                Launch time = min(mean duration between HIP events on the launch stream, pipelined step).  Both objects are
+                always present (`roofline.hbm`, `roofline.valu`); SURVEY 8.d3's accounting figure is kept as
                 `algorithmic_bytes_d3` and is not a roofline.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: "port") timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1 only)

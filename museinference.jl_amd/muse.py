@@ -256,17 +256,17 @@ def _muse_native(result, prob, theta0, rng, z0, maxsteps, theta_rtol, atol, nsim
         prob.set_zhat(0, np.tile(np.asarray(z0, dtype=np.float64), (nsims + 1, 1)))
     n, theta, hist, gs, info = prob.run_muse(rng, theta0, nsims=nsims, maxsteps=maxsteps, theta_rtol=theta_rtol,
                                              atol=atol, alpha=float(alpha), z0_warm=z0 is not None)
+    check_optim_soln(info[:n].reshape(-1), "muse!")   # (once for the run: 30 iterations x 513 records are one vector op)
     for i in range(n):
-        h = hist[i]
-        th = h[0:nth].copy()
-        seg = lambda k: h[k * nth:(k + 1) * nth].copy()
+        h = hist[i]                                      # (records are views of the arrays the library filled: no copies)
+        th = h[0:nth]
+        seg = lambda k: h[k * nth:(k + 1) * nth]
         Hinv_like = np.diag(seg(5))
-        check_optim_soln(info[i], "muse!")
         result.history.append({
             "θ": th, "θunreg": th, "θ′": th, "θunreg′": th,
             "g_like_sims": gs[i], "g_like_dat′": seg(1), "g_like_sims′": gs[i], "g_like′": seg(2),
             "g_prior′": seg(3), "g_post′": seg(4),
-            "H⁻¹_post′": h[7 * nth:7 * nth + nth * nth].reshape(nth, nth).copy(), "H_prior′": np.diag(seg(6)),
+            "H⁻¹_post′": h[7 * nth:7 * nth + nth * nth].reshape(nth, nth), "H_prior′": np.diag(seg(6)),
             "H⁻¹_like′": Hinv_like, "H⁻¹_like_sims′": Hinv_like,
             "ẑ_history_dat": info[i][0], "ẑ_history_sims": info[i][1:], "t": float(h[-1]),
             "ẑ_dat": None, "ẑ_sims": [None] * nsims,
