@@ -812,7 +812,9 @@ struct Solver {
         sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.cur.t.sd[0];
         if constexpr (MAXB > 1) {
             // FD batches sample at a theta that differs from the MAP theta
-            if (tid < MAXB) sh_sd[tid] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tid] : a.cur.t.sd[tid];
+            int tl = tid;
+            asm volatile("" : "+v"(tl));  // (else tid * 8 is formed at the kernel's entry and held -- spilled -- across it)
+            if (tl < MAXB) sh_sd[tl] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tl] : a.cur.t.sd[tl];
             __syncthreads();
         }
         // bind storage

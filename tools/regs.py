@@ -24,9 +24,9 @@ HOT = [
     # 21 / 13 / 33 spilled VGPRs and 172 / 114 / 353 spilled SGPRs here -- lane masks and LDS addresses derived from the packed
     # block indices, hoisted to the kernel's entry (solver.hpp, blk()).  What is left is a handful of values stored and
     # re-loaded ONCE per problem (nothing inside an element loop): tolerated up to the counts below.
-    ("FunnelModel<4>, PlaceResident<512, 10, true>", 6),
+    ("FunnelModel<4>, PlaceResident<512, 10, true>", 2),
     ("FunnelModel<4>, PlaceResident<512, 3, false, true>", 16),
-    ("FunnelModel<8>, PlaceResident<512, 10, true>", 16),
+    ("FunnelModel<8>, PlaceResident<512, 10, true>", 12),
     ("FunnelModel<1>, PlaceResident<512, 3, false, true>", 6),
     ("NoiseModel, PlaceStreaming<256, true>", 12),   # the background generator's sums across a pass: once per pass, not per trip
     ("SmoothModel<8>, PlaceStreaming<256, true, 2, true, true>", 0),   # configs[4]: clusters with the direction in LDS
