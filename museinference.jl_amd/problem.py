@@ -456,6 +456,8 @@ class HipMuseProblem(AbstractMuseProblem):
         th = self._theta(theta0)
         off = np.ascontiguousarray(np.asarray(offsets, dtype=np.float64))
         n = col_end - col_begin
+        if n < 0:
+            raise ValueError("col_end < col_begin")
         if off.ndim != 2 or off.shape[0] != (n if per_unit else self.ntheta):
             raise ValueError("offsets must be [ntheta, G], or [n_units, G] with per_unit")
         G = off.shape[1]

@@ -561,3 +561,52 @@ def test_concurrent_lanes_give_the_same_results(gpu, M, model, N, nth, split):
     assert np.all(i2["iterations"] == 0) and np.array_equal(g1, g2)
     prob.close()
     ref.close()
+
+
+def test_round3_entry_points_edge_cases(gpu, M, O):
+    """Empty and degenerate inputs of the round-3 entry points: an empty sim range (with and without the data element), one
+    map through the multi-map entry, N = 1 / ntheta = N, a finite-difference grid of one point at offset 0, bad arguments."""
+    x = np.array([0.3, -1.2, 0.7, 0.1, 2.0])
+    prob = M.HipMuseProblem(x, model="funnel", ntheta=5)               # ntheta = N: one element per block
+    th = np.linspace(-0.5, 0.5, 5)
+    assert prob.map_and_score_multi_async(1, 4, 4, np.stack([th, th + 0.1])) == 0          # nothing to do
+    g, info = prob.batch_wait(0, 0)
+    assert g.shape == (0, 5) and info.shape == (0,)
+    tot = prob.map_and_score_multi_async(1, 4, 4, np.stack([th, th + 0.1]), include_data=True, result_area=3)
+    g, info = prob.batch_wait(tot, 3)                                                        # two maps of the data element alone
+    for m, t in enumerate((th, th + 0.1)):
+        gm, im = prob.map_and_score_batch(1, 4, 4, t, include_data=True)
+        assert np.array_equal(g[m:m + 1], gm) and np.array_equal(info[m:m + 1], im)
+    tot = prob.map_and_score_multi_async(1, 0, 6, th[None, :])                              # one map through the multi entry
+    g1, i1 = prob.batch_wait(tot, 0)
+    g0, i0 = prob.map_and_score_batch(1, 0, 6, th)
+    assert np.array_equal(g1, g0) and np.array_equal(i1, i0)
+    prob.set_concurrency(3)
+    assert prob.map_and_score_batch_async(1, 2, 2, th, result_area=2) == 0                   # empty batch on a lane
+    prob.batch_wait(0, 2)
+    with pytest.raises(M.MuseError):
+        prob.set_concurrency(5)
+    prob.set_concurrency(1)
+    # finite differences: one grid point at offset 0 = the score at theta0 of the sim, MAP started from the fiducial MAP
+    F, info = prob.fd_values_columns(1, 0, 0, 5, th, np.zeros((5, 1)), atol=1e-10)
+    go, _, _ = O.map_and_score_batch("funnel", 5, 1, 0, 1, th, atol=1e-10, z0_mode=0)
+    np.testing.assert_allclose(F[:, 0, :], np.tile(go[0], (5, 1)), rtol=1e-9, atol=1e-12)
+    assert prob.fd_values_columns(1, 0, 3, 3, th, np.zeros((5, 2)))[0].shape == (0, 2, 5)    # empty column range
+    with pytest.raises(M.MuseError):
+        prob.fd_values_columns(1, 0, 0, 5, th, np.full((5, 1), np.nan))
+    with pytest.raises(ValueError):
+        prob.fd_values_columns(1, 0, 3, 2, th, np.zeros((5, 1)))
+    prob.close()
+    one = M.HipMuseProblem(np.array([0.4]), model="noise", ntheta=1)                        # N = 1
+    def loop(dev):   # (a one-element problem is a wild iteration: whatever happens -- an answer or an error -- happens in both loops)
+        try:
+            n, theta, hist, gs, info = one.run_muse(3, [0.2], nsims=5, maxsteps=4, theta_rtol=0.0, atol=1e-6, alpha=0.5, device_loop=dev)
+            return (n, theta.tobytes(), gs.tobytes())
+        except M.MuseError as e:
+            return str(e)
+    assert loop(True) == loop(False)
+    g, info = one.map_and_score_batch(3, 0, 5, [0.2], include_data=True, atol=1e-6)
+    go, _, io = O.map_and_score_batch("noise", 1, 3, 0, 5, [0.2], atol=1e-6, x_data=np.array([0.4]), z0_mode=0)
+    np.testing.assert_allclose(g, go, rtol=1e-10)
+    assert np.array_equal(info["iterations"], io["iterations"])
+    one.close()
