@@ -377,3 +377,35 @@ def test_get_H_other_orders_and_estimated_step(M, O, funnel512):
     np.testing.assert_allclose(np.diag(r.Hs[0]), want, rtol=1e-5)
     with pytest.raises(ValueError):
         M.get_H_(M.MuseResult(theta=th0.copy()), mk(OracleBatchedProblem), rng=seed, nsims=1, fdm="central_fdm(3,2)")
+
+
+def test_get_H_twice_adapted_method_falls_back_to_the_serial_path(M, O):
+    """central_fdm(3, 1; adapt = 2) estimates the step of its bound estimator too: the batched seam is built for adapt = 1 and
+    hands such a method to the element-by-element path (pjacobian, src/util.jl:9-27), which runs fdm(f, 0) as is."""
+    from museinference_jl_amd.fdm import central_fdm
+    from oracle_problem import OracleBatchedProblem
+    x, _ = O.sample_x_z("funnel", 64, 2, M.DATA_SIM, [0.0])
+    prob = OracleBatchedProblem(x, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+    m2 = central_fdm(3, 1, adapt=2)
+    assert m2.bound_estimator.bound_estimator is not None
+    r = M.MuseResult(theta=np.array([0.3]))
+    M.get_H_(r, prob, rng=4, nsims=1, fdm=m2, grad_z_logLike_atol=1e-12)
+    xs, zs = O.sample_x_z("funnel", 64, 4, 0, [0.3])
+    sig = 1 / (1 + np.exp(-0.3))
+    np.testing.assert_allclose(r.Hs[0][0, 0], 0.5 * np.exp(-0.3) * sig ** 2 * np.sum(xs * zs), rtol=1e-5)
+    assert getattr(prob, "fd_maps_done", 0) == 0          # the batched seam was not used
+
+
+def test_ignored_keywords_warn_once(M, O):
+    from oracle_problem import OracleBatchedProblem
+    import sys
+    MU = sys.modules["museinference_jl_amd.muse"]     # (the package attribute `muse` is the function)
+    MU._warned_ignored.clear()
+    x, _ = O.sample_x_z("funnel", 32, 2, M.DATA_SIM, [0.0])
+    prob = OracleBatchedProblem(x, "funnel", 1, prior=M.GaussianPrior(0.0, 3.0), nthreads=1)
+    with pytest.warns(RuntimeWarning, match="pool"):
+        M.muse(prob, [0.5], rng=1, nsims=4, maxsteps=1, pool="workers", native=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        M.muse(prob, [0.5], rng=1, nsims=4, maxsteps=1, pool="workers", native=False)    # said once, not again
