@@ -12,7 +12,10 @@
  *        funnel MAP  zhat = x/(1+e^-theta), score = 1/2 [e^-theta sum zhat^2 - N], ...
  *   (ii) scipy.optimize L-BFGS-B minimisers of the same objective,
  *   (iii) the Philox4x32-10 known-answer vectors of Salmon et al. (Random123 kat_vectors),
- *   (iv) the reference's own statistical criterion mu/sigma < 2 on its 512-dim funnel test.
+ *   (iv) the reference's own statistical criterion mu/sigma < 2 on its 512-dim funnel test,
+ *   (v)  a published known answer of the un-vendored dependency: the work counters the Optim.jl documentation prints for
+ *        LBFGS() on Rosenbrock's function from (0, 0) -- 24 iterations, 67 f/g evaluations -- which the restated
+ *        LBFGS/HagerZhang below reproduces exactly (tests/test_oracle.py; quoted from memory, no network here).
  *
  * What each function follows (paths relative to /root/reference):
  *   mo_sample_x_z           src/simple.jl:61-65, docs/src/index.md:156-160  (funnel closure)
@@ -283,8 +286,21 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
 
 /* F(z) = -logLike(x,z,theta) and G = dF/dz.  This is what Optim minimises
  * (src/interface.jl:163: only_fg(z -> .-logLike_and_grad_z)). */
+/* TEST-ONLY objective (model id 100): Rosenbrock's function, the example of the Optim.jl documentation
+ * ("Minimizing a multivariate function"): f = (1 - x1)^2 + 100 (x2 - x1^2)^2 from x0 = (0, 0).  It lets the restated
+ * LBFGS()/HagerZhang() be run on the one problem for which the package's own documentation prints the work counters. */
+#define MO_MODEL_ROSENBROCK 100
+
 double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, const double* z,
                           const double* theta, double* G) {
+    if (model == MO_MODEL_ROSENBROCK) {
+        const double a = 1.0 - z[0], b = z[1] - z[0] * z[0];
+        if (G) {
+            G[0] = -2.0 * a - 400.0 * b * z[0];
+            G[1] = 200.0 * b;
+        }
+        return a * a + 100.0 * b * b;
+    }
     double iv[64];
     for (int k = 0; k < ntheta; ++k) iv[k] = mo_exp(-theta[k]);
     double acc = 0.0, cst = 0.0;

@@ -74,6 +74,17 @@ def exp_fixed(x):
     return float(lib().mo_expd(float(x)))
 
 
+def lbfgs_rosenbrock(g_tol=1e-8, x0=(0.0, 0.0)):
+    """The restated Optim LBFGS()/HagerZhang() (mo_zhat_at_theta's solver) on Rosenbrock's function, the example of the
+    Optim.jl documentation: returns (minimizer, iterations, f_calls, status, f_min, gnorm)."""
+    z0 = np.array(x0, dtype=np.float64)
+    dummy, th, zout, info = np.zeros(2), np.zeros(1), np.zeros(2), Info()
+    rc = lib().mo_zhat_at_theta(C.c_int(100), C.c_int64(2), C.c_int(1), _p(dummy), _p(z0), _p(th), C.c_double(g_tol), _p(zout),
+                                C.byref(info))
+    assert rc == 0
+    return zout, info.iterations, info.f_calls, info.status, info.f_min, info.gnorm
+
+
 def philox4x32_10(ctr, key):
     c = np.asarray(ctr, dtype=np.uint32)
     k = np.asarray(key, dtype=np.uint32)

@@ -200,3 +200,17 @@ def test_fixed_sequence_exp_is_within_one_ulp(O):
             assert abs(got - want) <= 1.0 * np.spacing(want), (x, got, want)
     assert O.exp_fixed(710.0) == np.inf and O.exp_fixed(-746.0) == 0.0 and np.isnan(O.exp_fixed(np.nan))
     assert O.exp_fixed(0.0) == 1.0
+
+
+def test_lbfgs_hagerzhang_reproduces_the_optim_documentation_example(O):
+    """A known answer that does NOT come from this repository: the Optim.jl documentation ("Minimizing a multivariate
+    function", docs/src/user/minimization.md) runs `optimize(f, g!, [0.0, 0.0], LBFGS())` on Rosenbrock's function
+    f = (1 - x1)^2 + 100 (x2 - x1^2)^2 and prints `Iterations: 24`, `f(x) calls: 67`, `∇f(x) calls: 67` (default options:
+    m = 10, InitialStatic(), HagerZhang(), g_tol = 1e-8).  The oracle's restatement of that solver -- the one every parity
+    test compares the HIP path with -- reproduces both counters exactly.  (Quoted from memory: the documentation cannot
+    be fetched in this image.  The counters are sensitive to every decision of the line search: one different
+    bracketing step or Wolfe test moves them.)"""
+    x, iterations, f_calls, status, f_min, gnorm = O.lbfgs_rosenbrock(1e-8)
+    assert (iterations, f_calls) == (24, 67)
+    assert status == 0 and gnorm <= 1e-8 and f_min < 1e-20
+    np.testing.assert_allclose(x, [1.0, 1.0], rtol=0, atol=1e-9)
