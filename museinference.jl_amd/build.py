@@ -77,6 +77,31 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
     return lib_path
 
 
+# Diagnostic variants for tests/test_gpu_linesearch.py: the noise model's objective replaced by a non-quadratic one
+# (-DMUSE_HZTEST, models.hpp) and ONE solver instantiation each (-DMUSE_INSPECT: seconds to compile) -- the register/LDS
+# resident placement, the streaming one and the streaming cluster.  Never loaded by the product path.
+HZTEST_VARIANTS = {
+    "resident": "NoiseModel, PlaceResident<512, 10, true>",
+    "streaming": "NoiseModel, PlaceStreaming<512, false, MUSE_STREAM_U>",
+    "cluster": "NoiseModel, PlaceStreaming<256, true, MUSE_STREAM_U>",
+}
+
+
+def hztest_lib_path(kind):
+    return os.path.join(_HERE, f"libmuse_hip_hztest_{kind}.so")
+
+
+def build_linesearch_test_variants(force=False):
+    """Build (if missing or stale) the three -DMUSE_HZTEST libraries; returns {kind: path}."""
+    out = {}
+    for kind, inst in HZTEST_VARIANTS.items():
+        path = hztest_lib_path(kind)
+        if force or _stale(path, SOURCES + HEADERS):
+            build_extension(defines=["-DMUSE_HZTEST", "-DMUSE_INSPECT=" + inst], lib_path=path)
+        out[kind] = path
+    return out
+
+
 if __name__ == "__main__":
     import sys
     if "--stamps" in sys.argv:  # the -DMUSE_STAMPS diagnostic build read by tools/stamps.py

@@ -43,8 +43,18 @@ struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
     }
     __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
         const double r = x - z, t = iv * r;
+#ifdef MUSE_HZTEST
+        // DIAGNOSTIC BUILD ONLY (tests/test_gpu_linesearch.py builds it next to the product library): a NON-quadratic
+        // objective, F = 1/2 z^2 + 1/2 iv (x - z)^2 + 1/4 z^4 per element.  Every shipped model is Gaussian, i.e. quadratic
+        // in z, and on a quadratic HagerZhang ends with its first secant step; this objective drives the kernel's line
+        // search through bracket expansion, bisection and the secant^2 updates, against the oracle's test objective 101.
+        const double z2 = z * z;
+        facc = fma(0.5, z2 * z2, fma(z, z, fma(t, r, facc)));
+        return fma(z2, z, z - t);
+#else
         facc = fma(z, z, fma(t, r, facc));
         return z - t;
+#endif
     }
     __device__ static __forceinline__ double score_term(double x, double z) {
         const double r = x - z;

@@ -290,6 +290,11 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
  * ("Minimizing a multivariate function"): f = (1 - x1)^2 + 100 (x2 - x1^2)^2 from x0 = (0, 0).  It lets the restated
  * LBFGS()/HagerZhang() be run on the one problem for which the package's own documentation prints the work counters. */
 #define MO_MODEL_ROSENBROCK 100
+/* TEST-ONLY objective (model id 101), the one the engine's -DMUSE_HZTEST diagnostic build puts in place of the noise model's:
+ * F = sum_i 1/2 z_i^2 + 1/2 e^-theta (x_i - z_i)^2 + 1/4 z_i^4 (+ N theta / 2) -- NOT quadratic in z, so that the line search
+ * has to bracket, bisect and iterate its secant steps (tests/test_gpu_linesearch.py compares the kernel's solver with this
+ * one, evaluation count by evaluation count). */
+#define MO_MODEL_QUARTIC_TEST 101
 
 double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, const double* z,
                           const double* theta, double* G) {
@@ -304,7 +309,14 @@ double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, con
     double iv[64];
     for (int k = 0; k < ntheta; ++k) iv[k] = mo_exp(-theta[k]);
     double acc = 0.0, cst = 0.0;
-    if (model == MO_MODEL_NOISE) {
+    if (model == MO_MODEL_QUARTIC_TEST) {
+        for (int64_t i = 0; i < N; ++i) {
+            double r = x[i] - z[i], t = iv[0] * r, z2 = z[i] * z[i];
+            acc = fma(0.5, z2 * z2, fma(z[i], z[i], fma(t, r, acc)));
+            if (G) G[i] = fma(z2, z[i], z[i] - t);
+        }
+        cst = (double)N * theta[0];
+    } else if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) {
             double r = x[i] - z[i], t = iv[0] * r;
             acc = fma(z[i], z[i], fma(t, r, acc));

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmuse_oracle.so")
 
 MODEL_FUNNEL, MODEL_NOISE, MODEL_SMOOTH = 0, 1, 2
-MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH}
+MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH, "quartic_test": 101}
 STATUS = ["g_converged", "x_converged", "f_converged", "maxiter", "linesearch_failed", "nonfinite"]
 
 
