@@ -657,7 +657,7 @@ def main():
         placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
                                                           if model == "smooth" else "streaming")
         comp_bytes = compulsory_bytes(info, N, placement)
-        prow, why = profile_row(args.workload) if (world == 1 and split == 1) else (None, "profiles/ hold the 1-GPU, unsplit launch")
+        prow, why = profile_row(args.workload) if (world == 1 and split == 1 and not sharded) else (None, "profiles/ hold the 1-GPU, unsplit, unsharded launch")
         traffic = measured_traffic(args.workload) if prow is not None else None
         # The time a launch is charged with: its own duration between HIP events, unless the pipelined step is shorter --
         # the event pair costs a launch ~3 us (it cannot overlap the next launch's start), and with two lanes a launch's own
