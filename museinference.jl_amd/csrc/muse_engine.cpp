@@ -467,6 +467,10 @@ static void free_run_buffers(muse_ctx* c);
 int muse_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 int muse_ctx_comm_slot(muse_ctx* c, void*** comm, int* device, void** stream) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    // the communicator's stream order (RCCL transport: collective stream <- event on the solver's stream) is tied to lane 0:
+    // hand out lane 0's stream whatever lane the last map used
+    const int rc = use_lane(c, 0);
+    if (rc) return rc;
     *comm = &c->comm;
     *device = c->device;
     *stream = (void*)c->stream;

@@ -610,3 +610,22 @@ def test_round3_entry_points_edge_cases(gpu, M, O):
     np.testing.assert_allclose(g, go, rtol=1e-10)
     assert np.array_equal(info["iterations"], io["iterations"])
     one.close()
+
+
+def test_rccl_gather_with_lanes_enabled(gpu, M):
+    """The device-side (RCCL) gather is tied to lane 0's stream order: with concurrency > 1, and after maps that ran on other
+    lanes, a gathered map must still hand the collective the finished scores (one rank: the gathered block is the map's own)."""
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=2, N=10000)
+    prob.set_concurrency(2)
+    prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("rccl"))
+    th = np.array([0.4, -0.3])
+    want, _ = M.HipMuseProblem(None, model="funnel", ntheta=2, N=10000).map_and_score_batch(9, 0, 300, th)
+    for rep in range(6):
+        for a in (1, 3):                                   # maps on lane 1 (areas 1 and 3) right before the gather
+            prob.map_and_score_batch_async(9, 5, 505, th + 0.1 * rep, result_area=a)
+        n = prob.map_and_score_batch_gather_async(9, 0, 300, th, 300, result_area=0)
+        g_all, info = prob.batch_wait_gathered(n, 300, 0)
+        assert np.array_equal(g_all[0], want), rep
+        for a in (1, 3):
+            prob.batch_wait(500, a)
+    prob.close()
