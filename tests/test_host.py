@@ -409,3 +409,25 @@ def test_ignored_keywords_warn_once(M, O):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         M.muse(prob, [0.5], rng=1, nsims=4, maxsteps=1, pool="workers", native=False)    # said once, not again
+
+
+def test_bench_algorithmic_valu_accounting():
+    """bench.py's algorithmic VALU work of the resident placements (operation counts per element from the source x measured
+    issue costs): the isotropic funnel's E = 3, K = 1 solve is 78 + 14 + 8 + 5 = 105 fp64 operations, 20 32x32->64 multiplies
+    and 60 integer/select operations per element; a launch of 512 sims x 10^4 elements at 45.9 us and 2.4 GHz is ~0.5 of the
+    issue peak -- and can never exceed 1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(HERE), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    info = np.zeros(512, dtype=[("f_calls", "<i4"), ("iterations", "<i4"), ("hist_words", "<i4")])
+    info["f_calls"], info["iterations"] = 3, 1
+    cycles, fp64 = bench.algorithmic_valu(info, 10000, 2.4e9)
+    assert fp64 == 512 * 10000 * 105
+    per_elem = 105 * 4.4 + 20 * 4.75 + 60 * 2.7
+    assert abs(cycles - 512 * 10000 * per_elem / 64) < 1e-6 * cycles
+    frac = cycles / (1024 * 45.9e-6 * 2.4e9)
+    assert 0.45 < frac < 0.56
+    info["f_calls"], info["iterations"] = 9, 3          # two kept updates, six more trials
+    _, fp64b = bench.algorithmic_valu(info, 10000, 2.4e9)
+    assert fp64b == 512 * 10000 * (78 + 14 + 8 * 7 + 5 + 14 * 2)
