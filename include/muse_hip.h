@@ -29,6 +29,10 @@
  *                      (src/simple.jl:59-73, docs/src/index.md:154-168).
  *   MUSE_MODEL_NOISE   z_i ~ N(0,1), x_i ~ N(z_i, e^theta); ntheta = 1.
  *   MUSE_MODEL_SMOOTH  z as FUNNEL, x = A z + n with A the periodic (1/4,1/2,1/4) stencil.
+ *   MUSE_MODEL_USER    a user-supplied elementwise model (the closures of SimpleMuseProblem as compiled code): three C
+ *                      functions in a header (include/muse_model.h: the joint draw, d(-logLike)/dz with the objective's
+ *                      element term, the score's element term) compiled into an engine library of its own, which exports
+ *                      this same ABI for that one model.  muse_model_name() says what a given library holds.
  *
  * Random streams: simulation `sim` of master seed `seed` always sees the same normals
  * (Philox4x32-10 keyed by seed, counter = (element, sim)), in every call and on every GPU -- the
@@ -46,6 +50,7 @@ extern "C" {
 #define MUSE_MODEL_FUNNEL 0
 #define MUSE_MODEL_NOISE 1
 #define MUSE_MODEL_SMOOTH 2
+#define MUSE_MODEL_USER 3 /* only in a library built from a model header (include/muse_model.h) */
 
 #define MUSE_MEM_HOST 0
 #define MUSE_MEM_DEVICE 1
@@ -91,6 +96,10 @@ typedef struct muse_ctx muse_ctx;
 int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out);
 int muse_ctx_destroy(muse_ctx* ctx);
 const char* muse_last_error(void);
+/* The name of model id `model` in THIS library, or NULL when the library does not hold it: "funnel" / "noise" / "smooth" in
+ * libmuse_hip.so; MUSE_MODEL_NAME of the header in a library built from a user's model (and NULL for the built-in ids).
+ * The user's sample_x_z / logLike closures of SimpleMuseProblem (src/simple.jl:79-89) are that header's functions. */
+const char* muse_model_name(int model);
 /* prob.x, the observed data (src/simple.jl:5, used at src/muse.jl:170). */
 int muse_set_data(muse_ctx* ctx, const double* x, int mem);
 /* Run the context's work on a caller-owned hipStream_t (NULL = the context's own stream). */

@@ -13,7 +13,10 @@ import MuseInference: sample_x_z, logLike_and_∇z_logLike, ∇θ_logLike, ẑ_a
 using Random, Statistics, LinearAlgebra
 
 const libmuse_hip = get(ENV, "LIBMUSE_HIP", "libmuse_hip.so")
-const MODELS = Dict(:funnel => 0, :noise => 1, :smooth => 2)
+# :user = the model of a library built from a user's header (include/muse_model.h: the closures of SimpleMuseProblem,
+# src/simple.jl:79-89, as three C functions); point LIBMUSE_HIP at libmuse_hip_model_<name>.so
+const MODELS = Dict(:funnel => 0, :noise => 1, :smooth => 2, :user => 3)
+model_name(id) = (p = ccall((:muse_model_name, libmuse_hip), Cstring, (Cint,), id); p == C_NULL ? nothing : unsafe_string(p))
 const MEM_HOST = Cint(0)
 
 struct MuseInfo            # muse_info of include/muse_hip.h

@@ -10,8 +10,8 @@ import numpy as np
 
 from . import build as _build
 
-MODEL_FUNNEL, MODEL_NOISE, MODEL_SMOOTH = 0, 1, 2
-MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH}
+MODEL_FUNNEL, MODEL_NOISE, MODEL_SMOOTH, MODEL_USER = 0, 1, 2, 3
+MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH}   # the built-in models of libmuse_hip.so
 MEM_HOST, MEM_DEVICE = 0, 1
 Z0_ZERO, Z0_TRUE, Z0_WARM = 0, 1, 2
 MAX_THETA = 8
@@ -51,6 +51,7 @@ SIGNATURES = {
     "muse_ctx_create": (_i, [_i, _i64, _i, _i, C.POINTER(_vp)]),
     "muse_ctx_destroy": (_i, [_vp]),
     "muse_last_error": (C.c_char_p, []),
+    "muse_model_name": (C.c_char_p, [_i]),
     "muse_set_data": (_i, [_vp, _vp, _i]),
     "muse_set_stream": (_i, [_vp, _vp]),
     "muse_set_placement": (_i, [_vp, _i]),
@@ -95,6 +96,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_libs = {}   # path -> CDLL: libmuse_hip.so and the libraries built from users' model headers (models.ElementwiseModel)
 
 
 def library_path():
@@ -102,12 +104,17 @@ def library_path():
     return os.environ.get("MUSE_HIP_LIB") or _build.LIB_PATH
 
 
-def load_library():
-    """dlopen libmuse_hip.so (built in-tree by build.build_extension) and declare every signature."""
+def load_library(path=None):
+    """dlopen libmuse_hip.so (built in-tree by build.build_extension) -- or, given `path`, the engine library of a user's
+    model (build.build_model_library: the same ABI) -- and declare every signature."""
     global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+    if path is None:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+    path = os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise MuseError(-2, f"{path} is missing: run museinference.jl_amd.build.build_extension() "
                             "(there is no CPU fallback)")
@@ -116,13 +123,16 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
+    if path == os.path.abspath(library_path()):
+        _lib = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
+    """Raise MuseError for a negative status, with the message of the library the call went to."""
     if rc != 0:
-        raise MuseError(rc, load_library().muse_last_error().decode("utf-8", "replace"))
+        raise MuseError(rc, (lib or load_library()).muse_last_error().decode("utf-8", "replace"))
 
 
 def f8(a, n=None):

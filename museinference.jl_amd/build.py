@@ -15,7 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmuse_hip.so")
 OBJ_DIR = os.path.join(_HERE, "build")
 _API = os.path.join(_HERE, "..", "include", "muse_hip.h")
-_KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "solver.hpp", "step.hpp")]
+_KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "user_model.hpp", "solver.hpp",
+                                                    "step.hpp")]
 # source -> (headers it depends on, extra flags)
 # -ffp-contract=off: the sampler's log/sincos sequences and the model gradients are defined in terms
 # of individually rounded IEEE operations (bit-equal to a host evaluation of the same sequence).
@@ -23,7 +24,7 @@ UNITS = {
     "muse_kernels.hip": (_KERNEL_HEADERS + [_API], ["--offload-arch=gfx950", "-O3", "-ffp-contract=off"]),
     # host code: plain C++ against the HIP runtime API (no device pass)
     # (-ffp-contract=off here too: step.hpp's algebra must round on the host exactly as in the step kernel)
-    "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), _API],
+    "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), os.path.join(CSRC, "user_model.hpp"), _API],
                         ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
     "muse_comm.cpp": ([_API, os.path.join(CSRC, "shm_gather.hpp")], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
 }
@@ -77,28 +78,36 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
     return lib_path
 
 
-# Diagnostic variants for tests/test_gpu_linesearch.py: the noise model's objective replaced by a non-quadratic one
-# (-DMUSE_HZTEST, models.hpp) and ONE solver instantiation each (-DMUSE_INSPECT: seconds to compile) -- the register/LDS
-# resident placement, the streaming one and the streaming cluster.  Never loaded by the product path.
-HZTEST_VARIANTS = {
-    "resident": "NoiseModel, PlaceResident<512, 10, true>",
-    "streaming": "NoiseModel, PlaceStreaming<512, false, MUSE_STREAM_U>",
-    "cluster": "NoiseModel, PlaceStreaming<256, true, MUSE_STREAM_U>",
-}
+# ------------------------------------------------------------------------------------------------------------------
+# User-supplied elementwise models (include/muse_model.h; SimpleMuseProblem's closures, src/simple.jl:79-95, as compiled
+# code): the same three translation units with -DMUSE_USER_MODEL_HEADER="<header>" give an engine library of their own
+# that holds that one model (model id MUSE_MODEL_USER) behind the whole C ABI.
+INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
+MODELS_DIR = os.path.join(_HERE, "models")
 
 
-def hztest_lib_path(kind):
-    return os.path.join(_HERE, f"libmuse_hip_hztest_{kind}.so")
+def model_lib_path(name):
+    return os.path.join(_HERE, f"libmuse_hip_model_{name}.so")
 
 
-def build_linesearch_test_variants(force=False):
-    """Build (if missing or stale) the three -DMUSE_HZTEST libraries; returns {kind: path}."""
+def build_model_library(header, name, force=False, verbose=False):
+    """Compile (if missing or stale) the engine library of the model in `header`; returns its path (in-tree, next to
+    libmuse_hip.so, so that it travels with a snapshot of the repository)."""
+    header = os.path.abspath(header)
+    if not os.path.exists(header):
+        raise FileNotFoundError(header)
+    path = model_lib_path(name)
+    if force or _stale(path, SOURCES + HEADERS + [header, os.path.join(INCLUDE_DIR, "muse_model.h")]):
+        build_extension(defines=[f'-DMUSE_USER_MODEL_HEADER="{header}"', "-I" + INCLUDE_DIR], lib_path=path, verbose=verbose)
+    return path
+
+
+def build_packaged_models(force=False):
+    """The example models shipped in museinference.jl_amd/models/*.h -> {name: library path}."""
     out = {}
-    for kind, inst in HZTEST_VARIANTS.items():
-        path = hztest_lib_path(kind)
-        if force or _stale(path, SOURCES + HEADERS):
-            build_extension(defines=["-DMUSE_HZTEST", "-DMUSE_INSPECT=" + inst], lib_path=path)
-        out[kind] = path
+    for f in sorted(os.listdir(MODELS_DIR)):
+        if f.endswith(".h"):
+            out[f[:-2]] = build_model_library(os.path.join(MODELS_DIR, f), f[:-2], force=force)
     return out
 
 

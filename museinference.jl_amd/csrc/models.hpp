@@ -2,6 +2,7 @@
 #pragma once
 #include <type_traits>
 
+#include "user_model.hpp"
 #include "vec.hpp"
 
 namespace muse {
@@ -43,18 +44,8 @@ struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
     }
     __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
         const double r = x - z, t = iv * r;
-#ifdef MUSE_HZTEST
-        // DIAGNOSTIC BUILD ONLY (tests/test_gpu_linesearch.py builds it next to the product library): a NON-quadratic
-        // objective, F = 1/2 z^2 + 1/2 iv (x - z)^2 + 1/4 z^4 per element.  Every shipped model is Gaussian, i.e. quadratic
-        // in z, and on a quadratic HagerZhang ends with its first secant step; this objective drives the kernel's line
-        // search through bracket expansion, bisection and the secant^2 updates, against the oracle's test objective 101.
-        const double z2 = z * z;
-        facc = fma(0.5, z2 * z2, fma(z, z, fma(t, r, facc)));
-        return fma(z2, z, z - t);
-#else
         facc = fma(z, z, fma(t, r, facc));
         return z - t;
-#endif
     }
     __device__ static __forceinline__ double score_term(double x, double z) {
         const double r = x - z;
@@ -68,6 +59,22 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
     static constexpr int kId = MUSE_MODEL_SMOOTH;
     __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
 };
+
+#ifdef MUSE_USER_MODEL_HEADER
+template <int MAXB_>
+struct UserModel {  // include/muse_model.h: the three functions of the user's header behind the elementwise model concept
+    static constexpr int MAXB = MAXB_;
+    static constexpr bool kStencil = false;
+    static constexpr int kId = MUSE_MODEL_USER;
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+        muse_model_sample(sd, n1, n2, &z, &x);
+    }
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+        return muse_model_grad(iv, x, z, &facc);
+    }
+    __device__ static __forceinline__ double score_term(double x, double z) { return muse_model_score_term(x, z); }
+};
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Storage policies.

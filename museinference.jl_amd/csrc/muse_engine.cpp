@@ -17,6 +17,7 @@
 #include "../../include/muse_hip.h"
 #include "args.hpp"
 #include "step.hpp"
+#include "user_model.hpp"
 
 // ================================================================================================
 // Host side: context, workspace, launches, C ABI.
@@ -412,10 +413,33 @@ extern "C" {
 const char* muse_last_error(void) { return g_err.c_str(); }
 int64_t muse_max_resident_n(void) { return kMaxResidentN; }
 
+const char* muse_model_name(int model) {
+#ifdef MUSE_USER_MODEL_HEADER
+    return model == MUSE_MODEL_USER ? MUSE_MODEL_NAME : nullptr;
+#else
+    static const char* const names[3] = {"funnel", "noise", "smooth"};
+    return model >= 0 && model <= 2 ? names[model] : nullptr;
+#endif
+}
+
 int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out) {
     if (!out) return fail(MUSE_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (model < 0 || model > 2) return fail(MUSE_ERR_INVALID, "unknown model");
+    if (model < 0 || model > MUSE_MODEL_USER) return fail(MUSE_ERR_INVALID, "unknown model");
+    if (!muse_model_name(model))
+        return fail(MUSE_ERR_INVALID, model == MUSE_MODEL_USER
+                                          ? "MUSE_MODEL_USER: this library holds the built-in models only (build one from a model "
+                                            "header, include/muse_model.h)"
+                                          : "this library was built from a user's model header and holds MUSE_MODEL_USER only");
+#ifdef MUSE_USER_MODEL_HEADER
+    {   // the zero-element requirements of include/muse_model.h (the pad element of an odd-length vector must not contribute)
+        double acc = 1.25;
+        const double g0 = muse_model_grad(0.7, 0.0, 0.0, &acc);
+        if (!(g0 == 0.0 && acc == 1.25 && muse_model_score_term(0.0, 0.0) == 0.0))
+            return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": muse_model_grad(iv, 0, 0, &acc) must return 0 and leave acc "
+                                          "unchanged, muse_model_score_term(0, 0) must be 0 (include/muse_model.h)");
+    }
+#endif
     if (N < 1) return fail(MUSE_ERR_INVALID, "N must be >= 1");
     if (ntheta < 1 || ntheta > kMaxTheta) return fail(MUSE_ERR_INVALID, "ntheta must be in [1, MUSE_MAX_THETA]");
     if (model == MUSE_MODEL_NOISE && ntheta != 1) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_NOISE has ntheta = 1");
@@ -1431,6 +1455,9 @@ static int implicit_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t 
                          const double* theta0, double atol, int cg_maxiter, double* cols_out, int32_t* cg_iters_out) {
     const int nt = c->ntheta;
     const int64_t ne = e_end - e_begin;
+    if (c->model == MUSE_MODEL_USER)
+        return fail(MUSE_ERR_INVALID, "the implicit-differentiation H needs second derivatives, which a user model does not "
+                                      "supply (include/muse_model.h): use the finite-difference entries");
     if (ne == 0) return MUSE_OK;
     if (ne > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
     const int64_t s_lo = sim_begin + e_begin / nt, s_hi = sim_begin + (e_end - 1) / nt + 1;

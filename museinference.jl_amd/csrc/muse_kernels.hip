@@ -225,6 +225,16 @@ __global__ void __launch_bounds__(256) sample_kernel(BatchArgs a, uint64_t sim, 
         }
     }
 }
+#ifdef MUSE_USER_MODEL_HEADER
+__global__ void __launch_bounds__(256) sample_user_kernel(BatchArgs a, uint64_t sim, double* __restrict__ x, double* __restrict__ z) {
+    const int64_t N = a.N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = a.ntheta > 1 ? block_of(a, i) : 0;
+        const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+        UserModel<1>::sample(a.cur.t.sd[k], np.n1, np.n2, z[i], x[i]);
+    }
+}
+#endif
 __global__ void __launch_bounds__(256) smooth_finish_kernel(int64_t N, const double* __restrict__ z,
                                                             const double* __restrict__ noise, double* __restrict__ x) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -413,6 +423,9 @@ static hipError_t launch_place_implicit(const LaunchShape& s, const BatchArgs& a
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
 #ifdef MUSE_INSPECT  // development aid (tools/regs.py --check): instantiate ONE kernel, for a quick look at its assembly
     return launch_one<MUSE_INSPECT>(s, a, st);
+#elif defined(MUSE_USER_MODEL_HEADER)  // a library built from a user's model header holds that model only (user_model.hpp)
+    if (s.model != MUSE_MODEL_USER || s.implicit) return hipErrorInvalidValue;
+    return s.ntheta == 1 ? launch_place<UserModel<1>>(s, a, st) : launch_place<UserModel<kMaxTheta>>(s, a, st);
 #else
     const int nt = s.ntheta;
     if (s.implicit) {
@@ -456,6 +469,12 @@ hipError_t launch_time_stamp(unsigned long long* out, int* stop_flag, hipStream_
 
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t st) {
     const int grid = (int)((a.N + 255) / 256 < 4096 ? (a.N + 255) / 256 : 4096);
+#ifdef MUSE_USER_MODEL_HEADER
+    (void)noise;
+    if (model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sample_user_kernel, dim3(grid), dim3(256), 0, st, a, sim, x, z);
+    return hipGetLastError();
+#endif
     if (model == MUSE_MODEL_NOISE) hipLaunchKernelGGL(sample_kernel<MUSE_MODEL_NOISE>, dim3(grid), dim3(256), 0, st, a, sim, x, z);
     else if (model == MUSE_MODEL_FUNNEL) hipLaunchKernelGGL(sample_kernel<MUSE_MODEL_FUNNEL>, dim3(grid), dim3(256), 0, st, a, sim, x, z);
     else {
@@ -466,6 +485,11 @@ hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x,
 }
 
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t st) {
+#ifdef MUSE_USER_MODEL_HEADER
+    if (model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(loglike_kernel<UserModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
+    return hipGetLastError();
+#endif
     if (model == MUSE_MODEL_NOISE) hipLaunchKernelGGL(loglike_kernel<NoiseModel>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     else if (model == MUSE_MODEL_FUNNEL) hipLaunchKernelGGL(loglike_kernel<FunnelModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     else hipLaunchKernelGGL(loglike_kernel<SmoothModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);

@@ -1,0 +1,69 @@
+"""User-supplied elementwise models: SimpleMuseProblem's closures (src/simple.jl:79-95) as compiled code.
+
+The reference builds a problem from `sample_x_z`, `logLike` and `logPrior` closures and differentiates them by AD.  Here a
+model is a C header with three functions (include/muse_model.h states the contract and the family:
+-logLike = 1/2 sum_i [A(x_i, z_i) + e^-theta_k B(x_i, z_i)] + 1/2 sum_k n_k theta_k) that hipcc compiles into an engine
+library of its own -- every placement of the solver kernel, the sampler, the finite-difference and multi-map launches, the
+native muse! loop, behind the same C ABI:
+
+    model = ElementwiseModel.from_source("cubic", '''
+        #include "muse_model.h"
+        #define MUSE_MODEL_NAME "cubic"
+        MUSE_MODEL_FN void   muse_model_sample(double sd, double n1, double n2, double* z, double* x) { ... }
+        MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) { ... }
+        MUSE_MODEL_FN double muse_model_score_term(double x, double z) { ... }
+    ''')
+    prob = HipMuseProblem(x, model=model, ntheta=2, prior=GaussianPrior(0, 3))
+    result = muse(prob, [0.0, 0.0], get_covariance=True)          # get_H! by finite differences
+
+`ElementwiseModel.packaged("cubic")` is the example shipped in museinference.jl_amd/models/cubic.h.
+"""
+import hashlib
+import os
+import re
+
+from . import build as _build
+
+
+class ElementwiseModel:
+    def __init__(self, name, header):
+        if not re.fullmatch(r"[A-Za-z][A-Za-z0-9_]*", name or ""):
+            raise ValueError(f"model name {name!r}: letters, digits and underscores, starting with a letter")
+        self.name = name
+        self.header = os.path.abspath(header)
+        if not os.path.exists(self.header):
+            raise FileNotFoundError(self.header)
+        self._library = None
+
+    @classmethod
+    def packaged(cls, name):
+        """One of the example models in museinference.jl_amd/models/."""
+        return cls(name, os.path.join(_build.MODELS_DIR, name + ".h"))
+
+    @classmethod
+    def from_source(cls, name, source, directory=None):
+        """Write `source` to <directory>/<name>_<hash>.h (default: museinference.jl_amd/models/user/) and wrap it; the
+        library is named after name and hash, so that an edited source gets a library of its own."""
+        directory = directory or os.path.join(_build.MODELS_DIR, "user")
+        os.makedirs(directory, exist_ok=True)
+        tag = hashlib.sha256(source.encode()).hexdigest()[:10]
+        path = os.path.join(directory, f"{name}_{tag}.h")
+        if not os.path.exists(path):
+            with open(path, "w") as f:
+                f.write(source)
+        m = cls(name, path)
+        m._libname = f"{name}_{tag}"
+        return m
+
+    @property
+    def library_name(self):
+        return getattr(self, "_libname", self.name)
+
+    def library(self, force=False):
+        """Path of the model's engine library, compiled on first use (hipcc, ~1 min; cross-compiles without a GPU)."""
+        if self._library is None or force:
+            self._library = _build.build_model_library(self.header, self.library_name, force=force)
+        return self._library
+
+    def __repr__(self):
+        return f"ElementwiseModel({self.name!r}, {self.header!r})"

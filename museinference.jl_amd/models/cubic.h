@@ -1,0 +1,25 @@
+/* cubic.h -- example of a user-supplied elementwise model (include/muse_model.h): a funnel seen through a NON-LINEAR
+ * observation function,
+ *     z_i ~ N(0, e^theta_k),   x_i ~ N(h(z_i), 1),   h(z) = z + z^3 / 10        (h' = 1 + 3 z^2 / 10 > 0)
+ * so that  -logLike = 1/2 sum_i [ (x_i - h(z_i))^2 + e^-theta_k z_i^2 ] + 1/2 sum_k n_k theta_k :
+ * A = (x - h(z))^2, B = z^2.  The MAP objective is not quadratic in z (the line search does real work, unlike on the
+ * Gaussian models), the posterior is not Gaussian, and MUSE's estimate of theta is still unbiased. */
+#include "muse_model.h"
+#define MUSE_MODEL_NAME "cubic"
+
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x) {
+    const double zi = sd * n1;
+    *z = zi;
+    *x = fma(0.1 * (zi * zi), zi, zi) + n2;
+}
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) {
+    const double z2 = z * z;
+    const double r = x - fma(0.1 * z2, z, z);   /* x - h(z) */
+    const double t = iv * z;
+    *acc = fma(t, z, fma(r, r, *acc));
+    return t - r * fma(0.3, z2, 1.0);           /* iv z - (x - h) h'(z) */
+}
+MUSE_MODEL_FN double muse_model_score_term(double x, double z) {
+    (void)x;
+    return z * z;
+}

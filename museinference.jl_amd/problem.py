@@ -168,9 +168,15 @@ class HipMuseProblem(AbstractMuseProblem):
                                  # that forward attribute access to a HipMuseProblem do not inherit it)
 
     def __init__(self, x, model="funnel", ntheta=1, prior=None, device=0, N=None):
-        self._lib = _capi.load_library()
-        if model not in _capi.MODELS:
-            raise ValueError(f"unknown model {model!r}; choose from {sorted(_capi.MODELS)}")
+        from .models import ElementwiseModel
+        if isinstance(model, ElementwiseModel):     # a user's model: its own engine library, model id MUSE_MODEL_USER
+            self._lib = _capi.load_library(model.library())
+            model_id, self.user_model, model = _capi.MODEL_USER, model, model.name
+        else:
+            self._lib = _capi.load_library()
+            if model not in _capi.MODELS:
+                raise ValueError(f"unknown model {model!r}; choose from {sorted(_capi.MODELS)} or pass an ElementwiseModel")
+            model_id, self.user_model = _capi.MODELS[model], None
         if x is None and N is None:
             raise ValueError("give the observed data x (or N for a data-less problem)")
         self.x = None if x is None else _capi.f8(x)
@@ -180,11 +186,10 @@ class HipMuseProblem(AbstractMuseProblem):
         self.prior = as_prior(prior)
         self.device = int(device)
         ctx = C.c_void_p()
-        _capi.check(self._lib.muse_ctx_create(_capi.MODELS[model], self.N, self.ntheta, self.device,
-                                              C.byref(ctx)))
+        self._check(self._lib.muse_ctx_create(model_id, self.N, self.ntheta, self.device, C.byref(ctx)))
         self._ctx = ctx
         if self.x is not None:
-            _capi.check(self._lib.muse_set_data(self._ctx, _capi.ptr(self.x), _capi.MEM_HOST))
+            self._check(self._lib.muse_set_data(self._ctx, _capi.ptr(self.x), _capi.MEM_HOST))
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -198,62 +203,65 @@ class HipMuseProblem(AbstractMuseProblem):
             pass
 
     # -- helpers
+    def _check(self, rc):
+        _capi.check(rc, self._lib)
+
     def _theta(self, theta):
         return _capi.f8(theta, self.ntheta)
 
     def set_placement(self, placement):
         """-1 auto, 0 streaming, 1 resident (bitwise-identical results; for tests/benchmarks)."""
-        _capi.check(self._lib.muse_set_placement(self._ctx, int(placement)))
+        self._check(self._lib.muse_set_placement(self._ctx, int(placement)))
 
     def set_element_split(self, split):
         """Workgroups per map element: 0/1 = by N alone (default), 2/4/8/16 = that many workgroups share one
         element (for launches with fewer elements than compute units: the per-GPU share of a strongly scaled
         map, the axis choice of src/muse.jl:327-333).  Results depend on the split (summation tree), not on the
         batch or the GPU count."""
-        _capi.check(self._lib.muse_set_element_split(self._ctx, int(split)))
+        self._check(self._lib.muse_set_element_split(self._ctx, int(split)))
         self.element_split = int(split)
 
     def set_concurrency(self, nlanes):
         """Result area r runs on lane r mod nlanes (a stream, scratch and ticket counter of its own): consecutive launches on
         different areas overlap instead of queueing behind each other's last workgroup.  Results are unchanged."""
-        _capi.check(self._lib.muse_set_concurrency(self._ctx, int(nlanes)))
+        self._check(self._lib.muse_set_concurrency(self._ctx, int(nlanes)))
 
     def placement_info(self):
         """{'threads', 'workgroups_per_element', 'resident', 'direction_in_lds'} of this problem's batched maps."""
         v = [C.c_int() for _ in range(4)]
-        _capi.check(self._lib.muse_placement_info(self._ctx, *[C.byref(x) for x in v]))
+        self._check(self._lib.muse_placement_info(self._ctx, *[C.byref(x) for x in v]))
         return dict(threads=v[0].value, workgroups_per_element=v[1].value, resident=bool(v[2].value),
                     direction_in_lds=bool(v[3].value))
 
     def set_stream(self, hip_stream):
-        _capi.check(self._lib.muse_set_stream(self._ctx, _capi.ptr(hip_stream) if hip_stream else None))
+        self._check(self._lib.muse_set_stream(self._ctx, _capi.ptr(hip_stream) if hip_stream else None))
 
     def synchronize(self):
-        _capi.check(self._lib.muse_synchronize(self._ctx))
+        self._check(self._lib.muse_synchronize(self._ctx))
 
     def last_kernel_ms(self):
         ms = C.c_float()
-        _capi.check(self._lib.muse_last_kernel_ms(self._ctx, C.byref(ms)))
+        self._check(self._lib.muse_last_kernel_ms(self._ctx, C.byref(ms)))
         return ms.value
 
     def set_timing(self, enabled):
-        _capi.check(self._lib.muse_set_timing(self._ctx, int(bool(enabled))))
+        self._check(self._lib.muse_set_timing(self._ctx, int(bool(enabled))))
 
     def profile_begin(self, max_launches=1024):
-        _capi.check(self._lib.muse_profile_begin(self._ctx, int(max_launches)))
+        self._check(self._lib.muse_profile_begin(self._ctx, int(max_launches)))
         self._prof_cap = int(max_launches)
 
     def profile_end(self):
         """Per-launch solver kernel durations (ms) since profile_begin (HIP events on the launch stream)."""
         buf = (C.c_float * self._prof_cap)()
         n = C.c_int()
-        _capi.check(self._lib.muse_profile_end(self._ctx, buf, self._prof_cap, C.byref(n)))
+        self._check(self._lib.muse_profile_end(self._ctx, buf, self._prof_cap, C.byref(n)))
         return np.array(buf[: min(n.value, self._prof_cap)], dtype=np.float64)
 
     def profile_clock_hz(self):
         """Shader clock during the last launch profiled between profile_begin and profile_end (in-kernel counters)."""
         hz = C.c_double()
-        _capi.check(self._lib.muse_profile_clock_hz(self._ctx, C.byref(hz)))
+        self._check(self._lib.muse_profile_clock_hz(self._ctx, C.byref(hz)))
         return hz.value
 
     # -- prior (SimpleMuseProblem forwards to the user's function, src/simple.jl:93)
@@ -272,7 +280,7 @@ class HipMuseProblem(AbstractMuseProblem):
         x = np.empty(self.N)
         z = np.empty(self.N)
         th = self._theta(theta)
-        _capi.check(self._lib.muse_sample_x_z(self._ctx, rng.seed, rng.sim, _capi.ptr(th), _capi.ptr(x),
+        self._check(self._lib.muse_sample_x_z(self._ctx, rng.seed, rng.sim, _capi.ptr(th), _capi.ptr(x),
                                               _capi.ptr(z), _capi.MEM_HOST))
         return x, z
 
@@ -283,7 +291,7 @@ class HipMuseProblem(AbstractMuseProblem):
         th = self._theta(theta)
         g = np.empty(self.N)
         f = C.c_double()
-        _capi.check(self._lib.muse_logLike_and_grad_z(self._ctx, _capi.ptr(x), _capi.ptr(z), _capi.ptr(th),
+        self._check(self._lib.muse_logLike_and_grad_z(self._ctx, _capi.ptr(x), _capi.ptr(z), _capi.ptr(th),
                                                       C.byref(f), _capi.ptr(g), _capi.MEM_HOST))
         return f.value, g
 
@@ -293,7 +301,7 @@ class HipMuseProblem(AbstractMuseProblem):
         z = _capi.f8(z, self.N)
         th = self._theta(theta)
         g = np.empty(self.ntheta)
-        _capi.check(self._lib.muse_grad_theta(self._ctx, _capi.ptr(x), _capi.ptr(z), _capi.ptr(th), _capi.ptr(g),
+        self._check(self._lib.muse_grad_theta(self._ctx, _capi.ptr(x), _capi.ptr(z), _capi.ptr(th), _capi.ptr(g),
                                               _capi.MEM_HOST))
         return g
 
@@ -304,7 +312,7 @@ class HipMuseProblem(AbstractMuseProblem):
         th = self._theta(theta)
         z = np.empty(self.N)
         info = np.zeros(1, dtype=_capi.INFO_DTYPE)
-        _capi.check(self._lib.muse_zhat_at_theta(self._ctx, _capi.ptr(x), _capi.ptr(z0), _capi.ptr(th),
+        self._check(self._lib.muse_zhat_at_theta(self._ctx, _capi.ptr(x), _capi.ptr(z0), _capi.ptr(th),
                                                  float(grad_z_logLike_atol), _capi.ptr(z), _capi.ptr(info),
                                                  _capi.MEM_HOST))
         check_optim_soln(info, "ẑ_at_θ")
@@ -319,7 +327,7 @@ class HipMuseProblem(AbstractMuseProblem):
         n = (sim_end - sim_begin) + (1 if include_data else 0)
         g = np.empty((n, self.ntheta))
         info = np.zeros(n, dtype=_capi.INFO_DTYPE)
-        _capi.check(self._lib.muse_map_and_score_batch(self._ctx, _seed_of(rng), sim_begin, sim_end,
+        self._check(self._lib.muse_map_and_score_batch(self._ctx, _seed_of(rng), sim_begin, sim_end,
                                                        int(bool(include_data)), _capi.ptr(th), float(atol),
                                                        int(z0_mode), _capi.ptr(g), _capi.ptr(info)))
         return g, info
@@ -327,7 +335,7 @@ class HipMuseProblem(AbstractMuseProblem):
     def map_and_score_batch_async(self, rng, sim_begin, sim_end, theta, *, include_data=False, atol=1e-2,
                                   z0_mode=_capi.Z0_ZERO, result_area=0):
         th = self._theta(theta)
-        _capi.check(self._lib.muse_map_and_score_batch_async(self._ctx, _seed_of(rng), sim_begin, sim_end,
+        self._check(self._lib.muse_map_and_score_batch_async(self._ctx, _seed_of(rng), sim_begin, sim_end,
                                                              int(bool(include_data)), _capi.ptr(th), float(atol),
                                                              int(z0_mode), int(result_area)))
         return (sim_end - sim_begin) + (1 if include_data else 0)
@@ -340,7 +348,7 @@ class HipMuseProblem(AbstractMuseProblem):
         th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(-1, self.ntheta))
         if not 1 <= th.shape[0] <= _capi.MAX_MAPS:
             raise ValueError(f"1 <= nmaps <= {_capi.MAX_MAPS}")
-        _capi.check(self._lib.muse_map_and_score_multi_async(self._ctx, _seed_of(rng), sim_begin, sim_end,
+        self._check(self._lib.muse_map_and_score_multi_async(self._ctx, _seed_of(rng), sim_begin, sim_end,
                                                              int(bool(include_data)), th.shape[0], _capi.ptr(th), float(atol),
                                                              int(z0_mode), int(result_area)))
         return th.shape[0] * ((sim_end - sim_begin) + (1 if include_data else 0))
@@ -356,7 +364,7 @@ class HipMuseProblem(AbstractMuseProblem):
             if g.shape != (n, self.ntheta) or info.shape != (n,) or g.dtype != np.float64 or info.dtype != _capi.INFO_DTYPE \
                     or not (g.flags.c_contiguous and info.flags.c_contiguous):
                 raise ValueError("out must be (float64 [n, ntheta], INFO_DTYPE [n]), C-contiguous")
-        _capi.check(self._lib.muse_batch_wait(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
+        self._check(self._lib.muse_batch_wait(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
         return g, info
 
     def native_prior(self):
@@ -391,20 +399,20 @@ class HipMuseProblem(AbstractMuseProblem):
         n = C.c_int32()
         device_loop = bool(device_loop)
         fn = self._lib.muse_run_device if device_loop else self._lib.muse_run
-        _capi.check(fn(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
+        self._check(fn(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
                        _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
         return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
 
     def get_zhat(self, slot_begin, slot_end):
         out = np.empty((slot_end - slot_begin, self.N))
-        _capi.check(self._lib.muse_get_zhat(self._ctx, slot_begin, slot_end, _capi.ptr(out), _capi.MEM_HOST))
+        self._check(self._lib.muse_get_zhat(self._ctx, slot_begin, slot_end, _capi.ptr(out), _capi.MEM_HOST))
         return out
 
     def set_zhat(self, slot_begin, zs):
         zs = np.ascontiguousarray(np.atleast_2d(np.asarray(zs, dtype=np.float64)))
         if zs.shape[1] != self.N:
             raise ValueError("zhat rows must have N columns")
-        _capi.check(self._lib.muse_set_zhat(self._ctx, slot_begin, slot_begin + zs.shape[0], _capi.ptr(zs),
+        self._check(self._lib.muse_set_zhat(self._ctx, slot_begin, slot_begin + zs.shape[0], _capi.ptr(zs),
                                             _capi.MEM_HOST))
 
     def fd_jacobian_batch(self, rng, sim_begin, sim_end, theta0, step, *, atol=1e-2, fid_mode=0,
@@ -416,7 +424,7 @@ class HipMuseProblem(AbstractMuseProblem):
         ns = sim_end - sim_begin
         Hs = np.empty((ns, self.ntheta, self.ntheta))
         info = np.zeros((ns, self.ntheta, 2), dtype=_capi.INFO_DTYPE)
-        _capi.check(self._lib.muse_fd_jacobian_batch(self._ctx, _seed_of(rng), sim_begin, sim_end, _capi.ptr(th),
+        self._check(self._lib.muse_fd_jacobian_batch(self._ctx, _seed_of(rng), sim_begin, sim_end, _capi.ptr(th),
                                                      _capi.ptr(st), float(atol), int(fid_mode), int(fid_sim),
                                                      _capi.ptr(Hs), _capi.ptr(info)))
         return Hs, info
@@ -428,7 +436,7 @@ class HipMuseProblem(AbstractMuseProblem):
         ns = sim_end - sim_begin
         Hs = np.empty((ns, self.ntheta, self.ntheta))
         its = np.zeros((ns, self.ntheta), dtype=np.int32)
-        _capi.check(self._lib.muse_implicit_H_batch(self._ctx, _seed_of(rng), sim_begin, sim_end, _capi.ptr(th),
+        self._check(self._lib.muse_implicit_H_batch(self._ctx, _seed_of(rng), sim_begin, sim_end, _capi.ptr(th),
                                                     float(atol), int(cg_maxiter), _capi.ptr(Hs), _capi.ptr(its)))
         return Hs, its
 
@@ -442,7 +450,7 @@ class HipMuseProblem(AbstractMuseProblem):
         n = col_end - col_begin
         cols = np.empty((n, self.ntheta))
         info = np.zeros((n, 2), dtype=_capi.INFO_DTYPE)
-        _capi.check(self._lib.muse_fd_jacobian_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th),
+        self._check(self._lib.muse_fd_jacobian_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th),
                                                        _capi.ptr(st), float(atol), int(fid_mode), int(fid_sim),
                                                        _capi.ptr(cols), _capi.ptr(info)))
         return cols, info
@@ -463,7 +471,7 @@ class HipMuseProblem(AbstractMuseProblem):
         G = off.shape[1]
         F = np.empty((n, G, self.ntheta))
         info = np.zeros((n, G), dtype=_capi.INFO_DTYPE)
-        _capi.check(self._lib.muse_fd_values_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th), G,
+        self._check(self._lib.muse_fd_values_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th), G,
                                                      _capi.ptr(off), int(per_unit), float(atol), int(fid_mode), int(fid_sim),
                                                      _capi.ptr(F), _capi.ptr(info)))
         return F, info
@@ -474,7 +482,7 @@ class HipMuseProblem(AbstractMuseProblem):
         n = col_end - col_begin
         cols = np.empty((n, self.ntheta))
         its = np.zeros(n, dtype=np.int32)
-        _capi.check(self._lib.muse_implicit_H_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th),
+        self._check(self._lib.muse_implicit_H_columns(self._ctx, _seed_of(rng), sim_begin, col_begin, col_end, _capi.ptr(th),
                                                       float(atol), int(cg_maxiter), _capi.ptr(cols), _capi.ptr(its)))
         return cols, its
 
@@ -493,29 +501,29 @@ class HipMuseProblem(AbstractMuseProblem):
         if len(unique_id) != _capi.UNIQUE_ID_BYTES:
             raise ValueError("unique_id must be the bytes returned by comm_unique_id")
         buf = (C.c_char * _capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)  # (binary: not a C string)
-        _capi.check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), buf))
+        self._check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), buf))
         self._nranks = int(nranks)
 
     def comm_destroy(self):
         """Tear the communicator down (a context may then be given another one, e.g. the other transport)."""
-        _capi.check(self._lib.muse_comm_destroy(self._ctx))
+        self._check(self._lib.muse_comm_destroy(self._ctx))
         self._nranks = None
 
     def comm_ranks_seen(self):
         """Ranks the communicator itself counts (ncclCommCount / processes attached to the shared segment)."""
         n = C.c_int(-1)
-        _capi.check(self._lib.muse_comm_ranks_seen(self._ctx, C.byref(n)))
+        self._check(self._lib.muse_comm_ranks_seen(self._ctx, C.byref(n)))
         return n.value
 
     def comm_transport(self):
         t = C.c_int(-1)
-        _capi.check(self._lib.muse_comm_transport(self._ctx, C.byref(t)))
+        self._check(self._lib.muse_comm_transport(self._ctx, C.byref(t)))
         return {v: k for k, v in self.TRANSPORTS.items()}[t.value]
 
     def allgather_scores(self, send):
         send = _capi.f8(send)
         recv = np.empty((self._nranks, send.size))
-        _capi.check(self._lib.muse_allgather_scores(self._ctx, _capi.ptr(send), send.size, _capi.ptr(recv)))
+        self._check(self._lib.muse_allgather_scores(self._ctx, _capi.ptr(send), send.size, _capi.ptr(recv)))
         return recv
 
     def map_and_score_batch_gather_async(self, rng, sim_begin, sim_end, theta, rows_per_rank, *, include_data=False,
@@ -524,7 +532,7 @@ class HipMuseProblem(AbstractMuseProblem):
         on the communicator's own stream; shm: between the hosts, inside batch_wait_gathered).  Returns this rank's
         element count."""
         th = self._theta(theta)
-        _capi.check(self._lib.muse_map_and_score_batch_gather_async(
+        self._check(self._lib.muse_map_and_score_batch_gather_async(
             self._ctx, _seed_of(rng), sim_begin, sim_end, int(bool(include_data)), _capi.ptr(th), float(atol),
             int(z0_mode), int(rows_per_rank), int(result_area)))
         return (sim_end - sim_begin) + (1 if include_data else 0)
@@ -535,7 +543,7 @@ class HipMuseProblem(AbstractMuseProblem):
         for all of them; batch_wait_gathered(nmaps * n, nmaps * rows_per_rank, area) then returns
         g_all [nranks, nmaps * rows_per_rank, nθ] (map m of rank q: rows m*rows_per_rank ...) and info [nmaps * n]."""
         th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(-1, self.ntheta))
-        _capi.check(self._lib.muse_map_and_score_multi_gather_async(
+        self._check(self._lib.muse_map_and_score_multi_gather_async(
             self._ctx, _seed_of(rng), sim_begin, sim_end, int(bool(include_data)), th.shape[0], _capi.ptr(th), float(atol),
             int(z0_mode), int(rows_per_rank), int(result_area)))
         return th.shape[0] * ((sim_end - sim_begin) + (1 if include_data else 0))
@@ -551,12 +559,12 @@ class HipMuseProblem(AbstractMuseProblem):
             if g.shape != (self._nranks, int(rows_per_rank), self.ntheta) or info.shape != (n,) or g.dtype != np.float64 \
                     or info.dtype != _capi.INFO_DTYPE or not (g.flags.c_contiguous and info.flags.c_contiguous):
                 raise ValueError("out must be (float64 [nranks, rows_per_rank, ntheta], INFO_DTYPE [n]), C-contiguous")
-        _capi.check(self._lib.muse_batch_wait_gathered(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
+        self._check(self._lib.muse_batch_wait_gathered(self._ctx, int(result_area), _capi.ptr(g), _capi.ptr(info)))
         return g, info
 
     def allreduce_sum(self, buf):
         buf = _capi.f8(buf).copy()
-        _capi.check(self._lib.muse_allreduce_sum(self._ctx, _capi.ptr(buf), buf.size))
+        self._check(self._lib.muse_allreduce_sum(self._ctx, _capi.ptr(buf), buf.size))
         return buf
 
 

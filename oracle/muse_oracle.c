@@ -85,6 +85,18 @@ static double* ws_alloc(size_t n) {
 #define MO_MODEL_FUNNEL 0 /* z_i ~ N(0, e^theta_k(i)), x_i ~ N(z_i, 1)          */
 #define MO_MODEL_NOISE 1  /* z_i ~ N(0, 1),            x_i ~ N(z_i, e^theta)     */
 #define MO_MODEL_SMOOTH 2 /* z as funnel, x = A z + n, A = periodic (1/4,1/2,1/4) */
+/* A user-supplied elementwise model (include/muse_model.h; the engine compiles the header's three functions into a
+ * library of its own): built with -DMO_USER_MODEL_HEADER="<header>" (make user, below in the Makefile) this checker
+ * compiles the SAME text, so that the HIP path of a user's model has a CPU counterpart like the built-in ones:
+ * -logLike = 1/2 sum_i [A(x_i,z_i) + e^-theta_k B(x_i,z_i)] + 1/2 sum_k n_k theta_k, score_k = 1/2 (e^-theta_k sum B - n_k). */
+#define MO_MODEL_USER 3
+#ifdef MO_USER_MODEL_HEADER
+#define MUSE_MODEL_FN static inline
+#include MO_USER_MODEL_HEADER
+const char* mo_user_model_name(void) { return MUSE_MODEL_NAME; }
+#else
+const char* mo_user_model_name(void) { return 0; }
+#endif
 
 #define MO_STATUS_G_CONVERGED 0
 #define MO_STATUS_X_CONVERGED 1
@@ -259,6 +271,16 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
                    double* x, double* z) {
     double sd[64];
     for (int k = 0; k < ntheta; ++k) sd[k] = mo_exp(0.5 * theta[k]);
+#ifdef MO_USER_MODEL_HEADER
+    if (model == MO_MODEL_USER) {
+        for (int64_t i = 0; i < N; ++i) {
+            double n1, n2;
+            mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
+            muse_model_sample(sd[mo_block(i, N, ntheta)], n1, n2, &z[i], &x[i]);
+        }
+        return;
+    }
+#endif
     if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) {
             double n1, n2;
@@ -290,11 +312,6 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
  * ("Minimizing a multivariate function"): f = (1 - x1)^2 + 100 (x2 - x1^2)^2 from x0 = (0, 0).  It lets the restated
  * LBFGS()/HagerZhang() be run on the one problem for which the package's own documentation prints the work counters. */
 #define MO_MODEL_ROSENBROCK 100
-/* TEST-ONLY objective (model id 101), the one the engine's -DMUSE_HZTEST diagnostic build puts in place of the noise model's:
- * F = sum_i 1/2 z_i^2 + 1/2 e^-theta (x_i - z_i)^2 + 1/4 z_i^4 (+ N theta / 2) -- NOT quadratic in z, so that the line search
- * has to bracket, bisect and iterate its secant steps (tests/test_gpu_linesearch.py compares the kernel's solver with this
- * one, evaluation count by evaluation count). */
-#define MO_MODEL_QUARTIC_TEST 101
 
 double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, const double* z,
                           const double* theta, double* G) {
@@ -309,14 +326,16 @@ double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, con
     double iv[64];
     for (int k = 0; k < ntheta; ++k) iv[k] = mo_exp(-theta[k]);
     double acc = 0.0, cst = 0.0;
-    if (model == MO_MODEL_QUARTIC_TEST) {
+#ifdef MO_USER_MODEL_HEADER
+    if (model == MO_MODEL_USER) {
         for (int64_t i = 0; i < N; ++i) {
-            double r = x[i] - z[i], t = iv[0] * r, z2 = z[i] * z[i];
-            acc = fma(0.5, z2 * z2, fma(z[i], z[i], fma(t, r, acc)));
-            if (G) G[i] = fma(z2, z[i], z[i] - t);
+            const double gi = muse_model_grad(iv[mo_block(i, N, ntheta)], x[i], z[i], &acc);
+            if (G) G[i] = gi;
         }
-        cst = (double)N * theta[0];
-    } else if (model == MO_MODEL_NOISE) {
+        return 0.5 * (acc + mo_theta_const(N, ntheta, theta));
+    }
+#endif
+    if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) {
             double r = x[i] - z[i], t = iv[0] * r;
             acc = fma(z[i], z[i], fma(t, r, acc));
@@ -371,6 +390,15 @@ void mo_grad_theta(int model, int64_t N, int ntheta, const double* x, const doub
     double acc[64];
     int64_t cnt[64];
     for (int k = 0; k < ntheta; ++k) { acc[k] = 0.0; cnt[k] = 0; }
+#ifdef MO_USER_MODEL_HEADER
+    if (model == MO_MODEL_USER) {
+        for (int64_t i = 0; i < N; ++i) {
+            int k = mo_block(i, N, ntheta);
+            acc[k] += muse_model_score_term(x[i], z[i]);
+            cnt[k] += 1;
+        }
+    } else
+#endif
     for (int64_t i = 0; i < N; ++i) {
         int k = mo_block(i, N, ntheta);
         acc[k] += z[i] * z[i];

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmuse_oracle.so")
 
 MODEL_FUNNEL, MODEL_NOISE, MODEL_SMOOTH = 0, 1, 2
-MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH, "quartic_test": 101}
+MODELS = {"funnel": MODEL_FUNNEL, "noise": MODEL_NOISE, "smooth": MODEL_SMOOTH,
+          "user": 3}   # "user": only inside `with user_model(header, name)` (a build of this file with that header compiled in)
 STATUS = ["g_converged", "x_converged", "f_converged", "maxiter", "linesearch_failed", "nonfinite"]
 
 
@@ -45,20 +46,60 @@ def build(force=False):
 
 
 _lib = None
+_selected = None   # the library of a user's model while `with user_model(...)` is active
+
+
+def _declare(l):
+    l.mo_negloglike_grad.restype = C.c_double
+    l.mo_logLike_and_grad_z.restype = C.c_double
+    l.mo_num_threads.restype = C.c_int
+    l.mo_expd.restype = C.c_double
+    l.mo_expd.argtypes = [C.c_double]
+    l.mo_user_model_name.restype = C.c_char_p
+    return l
 
 
 def lib():
     global _lib
+    if _selected is not None:
+        return _selected
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.mo_negloglike_grad.restype = C.c_double
-        _lib.mo_logLike_and_grad_z.restype = C.c_double
-        _lib.mo_num_threads.restype = C.c_int
-        _lib.mo_expd.restype = C.c_double
-        _lib.mo_expd.argtypes = [C.c_double]
+        _lib = _declare(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def build_user_model(header, name, force=False):
+    """The checker of a user-supplied model (include/muse_model.h): this oracle with the model's header compiled in as
+    model "user" (Makefile target `user`) -> oracle/libmuse_oracle_model_<name>.so."""
+    header = os.path.abspath(header)
+    path = os.path.join(_HERE, f"libmuse_oracle_model_{name}.so")
+    deps = [header, os.path.join(_HERE, "muse_oracle.c"), os.path.join(_HERE, "..", "include", "muse_model.h")]
+    if force or not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "user", f"NAME={name}", f"HEADER={header}"], stdout=subprocess.DEVNULL)
+    return path
+
+
+class user_model:
+    """with user_model(header, name): every function of this module runs in the build that holds that model (model "user");
+    the built-in models are there too."""
+    _cache = {}
+
+    def __init__(self, header, name):
+        self.path = build_user_model(header, name)
+
+    def __enter__(self):
+        global _selected
+        if self.path not in self._cache:
+            self._cache[self.path] = _declare(C.CDLL(self.path))
+        self._prev, _selected = _selected, self._cache[self.path]
+        return self
+
+    def __exit__(self, *exc):
+        global _selected
+        _selected = self._prev
+        return False
 
 
 def _p(a):
