@@ -12,9 +12,10 @@ import numpy as np
 
 import museinference_jl_amd as M
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 N, nsims, AREAS = 10000, 512, 4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+THETA = float(os.environ.get("THETA", "1.0"))
 cases = [("funnel (built in)", "funnel", 1e-2), ("funnel_as_user", M.ElementwiseModel("funnel_as_user", os.path.join(ROOT, "tests", "models", "funnel_as_user.h")), 1e-2),
          ("cubic", M.ElementwiseModel.packaged("cubic"), 1e-2), ("cubic atol 1e-6", M.ElementwiseModel.packaged("cubic"), 1e-6)]
 for label, model, atol in cases:
@@ -26,17 +27,22 @@ for label, model, atol in cases:
         for k in range(K):
             if k >= AREAS - 1:
                 prob.batch_wait(nsims, (k + 1) % AREAS, out=outs[(k + 1) % AREAS])
-            prob.map_and_score_batch_async(0, k * nsims, (k + 1) * nsims, [1.0], atol=atol, z0_mode=0, result_area=k % AREAS)
+            prob.map_and_score_batch_async(0, k * nsims, (k + 1) * nsims, [THETA], atol=atol, z0_mode=0, result_area=k % AREAS)
         for k in range(max(0, K - AREAS + 1), K):
             prob.batch_wait(nsims, k % AREAS, out=outs[k % AREAS])
 
-    run(200)
+    run(20)
     prob.synchronize()
     t0 = time.perf_counter()
     run(steps)
     prob.synchronize()
     dt = time.perf_counter() - t0
     info = outs[(steps - 1) % AREAS][1]
-    print(f"{label:20s} {dt / steps * 1e6:8.1f} us per 512-sim step  {nsims * steps / dt / 1e6:6.2f} M sims/s   "
-          f"iterations {info['iterations'].mean():.2f}  evaluations {info['f_calls'].mean():.2f}  status max {info['status'].max()}")
+    # the resident placement keeps x, z, s, g on chip; the (dx, dg) history of L-BFGS lives in HBM: per iteration k the two-loop
+    # recursion reads its h_k pairs twice and the update writes one pair -> (4 sum h_k + 2 K) words of N doubles per sim, + zhat
+    words = 4 * info["hist_words"].astype(np.int64) + 2 * info["iterations"].astype(np.int64) + 1
+    tbs = 8.0 * N * words.sum() / (dt / steps) / 1e12
+    print(f"{label:20s} {dt / steps * 1e6:8.1f} us per 512-sim step  {nsims * steps / dt / 1e6:7.3f} M sims/s   "
+          f"iterations {info['iterations'].mean():.2f}  evaluations {info['f_calls'].mean():.2f}  status max {info['status'].max()}  "
+          f"history traffic {tbs:.2f} TB/s")
     prob.close()
