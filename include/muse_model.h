@@ -36,6 +36,9 @@
  * Requirements the engine checks when a context is created (it evaluates the functions on the host):
  *     muse_model_grad(iv, 0, 0, &acc) == 0 leaving acc as it was, and muse_model_score_term(0, 0) == 0
  *         (vectors are padded to an even length with one zero element, which must not contribute).
+ * Nothing differentiates the header: that muse_model_grad IS the derivative of the objective term and that muse_model_score_term
+ * IS its B is the author's statement -- museinference_jl_amd.check_model_consistency(prob, theta) checks both against finite
+ * differences of logLike through the problem's own operators (what AD guarantees in the reference, src/simple.jl:84-85).
  * Not supported for user models: the implicit-differentiation get_H! (muse_implicit_H_*: it needs second
  * derivatives) -- the finite-difference branch (muse_fd_*) is model-agnostic.
  */

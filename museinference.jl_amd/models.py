@@ -67,3 +67,44 @@ class ElementwiseModel:
 
     def __repr__(self):
         return f"ElementwiseModel({self.name!r}, {self.header!r})"
+
+
+def check_model_consistency(prob, theta, rng=0, n_probe=6, step=1e-5, rtol=2e-5):
+    """What AD guarantees in the reference (src/simple.jl:84-85: the gradients ARE derivatives of the user's logLike) has to be
+    checked for a hand-written header: through the problem's own per-simulation operators, at a draw (x, z) ~ P(x, z | theta),
+
+        grad_z logLike           against central differences of logLike in n_probe elements of z,
+        grad_theta logLike       against central differences of logLike in every theta_k
+                                 (the family identity of include/muse_model.h: the score assembled from B is the derivative),
+
+    and returns the residuals {"grad_z": ..., "grad_theta": ...} (relative to the larger of the gradient's size and 1);
+    raises AssertionError beyond rtol.  Works on any problem with sample_x_z / logLike_and_grad_z_logLike / grad_theta_logLike."""
+    import numpy as np
+    from .problem import SimRng
+    theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+    x, z = prob.sample_x_z(SimRng(int(rng), 0), theta)
+    z = 0.8 * np.asarray(z) + 0.05        # off the draw: residuals and latent values both non-zero
+    f0, g = prob.logLike_and_grad_z_logLike(x, z, theta)
+    N = z.size
+    res_z = 0.0
+    for i in np.unique(np.linspace(0, N - 1, n_probe).astype(int)):
+        e = np.zeros(N)
+        e[i] = step * max(1.0, abs(z[i]))
+        fp = prob.logLike_and_grad_z_logLike(x, z + e, theta)[0]
+        fm = prob.logLike_and_grad_z_logLike(x, z - e, theta)[0]
+        # the difference of two sums of N terms: its rounding error is ~ eps |f| / step
+        noise = 4 * np.finfo(np.float64).eps * abs(f0) / e[i]
+        res_z = max(res_z, max(0.0, abs((fp - fm) / (2 * e[i]) - g[i]) - noise) / max(1.0, abs(g[i])))
+    s = np.atleast_1d(prob.grad_theta_logLike(x, z, theta))
+    res_t = 0.0
+    for k in range(theta.size):
+        d = np.zeros(theta.size)
+        d[k] = step
+        fp = prob.logLike_and_grad_z_logLike(x, z, theta + d)[0]
+        fm = prob.logLike_and_grad_z_logLike(x, z, theta - d)[0]
+        noise = 4 * np.finfo(np.float64).eps * abs(f0) / step
+        res_t = max(res_t, max(0.0, abs((fp - fm) / (2 * step) - s[k]) - noise) / max(1.0, abs(s[k])))
+    out = {"grad_z": float(res_z), "grad_theta": float(res_t)}
+    for name, v in out.items():
+        assert v <= rtol, f"model consistency: {name} differs from the finite difference of logLike by {v:.3g} (relative)"
+    return out

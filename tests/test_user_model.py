@@ -75,6 +75,21 @@ def test_cubic_model_on_the_oracle_is_what_its_header_says(O):
     assert O.lib().mo_user_model_name() is None   # back in the plain oracle
 
 
+def test_check_model_consistency_on_the_oracle(M, O):
+    """check_model_consistency (what AD guarantees in the reference has to be checked for a hand-written header) through an
+    oracle-backed problem on CPU: the shipped example passes, a header whose score term is not its objective's B fails."""
+    from oracle_problem import OracleMuseProblem
+    with O.user_model(CUBIC, "cubic"):
+        res = M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=3, N=2001), [0.4, -0.3, 0.9], rng=5)
+        assert res["grad_z"] <= 2e-5 and res["grad_theta"] <= 2e-5
+    with O.user_model(os.path.join(HERE, "models", "wrong_score.h"), "wrong_score"):
+        with pytest.raises(AssertionError) as e:
+            M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=2, N=500), [0.4, -0.3])
+        assert "grad_theta" in str(e.value)
+    res = M.check_model_consistency(OracleMuseProblem(None, model="smooth", ntheta=2, N=300), [1.0, 2.0])   # any problem
+    assert max(res.values()) <= 2e-5
+
+
 def test_model_library_exports_and_refusals(M):
     """The model's engine library is the same C ABI (every symbol of include/muse_hip.h) holding MUSE_MODEL_USER only;
     libmuse_hip.so refuses MUSE_MODEL_USER; neither has a CPU path."""
@@ -216,6 +231,15 @@ def test_cubic_model_whole_muse_run(gpu, M, O):
     assert np.all(np.abs(res.theta - truth) / sigma < 4.0), (res.theta, sigma)
     assert np.all(sigma < 0.1)
     prob.close()
+
+
+@pytest.mark.gpu
+def test_check_model_consistency_on_hip(gpu, M):
+    for N, nth, theta in [(10000, 2, [0.5, -0.5]), (70000, 1, [0.2])]:
+        prob = M.HipMuseProblem(None, model=M.ElementwiseModel.packaged("cubic"), ntheta=nth, N=N)
+        res = M.check_model_consistency(prob, theta, rng=3)
+        assert max(res.values()) <= 2e-5, res
+        prob.close()
 
 
 @pytest.mark.gpu
