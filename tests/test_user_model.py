@@ -295,3 +295,22 @@ MUSE_MODEL_FN double muse_model_score_term(double x, double z) { const double r 
     with pytest.raises(M.MuseError) as e:
         M.HipMuseProblem(None, model=M.ElementwiseModel.from_source("badpad", bad, directory=str(tmp_path)), ntheta=1, N=100)
     assert "muse_model_score_term(0, 0) must be 0" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["shm", "rccl"])
+def test_user_model_through_the_exchange_between_ranks(gpu, M, transport):
+    """The sharded map body (solver launch + exchange of the score blocks) in a user model's library, one rank: the
+    communicator id comes from libmuse_hip.so, the communicator lives in the model's library; identical to the plain map."""
+    N, nth, theta = 6000, 2, [0.3, -0.4]
+    p = M.HipMuseProblem(np.random.default_rng(3).normal(size=N), model=M.ElementwiseModel.packaged("cubic"), ntheta=nth)
+    p.comm_init(1, 0, M.HipMuseProblem.comm_unique_id(transport))
+    assert p.comm_transport() == transport and p.comm_ranks_seen() == 1
+    rows = 32
+    for b in (0, 24):
+        g, info = p.map_and_score_batch(0, b, b + 24, theta, include_data=(b == 0), atol=1e-3)
+        n = p.map_and_score_batch_gather_async(0, b, b + 24, theta, rows, include_data=(b == 0), atol=1e-3, result_area=1)
+        g_all, info2 = p.batch_wait_gathered(n, rows, 1)
+        assert np.array_equal(g_all[0, :n], g) and np.all(g_all[0, n:] == 0.0) and np.array_equal(info, info2)
+    p.comm_destroy()
+    p.close()
