@@ -16,6 +16,9 @@
  *   (v)  a published known answer of the un-vendored dependency: the work counters the Optim.jl documentation prints for
  *        LBFGS() on Rosenbrock's function from (0, 0) -- 24 iterations, 67 f/g evaluations -- which the restated
  *        LBFGS/HagerZhang below reproduces exactly (tests/test_oracle.py; quoted from memory, no network here).
+ *   (vi) the exact marginal posterior of the (jointly Gaussian) models, for which MUSE is exact: muse() on this oracle returns
+ *        the closed-form posterior mode to sigma/sqrt(nsims) and the exact Fisher information from get_J! and get_H!
+ *        (tests/test_exact_marginal.py).
  *
  * What each function follows (paths relative to /root/reference):
  *   mo_sample_x_z           src/simple.jl:61-65, docs/src/index.md:156-160  (funnel closure)
