@@ -148,3 +148,27 @@ def test_muse_is_unbiased_around_the_exact_mode_on_hip(gpu, M):
         tmp.close()
         dev, J, H = ensemble(M, lambda: M.HipMuseProblem(x, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, PRIOR_SIGMA)), x, nth, 512, 24)
         assert_unbiased(dev, J, H, 512)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,nth,truth", [("funnel", 1, [1.0]), ("funnel", 4, [1.0, 0.0, -1.0, 2.0]), ("noise", 1, [0.5])])
+def test_both_get_H_branches_return_the_exact_information_on_hip(gpu, M, model, nth, truth):
+    """get_H! by finite differences (src/muse.jl:407-446) and by implicit differentiation (src/muse.jl:335-405) at the exact
+    posterior mode: both are the expected information N/2 (e^theta / (1 + e^theta))^2 per block, to 1 %."""
+    N = 10000
+    tmp = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+    x, _ = tmp.sample_x_z(M.SimRng(99, M.DATA_SIM), truth)
+    tmp.close()
+    mode, sigma = exact_scale_family(x, nth)
+    w = np.exp(mode) / (1 + np.exp(mode))
+    F = 0.5 * (N / nth) * w ** 2
+    prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, PRIOR_SIGMA))
+    for kw in (dict(step=0.1 * sigma), dict(implicit_diff=True)):
+        res = M.MuseResult()
+        res.theta = mode.copy()
+        M.get_H_(res, prob, mode, rng=7, nsims=64, grad_z_logLike_atol=1e-6, **kw)
+        H = np.atleast_2d(res.H)
+        np.testing.assert_allclose(np.diag(H), F, rtol=1e-2, err_msg=str(kw))
+        off = H - np.diag(np.diag(H))
+        assert np.abs(off).max() <= 2e-2 * F.min(), kw          # blocks are independent: no cross terms beyond sampling noise
+    prob.close()
