@@ -54,7 +54,8 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmuse_hip.so")
-    obj_dir = OBJ_DIR + ("_variant" if variant else "")
+    # a variant (diagnostic build, a user model's library) keeps its objects in a directory of its own: two of them may build at once
+    obj_dir = OBJ_DIR + ("_" + os.path.splitext(os.path.basename(lib_path))[0] if variant else "")
     os.makedirs(obj_dir, exist_ok=True)
     objs, procs = [], []
     for src, (deps, flags) in UNITS.items():
