@@ -1,0 +1,72 @@
+"""Randomized parity of a user-supplied model (museinference.jl_amd/models/cubic.h: a non-quadratic MAP objective, 5-100
+L-BFGS iterations with real line searches and a wrapping history) against the oracle's build of the same header: random
+N / ntheta / theta / seed / atol / start mode / placement / element split / maps per launch.  Classes of outcome:
+  same path   identical iteration, evaluation counts and status -> scores to 1e-6 (relative to the larger of |score| and N, the
+              size of its terms) and MAPs to 1e-9 ("tight": what the built-in, quadratic models get) or, after tens of
+              iterations of a non-quadratic objective along which the two summation orders drift apart, to 0.1 atol ("drift")
+  off path    counts differ (tree-ordered against sequential sums over many iterations) -> both converged, MAPs agree to 2 atol
+  MISMATCH    anything else (printed).
+Usage (GPU box): python tools/fuzz_user_model.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import museinference_jl_amd as M
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+model = M.ElementwiseModel.packaged("cubic")
+t0 = time.time()
+ncase = nsame = ntight = noff = nbad = 0
+maxit = 0
+with O.user_model(model.header, "cubic"):
+    while time.time() - t0 < budget:
+        N = int(rng.choice([int(rng.integers(5, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)),
+                            int(rng.integers(10000, 30000)), int(rng.integers(65000, 80000))]))
+        nth = min(int(rng.choice([1, 2, 3, 4, 8])), N)
+        theta = rng.uniform(-2.0, 0.8, size=nth)
+        atol = float(rng.choice([1e-2, 1e-4, 1e-6]))
+        z0 = int(rng.choice([0, 1]))
+        n = 4 if N < 20000 else 2
+        seed, s0 = int(rng.integers(1, 2**40)), int(rng.integers(0, 5000))
+        prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+        placement = int(rng.choice([-1, -1, 0]))
+        if placement >= 0:
+            prob.set_placement(placement)
+        split = int(rng.choice([0, 0, 2, 4, 8]))
+        if split and N > 512:
+            prob.set_element_split(split)
+        else:
+            split = 0
+        nmaps = int(rng.choice([1, 1, 2, 3]))
+        if nmaps > 1:
+            thetas = np.vstack([theta] + [rng.uniform(-2.0, 0.8, size=nth) for _ in range(nmaps - 1)])
+            tot = prob.map_and_score_multi_async(seed, s0, s0 + n, thetas, atol=atol, z0_mode=z0, result_area=2)
+            g, info = prob.batch_wait(tot, 2)
+            g, info = g[:n], info[:n]
+        else:
+            g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=atol, z0_mode=z0)
+        zh = prob.get_zhat(0, n)
+        prob.close()
+        go, zo, io = O.map_and_score_batch("user", N, seed, s0, s0 + n, theta, atol=atol, z0_mode=z0, nthreads=8)
+        ncase += 1
+        maxit = max(maxit, int(io["iterations"].max()))
+        same = (np.array_equal(info["iterations"], io["iterations"]) and np.array_equal(info["f_calls"], io["f_calls"])
+                and np.array_equal(info["status"], io["status"]))
+        dz = float(np.abs(zh - zo).max())
+        if same and dz <= max(1e-9, 0.1 * atol) and np.all(np.abs(g - go) <= 1e-6 * np.maximum(np.abs(go), N)):
+            nsame += 1
+            ntight += dz <= 1e-9
+        elif (not same) and info["status"].max() <= 2 and io["status"].max() <= 2 and dz <= 2 * atol:
+            noff += 1
+        else:
+            nbad += 1
+            print("MISMATCH", "N", N, "nth", nth, "placement", placement, "split", split, "nmaps", nmaps, theta.tolist(), atol, z0, seed, s0,
+                  info["iterations"], io["iterations"], info["f_calls"], io["f_calls"], info["status"], io["status"], dz,
+                  float(np.abs(g - go).max()), flush=True)
+print(f"{ncase} cases: {nsame} same path ({ntight} of them with MAPs to 1e-9), {noff} off path (converged, MAPs within 2 atol), {nbad} MISMATCHES; longest solve {maxit} iterations; "
+      f"{time.time() - t0:.0f} s")
