@@ -314,3 +314,24 @@ def test_user_model_through_the_exchange_between_ranks(gpu, M, transport):
         assert np.array_equal(g_all[0, :n], g) and np.all(g_all[0, n:] == 0.0) and np.array_equal(info, info2)
     p.comm_destroy()
     p.close()
+
+
+@pytest.mark.gpu
+def test_muse_is_calibrated_on_the_non_gaussian_user_model(gpu, M):
+    """The reference's acceptance criterion (test/runtests.jl:31,56,81: |theta - truth| / sigma small) as an ensemble: 24 data
+    sets of the cubic model -- a non-Gaussian posterior with no closed form, the case MUSE is for -- each with its own master
+    seed: the standardized errors (theta_hat - truth) / sigma_MUSE have mean 0 and a standard deviation of about 1."""
+    model, truth = M.ElementwiseModel.packaged("cubic"), np.array([0.0, -1.0])
+    zs = []
+    for d in range(24):
+        sim = M.HipMuseProblem(None, model=model, ntheta=2, N=20000)
+        x, _ = sim.sample_x_z(M.SimRng(100 + d, M.DATA_SIM), truth)
+        sim.close()
+        prob = M.HipMuseProblem(x, model=model, ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+        r = M.muse(prob, [0.0, 0.0], nsims=200, rng=d, grad_z_logLike_atol=1e-4, theta_rtol=1e-3, get_covariance=True)
+        zs.append((r.theta - truth) / np.sqrt(np.diag(r.Sigma)))
+        prob.close()
+    zs = np.array(zs)
+    assert np.all(np.abs(zs.mean(0)) < 4.0 / np.sqrt(24)), zs.mean(0)
+    assert np.all((0.5 < zs.std(0)) & (zs.std(0) < 1.5)), zs.std(0)
+    assert np.abs(zs).max() < 4.0
