@@ -303,6 +303,54 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     return out
 
 
+def user_model_rates(M, device, N=10000, nsims=512):
+    """User-supplied models (include/muse_model.h; the closures of SimpleMuseProblem, src/simple.jl:79-95, as a compiled header)
+    at the headline shape, pipelined over the result areas and two lanes like the timed loop: the built-in funnel written as a
+    header (models/gaussian_funnel.h: the same instructions, so the same speed -- what the seam costs) and the shipped
+    non-Gaussian example (models/cubic.h at theta = 0: ~18 L-BFGS iterations per sim, bound by the HBM traffic of the
+    L-BFGS history).  Only with the models' libraries already built (build(): ~45 s of hipcc each -- never inside the bench)."""
+    from museinference_jl_amd import build as _b
+    out = {}
+    for name, theta, steps in (("funnel_built_in_same_loop", 1.0, 400), ("gaussian_funnel", 1.0, 400), ("cubic", 0.0, 60)):
+        if name == "funnel_built_in_same_loop":   # the reference point: MUSE_MODEL_FUNNEL through this same Python loop
+            model = "funnel"
+        else:
+            header, lib = os.path.join(_b.MODELS_DIR, name + ".h"), _b.model_lib_path(name)
+            if _b._stale(lib, _b.SOURCES + _b.HEADERS + [header, os.path.join(_b.INCLUDE_DIR, "muse_model.h")]):
+                out[name] = {"skipped": "library not built (run __graft_entry__.build())"}
+                continue
+            model = M.ElementwiseModel.packaged(name)
+        prob = M.HipMuseProblem(None, model=model, ntheta=1, N=N, device=device)
+        prob.set_concurrency(2)
+        AREAS = 4
+        outs = [(np.empty((nsims, 1)), np.zeros(nsims, dtype=M._capi.INFO_DTYPE)) for _ in range(AREAS)]
+
+        def run(K):
+            for k in range(K):
+                if k >= AREAS - 1:
+                    prob.batch_wait(nsims, (k + 1) % AREAS, out=outs[(k + 1) % AREAS])
+                prob.map_and_score_batch_async(0, k * nsims, (k + 1) * nsims, [theta], atol=1e-2, z0_mode=0, result_area=k % AREAS)
+            for k in range(max(0, K - AREAS + 1), K):
+                prob.batch_wait(nsims, k % AREAS, out=outs[k % AREAS])
+
+        run(max(8, steps // 10))
+        prob.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        prob.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        info = outs[(steps - 1) % AREAS][1]
+        words = 4 * info["hist_words"].astype(np.int64) + 2 * info["iterations"].astype(np.int64) + 1
+        out[name] = {"us_per_step": 1e6 * dt, "sims_per_s": nsims / dt, "iterations_mean": float(info["iterations"].mean()),
+                     "f_calls_mean": float(info["f_calls"].mean()), "theta": theta,
+                     "lbfgs_history_TBps": 8.0 * N * float(words.sum()) / dt / 1e12}
+        prob.close()
+    out["note"] = ("a model given as a C header with three functions, compiled into an engine library of its own (MUSE_MODEL_USER); "
+                   "lbfgs_history_TBps: (4 sum h_k + 2 K + 1) N doubles per sim / step time -- the (dx, dg) history is what the resident "
+                   "placement keeps in HBM (meaningful for the many-iteration cubic model, not for the one-iteration funnel)")
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -778,6 +826,11 @@ def main():
     best_t = out.get("transport")
     if rank == 0 and world == 1 and not sharded and not args.no_extra:
         out["extra"] = extra_rates(M, prob, model, N, nth, theta, nsims, seed, local_rank)
+        if args.workload == "funnel_1e4":
+            try:
+                out["extra"]["user_model"] = user_model_rates(M, local_rank)
+            except Exception as e:  # an extra: never at the cost of the line
+                out["extra"]["user_model"] = {"skipped": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, N, theta, seed)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

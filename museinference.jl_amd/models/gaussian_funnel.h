@@ -1,0 +1,21 @@
+/* gaussian_funnel.h -- the built-in funnel (MUSE_MODEL_FUNNEL: z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1); the reference's example,
+ * src/simple.jl:59-73) written as a user-supplied model (include/muse_model.h), operation for operation as csrc/models.hpp's
+ * FunnelModel: a template for a model of one's own, and the proof that the user-model seam costs nothing --
+ * tests/test_user_model.py checks that this header and the built-in model give the same bits, bench.py (extra.user_model)
+ * that they run at the same speed. */
+#include "muse_model.h"
+#define MUSE_MODEL_NAME "gaussian_funnel"
+
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x) {
+    *z = sd * n1;
+    *x = *z + n2;
+}
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) {
+    const double r = x - z, t = iv * z;
+    *acc = fma(t, z, fma(r, r, *acc));
+    return t - r;
+}
+MUSE_MODEL_FN double muse_model_score_term(double x, double z) {
+    (void)x;
+    return z * z;
+}

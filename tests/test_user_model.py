@@ -21,7 +21,6 @@ from test_gpu_parity import assert_same_path_or_close
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CUBIC = os.path.join(ROOT, "museinference.jl_amd", "models", "cubic.h")
-FUNNEL_AS_USER = os.path.join(HERE, "models", "funnel_as_user.h")
 
 
 def h(z):
@@ -244,10 +243,10 @@ def test_check_model_consistency_on_hip(gpu, M):
 
 @pytest.mark.gpu
 def test_funnel_as_user_model_equals_the_built_in_funnel(gpu, M):
-    """The built-in funnel written as a user's header (tests/models/funnel_as_user.h: the same arithmetic) gives the same
+    """The built-in funnel written as a user's header (museinference.jl_amd/models/gaussian_funnel.h: the same arithmetic) gives the same
     BITS as MUSE_MODEL_FUNNEL -- scores, MAPs, solver infos -- in the resident, streaming and cluster placements: the
     user-model seam adds nothing to the kernel."""
-    model = M.ElementwiseModel("funnel_as_user", FUNNEL_AS_USER)
+    model = M.ElementwiseModel.packaged("gaussian_funnel")
     for N, nth, theta, placement in [(10000, 1, [1.0], -1), (10000, 3, [1.0, 0.0, -1.0], -1), (5000, 2, [0.3, 0.6], 0), (70000, 1, [0.5], -1)]:
         a = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
         b = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)

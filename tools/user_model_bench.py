@@ -16,7 +16,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 N, nsims, AREAS = 10000, 512, 4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 THETA = float(os.environ.get("THETA", "1.0"))
-cases = [("funnel (built in)", "funnel", 1e-2), ("funnel_as_user", M.ElementwiseModel("funnel_as_user", os.path.join(ROOT, "tests", "models", "funnel_as_user.h")), 1e-2),
+cases = [("funnel (built in)", "funnel", 1e-2), ("gaussian_funnel (header)", M.ElementwiseModel.packaged("gaussian_funnel"), 1e-2),
          ("cubic", M.ElementwiseModel.packaged("cubic"), 1e-2), ("cubic atol 1e-6", M.ElementwiseModel.packaged("cubic"), 1e-6)]
 for label, model, atol in cases:
     prob = M.HipMuseProblem(None, model=model, ntheta=1, N=N)
