@@ -74,6 +74,38 @@ def test_cubic_model_on_the_oracle_is_what_its_header_says(O):
     assert O.lib().mo_user_model_name() is None   # back in the plain oracle
 
 
+def test_gaussian_funnel_header_equals_the_built_in_funnel_on_the_oracle(O):
+    """models/gaussian_funnel.h (the built-in funnel written as a user's header) in the oracle's user-model build: the same bits
+    as the oracle's own funnel -- draw, logLike, gradient, MAP, solver record, score (the GPU twin of this test compares
+    the two engine libraries)."""
+    hdr = os.path.join(ROOT, "museinference.jl_amd", "models", "gaussian_funnel.h")
+    N, theta = 1500, [0.7, -0.4, 1.2]
+    ref = {}
+    for tag in ("funnel", "user"):
+        ctx = O.user_model(hdr, "gaussian_funnel")
+        with ctx:   # (the user build holds the built-in models too: both run in the same library)
+            x, z = O.sample_x_z(tag, N, 3, 9, theta)
+            f, g = O.logLike_and_grad_z(tag, x, 0.5 * z, theta)
+            zh, info = O.zhat_at_theta(tag, x, np.zeros(N), theta, 1e-8)
+            ref[tag] = (x, z, f, g, zh, tuple(info[k] for k in ("iterations", "f_calls", "status", "f_min", "gnorm")), O.grad_theta(tag, x, zh, theta))
+    for a, b in zip(ref["funnel"], ref["user"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_examples_and_packaged_headers_are_well_formed():
+    """examples/*.py compile; every packaged model header is plain C (gcc -fsyntax-only with the contract's macro)."""
+    import glob
+    import py_compile
+    import subprocess
+    for f in glob.glob(os.path.join(ROOT, "examples", "*.py")):
+        py_compile.compile(f, doraise=True)
+    headers = glob.glob(os.path.join(ROOT, "museinference.jl_amd", "models", "*.h")) + glob.glob(os.path.join(HERE, "models", "*.h"))
+    assert len(headers) >= 4
+    for h_ in headers:
+        subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"),
+                               "-include", "math.h", "-x", "c", h_])
+
+
 def test_check_model_consistency_on_the_oracle(M, O):
     """check_model_consistency (what AD guarantees in the reference has to be checked for a hand-written header) through an
     oracle-backed problem on CPU: the shipped example passes, a header whose score term is not its objective's B fails."""
