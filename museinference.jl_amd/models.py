@@ -77,8 +77,10 @@ def check_model_consistency(prob, theta, rng=0, n_probe=6, step=1e-5, rtol=2e-5)
         grad_theta logLike       against central differences of logLike in every theta_k
                                  (the family identity of include/muse_model.h: the score assembled from B is the derivative),
 
-    and returns the residuals {"grad_z": ..., "grad_theta": ...} (relative to the larger of the gradient's size and 1);
-    raises AssertionError beyond rtol.  Works on any problem with sample_x_z / logLike_and_grad_z_logLike / grad_theta_logLike."""
+    and returns {"grad_z": worst residual, "grad_theta": worst residual, "noise_floor": ...} -- residuals relative to the larger
+    of the gradient's size and 1; noise_floor: what the rounding of logLike (a sum of N terms) alone puts into such a
+    difference quotient.  Raises AssertionError when a residual exceeds rtol + noise_floor.  Works on any problem with
+    sample_x_z / logLike_and_grad_z_logLike / grad_theta_logLike."""
     import numpy as np
     from .problem import SimRng
     theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
@@ -86,25 +88,27 @@ def check_model_consistency(prob, theta, rng=0, n_probe=6, step=1e-5, rtol=2e-5)
     z = 0.8 * np.asarray(z) + 0.05        # off the draw: residuals and latent values both non-zero
     f0, g = prob.logLike_and_grad_z_logLike(x, z, theta)
     N = z.size
-    res_z = 0.0
+    eps = np.finfo(np.float64).eps
+    res_z = res_t = floor = 0.0
     for i in np.unique(np.linspace(0, N - 1, n_probe).astype(int)):
         e = np.zeros(N)
         e[i] = step * max(1.0, abs(z[i]))
         fp = prob.logLike_and_grad_z_logLike(x, z + e, theta)[0]
         fm = prob.logLike_and_grad_z_logLike(x, z - e, theta)[0]
-        # the difference of two sums of N terms: its rounding error is ~ eps |f| / step
-        noise = 4 * np.finfo(np.float64).eps * abs(f0) / e[i]
-        res_z = max(res_z, max(0.0, abs((fp - fm) / (2 * e[i]) - g[i]) - noise) / max(1.0, abs(g[i])))
+        scale = max(1.0, abs(g[i]))
+        floor = max(floor, 4 * eps * abs(f0) / e[i] / scale)
+        res_z = max(res_z, abs((fp - fm) / (2 * e[i]) - g[i]) / scale)
     s = np.atleast_1d(prob.grad_theta_logLike(x, z, theta))
-    res_t = 0.0
     for k in range(theta.size):
         d = np.zeros(theta.size)
         d[k] = step
         fp = prob.logLike_and_grad_z_logLike(x, z, theta + d)[0]
         fm = prob.logLike_and_grad_z_logLike(x, z, theta - d)[0]
-        noise = 4 * np.finfo(np.float64).eps * abs(f0) / step
-        res_t = max(res_t, max(0.0, abs((fp - fm) / (2 * step) - s[k]) - noise) / max(1.0, abs(s[k])))
-    out = {"grad_z": float(res_z), "grad_theta": float(res_t)}
-    for name, v in out.items():
-        assert v <= rtol, f"model consistency: {name} differs from the finite difference of logLike by {v:.3g} (relative)"
+        scale = max(1.0, abs(s[k]))
+        floor = max(floor, 4 * eps * abs(f0) / step / scale)
+        res_t = max(res_t, abs((fp - fm) / (2 * step) - s[k]) / scale)
+    out = {"grad_z": float(res_z), "grad_theta": float(res_t), "noise_floor": float(floor)}
+    for name in ("grad_z", "grad_theta"):
+        assert out[name] <= rtol + floor, (f"model consistency: {name} differs from the finite difference of logLike by {out[name]:.3g} "
+                                           f"(relative; tolerance {rtol:g} + noise floor {floor:.3g})")
     return out

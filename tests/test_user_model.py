@@ -112,13 +112,13 @@ def test_check_model_consistency_on_the_oracle(M, O):
     from oracle_problem import OracleMuseProblem
     with O.user_model(CUBIC, "cubic"):
         res = M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=3, N=2001), [0.4, -0.3, 0.9], rng=5)
-        assert res["grad_z"] <= 2e-5 and res["grad_theta"] <= 2e-5
+        assert res["grad_z"] <= 2e-5 + res["noise_floor"] and res["grad_theta"] <= 2e-5 + res["noise_floor"] and res["noise_floor"] < 1e-4
     with O.user_model(os.path.join(HERE, "models", "wrong_score.h"), "wrong_score"):
         with pytest.raises(AssertionError) as e:
             M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=2, N=500), [0.4, -0.3])
         assert "grad_theta" in str(e.value)
     res = M.check_model_consistency(OracleMuseProblem(None, model="smooth", ntheta=2, N=300), [1.0, 2.0])   # any problem
-    assert max(res.values()) <= 2e-5
+    assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"]
 
 
 def test_model_library_exports_and_refusals(M):
@@ -269,7 +269,7 @@ def test_check_model_consistency_on_hip(gpu, M):
     for N, nth, theta in [(10000, 2, [0.5, -0.5]), (70000, 1, [0.2])]:
         prob = M.HipMuseProblem(None, model=M.ElementwiseModel.packaged("cubic"), ntheta=nth, N=N)
         res = M.check_model_consistency(prob, theta, rng=3)
-        assert max(res.values()) <= 2e-5, res
+        assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"], res
         prob.close()
 
 
