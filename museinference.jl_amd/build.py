@@ -40,6 +40,26 @@ def _stale(target, deps):
     return any(os.path.exists(f) and os.path.getmtime(f) > t for f in deps)
 
 
+class _BuildLock:
+    """One builder per library at a time, across processes (the ranks of a job all ask for the same model's library on first
+    use): an flock on <library>.lock; whoever comes second finds the library fresh."""
+
+    def __init__(self, lib_path):
+        self.path = lib_path + ".lock"
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
 def needs_build():
     return _stale(LIB_PATH, SOURCES + HEADERS)
 
@@ -98,8 +118,11 @@ def build_model_library(header, name, force=False, verbose=False):
     if not os.path.exists(header):
         raise FileNotFoundError(header)
     path = model_lib_path(name)
-    if force or _stale(path, SOURCES + HEADERS + [header, os.path.join(INCLUDE_DIR, "muse_model.h")]):
-        build_extension(defines=[f'-DMUSE_USER_MODEL_HEADER="{header}"', "-I" + INCLUDE_DIR], lib_path=path, verbose=verbose)
+    deps = SOURCES + HEADERS + [header, os.path.join(INCLUDE_DIR, "muse_model.h")]
+    if force or _stale(path, deps):
+        with _BuildLock(path):
+            if force or _stale(path, deps):     # (another process may have built it while this one waited)
+                build_extension(defines=[f'-DMUSE_USER_MODEL_HEADER="{header}"', "-I" + INCLUDE_DIR], lib_path=path, verbose=verbose)
     return path
 
 
