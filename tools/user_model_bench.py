@@ -2,7 +2,7 @@
 (N = 10^4, 512 sims per step, pipelined over result areas and two lanes as bench.py does): the packaged `cubic` model (a
 non-quadratic MAP objective: several L-BFGS iterations per simulation) and the funnel written as a user's header (the same
 bits as the built-in one -- and the same speed, if the seam costs nothing).  Development aid; prints one line per model.
-Usage (GPU box): python tools/user_model_bench.py [steps]"""
+Usage (GPU box): [THETA=0.0] python tools/user_model_bench.py [steps] [only the cases whose label contains this]"""
 import os
 import sys
 import time
@@ -18,7 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 THETA = float(os.environ.get("THETA", "1.0"))
 cases = [("funnel (built in)", "funnel", 1e-2), ("gaussian_funnel (header)", M.ElementwiseModel.packaged("gaussian_funnel"), 1e-2),
          ("cubic", M.ElementwiseModel.packaged("cubic"), 1e-2), ("cubic atol 1e-6", M.ElementwiseModel.packaged("cubic"), 1e-6)]
+only = sys.argv[2] if len(sys.argv) > 2 else ""
 for label, model, atol in cases:
+    if only not in label:
+        continue
     prob = M.HipMuseProblem(None, model=model, ntheta=1, N=N)
     prob.set_concurrency(2)
     outs = [(np.empty((nsims, 1)), np.zeros(nsims, dtype=M._capi.INFO_DTYPE)) for _ in range(AREAS)]
@@ -44,5 +47,5 @@ for label, model, atol in cases:
     tbs = 8.0 * N * words.sum() / (dt / steps) / 1e12
     print(f"{label:20s} {dt / steps * 1e6:8.1f} us per 512-sim step  {nsims * steps / dt / 1e6:7.3f} M sims/s   "
           f"iterations {info['iterations'].mean():.2f}  evaluations {info['f_calls'].mean():.2f}  status max {info['status'].max()}  "
-          f"history traffic {tbs:.2f} TB/s")
+          f"history traffic {tbs:.2f} TB/s ({8.0 * N * words.sum() / 1e9:.3f} GB per launch)")
     prob.close()
