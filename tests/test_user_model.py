@@ -366,3 +366,28 @@ def test_muse_is_calibrated_on_the_non_gaussian_user_model(gpu, M):
     assert np.all(np.abs(zs.mean(0)) < 4.0 / np.sqrt(24)), zs.mean(0)
     assert np.all((0.5 < zs.std(0)) & (zs.std(0) < 1.5)), zs.std(0)
     assert np.abs(zs).max() < 4.0
+
+
+@pytest.mark.gpu
+def test_user_model_contexts_do_not_leak(gpu, M):
+    """Contexts of two engine libraries (built-in models / a user's model) created, used and destroyed in turn: the device's
+    free memory comes back (every library frees its own scratch, results, history and lanes)."""
+    import torch
+    cubic = M.ElementwiseModel.packaged("cubic")
+
+    def cycle(k):
+        p = M.HipMuseProblem(None, model=cubic if k % 2 else "funnel", ntheta=2, N=10000)
+        p.set_concurrency(2)
+        p.map_and_score_batch(1, 0, 64, [0.1, -0.2], atol=1e-3)
+        p.fd_jacobian_batch(1, 0, 4, [0.1, -0.2], [0.05, 0.05], atol=1e-3)
+        p.close()
+
+    for k in range(4):
+        cycle(k)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(60):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)
