@@ -20,12 +20,14 @@ SOURCE = r'''
 #include "muse_model.h"
 #define MUSE_MODEL_NAME "saturating"
 /* -logLike = 1/2 sum_i [ (x_i - h(z_i))^2 + exp(-theta_k) z_i^2 ] + 1/2 sum_k n_k theta_k :   A = (x - h)^2,  B = z^2 */
-MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x) {
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) {
+    (void)i;
     const double zi = sd * n1;
     *z = zi;
     *x = zi / sqrt(fma(0.0625 * zi, zi, 1.0)) + n2;
 }
-MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) {
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) {
+    (void)i;
     const double q = fma(0.0625 * z, z, 1.0);       /* 1 + z^2/16 */
     const double rq = 1.0 / sqrt(q);
     const double r = x - z * rq;                    /* x - h(z)   */
@@ -33,7 +35,7 @@ MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc)
     *acc = fma(t, z, fma(r, r, *acc));
     return t - r * (rq / q);                        /* iv z - (x - h) h'(z),  h' = (1 + z^2/16)^(-3/2) */
 }
-MUSE_MODEL_FN double muse_model_score_term(double x, double z) { (void)x; return z * z; }
+MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) { (void)x; (void)i; return z * z; }
 '''
 
 model = M.ElementwiseModel.from_source("saturating", SOURCE)

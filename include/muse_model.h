@@ -24,17 +24,24 @@
  * floating-point contraction, which is what makes their results comparable bit for bit):
  *
  *     #define MUSE_MODEL_NAME "cubic"
- *     MUSE_MODEL_FN void   muse_model_sample(double sd, double n1, double n2, double* z, double* x);
+ *     MUSE_MODEL_FN void   muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i);
  *         the joint draw (src/interface.jl:92-99) of one element from the block's sd and two standard normals
- *     MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc);
+ *     MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i);
  *         returns d(-logLike)/dz_i = 1/2 d(A + iv B)/dz and ADDS A(x, z) + iv B(x, z) to *acc -- the running sum of
  *         the elements a thread owns, so the additions may be folded into fma()s as the built-in models do
  *         (src/interface.jl:68-83 with the sign Optim minimises, src/interface.jl:163)
- *     MUSE_MODEL_FN double muse_model_score_term(double x, double z);
+ *     MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i);
  *         B(x, z) (src/interface.jl:41-58: the engine assembles grad_theta logLike from its block sums)
  *
+ * `i` is the element's index, 0 <= i < N -- and i >= N for the zero pad element of an odd-length vector and the phantom slots
+ * behind it (x = z = 0 there: the functions must stay finite; the accessors of from_source's tables clamp the index): what lets a model
+ * depend on the element through constants of its own (a known spectrum P_i: z_i ~ N(0, e^theta P_i); a noise-variance map; a
+ * mask), as a table compiled into the header -- `static const double P[N + 1] = {...};`, which
+ * ElementwiseModel.from_source(name, source, constants={"P": array}) writes for you -- or as a formula in i: what a closure of
+ * the reference's SimpleMuseProblem would capture.  A model that does not need it ignores it.
+ *
  * Requirements the engine checks when a context is created (it evaluates the functions on the host):
- *     muse_model_grad(iv, 0, 0, &acc) == 0 leaving acc as it was, and muse_model_score_term(0, 0) == 0
+ *     muse_model_grad(iv, 0, 0, &acc, N) == 0 leaving acc as it was, and muse_model_score_term(0, 0, N) == 0
  *         (vectors are padded to an even length with one zero element, which must not contribute).
  * Nothing differentiates the header: that muse_model_grad IS the derivative of the objective term and that muse_model_score_term
  * IS its B is the author's statement -- museinference_jl_amd.check_model_consistency(prob, theta) checks both against finite

@@ -23,31 +23,31 @@ struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
     static constexpr int MAXB = MAXB_;
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_FUNNEL;
-    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x, int) {
         z = sd * n1;
         x = z + n2;
     }
-    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc, int) {
         const double r = x - z, t = iv * z;
         facc = fma(t, z, fma(r, r, facc));
         return t - r;
     }
-    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
+    __device__ static __forceinline__ double score_term(double, double z, int) { return z * z; }
 };
 struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
     static constexpr int MAXB = 1;
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_NOISE;
-    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x, int) {
         z = n1;
         x = n1 + sd * n2;
     }
-    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc, int) {
         const double r = x - z, t = iv * r;
         facc = fma(z, z, fma(t, r, facc));
         return z - t;
     }
-    __device__ static __forceinline__ double score_term(double x, double z) {
+    __device__ static __forceinline__ double score_term(double x, double z, int) {
         const double r = x - z;
         return r * r;
     }
@@ -57,7 +57,7 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
     static constexpr int MAXB = MAXB_;
     static constexpr bool kStencil = true;
     static constexpr int kId = MUSE_MODEL_SMOOTH;
-    __device__ static __forceinline__ double score_term(double, double z) { return z * z; }
+    __device__ static __forceinline__ double score_term(double, double z, int) { return z * z; }
 };
 
 #ifdef MUSE_USER_MODEL_HEADER
@@ -66,13 +66,13 @@ struct UserModel {  // include/muse_model.h: the three functions of the user's h
     static constexpr int MAXB = MAXB_;
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_USER;
-    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x) {
-        muse_model_sample(sd, n1, n2, &z, &x);
+    __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x, int i) {
+        muse_model_sample(sd, n1, n2, &z, &x, (long)i);
     }
-    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc) {
-        return muse_model_grad(iv, x, z, &facc);
+    __device__ static __forceinline__ double grad(double iv, double x, double z, double& facc, int i) {
+        return muse_model_grad(iv, x, z, &facc, (long)i);
     }
-    __device__ static __forceinline__ double score_term(double x, double z) { return muse_model_score_term(x, z); }
+    __device__ static __forceinline__ double score_term(double x, double z, int i) { return muse_model_score_term(x, z, (long)i); }
 };
 #endif
 

@@ -431,20 +431,23 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
                                           ? "MUSE_MODEL_USER: this library holds the built-in models only (build one from a model "
                                             "header, include/muse_model.h)"
                                           : "this library was built from a user's model header and holds MUSE_MODEL_USER only");
-#ifdef MUSE_USER_MODEL_HEADER
-    {   // the zero-element requirements of include/muse_model.h (the pad element of an odd-length vector must not contribute)
-        double acc = 1.25;
-        const double g0 = muse_model_grad(0.7, 0.0, 0.0, &acc);
-        if (!(g0 == 0.0 && acc == 1.25 && muse_model_score_term(0.0, 0.0) == 0.0))
-            return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": muse_model_grad(iv, 0, 0, &acc) must return 0 and leave acc "
-                                          "unchanged, muse_model_score_term(0, 0) must be 0 (include/muse_model.h)");
-    }
-#endif
     if (N < 1) return fail(MUSE_ERR_INVALID, "N must be >= 1");
     if (ntheta < 1 || ntheta > kMaxTheta) return fail(MUSE_ERR_INVALID, "ntheta must be in [1, MUSE_MAX_THETA]");
     if (model == MUSE_MODEL_NOISE && ntheta != 1) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_NOISE has ntheta = 1");
     if (ntheta > N) return fail(MUSE_ERR_INVALID, "ntheta must be <= N");
     if (model == MUSE_MODEL_SMOOTH && N < 5) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_SMOOTH needs N >= 5");
+#ifdef MUSE_USER_MODEL_HEADER
+#ifdef MUSE_MODEL_N  // a model with per-element tables is built for one N (include/muse_model.h)
+    if (N != (int64_t)(MUSE_MODEL_N)) return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME " was built for another N (MUSE_MODEL_N)");
+#endif
+    {   // the zero-element requirements of include/muse_model.h (the pad element of an odd-length vector must not contribute)
+        double acc = 1.25;
+        const double g0 = muse_model_grad(0.7, 0.0, 0.0, &acc, (long)N);
+        if (!(g0 == 0.0 && acc == 1.25 && muse_model_score_term(0.0, 0.0, (long)N) == 0.0))
+            return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": muse_model_grad(iv, 0, 0, &acc, N) must return 0 and leave acc "
+                                          "unchanged, muse_model_score_term(0, 0, N) must be 0 (include/muse_model.h)");
+    }
+#endif
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(MUSE_ERR_HIP, "no HIP device available (libmuse_hip has no CPU fallback)");

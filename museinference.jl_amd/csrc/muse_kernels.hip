@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) sample_user_kernel(BatchArgs a, uint64_t 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = a.ntheta > 1 ? block_of(a, i) : 0;
         const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
-        UserModel<1>::sample(a.cur.t.sd[k], np.n1, np.n2, z[i], x[i]);
+        UserModel<1>::sample(a.cur.t.sd[k], np.n1, np.n2, z[i], x[i], (int)i);
     }
 }
 #endif
@@ -277,10 +277,10 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
             sum[0] = valid ? fma(t, z0, fma(r0, r0, sum[0])) : sum[0];
             gi = valid ? t - fma(0.25, rm + rp, 0.5 * r0) : 0.0;
         } else {
-            gi = Model::grad(ivk, xin[i], zin[i], sum[0]);
+            gi = Model::grad(ivk, xin[i], zin[i], sum[0], i);
         }
         if (gout) gout[i] = -gi;
-        const double t = Model::score_term(xin[i], zin[i]);
+        const double t = Model::score_term(xin[i], zin[i], i);
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
     });

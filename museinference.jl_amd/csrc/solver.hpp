@@ -384,15 +384,15 @@ struct Solver {
             const int i = i0 + v;
             const bool valid = i < N;
             double zt, xt;
-            Model::sample(sdk(v, i), np[v].n1, np[v].n2, zt, xt);
+            Model::sample(sdk(v, i), np[v].n1, np[v].n2, zt, xt, i);
             xt = valid ? xt : 0.0;
             const double ivi = ivk(v, i);
-            const double gi = Model::grad(ivi, xt, 0.0, gen.sum[0]);
+            const double gi = Model::grad(ivi, xt, 0.0, gen.sum[0], i);
             const double sd = -gi;
             gen.sum[1] = fma(gi, sd, gen.sum[1]);
             gen.mx[0] = absmax(gen.mx[0], gi);
             const double zt1 = fma(1.0, sd, 0.0);
-            const double gt = Model::grad(ivi, xt, zt1, gen.sum[2]);
+            const double gt = Model::grad(ivi, xt, zt1, gen.sum[2], i);
             gen.sum[3] = fma(gt, sd, gen.sum[3]);
             gen.mx[1] = absmax(gen.mx[1], gt);
             xo[v] = xt;
@@ -494,7 +494,7 @@ struct Solver {
                     si = s.get(jj, i);
                     zi = fma(c, si, zi);
                 }
-                const double gi = Model::grad(ivk(jj, i), x.get(jj, i), zi, sum[0]);
+                const double gi = Model::grad(ivk(jj, i), x.get(jj, i), zi, sum[0], i);
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
                 if constexpr (INIT_S) {
@@ -542,13 +542,13 @@ struct Solver {
         double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
         for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) {
             const double zi = z.get(jj, i), xi = x.get(jj, i), ivi = ivk(jj, i);
-            const double gi = Model::grad(ivi, xi, zi, sum[0]);
+            const double gi = Model::grad(ivi, xi, zi, sum[0], i);
             const double sd = -gi;
             s.set(jj, i, sd);
             sum[1] = fma(gi, sd, sum[1]);
             mx[0] = absmax(mx[0], gi);
             const double zt = fma(c0, sd, zi);  // exactly the trial point eval<true, false>(c0) would form
-            const double gt = Model::grad(ivi, xi, zt, sum[2]);
+            const double gt = Model::grad(ivi, xi, zt, sum[2], i);
             sum[3] = fma(gt, sd, sum[3]);
             mx[1] = absmax(mx[1], gt);
         }, s);
@@ -879,8 +879,8 @@ struct Solver {
                     for (int j = 0; j < EPT; ++j) {
                         const int i0 = 2 * (tl + j * T);
                         double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0);
-                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1);
+                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
+                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
                         const bool valid1 = i0 + 1 < (int)N;
                         x.set(2 * j, i0, xt0);
                         x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
@@ -923,8 +923,8 @@ struct Solver {
                                 store_f64x2(n2r, j0, np[2 * q].n2, np[2 * q + 1].n2);
                             }
                             double zt0, xt0, zt1, xt1;
-                            Model::sample(sd_of(2 * (j + q)), np[2 * q].n1, np[2 * q].n2, zt0, xt0);
-                            Model::sample(sd_of(2 * (j + q) + 1), np[2 * q + 1].n1, np[2 * q + 1].n2, zt1, xt1);
+                            Model::sample(sd_of(2 * (j + q)), np[2 * q].n1, np[2 * q].n2, zt0, xt0, j0);
+                            Model::sample(sd_of(2 * (j + q) + 1), np[2 * q + 1].n1, np[2 * q + 1].n2, zt1, xt1, j0 + 1);
                             const bool valid1 = j0 + 1 < (int)N;
                             x.p[j0] = xt0;
                             g.p[j0] = zt0;
@@ -1023,7 +1023,7 @@ struct Solver {
                             const bool valid = i < N;
                             const NormalPair np = npv[jj % (2 * kGenU)];
                             double zt, xt;
-                            Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
+                            Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt, i);
                             zt = valid ? zt : 0.0;
                             xt = valid ? xt : 0.0;
                             if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
@@ -1031,13 +1031,13 @@ struct Solver {
                             const double z0v = ztrue_start ? zt : 0.0;
                             if (Place::kResident || ztrue_start) z.set(jj, i, z0v);  // registers: always defined
                             const double ivi = ivk(jj, i);
-                            const double gi = Model::grad(ivi, xt, z0v, sum[0]);
+                            const double gi = Model::grad(ivi, xt, z0v, sum[0], i);
                             const double sd = -gi;
                             s.set(jj, i, sd);
                             sum[1] = fma(gi, sd, sum[1]);
                             mx[0] = absmax(mx[0], gi);
                             const double zt1 = fma(1.0, sd, z0v);
-                            const double gt = Model::grad(ivi, xt, zt1, sum[2]);
+                            const double gt = Model::grad(ivi, xt, zt1, sum[2], i);
                             sum[3] = fma(gt, sd, sum[3]);
                             mx[1] = absmax(mx[1], gt);
                         }, when(KEEP_ZTRUE, ztrue), x, s, when(Place::kResident || ztrue_start, z));
@@ -1063,7 +1063,7 @@ struct Solver {
                         xt = np.n2;                           // noise now, + A z after the barrier
                         g.set(jj, i, valid ? zt : 0.0);       // true z staged in the (still unused) gradient buffer
                     } else {
-                        Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt);
+                        Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt, i);
                     }
                     zt = valid ? zt : 0.0;
                     xt = valid ? xt : 0.0;
@@ -1255,7 +1255,7 @@ struct Solver {
                         for_elems_zz([&](auto zz, int jj, int i) {
                             double unused = 0.0;
                             const double zi = decltype(zz)::value ? 0.0 : z.get(jj, i);
-                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), zi, unused));
+                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), zi, unused, i));
                         }, g);
                         g_stored = true;
                     }
@@ -1311,7 +1311,7 @@ struct Solver {
                     if constexpr (Place::kResident) {
                         if (store) zout.set(jj, i, zn);
                     }
-                    const double t = Model::score_term(x.get(jj, i), zn);
+                    const double t = Model::score_term(x.get(jj, i), zn, i);
                     if constexpr (MAXB == 1) {
                         acc[0] += t;
                     } else {
@@ -1346,10 +1346,10 @@ struct Solver {
                     mx[0] = absmax(mx[0], zn - zo);
                     double unused = 0.0;
                     const double xi = x.get(jj, i), ivi = ivk(jj, i);
-                    const double gn = Model::grad(ivi, xi, zn, unused);
+                    const double gn = Model::grad(ivi, xi, zn, unused, i);
                     double go;
                     if constexpr (decltype(have_g)::value) go = g.get(jj, i);
-                    else go = Model::grad(ivi, xi, zo, unused);  // what the initial evaluation computed
+                    else go = Model::grad(ivi, xi, zo, unused, i);  // what the initial evaluation computed
                     const double dgi = gn - go;
                     sum[0] = fma(dxi, dgi, sum[0]);
                     sum[1] = fma(dgi, dgi, sum[1]);
@@ -1622,7 +1622,7 @@ struct Solver {
                     if constexpr (Place::kResident) {
                         if (store) zout.set(jj, i, zi);
                     }
-                    const double t = Model::score_term(x.get(jj, i), zi);
+                    const double t = Model::score_term(x.get(jj, i), zi, i);
                     if constexpr (MAXB == 1) {
                         acc[0] += t;
                     } else {

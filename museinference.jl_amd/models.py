@@ -9,9 +9,9 @@ native muse! loop, behind the same C ABI:
     model = ElementwiseModel.from_source("cubic", '''
         #include "muse_model.h"
         #define MUSE_MODEL_NAME "cubic"
-        MUSE_MODEL_FN void   muse_model_sample(double sd, double n1, double n2, double* z, double* x) { ... }
-        MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) { ... }
-        MUSE_MODEL_FN double muse_model_score_term(double x, double z) { ... }
+        MUSE_MODEL_FN void   muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) { ... }
+        MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) { ... }
+        MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) { ... }
     ''')
     prob = HipMuseProblem(x, model=model, ntheta=2, prior=GaussianPrior(0, 3))
     result = muse(prob, [0.0, 0.0], get_covariance=True)          # get_H! by finite differences
@@ -41,11 +41,18 @@ class ElementwiseModel:
         return cls(name, os.path.join(_build.MODELS_DIR, name + ".h"))
 
     @classmethod
-    def from_source(cls, name, source, directory=None):
+    def from_source(cls, name, source, directory=None, constants=None):
         """Write `source` to <directory>/<name>_<hash>.h (default: museinference.jl_amd/models/user/) and wrap it; the
-        library is named after name and hash, so that an edited source gets a library of its own."""
+        library is named after name and hash, so that an edited source gets a library of its own.
+
+        constants: {"P": array of N doubles, ...} -- per-element constants the model's functions look up by the element index
+        they are given (what a closure of the reference's SimpleMuseProblem would capture: a known spectrum, a noise-variance
+        map, a mask).  Each becomes a table compiled into the header and an accessor `double P(long i)`; the model is then
+        built for that N (MUSE_MODEL_N: the engine refuses a context of another size)."""
         directory = directory or os.path.join(_build.MODELS_DIR, "user")
         os.makedirs(directory, exist_ok=True)
+        if constants:
+            source = cls._tables(constants) + source
         tag = hashlib.sha256(source.encode()).hexdigest()[:10]
         path = os.path.join(directory, f"{name}_{tag}.h")
         if not os.path.exists(path):
@@ -54,6 +61,26 @@ class ElementwiseModel:
         m = cls(name, path)
         m._libname = f"{name}_{tag}"
         return m
+
+    @staticmethod
+    def _tables(constants):
+        import numpy as np
+        arrays = {k: np.ascontiguousarray(np.asarray(v, dtype=np.float64)).reshape(-1) for k, v in constants.items()}
+        sizes = {a.size for a in arrays.values()}
+        if len(sizes) != 1:
+            raise ValueError("constants: every array needs one entry per element (the same N)")
+        n = sizes.pop()
+        out = ['#include "muse_model.h"', f"#define MUSE_MODEL_N {n}"]
+        for k, a in arrays.items():
+            if not re.fullmatch(r"[A-Za-z][A-Za-z0-9_]*", k):
+                raise ValueError(f"constants: {k!r} is not a C identifier")
+            if not np.all(np.isfinite(a)):
+                raise ValueError(f"constants: {k} has non-finite entries")
+            body = ",\n".join(", ".join(repr(float(v)) for v in a[j:j + 8]) for j in range(0, n, 8))
+            # entry N serves the zero pad element of an odd-length vector and the phantom slots beyond it (x = z = 0 there)
+            out.append(f"static const double {k}_table[{n + 1}] = {{\n{body},\n1.0}};")
+            out.append(f"MUSE_MODEL_FN double {k}(long i) {{ return {k}_table[i < MUSE_MODEL_N ? i : MUSE_MODEL_N]; }}")
+        return "\n".join(out) + "\n"
 
     @property
     def library_name(self):

@@ -7,19 +7,22 @@
 #include "muse_model.h"
 #define MUSE_MODEL_NAME "cubic"
 
-MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x) {
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) {
+    (void)i;
     const double zi = sd * n1;
     *z = zi;
     *x = fma(0.1 * (zi * zi), zi, zi) + n2;
 }
-MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) {
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) {
+    (void)i;
     const double z2 = z * z;
     const double r = x - fma(0.1 * z2, z, z);   /* x - h(z) */
     const double t = iv * z;
     *acc = fma(t, z, fma(r, r, *acc));
     return t - r * fma(0.3, z2, 1.0);           /* iv z - (x - h) h'(z) */
 }
-MUSE_MODEL_FN double muse_model_score_term(double x, double z) {
+MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) {
+    (void)i;
     (void)x;
     return z * z;
 }

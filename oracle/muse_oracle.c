@@ -97,6 +97,11 @@ static double* ws_alloc(size_t n) {
 #define MUSE_MODEL_FN static inline
 #include MO_USER_MODEL_HEADER
 const char* mo_user_model_name(void) { return MUSE_MODEL_NAME; }
+#ifdef MUSE_MODEL_N /* a model with per-element tables is built for one N */
+#define MO_USER_CHECK_N(N) do { if ((N) != (int64_t)(MUSE_MODEL_N)) abort(); } while (0)
+#else
+#define MO_USER_CHECK_N(N) do { } while (0)
+#endif
 #else
 const char* mo_user_model_name(void) { return 0; }
 #endif
@@ -276,10 +281,11 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
     for (int k = 0; k < ntheta; ++k) sd[k] = mo_exp(0.5 * theta[k]);
 #ifdef MO_USER_MODEL_HEADER
     if (model == MO_MODEL_USER) {
+        MO_USER_CHECK_N(N);
         for (int64_t i = 0; i < N; ++i) {
             double n1, n2;
             mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
-            muse_model_sample(sd[mo_block(i, N, ntheta)], n1, n2, &z[i], &x[i]);
+            muse_model_sample(sd[mo_block(i, N, ntheta)], n1, n2, &z[i], &x[i], (long)i);
         }
         return;
     }
@@ -331,8 +337,9 @@ double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, con
     double acc = 0.0, cst = 0.0;
 #ifdef MO_USER_MODEL_HEADER
     if (model == MO_MODEL_USER) {
+        MO_USER_CHECK_N(N);
         for (int64_t i = 0; i < N; ++i) {
-            const double gi = muse_model_grad(iv[mo_block(i, N, ntheta)], x[i], z[i], &acc);
+            const double gi = muse_model_grad(iv[mo_block(i, N, ntheta)], x[i], z[i], &acc, (long)i);
             if (G) G[i] = gi;
         }
         return 0.5 * (acc + mo_theta_const(N, ntheta, theta));
@@ -395,9 +402,10 @@ void mo_grad_theta(int model, int64_t N, int ntheta, const double* x, const doub
     for (int k = 0; k < ntheta; ++k) { acc[k] = 0.0; cnt[k] = 0; }
 #ifdef MO_USER_MODEL_HEADER
     if (model == MO_MODEL_USER) {
+        MO_USER_CHECK_N(N);
         for (int64_t i = 0; i < N; ++i) {
             int k = mo_block(i, N, ntheta);
-            acc[k] += muse_model_score_term(x[i], z[i]);
+            acc[k] += muse_model_score_term(x[i], z[i], (long)i);
             cnt[k] += 1;
         }
     } else

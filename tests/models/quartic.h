@@ -6,16 +6,19 @@
 #include "muse_model.h"
 #define MUSE_MODEL_NAME "quartic"
 
-MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x) {
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) {
+    (void)i;
     *z = n1;
     *x = n1 + sd * n2;
 }
-MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) {
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) {
+    (void)i;
     const double r = x - z, t = iv * r, z2 = z * z;
     *acc = fma(0.5, z2 * z2, fma(z, z, fma(t, r, *acc)));
     return fma(z2, z, z - t);
 }
-MUSE_MODEL_FN double muse_model_score_term(double x, double z) {
+MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) {
+    (void)i;
     const double r = x - z;
     return r * r;
 }

@@ -1,0 +1,29 @@
+"""The model libraries the GPU tests and examples/user_model.py ask for by source text (ElementwiseModel.from_source: a library
+per hash of the generated header, ~40 s of hipcc each): `models()` lists them so that __graft_entry__.build() can compile them
+ahead of time next to the product library -- a GPU test run then loads them instead of compiling on the GPU box."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def models():
+    import museinference_jl_amd as M
+    import test_user_model as T
+    text = open(os.path.join(ROOT, "tests", "test_user_model.py")).read()
+    soft = text.split("src = '''")[1].split("'''")[0]
+    bad = soft.replace('"softprior"', '"badpad"').replace("return r * r;", "return r * r + 1.0;")
+    example = open(os.path.join(ROOT, "examples", "user_model.py")).read().split("SOURCE = r'''")[1].split("'''")[0]
+    out = [M.ElementwiseModel.from_source("spectrum", T.SPECTRUM_SOURCE, constants={"P": T.spectrum(N)}) for N in T.SPECTRUM_SIZES]
+    out += [M.ElementwiseModel.from_source("softprior", soft), M.ElementwiseModel.from_source("badpad", bad),
+            M.ElementwiseModel.from_source("saturating", example)]
+    return out
+
+
+if __name__ == "__main__":
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(4) as pool:
+        print(list(pool.map(lambda m: m.library(), models())))

@@ -295,7 +295,7 @@ def test_funnel_as_user_model_equals_the_built_in_funnel(gpu, M):
 
 
 @pytest.mark.gpu
-def test_model_from_source_text(gpu, M, tmp_path):
+def test_model_from_source_text(gpu, M):
     """ElementwiseModel.from_source: a header given as text (here the noise-scale member of the family with a Laplace-like
     smooth prior), compiled on first use on the GPU box itself, and its contract check."""
     src = '''
@@ -303,15 +303,16 @@ def test_model_from_source_text(gpu, M, tmp_path):
 #define MUSE_MODEL_NAME "softprior"
 /* z = n1 (prior N(0,1) times exp(-z^4/4), handled as part of A; the draw ignores the quartic factor: a MAP objective, not a
    sampler test), x ~ N(z, e^theta):  A = z^2 + z^4/2, B = (x - z)^2 */
-MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x) { *z = n1; *x = n1 + sd * n2; }
-MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc) {
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) { (void)i; *z = n1; *x = n1 + sd * n2; }
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) {
+    (void)i;
     const double r = x - z, t = iv * r, z2 = z * z;
     *acc = fma(0.5, z2 * z2, fma(z, z, fma(t, r, *acc)));
     return fma(z2, z, z - t);
 }
-MUSE_MODEL_FN double muse_model_score_term(double x, double z) { const double r = x - z; return r * r; }
+MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) { (void)i; const double r = x - z; return r * r; }
 '''
-    model = M.ElementwiseModel.from_source("softprior", src, directory=str(tmp_path))
+    model = M.ElementwiseModel.from_source("softprior", src)
     prob = M.HipMuseProblem(None, model=model, ntheta=1, N=4000)
     g, info = prob.map_and_score_batch(1, 0, 8, [0.2], atol=1e-6, z0_mode=0)
     assert np.all(info["status"] == 0) and np.all(info["gnorm"] <= 1e-6) and np.all(info["iterations"] >= 2)
@@ -324,8 +325,8 @@ MUSE_MODEL_FN double muse_model_score_term(double x, double z) { const double r 
     prob.close()
     bad = src.replace('"softprior"', '"badpad"').replace("return r * r;", "return r * r + 1.0;")
     with pytest.raises(M.MuseError) as e:
-        M.HipMuseProblem(None, model=M.ElementwiseModel.from_source("badpad", bad, directory=str(tmp_path)), ntheta=1, N=100)
-    assert "muse_model_score_term(0, 0) must be 0" in str(e.value)
+        M.HipMuseProblem(None, model=M.ElementwiseModel.from_source("badpad", bad), ntheta=1, N=100)
+    assert "muse_model_score_term(0, 0, N) must be 0" in str(e.value)
 
 
 @pytest.mark.gpu
@@ -391,3 +392,106 @@ def test_user_model_contexts_do_not_leak(gpu, M):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+# ---------------------------------------------------------------------------------- per-element constants (what a closure captures)
+SPECTRUM_SOURCE = '''
+#define MUSE_MODEL_NAME "spectrum"
+/* z_i ~ N(0, e^theta_k P_i) with a KNOWN spectrum P_i (a table compiled into the header: accessor P(i)), x_i ~ N(z_i, 1):
+   -logLike = 1/2 sum [ (x - z)^2 + e^-theta z^2 / P_i ] + 1/2 sum n_k theta_k (+ the theta-free 1/2 sum log P_i) */
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) {
+    *z = (sd * sqrt(P(i))) * n1;
+    *x = *z + n2;
+}
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) {
+    const double r = x - z, t = (iv / P(i)) * z;
+    *acc = fma(t, z, fma(r, r, *acc));
+    return t - r;
+}
+MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) {
+    (void)x;
+    return (z * z) / P(i);
+}
+'''
+
+
+def spectrum(N):
+    k = np.arange(N) % 200
+    return 25.0 / (1.0 + k) ** 1.5 + 0.05        # a repeated power law: three decades of signal-to-noise
+
+
+def spectrum_exact(x, P, nth, prior_sigma=3.0):
+    """Posterior mode and sigma per block of x_i ~ N(0, 1 + e^theta_k P_i): the model is jointly Gaussian, MUSE is exact."""
+    from scipy.optimize import brentq
+    N = x.size
+    kb = (np.arange(N) * nth) // N
+    mode, sigma = np.empty(nth), np.empty(nth)
+    for b in range(nth):
+        xb, Pb = x[kb == b], P[kb == b]
+        f = lambda t: 0.5 * np.sum(np.exp(t) * Pb * (xb ** 2 - (1 + np.exp(t) * Pb)) / (1 + np.exp(t) * Pb) ** 2) - t / prior_sigma ** 2
+        mode[b] = brentq(f, -8.0, 8.0, xtol=1e-13)
+        w = np.exp(mode[b]) * Pb / (1 + np.exp(mode[b]) * Pb)
+        sigma[b] = 1.0 / np.sqrt(0.5 * np.sum(w ** 2) + 1.0 / prior_sigma ** 2)
+    return mode, sigma
+
+
+def test_model_with_per_element_constants_on_the_oracle(M, O, tmp_path):
+    """ElementwiseModel.from_source(constants={"P": ...}): the table is compiled into the header (accessor P(i), MUSE_MODEL_N).
+    On the oracle's build of the generated header: muse() returns the exact marginal posterior (mode to sigma/sqrt(nsims),
+    Sigma = sigma^2) -- the spectrum enters draw, gradient and score consistently."""
+    from oracle_problem import OracleBatchedProblem
+    N, nth, truth, nsims = 3001, 2, [0.5, -0.7], 200
+    P = spectrum(N)
+    model = M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": P})
+    text = open(model.header).read()
+    assert "#define MUSE_MODEL_N 3001" in text and "static const double P_table[3002]" in text
+    with O.user_model(model.header, model.library_name):
+        x, z = O.sample_x_z("user", N, 99, M.DATA_SIM, truth)
+        n1, n2 = O.normals(99, M.DATA_SIM, N)
+        kb = (np.arange(N) * nth) // N
+        np.testing.assert_allclose(z, np.exp(0.5 * np.asarray(truth))[kb] * np.sqrt(P) * n1, rtol=1e-14)
+        res = M.check_model_consistency(OracleBatchedProblem(None, model="user", ntheta=nth, N=N), truth)
+        assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"]
+        prob = OracleBatchedProblem(x, model="user", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0), nthreads=8)
+        r = M.muse(prob, [0.0] * nth, rng=20240, nsims=nsims, maxsteps=60, theta_rtol=1e-5, grad_z_logLike_atol=1e-7, alpha=1.0, get_covariance=True)
+    mode, sigma = spectrum_exact(x, P, nth)
+    assert np.all(np.abs(r.theta - mode) / (sigma / np.sqrt(nsims)) < 4.0), (r.theta, mode)
+    assert np.all(np.abs(np.sqrt(np.diag(r.Sigma)) / sigma - 1.0) < 0.3)
+    assert np.all(np.abs(mode - np.asarray(truth)) / sigma < 4.0)
+    with pytest.raises(ValueError):
+        M.ElementwiseModel.from_source("bad", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": P, "Q": P[:10]})
+
+
+SPECTRUM_SIZES = (10000, 9999, 70001)     # (tests/prebuild_models.py compiles these libraries ahead of time)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nth,truth,placement,split", [(10000, 2, [0.5, -0.7], -1, 0), (9999, 1, [0.3], -1, 4), (70001, 2, [0.2, -0.3], -1, 0)])
+def test_model_with_per_element_constants_on_hip(gpu, M, O, N, nth, truth, placement, split):
+    """The same model on the engine, in the resident, cluster and streaming placements (odd N: the pad element and the phantom
+    slots behind it index the table's last entry): draw bit for bit and MAP / counts / scores against the oracle's build of the
+    generated header; the engine refuses another N; muse() returns the exact marginal posterior."""
+    P = spectrum(N)
+    # (default directory, museinference.jl_amd/models/user/: the library, named after the hash of the generated header, is
+    #  compiled once per tree and N -- ~40 s -- not once per test run)
+    model = M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, constants={"P": P})
+    with pytest.raises(M.MuseError) as e:
+        M.HipMuseProblem(None, model=model, ntheta=nth, N=N + 1)
+    assert "built for another N" in str(e.value)
+    with O.user_model(model.header, model.library_name):
+        x, _ = O.sample_x_z("user", N, 99, M.DATA_SIM, truth)
+        prob = make(M, x, N, nth, placement, split, model=model, prior=M.GaussianPrior(0.0, 3.0))
+        xs, zs = prob.sample_x_z(M.SimRng(5, 3), truth)
+        xo, zo = O.sample_x_z("user", N, 5, 3, truth)
+        assert np.array_equal(xs, xo) and np.array_equal(zs, zo)
+        n = 9
+        g, info = prob.map_and_score_batch(42, 0, n, truth, include_data=True, atol=1e-6, z0_mode=0)
+        go, zo, io = O.map_and_score_batch("user", N, 42, 0, n, truth, atol=1e-6, x_data=x, z0_mode=0)
+        same = assert_same_path_or_close(info, io, prob.get_zhat(0, n + 1), zo, g, go, 1e-6, truth, "funnel")
+        assert same.all()
+    nsims = 256 if N <= 10000 else 64
+    r = M.muse(prob, [0.0] * nth, rng=20240, nsims=nsims, maxsteps=60, theta_rtol=1e-5, grad_z_logLike_atol=1e-7, alpha=1.0, get_covariance=True)
+    mode, sigma = spectrum_exact(x, P, nth)
+    assert np.all(np.abs(r.theta - mode) / (sigma / np.sqrt(nsims)) < 4.0), (r.theta, mode)
+    assert np.all(np.abs(np.sqrt(np.diag(r.Sigma)) / sigma - 1.0) < 0.3)
+    prob.close()
