@@ -12,7 +12,7 @@ native muse! loop, behind the same C ABI:
         MUSE_MODEL_FN void   muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) { ... }
         MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) { ... }
         MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) { ... }
-    ''')
+    ''', constants={"P": spectrum})        # optional: per-element tables the functions read as P(i) -- what a closure captures
     prob = HipMuseProblem(x, model=model, ntheta=2, prior=GaussianPrior(0, 3))
     result = muse(prob, [0.0, 0.0], get_covariance=True)          # get_H! by finite differences
 
