@@ -18,6 +18,11 @@ def models():
     bad = soft.replace('"softprior"', '"badpad"').replace("return r * r;", "return r * r + 1.0;")
     example = open(os.path.join(ROOT, "examples", "user_model.py")).read().split("SOURCE = r'''")[1].split("'''")[0]
     out = [M.ElementwiseModel.from_source("spectrum", T.SPECTRUM_SOURCE, constants={"P": T.spectrum(N)}) for N in T.SPECTRUM_SIZES]
+    import numpy as np
+    spec = open(os.path.join(ROOT, "examples", "spectrum.py")).read()
+    spec_src = spec.split("SOURCE = r'''")[1].split("'''")[0]
+    P = 30.0 / (1.0 + np.arange(10000) % 250) ** 1.7 + 0.02          # (examples/spectrum.py's table)
+    out.append(M.ElementwiseModel.from_source("known_spectrum", spec_src, constants={"P": P}))
     out += [M.ElementwiseModel.from_source("softprior", soft), M.ElementwiseModel.from_source("badpad", bad),
             M.ElementwiseModel.from_source("saturating", example)]
     return out
