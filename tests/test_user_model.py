@@ -460,6 +460,13 @@ def test_model_with_per_element_constants_on_the_oracle(M, O, tmp_path):
     assert np.all(np.abs(mode - np.asarray(truth)) / sigma < 4.0)
     with pytest.raises(ValueError):
         M.ElementwiseModel.from_source("bad", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": P, "Q": P[:10]})
+    with pytest.raises(ValueError):
+        M.ElementwiseModel.from_source("bad", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": np.where(np.arange(N) == 7, np.nan, P)})
+    with pytest.raises(ValueError):
+        M.ElementwiseModel.from_source("bad", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P q": P})
+    # the same source with another table is another header, hence another library
+    other = M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": 2.0 * P})
+    assert other.header != model.header and other.library_name != model.library_name
 
 
 SPECTRUM_SIZES = (10000, 9999, 70001)     # (tests/prebuild_models.py compiles these libraries ahead of time)
