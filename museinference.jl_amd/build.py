@@ -107,8 +107,18 @@ INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
 MODELS_DIR = os.path.join(_HERE, "models")
 
 
+def model_out_dir():
+    """Where model libraries (and the headers from_source writes) go: next to libmuse_hip.so, so that they travel with a
+    snapshot of the repository -- or MUSE_MODEL_DIR (an installed, read-only package)."""
+    d = os.environ.get("MUSE_MODEL_DIR")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        return os.path.abspath(d)
+    return _HERE
+
+
 def model_lib_path(name):
-    return os.path.join(_HERE, f"libmuse_hip_model_{name}.so")
+    return os.path.join(model_out_dir(), f"libmuse_hip_model_{name}.so")
 
 
 def build_model_library(header, name, force=False, verbose=False):

@@ -42,14 +42,15 @@ class ElementwiseModel:
 
     @classmethod
     def from_source(cls, name, source, directory=None, constants=None):
-        """Write `source` to <directory>/<name>_<hash>.h (default: museinference.jl_amd/models/user/) and wrap it; the
+        """Write `source` to <directory>/<name>_<hash>.h (default: museinference.jl_amd/models/user/, or $MUSE_MODEL_DIR/headers) and wrap it; the
         library is named after name and hash, so that an edited source gets a library of its own.
 
         constants: {"P": array of N doubles, ...} -- per-element constants the model's functions look up by the element index
         they are given (what a closure of the reference's SimpleMuseProblem would capture: a known spectrum, a noise-variance
         map, a mask).  Each becomes a table compiled into the header and an accessor `double P(long i)`; the model is then
         built for that N (MUSE_MODEL_N: the engine refuses a context of another size)."""
-        directory = directory or os.path.join(_build.MODELS_DIR, "user")
+        directory = directory or (os.path.join(_build.model_out_dir(), "headers") if os.environ.get("MUSE_MODEL_DIR")
+                                  else os.path.join(_build.MODELS_DIR, "user"))
         os.makedirs(directory, exist_ok=True)
         if constants:
             source = cls._tables(constants) + source
