@@ -802,7 +802,8 @@ def main():
 
     # A transport whose collective never completes (RCCL over a broken link, a peer that died) must not cost the line: every
     # rank arms a watchdog for the transports after the first; when it fires, rank 0 prints the line of what finished -- the
-    # hung transport marked failed -- and every rank leaves (os._exit: the main thread is inside a C call).
+    # hung transport marked failed ("transport_failed") -- and every rank leaves with status 3 (os._exit: the main thread is
+    # inside a C call; the status is non-zero because a collective hung with GPU work in flight).
     import threading
     measured = {}
     deadline = float(os.environ.get("MUSE_BENCH_TRANSPORT_DEADLINE_S", "240"))
@@ -813,9 +814,12 @@ def main():
                 print(f"[bench rank {rank}] transport {t} did not finish within {deadline:.0f} s: reporting without it", file=sys.stderr)
                 if rank == 0:
                     line = build_line(dict(measured, **{t: {"skipped": f"did not finish within {deadline:.0f} s (watchdog)"}}))
+                    line["transport_failed"] = t
                     sys.stdout.write(json.dumps(line) + "\n")
                     sys.stdout.flush()
-                os._exit(0)
+                # non-zero: these ranks have GPU work of a hung collective in flight -- the launcher (and CI) must see a failed
+                # run, not a success with a "skipped" string inside the line
+                os._exit(3)
             timer = threading.Timer(deadline, fire)
             timer.daemon = True
             timer.start()

@@ -210,12 +210,14 @@ typedef struct muse_run_options {
 #define MUSE_RUN_HIST(ntheta) (7 * (ntheta) + (ntheta) * (ntheta) + 1)
 int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
              double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
-/* The same loop, same arguments, same results bit for bit, with NO host round trip between two maps: after every map
- * launch a one-workgroup step kernel forms the reductions, the prior terms, H^-1_post', the Newton-Raphson step, the
- * history record and the convergence test on the device and leaves the next theta in device memory, where the next map
- * launch reads it; the host enqueues (map, step) pairs a few iterations ahead and watches completion events.  Launches
- * enqueued past the end of the loop find a stop flag set and drain as no-ops.  (exp(theta/2), exp(-theta) are a fixed
- * sequence of IEEE operations on host and device for this reason.)  nsims * ntheta <= 18000. */
+/* The same loop, same arguments, same results bit for bit, with NO host in it: ONE launch runs every outer iteration.
+ * Its workgroups are all resident (the grid is what the occupancy query admits); workgroup w owns elements w, w + grid,
+ * ... in every iteration, publishes their scores as tagged 8-byte granules, sweeps everybody's granules at the end of the
+ * iteration (no fence, no barrier, no counter) and forms the reductions, the prior terms, H^-1_post', the Newton-Raphson
+ * step, the history record and the convergence test for itself from the same bits; the next theta never leaves the
+ * chip.  (exp(theta/2), exp(-theta) are a fixed sequence of IEEE operations on host and device, and the score moments one
+ * fixed 64-leaf summation tree, for this reason.)  Placements without a loop kernel (an element split, N >= 65 536) and
+ * score blocks beyond the step's LDS arrays (nsims * ntheta above ~19 000) run muse_run's loop instead. */
 int muse_run_device(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
                     double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 

@@ -75,7 +75,9 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmuse_hip.so")
     # a variant (diagnostic build, a user model's library) keeps its objects in a directory of its own: two of them may build at once
-    obj_dir = OBJ_DIR + ("_" + os.path.splitext(os.path.basename(lib_path))[0] if variant else "")
+    # (next to the library it builds: with MUSE_MODEL_DIR the package directory may be read-only)
+    obj_dir = (os.path.join(os.path.dirname(os.path.abspath(lib_path)), "build_" + os.path.splitext(os.path.basename(lib_path))[0])
+               if variant else OBJ_DIR)
     os.makedirs(obj_dir, exist_ok=True)
     objs, procs = [], []
     for src, (deps, flags) in UNITS.items():

@@ -92,14 +92,10 @@ struct BatchArgs {
     int debug;        // profiling aids: bit0 skip the solve (sample + score only), bit1 take x from the data vector
     int64_t sim_begin, fid_slot, slot0;
     MapTheta cur;                  // theta of the MAP problem and of the score.  The LDS copy of this field is re-written at the
-                                   // start of a problem when the launch carries several maps (maps[p / n_per_map]) or takes
-                                   // theta from device memory (cur_dev)
-    const MapTheta* cur_dev;       // non-null: theta lives in device memory (written by the previous step kernel of a
-                                   // device-resident muse! loop), cur is only a placeholder
+                                   // start of a problem when the launch carries several maps (maps[p / n_per_map]), and by the
+                                   // step between two iterations of the device-resident muse! loop (muse_loop_kernel)
     int nmaps, n_per_map;          // BATCH_STD: problem p is element p % n_per_map of map p / n_per_map
     int64_t map_stride;            // score rows per map in the output block (>= n_per_map: a gathered block is padded)
-    const int* stop_flag;          // non-null and *stop_flag != 0: the launch has nothing to do (the device-resident outer loop
-                                   // has converged; the launches enqueued ahead of the host's knowledge drain as no-ops)
     const SampleSd* tsample;       // FD: exp(theta/2) of the sampling thetas, [fd_grid * ntheta] (column j, grid point g at
                                    // j * fd_grid + g; shared by the simulations) or, fd_per_problem, one entry per problem
     int fd_grid, fd_per_problem;   // BATCH_FD: grid points per (simulation, column) unit (central_fdm(3,1): +step, -step = 2)
@@ -133,6 +129,12 @@ struct BatchArgs {
     int nstd;  // BATCH_STD: elements >= nstd only draw (and store) the normals of sim norm_sim0 + (p - nstd)
     int imp_split;  // BATCH_IMPLICIT: elements per simulation (1: all H columns in one element; ntheta: one each)
     int64_t norm_sim0;
+    // device-resident muse! loop (muse_loop_kernel): every element also publishes its score components as tagged 8-byte
+    // granules {32-bit half, 32-bit tag} -- [row * ntheta + k][2], one write-through store each -- which every workgroup
+    // sweeps at the end of the iteration (no fence, no barrier: solver.hpp, cluster_exchange, has the argument)
+    unsigned long long* gran;
+    unsigned int gran_tag;         // this iteration's tag
+    int pad1_;
     alignas(16) MapTheta maps[kMaxMaps];  // LAST, read from the kernarg segment only (never copied to LDS): theta of every map, nmaps > 1
 };
 constexpr size_t kArgsHeadBytes = offsetof(BatchArgs, maps);  // what the kernel keeps in LDS
@@ -216,23 +218,19 @@ struct StepParams {
     double alpha, theta_rtol;
     double prior_mean[kMaxTheta], prior_sigma[kMaxTheta];
 };
-// Arguments of the step kernel of the device-resident muse! loop (muse_kernels.hip: muse_step_kernel): iteration `iter`'s
-// scores -> its history record, the next theta (for the next map launch: BatchArgs::cur_dev) and the stop flag.
-struct StepArgs {
+// Arguments of the device-resident muse! loop beside the map's own (muse_kernels.hip: muse_loop_kernel): ONE launch runs
+// every outer iteration -- map, exchange of the scores between the workgroups, step (step.hpp), next map.
+struct LoopArgs {
     StepParams sp;
-    int iter, maxsteps;              // 1-based iteration this step closes
-    int64_t bnd[kMaxTheta + 1];
-    const double* scores;            // device [nsims + 1][ntheta]: the map's scores, data element first
-    const muse_info* info;           // device [nsims + 1]
-    MapTheta* theta_dev;             // in: theta of this iteration's map; out: the next iterate
-    double* prev_rec;                // device [MUSE_RUN_HIST]: the previous record (in), this one (out)
+    int maxsteps, z0_warm;
+    unsigned int tag_base;           // the granule tag of iteration i is tag_base + i (grows from run to run: nothing is reset)
+    int pad_;
     double* hist_out;                // pinned [maxsteps][MUSE_RUN_HIST]
-    double* gsims_out;               // pinned [maxsteps][nsims][ntheta]
-    muse_info* info_out;             // pinned [maxsteps][nsims + 1]
+    double* scores_out;              // pinned [maxsteps][nsims + 1][ntheta]: every iteration's scores, data element first
+    muse_info* info_out;             // pinned [maxsteps][nsims + 1], or a device dummy of one iteration (info_stride 0)
+    int64_t info_stride;             // nsims + 1, or 0
     double* theta_out;               // pinned [ntheta]: the iterate after the last executed step
-    int* stop_flag;                  // device: set when the loop has ended (converged, or failed)
     int* status;                     // pinned: [0] iterations executed, [1] STEP_* error, [2] converged
-    unsigned long long* tprev;       // device: s_memrealtime (100 MHz) at the end of the previous step / the start of the run
 };
 
 // launch shims of muse_kernels.hip (the only translation unit that holds device code)
@@ -246,8 +244,13 @@ struct LaunchShape {
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t stream);
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t stream);
-hipError_t launch_step(const StepArgs& s, hipStream_t stream, void* done_event);
-hipError_t launch_time_stamp(unsigned long long* out, int* stop_flag, hipStream_t stream);
+// the device-resident loop: false where the placement has no loop kernel (cluster placements); max_grid = the number of
+// workgroups that are certainly resident at once (they meet at the end of every iteration)
+bool loop_supported(const LaunchShape& s);
+hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid);
+hipError_t launch_loop(const LaunchShape& s, const BatchArgs& a, const LoopArgs& l, hipStream_t stream);
+size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta);  // LDS of the loop kernel beside the map kernel's
+size_t loop_step_bytes(int64_t nprob, int ntheta);              // the step's own arrays (they alias x and g in the LDS-resident layout)
 constexpr int kArgsDoubles = (int)((kArgsHeadBytes + 15) / 16 * 2);  // LDS copy of the kernel arguments (without the trailing maps[])
 
 

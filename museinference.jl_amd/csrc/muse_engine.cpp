@@ -101,8 +101,12 @@ struct muse_ctx {
     std::vector<hipEvent_t> prof_ev;
     int prof_count = 0;
     bool prof_on = false;
-    double* ncache = nullptr;            // normals cache [ncache_slots][2][ld] (muse_run, FD batches)
+    double* ncache = nullptr;            // normals cache [ncache_slots][2][ld] (muse_run, FD batches, repeated maps)
     int64_t ncache_slots = 0;
+    // what the cache holds: the standard normals of simulations [nc_sim0, nc_sim0 + nc_count) of master seed nc_seed (none:
+    // nc_count == 0), and the simulation range of the last plain map (a range is cached when it is asked for AGAIN)
+    uint64_t nc_seed = 0, nc_seen_seed = 0;
+    int64_t nc_sim0 = 0, nc_count = 0, nc_seen_sim0 = 0, nc_seen_count = 0;
     double* cl_part = nullptr;           // [cl_cap][kClusterSlotDoubles]
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
@@ -233,6 +237,7 @@ static bool ensure_ncache(muse_ctx* c, int64_t slots) {
     if (c->ncache) hipFree(c->ncache);
     c->ncache = nullptr;
     c->ncache_slots = 0;
+    c->nc_count = 0;
     if (hipMalloc(&c->ncache, (size_t)slots * 2 * c->ld * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError();
         static bool warned = false;
@@ -251,6 +256,9 @@ static bool ensure_ncache(muse_ctx* c, int64_t slots) {
 // writes per batch), so no device->host copy sits between consecutive launches.
 static size_t result_bytes(const muse_ctx* c, int64_t cap) {
     return (size_t)cap * (size_t)c->ntheta * sizeof(double) + (size_t)cap * sizeof(muse_info);
+}
+static bool ncache_holds(const muse_ctx* c, uint64_t seed, int64_t sim0, int64_t count) {
+    return c->ncache && c->nc_count > 0 && c->nc_seed == seed && sim0 >= c->nc_sim0 && sim0 + count <= c->nc_sim0 + c->nc_count;
 }
 static int ensure_results(muse_ctx* c, int area, int64_t n) {
     if (n <= c->res_cap[area]) return MUSE_OK;
@@ -406,6 +414,18 @@ static int for_each_lane(muse_ctx* c, F&& f) {   // f() with every lane that exi
     }
     const int rc0 = use_lane(c, 0);
     return rc ? rc : rc0;
+}
+
+// A result area that is launched again (or whose pinned block an FD / implicit-diff map is about to reuse: those are
+// hard-wired to area 1 on lane 0) while its previous launch is still in flight on ANOTHER lane: with one stream, stream order
+// serialised the two; with lanes nothing does, and ensure_results / ensure_tsample / ensure_ncache only drain the current
+// lane.  Drain every lane first (never taken by a caller that waits for an area before launching on it again).
+static int settle_area(muse_ctx* c, int area) {
+    if (!c->area_inflight[area] || c->nlanes <= 1) return MUSE_OK;
+    return for_each_lane(c, [&]() -> int {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return MUSE_OK;
+    });
 }
 
 extern "C" {
@@ -857,10 +877,6 @@ struct MapOpts {
     double* scores_dev = nullptr;
     int ncache_mode = 0;      // 1: the batch also stores the normals of its simulations; 2: it loads them (same seed and range
                               // as the storing batch of the same host call).  Silently 0 where the cache does not apply.
-    const MapTheta* theta_dev = nullptr;  // theta from device memory (device-resident muse! loop); thetas is then only a placeholder
-    const int* stop_flag = nullptr;
-    muse_info* info_dev = nullptr;        // solver infos to a device buffer (NULL: the area's pinned block)
-    bool no_event = false;                // the caller watches a later kernel's completion instead of this launch's
     bool lanes_ok = true;                 // the launch may run on the result area's lane (muse_set_concurrency)
 };
 static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data,
@@ -878,6 +894,8 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     if (stride < n) return fail(MUSE_ERR_INVALID, "map_stride smaller than the element count");
     c->area_failed[area] = false;
     if (n == 0) { c->res_n[area] = 0; c->res_rows[area] = 0; return MUSE_OK; }
+    rc = settle_area(c, area);
+    if (rc) return rc;
     // the area's lane (muse_set_concurrency).  A lane has resident zhat slots of its own (a streaming solve works in its
     // slot): a warm start, which means "from the MAPs muse_get_zhat / the last plain map left", stays on lane 0; so does a
     // map whose scores feed a device-side collective (its stream order is tied to lane 0's)
@@ -903,34 +921,65 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     a.sim_begin = sim_begin;
     a.slot0 = 0;
     a.scores = o.scores_dev ? o.scores_dev : c->scores_dev[area];
-    a.info = o.info_dev ? o.info_dev : c->info_dev[area];
+    a.info = c->info_dev[area];
     a.nmaps = o.nmaps;
     a.n_per_map = (int)n;
     a.map_stride = stride;
-    a.cur_dev = o.theta_dev;
-    a.stop_flag = o.stop_flag;
     if (o.nmaps > 1)
         for (int m = 0; m < o.nmaps; ++m) {
             make_thetaset(c, thetas + (size_t)m * c->ntheta, a.maps[m].t);
             a.maps[m].f_const = theta_const(c, thetas + (size_t)m * c->ntheta);
         }
-    if (o.ncache_mode != 0 && o.nmaps == 1 && sim_end > sim_begin && ensure_ncache(c, sim_end - sim_begin)) {
-        a.ncache = c->ncache;
-        a.ncache_sim0 = sim_begin;
-        a.ncache_count = (int)(sim_end - sim_begin);
-        a.ncache_mode = o.ncache_mode;
+    const int64_t nsim = sim_end - sim_begin;
+    if (o.ncache_mode != 0) {   // the caller (muse_run) says which: store with the first iteration, load with the later ones
+        if (o.nmaps == 1 && nsim > 0 && o.ncache_mode == 2 && ncache_holds(c, seed, sim_begin, nsim)) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = c->nc_sim0;
+            a.ncache_count = (int)c->nc_count;
+            a.ncache_mode = 2;
+        } else if (o.nmaps == 1 && nsim > 0 && o.ncache_mode == 1 && ensure_ncache(c, nsim)) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = sim_begin;
+            a.ncache_count = (int)nsim;
+            a.ncache_mode = 1;
+            c->nc_seed = seed; c->nc_sim0 = sim_begin; c->nc_count = nsim;
+        }
+    } else if (o.ncache_mode == 0 && o.nmaps == 1 && nsim > 0 && c->cur_lane == 0 && ncache_applies(c)) {
+        // A map over simulations the context has drawn before -- every iteration of a muse! loop the HOST drives (muse.py:
+        // the same streams at a new theta, src/muse.jl:134,169), a get_J! pass after it: the second time a range is asked
+        // for its normals are stored beside the solve, from the third time on they are loaded instead of generated (the
+        // same doubles: bit-identical results).  Lane 0 only: stream order is what puts the storing launch before the
+        // loading ones.  A map that never repeats (the pipelined cold steps of bench.py) stores nothing.
+        static const int64_t budget = [] {
+            const char* e = getenv("MUSE_NCACHE_MAX_MB");
+            return (e ? atoll(e) : 8192ll) << 20;
+        }();
+        if (ncache_holds(c, seed, sim_begin, nsim)) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = c->nc_sim0;
+            a.ncache_count = (int)c->nc_count;
+            a.ncache_mode = 2;
+        } else if (c->nc_seen_count == nsim && c->nc_seen_seed == seed && c->nc_seen_sim0 == sim_begin &&
+                   nsim * 2 * c->ld * (int64_t)sizeof(double) <= budget && ensure_ncache(c, nsim)) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = sim_begin;
+            a.ncache_count = (int)nsim;
+            a.ncache_mode = 1;
+            c->nc_seed = seed; c->nc_sim0 = sim_begin; c->nc_count = nsim;
+        }
+        c->nc_seen_seed = seed; c->nc_seen_sim0 = sim_begin; c->nc_seen_count = nsim;
     }
     // the area's completion event is signalled by this launch itself; with timing events around the launch (profiling)
     // the plain record after it keeps the order start, kernel, stop, done
     static const bool no_ext = getenv("MUSE_DEBUG_NO_EXT_LAUNCH") != nullptr;
-    c->launch_done = (c->timing || c->prof_on || no_ext || o.no_event) ? nullptr : c->area_done[area];
+    c->launch_done = (c->timing || c->prof_on || no_ext) ? nullptr : c->area_done[area];
     c->launch_done_used = false;
     rc = launch_batch(c, a);
     c->launch_done = nullptr;
     if (rc) return rc;
     c->area_inflight[area] = true;
     c->res_rows[area] = rows;
-    if (c->launch_done_used || o.no_event) {
+    if (c->launch_done_used) {
         c->res_n[area] = total;
         return MUSE_OK;
     }
@@ -1059,7 +1108,7 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
         // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
         // standard normals, the later ones load them instead of running the generator again
         MapOpts mo;
-        mo.ncache_mode = i == 1 ? 1 : 2;
+        mo.ncache_mode = (i == 1 && !ncache_holds(c, seed, 0, S)) ? 1 : 2;
         mo.lanes_ok = false;
         rc = map_async_impl(c, seed, 0, S, 1, theta, o->atol, z0_mode, 0, mo);
         if (rc) return rc;
@@ -1083,73 +1132,83 @@ int muse_run(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_op
     return MUSE_OK;
 }
 
-// The same loop with NO host round trip between two maps: after every map a one-workgroup step kernel (muse_kernels.hip,
-// muse_step_kernel: step.hpp's arithmetic, the same bits as the loop above) turns the scores into the history record and
-// the next theta, which the next map launch reads from device memory (BatchArgs::cur_dev); the host only enqueues
-// (map, step) pairs a few iterations ahead and watches the steps' completion events; launches enqueued past the end of
-// the loop find the stop flag set and drain as no-ops.
+// The same loop with NO host in it: ONE launch of the loop kernel (muse_kernels.hip, muse_loop_kernel) runs every
+// iteration -- the map, the exchange of the scores between the workgroups (tagged granules, no fence), the step (step.hpp's
+// arithmetic, the same bits as the loop above) by every workgroup for itself, the next map.  Every workgroup must be
+// resident for that (they meet once per iteration), so the grid is what the occupancy query admits and elements are dealt
+// statically, w, w + grid, ...; the cluster placements (an element split, N >= 65 536), whose kernels are not built in loop
+// form, and score blocks that do not fit the step's LDS arrays run the host loop -- the same bits either way.
 struct RunBuffers {
-    // device
-    MapTheta* theta_dev = nullptr;
-    double* prev_rec = nullptr;
-    int* stop_flag = nullptr;
-    unsigned long long* tprev = nullptr;
-    double* scores = nullptr;
-    muse_info* info = nullptr;
-    int64_t elems = 0;
+    unsigned long long* gran = nullptr;   // device [gran_cap] tagged granules of the scores
+    int64_t gran_cap = 0;
+    unsigned int tag = 0;                 // the last granule tag used (tags grow from run to run: nothing is reset)
+    muse_info* info_dummy = nullptr;      // device [info_cap]: where the solver infos go when the caller does not want them
+    int64_t info_cap = 0;
     // pinned
     double* hist = nullptr;
-    double* gsims = nullptr;
+    double* scores = nullptr;
     muse_info* infos = nullptr;
     double* theta_out = nullptr;
     int* status = nullptr;
-    int64_t cap_steps = 0, cap_sims = 0;
-    hipEvent_t done[8] = {nullptr};
+    int64_t cap_hist = 0, cap_scores = 0, cap_infos = 0;
 };
-static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S) {
+static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, bool want_info) {
     if (!c->run) c->run = new RunBuffers();
     RunBuffers& r = *c->run;
     const int nt = c->ntheta;
-    if (!r.theta_dev) {
-        HIPCHK(hipMalloc(&r.theta_dev, sizeof(MapTheta)));
-        HIPCHK(hipMalloc(&r.prev_rec, MUSE_RUN_HIST(kMaxTheta) * sizeof(double)));
-        HIPCHK(hipMalloc(&r.stop_flag, 64));
-        HIPCHK(hipMalloc(&r.tprev, 64));
+    if (!r.theta_out) {
         HIPCHK(hipHostMalloc(&r.theta_out, kMaxTheta * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&r.status, 64, hipHostMallocDefault));
-        for (int k = 0; k < 8; ++k) HIPCHK(hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
     }
-    if (S + 1 > r.elems) {
+    const int64_t ngran = (int64_t)2 * nt * (S + 1);
+    if (ngran > r.gran_cap || r.tag > 0x70000000u) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (r.scores) HIPCHK(hipFree(r.scores));
-        if (r.info) HIPCHK(hipFree(r.info));
-        r.scores = nullptr; r.info = nullptr; r.elems = 0;
-        HIPCHK(hipMalloc(&r.scores, (size_t)(S + 1) * nt * sizeof(double)));
-        HIPCHK(hipMalloc(&r.info, (size_t)(S + 1) * sizeof(muse_info)));
-        r.elems = S + 1;
+        if (ngran > r.gran_cap) {
+            if (r.gran) HIPCHK(hipFree(r.gran));
+            r.gran = nullptr; r.gran_cap = 0;
+            HIPCHK(hipMalloc(&r.gran, (size_t)ngran * sizeof(unsigned long long)));
+            r.gran_cap = ngran;
+        }
+        HIPCHK(hipMemsetAsync(r.gran, 0, (size_t)r.gran_cap * sizeof(unsigned long long), c->stream));  // tag 0 is never used
+        r.tag = 0;
     }
-    if (maxsteps > r.cap_steps || S > r.cap_sims) {
+    if (S + 1 > r.info_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (r.info_dummy) HIPCHK(hipFree(r.info_dummy));
+        r.info_dummy = nullptr; r.info_cap = 0;
+        HIPCHK(hipMalloc(&r.info_dummy, (size_t)(S + 1) * sizeof(muse_info)));
+        r.info_cap = S + 1;
+    }
+    const int64_t nh = (int64_t)maxsteps * MUSE_RUN_HIST(kMaxTheta), ns = (int64_t)maxsteps * (S + 1) * nt,
+                  ni = want_info ? (int64_t)maxsteps * (S + 1) : 0;
+    if (nh > r.cap_hist) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (r.hist) HIPCHK(hipHostFree(r.hist));
-        if (r.gsims) HIPCHK(hipHostFree(r.gsims));
+        r.hist = nullptr; r.cap_hist = 0;
+        HIPCHK(hipHostMalloc(&r.hist, (size_t)nh * sizeof(double), hipHostMallocDefault));
+        r.cap_hist = nh;
+    }
+    if (ns > r.cap_scores) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (r.scores) HIPCHK(hipHostFree(r.scores));
+        r.scores = nullptr; r.cap_scores = 0;
+        HIPCHK(hipHostMalloc(&r.scores, (size_t)ns * sizeof(double), hipHostMallocDefault));
+        r.cap_scores = ns;
+    }
+    if (ni > r.cap_infos) {
+        HIPCHK(hipStreamSynchronize(c->stream));
         if (r.infos) HIPCHK(hipHostFree(r.infos));
-        r.hist = nullptr; r.gsims = nullptr; r.infos = nullptr; r.cap_steps = r.cap_sims = 0;
-        const int64_t ms = maxsteps > r.cap_steps ? maxsteps : r.cap_steps, ss = S > r.cap_sims ? S : r.cap_sims;
-        HIPCHK(hipHostMalloc(&r.hist, (size_t)ms * MUSE_RUN_HIST(kMaxTheta) * sizeof(double), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(&r.gsims, (size_t)ms * ss * nt * sizeof(double), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(&r.infos, (size_t)ms * (ss + 1) * sizeof(muse_info), hipHostMallocDefault));
-        r.cap_steps = ms;
-        r.cap_sims = ss;
+        r.infos = nullptr; r.cap_infos = 0;
+        HIPCHK(hipHostMalloc(&r.infos, (size_t)ni * sizeof(muse_info), hipHostMallocDefault));
+        r.cap_infos = ni;
     }
     return MUSE_OK;
 }
 static void free_run_buffers(muse_ctx* c) {
     if (!c->run) return;
     RunBuffers& r = *c->run;
-    hipFree(r.theta_dev); hipFree(r.prev_rec); hipFree(r.stop_flag); hipFree(r.tprev); hipFree(r.scores); hipFree(r.info);
-    hipHostFree(r.hist); hipHostFree(r.gsims); hipHostFree(r.infos); hipHostFree(r.theta_out); hipHostFree(r.status);
-    for (int k = 0; k < 8; ++k)
-        if (r.done[k]) hipEventDestroy(r.done[k]);
+    hipFree(r.gran); hipFree(r.info_dummy);
+    hipHostFree(r.hist); hipHostFree(r.scores); hipHostFree(r.infos); hipHostFree(r.theta_out); hipHostFree(r.status);
     delete c->run;
     c->run = nullptr;
 }
@@ -1161,75 +1220,115 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     rc = check_run_args(c, theta0, o, niter_out, theta_out, hist_out, gsims_out);
     if (rc) return rc;
     const int nt = c->ntheta, S = o->nsims, maxsteps = o->maxsteps;
-    const int64_t H = MUSE_RUN_HIST(nt);
-    if ((size_t)S * nt > 18000)  // the step kernel keeps the simulation scores in LDS (144 KB of the 160)
-        return fail(MUSE_ERR_INVALID, "muse_run_device: nsims * ntheta too large for the step kernel (use muse_run)");
-    rc = ensure_run_buffers(c, maxsteps, S);
+    const int64_t H = MUSE_RUN_HIST(nt), nprob = (int64_t)S + 1;
+    const int pl = choose_place(c);
+    LaunchShape shape;
+    shape.model = c->model; shape.ntheta = nt; shape.place = pl; shape.grid = 0; shape.implicit = false; shape.lds_s = false;
+    shape.done_event = nullptr;
+    const bool xg_lds = pl == P_R512x10;
+    shape.lds = place_lds(c, pl) + loop_extra_lds(xg_lds, nprob, nt);
+    static const bool host_only = getenv("MUSE_DEBUG_NO_LOOP_KERNEL") != nullptr;  // tuning aid
+    const size_t lds_limit = 160 * 1024;
+    if (host_only || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
+        (xg_lds && loop_step_bytes(nprob, nt) > (size_t)2 * (c->ld + 2) * sizeof(double)))
+        return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
+    rc = muse_synchronize(c);   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
+    if (rc) return rc;
+    int max_grid = 0;
+    {
+        const hipError_t e = loop_max_grid(shape, c->num_cus, &max_grid);
+        if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("loop kernel occupancy: ") + hipGetErrorString(e));
+    }
+    if (max_grid < 1) return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
+    rc = ensure_run_buffers(c, maxsteps, S, info_out != nullptr);
     if (rc) return rc;
     RunBuffers& r = *c->run;
-    MapTheta m0;
-    make_map_theta(nt, c->bnd, theta0, m0);
-    HIPCHK(hipMemcpyAsync(r.theta_dev, &m0, sizeof m0, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // (m0 is on this stack frame)
+    rc = ensure_zhat(c, nprob);
+    if (rc) return rc;
+    BatchArgs a;
+    base_args(c, a, theta0);
+    a.kind = BATCH_STD;
+    a.seed = seed;
+    a.atol = o->atol;
+    a.nproblems = (int)nprob;
+    a.include_data = 1;
+    a.z0_mode = MUSE_Z0_ZERO;   // (per iteration, set by the kernel)
+    a.store_zhat = 1;
+    a.sim_begin = 0;
+    a.slot0 = 0;
+    a.nmaps = 1;
+    a.n_per_map = (int)nprob;
+    a.map_stride = nprob;
+    {
+        const bool held = ncache_holds(c, seed, 0, S);   // (an earlier run, or maps of the host driver, drew these streams)
+        if (held || ensure_ncache(c, S)) {
+            a.ncache = c->ncache;
+            a.ncache_sim0 = held ? c->nc_sim0 : 0;
+            a.ncache_count = held ? (int)c->nc_count : S;
+            a.ncache_mode = held ? 2 : 1;   // of the FIRST iteration; the later ones load
+            if (!held) { c->nc_seed = seed; c->nc_sim0 = 0; c->nc_count = S; }
+        }
+    }
+    a.gran = r.gran;
+    // the common fields, as launch_batch fills them
+    a.N = c->N;
+    a.ld = c->ld;
+    a.ntheta = nt;
+    for (int k = 0; k <= kMaxTheta; ++k) {
+        a.bnd[k] = c->bnd[k];
+        a.bnd32[k] = k < nt ? (int)c->bnd[k] : 0x7fffffff;
+    }
+    a.x_data = c->x_data;
+    a.zhat = c->zhat;
+    a.work_counter = c->counter;
+    a.ticket_base = (int)c->ticket_base;   // (no tickets are drawn: elements are dealt statically)
+    a.debug = c->debug;
+    a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
+    a.csize = 1;
+    a.error_flag = c->error_flag;
+    int grid = max_grid < (int)nprob ? max_grid : (int)nprob;
+    if (const char* e = getenv("MUSE_DEBUG_LOOP_GRID")) {   // tuning aid (never more than what is resident at once)
+        const int g = atoi(e);
+        if (g >= 1 && g < grid) grid = g;
+    }
+    shape.grid = grid;
+    a.scratch_stride = place_scratch_vectors(pl) * c->ld;
+    rc = ensure_scratch(c, (size_t)grid * a.scratch_stride);
+    if (rc) return rc;
+    a.scratch = c->scratch;
+    LoopArgs l;
+    memset(&l, 0, sizeof l);
+    step_params(c, o, l.sp);
+    l.maxsteps = maxsteps;
+    l.z0_warm = o->z0_warm ? 1 : 0;
+    l.tag_base = r.tag;
+    r.tag += (unsigned)maxsteps + 1;
+    l.hist_out = r.hist;
+    l.scores_out = r.scores;
+    l.info_out = info_out ? r.infos : r.info_dummy;
+    l.info_stride = info_out ? nprob : 0;
+    l.theta_out = r.theta_out;
+    l.status = r.status;
     r.status[0] = r.status[1] = r.status[2] = 0;
     for (int k = 0; k < nt; ++k) r.theta_out[k] = theta0[k];
-    HIPCHK(launch_time_stamp(r.tprev, r.stop_flag, c->stream));
-    StepArgs sa;
-    memset(&sa, 0, sizeof sa);
-    step_params(c, o, sa.sp);
-    sa.maxsteps = maxsteps;
-    for (int k = 0; k <= kMaxTheta; ++k) sa.bnd[k] = c->bnd[k];
-    sa.scores = r.scores;
-    sa.info = r.info;
-    sa.theta_dev = r.theta_dev;
-    sa.prev_rec = r.prev_rec;
-    sa.hist_out = r.hist;
-    sa.gsims_out = r.gsims;
-    sa.info_out = info_out ? r.infos : nullptr;
-    sa.theta_out = r.theta_out;
-    sa.stop_flag = r.stop_flag;
-    sa.status = r.status;
-    sa.tprev = r.tprev;
-    // how far the host runs ahead of the device: deep enough that the device never waits for a launch (a pair takes the
-    // host ~15 us to enqueue, the device ~60 us to run), shallow enough that few no-op pairs follow the end of the loop
-    constexpr int kAhead = 3, kRing = 8;
-    int enq = 0, done = 0;
-    bool stopped = false;
-    while (true) {
-        while (!stopped && enq < maxsteps && enq - done < kAhead) {
-            const int i = enq + 1;
-            MapOpts mo;
-            mo.ncache_mode = i == 1 ? 1 : 2;
-            mo.theta_dev = r.theta_dev;
-            mo.stop_flag = r.stop_flag;
-            mo.scores_dev = r.scores;
-            mo.info_dev = r.info;
-            mo.no_event = true;
-            mo.lanes_ok = false;
-            const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
-            rc = map_async_impl(c, seed, 0, S, 1, theta0 /* placeholder: theta comes from the device */, o->atol, z0_mode, 0, mo);
-            if (rc) return rc;
-            sa.iter = i;
-            HIPCHK(launch_step(sa, c->stream, r.done[enq % kRing]));
-            enq += 1;
-        }
-        if (done == enq) break;
-        rc = muse_wait_event(r.done[done % kRing]);
-        if (rc) return rc;
-        done += 1;
-        if (r.status[1] != 0 || r.status[2] != 0 || r.status[0] < done) stopped = true;  // failed, converged, or a no-op step
+    {
+        const hipError_t e = launch_loop(shape, a, l, c->stream);
+        if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("loop kernel launch: ") + hipGetErrorString(e));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->area_inflight[0] = false;
     rc = check_error_flag(c);
     if (rc) return rc;
+    if (r.status[1] == 100) return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident");
     if (r.status[1] != 0) return step_error(r.status[1]);
     const int n = r.status[0];
     *niter_out = n;
     for (int k = 0; k < nt; ++k) theta_out[k] = r.theta_out[k];
-    memcpy(hist_out, r.hist, (size_t)n * H * sizeof(double));
-    memcpy(gsims_out, r.gsims, (size_t)n * S * nt * sizeof(double));
-    if (info_out) memcpy(info_out, r.infos, (size_t)n * (S + 1) * sizeof(muse_info));
+    for (int i = 0; i < n; ++i) {
+        memcpy(hist_out + (int64_t)i * H, r.hist + (int64_t)i * H, (size_t)H * sizeof(double));
+        memcpy(gsims_out + (int64_t)i * S * nt, r.scores + ((int64_t)i * nprob + 1) * nt, (size_t)S * nt * sizeof(double));
+    }
+    if (info_out) memcpy(info_out, r.infos, (size_t)n * nprob * sizeof(muse_info));
     return MUSE_OK;
 }
 
@@ -1291,7 +1390,9 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     const int64_t nsims = s_hi - s_lo;
     // 1. fiducial MAPs at theta0 from zero(z) (src/muse.jl:417-423)
     const int64_t nfid = fid_mode == 0 ? 1 : nsims;
-    int rc = ensure_zhat(c, nfid);
+    int rc = settle_area(c, 1);
+    if (rc) return rc;
+    rc = ensure_zhat(c, nfid);
     if (rc) return rc;
     // every simulation is drawn G*ntheta times (same randoms, perturbed theta; src/muse.jl:426-432): its standard
     // normals are generated once -- by its own fiducial problem (fid_mode 1) or by a normals-only element of the
@@ -1316,6 +1417,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             a.ncache_sim0 = s_lo;
             a.ncache_count = (int)nsims;
             a.ncache_mode = 1;
+            c->nc_seed = seed; c->nc_sim0 = s_lo; c->nc_count = nsims;
         }
         a.include_data = 0;
         a.z0_mode = MUSE_Z0_ZERO;
@@ -1465,7 +1567,9 @@ static int implicit_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t 
     if (ne > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
     const int64_t s_lo = sim_begin + e_begin / nt, s_hi = sim_begin + (e_end - 1) / nt + 1;
     const int64_t nsims = s_hi - s_lo;
-    int rc = ensure_zhat(c, 1);
+    int rc = settle_area(c, 2);
+    if (rc) return rc;
+    rc = ensure_zhat(c, 1);
     if (rc) return rc;
     rc = ensure_results(c, 2, nsims * nt);
     if (rc) return rc;

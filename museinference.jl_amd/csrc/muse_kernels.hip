@@ -44,23 +44,16 @@ namespace muse {
 // field addresses is formed, and every access then becomes a scratch access.  LDS loads at uniform
 // addresses are uniform values, so control flow on them stays scalar.
 typedef __attribute__((address_space(4))) const uint32_t* kernarg_ptr;
-// theta of problem p into the LDS copy of the arguments (BatchArgs::cur): from device memory (cur_dev: the theta the previous
-// step kernel of a device-resident muse! loop left there), or -- a launch that carries several maps -- from the map's entry of
-// maps[], read straight from the kernarg segment.  Workgroup-uniform; a no-op (no barrier) for the plain launch.
+// theta of problem p into the LDS copy of the arguments (BatchArgs::cur) -- a launch that carries several maps -- from the
+// map's entry of maps[], read straight from the kernarg segment.  Workgroup-uniform; a no-op (no barrier) for the plain launch.
 __device__ __forceinline__ void load_problem_theta(const BatchArgs& a, double* args_lds, int p, int tid) {
-    if (a.nmaps > 1 || a.cur_dev) {
+    if (a.nmaps > 1) {
         __syncthreads();  // every thread is done with the previous problem's theta
         asm volatile("" : "+v"(tid));  // (else the source address is formed at the kernel's entry and held -- spilled -- across it)
         if (tid < (int)(sizeof(MapTheta) / 4)) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(args_lds) + offsetof(BatchArgs, cur) / 4;
-            uint32_t v;
-            if (a.cur_dev) {
-                v = reinterpret_cast<const uint32_t*>(a.cur_dev)[tid];
-            } else {
-                kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-                v = kp[(offsetof(BatchArgs, maps) + (size_t)(p / a.n_per_map) * sizeof(MapTheta)) / 4 + tid];
-            }
-            dst[tid] = v;
+            kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            dst[tid] = kp[(offsetof(BatchArgs, maps) + (size_t)(p / a.n_per_map) * sizeof(MapTheta)) / 4 + tid];
         }
         __syncthreads();
     }
@@ -88,12 +81,6 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
     }
     __syncthreads();
     const BatchArgs& a = *reinterpret_cast<const BatchArgs*>(args_lds);
-    if (a.stop_flag && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(a.stop_flag)) != 0) {
-        // the device-resident outer loop has converged: this launch was enqueued ahead of the host's knowledge and drains as
-        // a no-op.  The ticket counter still advances by exactly nproblems (muse_engine.cpp, launch_batch).
-        if (!Place::kCluster && blockIdx.x == 0 && tid == 0) atomicAdd(a.work_counter, a.nproblems);
-        return;
-    }
     double* exch = args_lds + kArgsDoubles;   // cluster placements: [kMaxCluster][8] values of the epoch's exchange
     double* lds_x = exch + (Place::kCluster ? kMaxCluster * 8 : 0);  // [ld + 2]: elements, dummy slot (index ld), pad
     double* lds_g = lds_x + a.ld + 2;         // [ld + 2]
@@ -294,79 +281,231 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
 }
 
 // ------------------------------------------------------------------------------------------------
-// The device-resident muse! loop (muse_run_device, muse_engine.cpp): between two map launches this ONE workgroup does
-// what the host loop does between them -- the reductions over the simulation scores, the prior terms, H^-1_post, the
-// Newton-Raphson step, the history record, the convergence test (src/muse.jl:163-166,177-232; the arithmetic is
-// step.hpp's, shared with the host loop, so the two trajectories are the same bits) -- and leaves the next theta in
-// device memory for the next map launch, so that no host round trip sits between two maps.  Component k's sequential
-// sums run in lane k; the dense part (nθ <= 8) in lane 0.
-__global__ void __launch_bounds__(256) muse_step_kernel(StepArgs s) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nt = s.sp.ntheta, S = s.sp.nsims;
-    if (*reinterpret_cast<const volatile int*>(s.stop_flag) != 0) return;   // the loop ended before this step
-    double* gs = reinterpret_cast<double*>(smem);      // [S][nt] simulation scores
-    double* small = gs + (size_t)S * nt;               // g_dat [8], mean [8], var [8]
-    const int64_t H = MUSE_RUN_HIST(nt);
-    double* gs_out = s.gsims_out + (int64_t)(s.iter - 1) * S * nt;
-    for (int w = tid; w < (S + 1) * nt; w += 256) {
-        const double v = s.scores[w];
-        if (w < nt) small[w] = v;
-        else {
-            gs[w - nt] = v;
-            gs_out[w - nt] = v;
-        }
+// The device-resident muse! loop (muse_run_device, muse_engine.cpp): ONE launch runs every outer iteration
+// (src/muse.jl:159-232).  The grid is sized so that every workgroup is resident (loop_max_grid); workgroup w owns elements
+// w, w + grid, ... in EVERY iteration (an element's MAP stays with the compute unit that wrote it).  An iteration:
+//   1. the map: the workgroup's elements, exactly as map_score_kernel runs them (Solver::run); every element also
+//      publishes its score as tagged granules (Solver::finish);
+//   2. the exchange: every workgroup sweeps the (nsims + 1) x ntheta x 2 granules until all carry this iteration's tag --
+//      no fence, no barrier, no atomic counter (the argument is solver.hpp's cluster_exchange: an aligned 8-byte granule
+//      written by one write-through store and read past the L1 is not torn and needs no ordering against a flag);
+//   3. the step, by EVERY workgroup for itself from the same bits (step.hpp: moments in the fixed 64-leaf tree, one wavefront
+//      per theta component; the dense part on one lane, its arrays in LDS): the history record, the next theta -- written
+//      into the workgroup's LDS copy of the arguments, where its next problems read it -- and the convergence test
+//      (src/muse.jl:163-166).  Workgroup 0 also writes the record, the iterate and the status to pinned host memory.
+// Nothing leaves the GPU between two iterations and no launch sits between them.  The arithmetic is the host loop's
+// (muse_run), so the two trajectories are the same bits.
+constexpr int kLoopArgsDoubles = (int)((sizeof(LoopArgs) + 7) / 8);
+constexpr int kLoopRecDoubles = 7 * kMaxTheta + kMaxTheta * kMaxTheta + 1;
+constexpr int kLoopPersistDoubles = kLoopArgsDoubles + kLoopRecDoubles + 3;   // LoopArgs, the previous record, flags
+enum { STEP_TIMEOUT = 100 };  // a workgroup's sweep of the granules expired (the workgroups were not all resident)
+
+// Where things are in the loop kernel's LDS, re-derived where they are used from a laundered zero: computed once at the
+// kernel's entry, the dozen addresses and the loop's scalars stay live across the problems of every iteration and spill
+// (13 VGPRs and 95 SGPRs in the first version).
+template <class Place>
+struct LoopLds {
+    BatchArgs* a;
+    double *red, *shs, *lds_x, *lds_g, *persist, *stepbuf, *rec;
+    LoopArgs* L;
+    int* flags;                 // [0] err, [1] converged, [2] sweep expired
+    unsigned long long* t_prev; // s_memrealtime at the end of the previous step (workgroup 0's is the one that is reported)
+    __device__ __forceinline__ LoopLds(unsigned char* smem) {
+        unsigned z = 0;
+        asm volatile("" : "+s"(z));
+        red = reinterpret_cast<double*>(smem + z);
+        shs = red + 2 * (Place::T / 64) * 8;
+        double* args_lds = shs + 42;
+        a = reinterpret_cast<BatchArgs*>(args_lds);
+        lds_x = args_lds + kArgsDoubles;
+        lds_g = lds_x + a->ld + 2;
+        // after x and g (or right behind the arguments): what lives across iterations; the step's own arrays alias x and g
+        // in the LDS-resident layout (both are dead between two iterations), and follow the persistent block otherwise
+        persist = Place::kXgLds ? lds_g + a->ld + 2 : lds_x;
+        stepbuf = Place::kXgLds ? lds_x : persist + kLoopPersistDoubles;
+        L = reinterpret_cast<LoopArgs*>(persist);
+        rec = persist + kLoopArgsDoubles;
+        flags = reinterpret_cast<int*>(rec + kLoopRecDoubles);
+        t_prev = reinterpret_cast<unsigned long long*>(rec + kLoopRecDoubles + 2);
     }
-    if (s.info_out)
-        for (int w = tid; w < S + 1; w += 256) s.info_out[(int64_t)(s.iter - 1) * (S + 1) + w] = s.info[w];
+};
+
+template <class Model, class Place>
+__global__ void __launch_bounds__(Place::T) __attribute__((amdgpu_waves_per_eu(Place::kWavesPerEu)))
+muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArgs /*likewise*/) {
+    static_assert(!Place::kCluster, "one workgroup per element");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Place::T, NW = T / 64;
+    const int tid = threadIdx.x;
+    {
+        kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<double*>(smem) + 2 * (T / 64) * 8 + 42);
+        for (int w = tid; w < (int)(kArgsHeadBytes / 4); w += T) dst[w] = kp[w];
+    }
     __syncthreads();
-    if (tid < nt) step_moments(tid, nt, S, gs, small[8 + tid], small[16 + tid]);
-    __syncthreads();
-    // the dense part in ONE lane, every array it indexes at run time in LDS (StepWork)
-    StepWork& w = *reinterpret_cast<StepWork*>(small + 24);
-    int* flags = reinterpret_cast<int*>(small + 24 + sizeof(StepWork) / 8);  // [0] err, [1] converged
-    if (tid == 0) {
-        for (int k = 0; k < nt; ++k) w.theta[k] = s.theta_dev->t.theta[k];
-        int err = step_record(s.sp, w.theta, small, small + 8, small + 16, w.rec, w.theta_next, w);
-        int converged = 0;
-        if (err == STEP_OK) {
+    {
+        LoopLds<Place> m(smem);
+        kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(m.persist);
+        for (int w = tid; w < (int)(sizeof(LoopArgs) / 4); w += T) dst[w] = kp[sizeof(BatchArgs) / 4 + w];
+        if (tid == 0) {
             unsigned long long now;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            w.rec[7 * nt + nt * nt] = (double)(now - *s.tprev) * 1e-8;   // seconds of this iteration
-            *s.tprev = now;
-            // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
-            if (s.iter >= 2 && s.iter < s.maxsteps) {
-                const int c = step_converged(nt, w.rec, s.prev_rec, s.sp.theta_rtol);
-                if (c < 0) err = STEP_DOMAIN;
-                converged = c > 0;
+            *m.t_prev = now;
+        }
+    }
+    unsigned pk0, pk1;
+    {
+        LoopLds<Place> m(smem);
+        Solver<Model, Place> s0(*m.a, tid, m.red, m.shs);
+        s0.pack_blocks();
+        pk0 = s0.pk[0];
+        pk1 = s0.pk[1];
+    }
+    for (int iter = 1;; ++iter) {
+        __syncthreads();
+        if (tid == 0) {
+            LoopLds<Place> m(smem);
+            BatchArgs& a = *m.a;   // (mutable here: the step re-writes theta and the per-iteration fields)
+            const LoopArgs& L = *m.L;
+            a.z0_mode = (iter > 1 || L.z0_warm) ? Z0_WARM : Z0_ZERO;
+            // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
+            // standard normals, the later ones load them instead of running the generator again
+            if (iter > 1 && a.ncache) a.ncache_mode = 2;   // (the first iteration's mode is the host's: 1, or 2 when the cache holds them)
+            a.scores = L.scores_out + (int64_t)(iter - 1) * a.nproblems * a.ntheta;
+            a.info = L.info_out + (int64_t)(iter - 1) * L.info_stride;
+            a.gran_tag = L.tag_base + (unsigned)iter;
+            m.flags[0] = m.flags[1] = m.flags[2] = 0;
+            if constexpr (Place::kXgLds) {  // the dummy slot and the pad element (N odd) hold 0 while problems run
+                m.lds_x[a.ld] = 0.0;
+                m.lds_g[a.ld] = 0.0;
+                m.lds_x[a.ld + 1] = 0.0;
+                m.lds_g[a.ld + 1] = 0.0;
+                if (a.N < a.ld) {
+                    m.lds_x[a.N] = 0.0;
+                    m.lds_g[a.N] = 0.0;
+                }
             }
-            make_map_theta(nt, s.bnd, w.theta_next, *s.theta_dev);
         }
-        if (err != STEP_OK || converged || s.iter == s.maxsteps) *s.stop_flag = 1;
-        flags[0] = err;
-        flags[1] = converged;
-    }
-    __syncthreads();
-    const int err = flags[0];
-    if (err == STEP_OK) {   // the record to the host (pinned) and to device memory (the next step's h0), by all lanes
-        double* h = s.hist_out + (int64_t)(s.iter - 1) * H;
-        for (int k = tid; k < (int)H; k += 256) {
-            h[k] = w.rec[k];
-            s.prev_rec[k] = w.rec[k];
+        __syncthreads();
+        {
+            LoopLds<Place> m(smem);
+            const BatchArgs& a = *m.a;
+            double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+            for (int p = (int)blockIdx.x; p < a.nproblems; p += (int)gridDim.x) {
+                Solver<Model, Place> sv(a, tid, m.red, m.shs);
+                sv.pk[0] = pk0;
+                sv.pk[1] = pk1;
+                sv.run(p, wg_scratch, m.lds_x, m.lds_g);
+                __syncthreads();
+            }
         }
-        if (tid < nt) s.theta_out[tid] = w.theta_next[tid];
+        // ---- the exchange: this iteration's scores of every element, as 32-bit halves, into the step's score array
+        {
+            LoopLds<Place> m(smem);
+            const BatchArgs& a = *m.a;
+            typedef __attribute__((address_space(1))) unsigned long long gu64;
+            const gu64* gran = (const gu64*)a.gran;
+            const unsigned tag = a.gran_tag;
+            const int ngran = 2 * a.ntheta * a.nproblems;
+            unsigned* gsw = reinterpret_cast<unsigned*>(m.stepbuf);
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            unsigned spins = 0;
+            unsigned long long t_wait0 = 0;
+            bool expired = false;
+            for (int q0 = 0; q0 < ngran; q0 += T) {
+                const int q = q0 + tl;
+                const bool live = q < ngran;
+                unsigned long long gv = 0;
+                for (;;) {
+                    bool ok = true;
+                    if (live) {
+                        gv = __hip_atomic_load(gran + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (unsigned)(gv >> 32) == tag;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || expired) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    // bounded by TIME (s_memrealtime, 100 MHz; looked at every 256 sweeps): workgroups that are not all resident
+                    // must not hang the GPU -- 4 seconds
+                    if ((++spins & 0xffu) == 0) {
+                        unsigned long long now;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                        if (t_wait0 == 0) t_wait0 = now;
+                        else if (now - t_wait0 > 400000000ull) {
+                            __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            expired = true;
+                        }
+                    }
+                }
+                if (live) gsw[q] = (unsigned)(gv & 0xffffffffull);
+            }
+            if (expired && (tl & 63) == 0) m.flags[2] = 1;
+        }
+        __syncthreads();
+        // ---- the step (step.hpp).  stepbuf: scores [nprob][nt] (data element first), small[24] = {-, mean[8], var[8]}, StepWork
+        int err, converged;
+        {
+            LoopLds<Place> m(smem);
+            BatchArgs& a = *m.a;
+            const LoopArgs& L = *m.L;
+            const int nt = a.ntheta, S = L.sp.nsims;
+            const int64_t H = MUSE_RUN_HIST(nt);
+            double* gs = m.stepbuf;
+            double* small = gs + (int64_t)a.nproblems * nt;
+            StepWork& w = *reinterpret_cast<StepWork*>(small + 24);
+            {
+                const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+                for (int k = wave; k < nt; k += NW) {
+                    double mk, vk;
+                    step_moments_wave(tid & 63, k, nt, S, gs + nt, mk, vk);
+                    if ((tid & 63) == 0) {
+                        small[8 + k] = mk;
+                        small[16 + k] = vk;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int k = 0; k < nt; ++k) w.theta[k] = a.cur.t.theta[k];
+                int e = m.flags[2] ? (int)STEP_TIMEOUT : step_record(L.sp, w.theta, gs, small + 8, small + 16, w.rec, w.theta_next, w);
+                int cv = 0;
+                if (e == STEP_OK) {
+                    unsigned long long now;
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                    w.rec[7 * nt + nt * nt] = (double)(now - *m.t_prev) * 1e-8;   // seconds of this iteration
+                    *m.t_prev = now;
+                    // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
+                    if (iter >= 2 && iter < L.maxsteps) {
+                        const int c = step_converged(nt, w.rec, m.rec, L.sp.theta_rtol);
+                        if (c < 0) e = STEP_DOMAIN;
+                        cv = c > 0;
+                    }
+                }
+                m.flags[0] = e;
+                m.flags[1] = cv;
+            }
+            __syncthreads();
+            err = __builtin_amdgcn_readfirstlane(m.flags[0]);
+            converged = __builtin_amdgcn_readfirstlane(m.flags[1]);
+            if (err == STEP_OK) {
+                for (int k = tid; k < (int)H; k += T) {
+                    const double v = w.rec[k];
+                    m.rec[k] = v;
+                    if (blockIdx.x == 0) L.hist_out[(int64_t)(iter - 1) * H + k] = v;
+                }
+                if (blockIdx.x == 0 && tid < nt) L.theta_out[tid] = w.theta_next[tid];
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                L.status[0] = err == STEP_OK ? iter : iter - 1;
+                L.status[1] = err;
+                L.status[2] = converged;
+            }
+            if (err != STEP_OK || converged || iter == L.maxsteps) break;
+            if (tid == 0) make_map_theta(nt, a.bnd, w.theta_next, a.cur);
+            // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
+        }
     }
-    if (tid == 0) {
-        s.status[0] = err == STEP_OK ? s.iter : s.iter - 1;
-        s.status[1] = err;
-        s.status[2] = flags[1];
-    }
-}
-// the start of the run on the 100 MHz counter (the first iteration's time is measured from here); also clears the stop flag
-__global__ void muse_time_stamp_kernel(unsigned long long* out, int* stop_flag) {
-    unsigned long long now;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-    *out = now;
-    *stop_flag = 0;
 }
 
 }  // namespace muse
@@ -376,14 +515,18 @@ __global__ void muse_time_stamp_kernel(unsigned long long* out, int* stop_flag) 
 // ================================================================================================
 namespace muse {
 
+constexpr int kMaxDevices = 64;  // devices of one process (HIP device ordinals)
 template <class Model, class Place, bool IMPLICIT = false>
 static hipError_t launch_one(const LaunchShape& s, const BatchArgs& a, hipStream_t stream) {
     auto kern = map_score_kernel<Model, Place, IMPLICIT>;
-    static size_t lds_allowed = 48 * 1024;  // per instantiation: the attribute is raised once, not per launch
-    if (s.lds > lds_allowed) {
+    // per instantiation AND per device (the attribute belongs to the device's copy of the function): raised once, not per launch
+    static size_t lds_allowed[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if (s.lds > (lds_allowed[dev] ? lds_allowed[dev] : (size_t)48 * 1024)) {
         const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds);
         if (e != hipSuccess) return e;
-        lds_allowed = s.lds;
+        lds_allowed[dev] = s.lds;
     }
     // The completion event of a result area rides on the dispatch itself (its completion signal) instead of following
     // it as a packet of its own, which the next launch would have to wait behind.
@@ -451,21 +594,94 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
 #endif
 }
 
-hipError_t launch_step(const StepArgs& s, hipStream_t st, void* done_event) {
-    const size_t lds = ((size_t)s.sp.nsims * s.sp.ntheta + 24) * sizeof(double) + sizeof(StepWork) + 64;
-    static size_t lds_allowed = 48 * 1024;
-    if (lds > lds_allowed) {
-        const hipError_t e = hipFuncSetAttribute((const void*)muse_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// ---- the device-resident loop: one instantiation per (model, non-cluster placement) -------------------------------------
+enum LoopOp { LOOP_QUERY, LOOP_GRID, LOOP_LAUNCH };
+struct LoopCall {
+    LoopOp op;
+    const BatchArgs* a;
+    const LoopArgs* l;
+    hipStream_t st;
+    int num_cus;
+    int* max_grid;
+};
+template <class Model, class Place>
+static hipError_t loop_one(const LaunchShape& s, const LoopCall& c) {
+    auto kern = muse_loop_kernel<Model, Place>;
+    if (c.op == LOOP_QUERY) return hipSuccess;
+    static size_t lds_allowed[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if (s.lds > (lds_allowed[dev] ? lds_allowed[dev] : (size_t)48 * 1024)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds);
         if (e != hipSuccess) return e;
-        lds_allowed = lds;
+        lds_allowed[dev] = s.lds;
     }
-    hipExtLaunchKernelGGL(muse_step_kernel, dim3(1), dim3(256), lds, st, nullptr, (hipEvent_t)done_event, 0, s);
+    if (c.op == LOOP_GRID) {
+        int per_cu = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, Place::T, s.lds);
+        if (e != hipSuccess) return e;
+        *c.max_grid = per_cu * c.num_cus;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(kern, dim3(s.grid), dim3(Place::T), s.lds, c.st, *c.a, *c.l);
     return hipGetLastError();
 }
-hipError_t launch_time_stamp(unsigned long long* out, int* stop_flag, hipStream_t st) {
-    hipLaunchKernelGGL(muse_time_stamp_kernel, dim3(1), dim3(1), 0, st, out, stop_flag);
-    return hipGetLastError();
+template <class Model>
+static hipError_t loop_place(const LaunchShape& s, const LoopCall& c) {
+    if constexpr (Model::kStencil) {
+        if (s.place == P_S256) return loop_one<Model, PlaceStreaming<256, false, kStencilU>>(s, c);
+        if (s.place == P_S512) return loop_one<Model, PlaceStreaming<512, false, kStencilU>>(s, c);
+    } else {
+        switch (s.place) {
+            case P_R256x1: return loop_one<Model, PlaceResident<256, 1, false>>(s, c);
+            case P_R512x4: return loop_one<Model, PlaceResident<512, 4, false>>(s, c);
+            case P_R512x10: return loop_one<Model, PlaceResident<512, 10, true>>(s, c);
+            case P_S256: return loop_one<Model, PlaceStreaming<256, false, kStreamU>>(s, c);
+            case P_S512: return loop_one<Model, PlaceStreaming<512, false, kStreamU>>(s, c);
+            default: break;
+        }
+    }
+    return hipErrorNotSupported;  // cluster placements: the host loop (muse_run) runs those
 }
+static hipError_t loop_dispatch(const LaunchShape& s, const LoopCall& c) {
+#ifdef MUSE_INSPECT_LOOP  // development aid (tools/regs.py --check): ONE loop kernel
+    return loop_one<MUSE_INSPECT_LOOP>(s, c);
+#elif defined(MUSE_INSPECT)
+    return hipErrorNotSupported;
+#elif defined(MUSE_USER_MODEL_HEADER)
+    if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+    return s.ntheta == 1 ? loop_place<UserModel<1>>(s, c) : loop_place<UserModel<kMaxTheta>>(s, c);
+#else
+    const int nt = s.ntheta;
+    if (s.model == MUSE_MODEL_NOISE) return loop_place<NoiseModel>(s, c);
+    if (s.model == MUSE_MODEL_FUNNEL)
+        return nt == 1   ? loop_place<FunnelModel<1>>(s, c)
+               : nt == 2 ? loop_place<FunnelModel<2>>(s, c)
+               : nt <= 4 ? loop_place<FunnelModel<4>>(s, c)
+                         : loop_place<FunnelModel<kMaxTheta>>(s, c);
+    return nt <= 2   ? loop_place<SmoothModel<2>>(s, c)
+           : nt <= 4 ? loop_place<SmoothModel<4>>(s, c)
+                     : loop_place<SmoothModel<kMaxTheta>>(s, c);
+#endif
+}
+bool loop_supported(const LaunchShape& s) {
+    LoopCall c{LOOP_QUERY, nullptr, nullptr, nullptr, 0, nullptr};
+    return loop_dispatch(s, c) == hipSuccess;
+}
+hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid) {
+    LoopCall c{LOOP_GRID, nullptr, nullptr, nullptr, num_cus, max_grid};
+    return loop_dispatch(s, c);
+}
+hipError_t launch_loop(const LaunchShape& s, const BatchArgs& a, const LoopArgs& l, hipStream_t st) {
+    LoopCall c{LOOP_LAUNCH, &a, &l, st, 0, nullptr};
+    return loop_dispatch(s, c);
+}
+// LDS of the loop kernel beside the map kernel's: the persistent block, and -- where x and g are not in LDS -- the step's arrays
+size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta) {
+    const size_t step = ((size_t)nprob * ntheta + 24) * sizeof(double) + sizeof(StepWork);
+    return (size_t)kLoopPersistDoubles * sizeof(double) + (xg_lds ? 0 : step);
+}
+size_t loop_step_bytes(int64_t nprob, int ntheta) { return ((size_t)nprob * ntheta + 24) * sizeof(double) + sizeof(StepWork); }
 
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t st) {
     const int grid = (int)((a.N + 255) / 256 < 4096 ? (a.N + 255) / 256 : 4096);

@@ -1641,8 +1641,15 @@ struct Solver {
                 for (int b = 1; b < MAXB; ++b) mine = (tl == b) ? acc[b] : mine;
                 const double cnt = (double)(a.bnd32[tl < a.ntheta - 1 ? tl + 1 : 0] - a.bnd32[tl]);
                 const double cnt_last = (double)((int)a.N - a.bnd32[tl]);  // bnd32[ntheta] is a sentinel, not N
-                a.scores[d.row * a.ntheta + tl] =
-                    0.5 * (a.cur.t.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
+                const double sc = 0.5 * (a.cur.t.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
+                a.scores[d.row * a.ntheta + tl] = sc;
+                if (a.gran) {  // device-resident muse! loop: the component also leaves as two tagged granules (args.hpp)
+                    typedef __attribute__((address_space(1))) unsigned long long gu64;
+                    gu64* gq = (gu64*)a.gran + (d.row * a.ntheta + tl) * 2;
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(sc), tg = (unsigned long long)a.gran_tag << 32;
+                    __hip_atomic_store(gq, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(gq + 1, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if (tid == 0 && crank == 0) {
                 muse_info inf;

@@ -1,6 +1,6 @@
 // step.hpp -- the scalar algebra between two maps of the muse! outer loop (src/muse.jl:163-166, 177-232), written ONCE for
-// the host (muse_run's loop in muse_engine.cpp) and for the device (the step kernel of the device-resident loop in
-// muse_kernels.hip): the same statements in the same order, compiled without floating-point contraction on both sides,
+// the host (muse_run's loop in muse_engine.cpp) and for the device (the step between two iterations of the device-resident
+// loop, muse_loop_kernel in muse_kernels.hip): the same statements in the same order, compiled without floating-point contraction on both sides,
 // every operation an IEEE +, -, *, / or sqrt -- so the two loops produce the same bits.  Also muse_exp, the exponential
 // behind ThetaSet::sd / ::iv: a fixed fdlibm-style sequence instead of the host's libm, for the same reason (the device
 // loop forms the next theta's exp(theta/2), exp(-theta) itself).
@@ -12,6 +12,7 @@
 #include "args.hpp"
 
 #if defined(__HIPCC__)
+#include "reduce.hpp"
 #define MUSE_HD __host__ __device__ inline
 #else
 #define MUSE_HD inline
@@ -107,17 +108,52 @@ MUSE_HD bool small_inverse(int n, const double* A, double* inv, double (*M)[2 * 
 
 enum { STEP_OK = 0, STEP_SINGULAR_LIKE = 1, STEP_SINGULAR_POST = 2, STEP_DOMAIN = 3 };
 
-// mean and corrected variance of component k of the S simulation scores gs[s * ntheta + k] (src/muse.jl:183,188):
-// sequential sums in simulation order.
-MUSE_HD void step_moments(int k, int ntheta, int S, const double* gs, double& mean, double& var) {
+// mean and corrected variance of component k of the S simulation scores gs[s * ntheta + k] (src/muse.jl:183,188).
+// Summation order (ONE shape for the host loop and for the device-resident loop, which runs it on a 64-lane wavefront;
+// Julia's own sum is pairwise over blocks with a reassociating inner loop, so no order is "the reference's"): 64 partial
+// sums, partial l over the simulations s = l, l + 64, ... in increasing s, then the balanced pairwise tree over l in natural
+// order -- what reduce.hpp's wave_total computes with its four DPP steps and the final (r0 + r1) + (r2 + r3).
+#if defined(__HIPCC__)
+// (device form: called by ALL 64 lanes of one wavefront; every lane returns the same values)
+__device__ inline void step_moments_wave(int lane, int k, int ntheta, int S, const double* gs, double& mean, double& var) {
     double m = 0.0;
-    for (int s = 0; s < S; ++s) m += gs[(int64_t)s * ntheta + k];
+    for (int s = lane; s < S; s += 64) m += gs[(int64_t)s * ntheta + k];
+    m = wave_total<false>(m);
     m /= S;
     double v = 0.0;
-    for (int s = 0; s < S; ++s) {
+    for (int s = lane; s < S; s += 64) {
         const double dlt = gs[(int64_t)s * ntheta + k] - m;
         v += dlt * dlt;
     }
+    v = wave_total<false>(v);
+    v /= (S - 1);  // corrected (src/muse.jl:188)
+    mean = m;
+    var = v;
+}
+#endif
+inline double step_tree64(double* p) {   // in place: the balanced pairwise tree over 64 leaves in natural order
+    for (int stride = 1; stride < 64; stride *= 2)
+        for (int i = 0; i < 64; i += 2 * stride) p[i] = p[i] + p[i + stride];
+    return p[0];
+}
+inline void step_moments(int k, int ntheta, int S, const double* gs, double& mean, double& var) {
+    double part[64];
+    for (int l = 0; l < 64; ++l) {
+        double m = 0.0;
+        for (int s = l; s < S; s += 64) m += gs[(int64_t)s * ntheta + k];
+        part[l] = m;
+    }
+    double m = step_tree64(part);
+    m /= S;
+    for (int l = 0; l < 64; ++l) {
+        double v = 0.0;
+        for (int s = l; s < S; s += 64) {
+            const double dlt = gs[(int64_t)s * ntheta + k] - m;
+            v += dlt * dlt;
+        }
+        part[l] = v;
+    }
+    double v = step_tree64(part);
     v /= (S - 1);  // corrected (src/muse.jl:188)
     mean = m;
     var = v;

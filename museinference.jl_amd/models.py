@@ -49,6 +49,8 @@ class ElementwiseModel:
         they are given (what a closure of the reference's SimpleMuseProblem would capture: a known spectrum, a noise-variance
         map, a mask).  Each becomes a table compiled into the header and an accessor `double P(long i)`; the model is then
         built for that N (MUSE_MODEL_N: the engine refuses a context of another size)."""
+        if not re.fullmatch(r"[A-Za-z][A-Za-z0-9_]*", str(name)):   # before any path is formed from it
+            raise ValueError(f"model name {name!r}: letters, digits and underscores, starting with a letter")
         directory = directory or (os.path.join(_build.model_out_dir(), "headers") if os.environ.get("MUSE_MODEL_DIR")
                                   else os.path.join(_build.MODELS_DIR, "user"))
         os.makedirs(directory, exist_ok=True)

@@ -379,11 +379,10 @@ class HipMuseProblem(AbstractMuseProblem):
 
     def run_muse(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False, device_loop=None):
         """The muse! outer loop in the library's native code (muse_run / muse_run_device, include/muse_hip.h): returns
-        (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]).  device_loop=True: the per-iteration algebra in a
-        step kernel on the GPU and the next theta read from device memory, no host round trip between two maps
-        (nsims * nθ <= 18000); default False: the algebra on the host -- measured faster at configs[1] (57.6 against 72.8 us
-        per iteration: the host's round trip costs ~4 us of idle GPU, the extra kernel and its sequential sums ~12).  The
-        same results bit for bit either way."""
+        (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]).  device_loop=True: ONE launch runs every
+        iteration -- map, exchange of the scores between the (all resident) workgroups, step, next map -- and nothing leaves
+        the GPU in between; False: one launch per iteration, the algebra on the host.  The same results bit for bit either
+        way; placements without a loop kernel (an element split, N >= 65 536) run the host loop whatever is asked."""
         kind, mean, sigma = self.native_prior()
         o = _capi.RunOptions()
         o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)

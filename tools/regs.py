@@ -33,22 +33,32 @@ HOT = [
 ]
 
 
+# the device-resident muse! loop (muse_loop_kernel): the same budget as the map kernel of the placement
+# (what is tolerated is a value stored once at the kernel's entry and re-loaded once per ITERATION, at the step)
+HOT_LOOP = [
+    ("FunnelModel<1>, PlaceResident<512, 10, true>", 2),
+    ("NoiseModel, PlaceResident<512, 10, true>", 2),
+    ("FunnelModel<4>, PlaceResident<512, 10, true>", 4),
+]
+
+
 def report(path):
     rows = []
     txt = open(path).read()
     for b in txt.split('  - .agpr_count:')[1:]:
         name = re.search(r'\.name:\s+(\S+)', b).group(1)
-        if 'map_score' not in name:
+        if 'map_score' not in name and 'muse_loop' not in name:
             continue
         g = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, b).group(1))
-        short = name.replace('_ZN4muse16map_score_kernelINS_', '').replace('EvNS_9BatchArgsE', '')
+        short = name.replace('_ZN4muse16map_score_kernelINS_', '').replace('_ZN4muse16muse_loop_kernelINS_', 'loop:').replace('EvNS_9BatchArgsE', '')
         rows.append((short, g('vgpr_count'), g('vgpr_spill_count'), g('sgpr_spill_count'), g('private_segment_fixed_size')))
     return rows
 
 
-def compile_one(inst, out):
+def compile_one(inst, out, loop=False):
     hipcc = "/opt/rocm/bin/hipcc"
-    subprocess.check_call([hipcc] + FLAGS + ["-DMUSE_INSPECT=" + inst, os.path.join(CSRC, "muse_kernels.hip"), "-o", out],
+    defs = ["-DMUSE_INSPECT=" + inst] + (["-DMUSE_INSPECT_LOOP=" + inst] if loop else [])
+    subprocess.check_call([hipcc] + FLAGS + defs + [os.path.join(CSRC, "muse_kernels.hip"), "-o", out],
                           cwd=CSRC, stderr=subprocess.DEVNULL)
 
 
@@ -63,6 +73,15 @@ def check():
             print(f"{inst:55s} vgpr {vgpr:3d} vspill {vspill:3d} (limit {limit:2d}) sspill {sspill:3d} scratch {scratch:3d} {'ok' if ok else 'FAIL'}")
             if not ok:
                 bad.append(inst)
+        for inst, limit in HOT_LOOP:
+            out = os.path.join(d, "loop.s")
+            compile_one(inst, out, loop=True)
+            rows = [r for r in report(out) if r[0].startswith("loop:")]
+            (short, vgpr, vspill, sspill, scratch), = rows
+            ok = vspill <= limit
+            print(f"{'loop kernel: ' + inst:55s} vgpr {vgpr:3d} vspill {vspill:3d} (limit {limit:2d}) sspill {sspill:3d} scratch {scratch:3d} {'ok' if ok else 'FAIL'}")
+            if not ok:
+                bad.append("loop: " + inst)
     return bad
 
 
