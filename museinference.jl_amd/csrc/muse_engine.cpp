@@ -1021,6 +1021,18 @@ int muse_wait_event(void* event) {
     return MUSE_OK;
 }
 
+// the same for everything enqueued on the context's stream
+static int muse_wait_event_or_stream(muse_ctx* c) {
+    for (int spin = 0; spin < 4000000; ++spin) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return MUSE_OK;
+        if (e != hipErrorNotReady) return fail(MUSE_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        MUSE_CPU_RELAX();
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MUSE_OK;
+}
+
 int muse_batch_wait(muse_ctx* c, int area, double* g_out, muse_info* info_out) {
     int rc = check_ctx(c);
     if (rc) return rc;
@@ -1151,6 +1163,8 @@ struct RunBuffers {
     double* theta_out = nullptr;
     int* status = nullptr;
     int64_t cap_hist = 0, cap_scores = 0, cap_infos = 0;
+    int grid_place = -1, grid_max = 0;    // the occupancy query's answer for (placement, LDS bytes): asked once
+    size_t grid_lds = 0;
 };
 static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, bool want_info) {
     if (!c->run) c->run = new RunBuffers();
@@ -1160,7 +1174,7 @@ static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, bool want_info) 
         HIPCHK(hipHostMalloc(&r.theta_out, kMaxTheta * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&r.status, 64, hipHostMallocDefault));
     }
-    const int64_t ngran = (int64_t)2 * nt * (S + 1);
+    const int64_t ngran = (int64_t)2 * nt * (S + 1) + 2 * (kMaxTheta + 1);   // the scores, then the stepper's theta and status
     if (ngran > r.gran_cap || r.tag > 0x70000000u) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (ngran > r.gran_cap) {
@@ -1232,17 +1246,23 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     if (host_only || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
         (xg_lds && loop_step_bytes(nprob, nt) > (size_t)2 * (c->ld + 2) * sizeof(double)))
         return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
-    rc = muse_synchronize(c);   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
-    if (rc) return rc;
-    int max_grid = 0;
-    {
-        const hipError_t e = loop_max_grid(shape, c->num_cus, &max_grid);
-        if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("loop kernel occupancy: ") + hipGetErrorString(e));
+    if (c->nlanes > 1) {   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
+        rc = muse_synchronize(c);
+        if (rc) return rc;
     }
-    if (max_grid < 1) return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
     rc = ensure_run_buffers(c, maxsteps, S, info_out != nullptr);
     if (rc) return rc;
     RunBuffers& r = *c->run;
+    if (r.grid_place != pl || r.grid_lds != shape.lds) {
+        int mg = 0;
+        const hipError_t e = loop_max_grid(shape, c->num_cus, &mg);
+        if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("loop kernel occupancy: ") + hipGetErrorString(e));
+        r.grid_place = pl;
+        r.grid_lds = shape.lds;
+        r.grid_max = mg;
+    }
+    const int max_grid = r.grid_max;
+    if (max_grid < 2) return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
     rc = ensure_zhat(c, nprob);
     if (rc) return rc;
     BatchArgs a;
@@ -1283,14 +1303,16 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     a.work_counter = c->counter;
     a.ticket_base = (int)c->ticket_base;   // (no tickets are drawn: elements are dealt statically)
     a.debug = c->debug;
-    a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
+    a.stamps = (c->stamps && a.nproblems + 3 <= c->stamps_cap) ? c->stamps : nullptr;   // (+3: the loop kernel's own rows)
     a.csize = 1;
     a.error_flag = c->error_flag;
-    int grid = max_grid < (int)nprob ? max_grid : (int)nprob;
+    // workers (each owns elements w, w + nworkers, ...) and one stepper, all resident at once
+    int nworkers = max_grid - 1 < (int)nprob ? max_grid - 1 : (int)nprob;
     if (const char* e = getenv("MUSE_DEBUG_LOOP_GRID")) {   // tuning aid (never more than what is resident at once)
         const int g = atoi(e);
-        if (g >= 1 && g < grid) grid = g;
+        if (g >= 1 && g < nworkers) nworkers = g;
     }
+    const int grid = nworkers + 1;
     shape.grid = grid;
     a.scratch_stride = place_scratch_vectors(pl) * c->ld;
     rc = ensure_scratch(c, (size_t)grid * a.scratch_stride);
@@ -1311,11 +1333,17 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     l.status = r.status;
     r.status[0] = r.status[1] = r.status[2] = 0;
     for (int k = 0; k < nt; ++k) r.theta_out[k] = theta0[k];
+    static const bool trace = getenv("MUSE_DEBUG_RUN_TIMING") != nullptr;   // tuning aid: where a call's own time goes
+    auto now_us = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
+    const double t_a = trace ? now_us() : 0.0;
     {
         const hipError_t e = launch_loop(shape, a, l, c->stream);
         if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("loop kernel launch: ") + hipGetErrorString(e));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const double t_b = trace ? now_us() : 0.0;
+    rc = muse_wait_event_or_stream(c);
+    if (rc) return rc;
+    if (trace) fprintf(stderr, "[muse_run_device] launch call %.1f us, kernel + wait %.1f us (%d iterations)\n", t_b - t_a, now_us() - t_b, r.status[0]);
     c->area_inflight[0] = false;
     rc = check_error_flag(c);
     if (rc) return rc;

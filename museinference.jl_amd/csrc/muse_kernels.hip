@@ -352,6 +352,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             unsigned long long now;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
             *m.t_prev = now;
+            m.flags[0] = m.flags[1] = m.flags[2] = 0;
         }
     }
     unsigned pk0, pk1;
@@ -362,90 +363,136 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
         pk0 = s0.pk[0];
         pk1 = s0.pk[1];
     }
+    // Roles.  The LAST workgroup is the stepper: it owns no element, sweeps the score granules, forms the step and publishes
+    // the next theta (with the error and convergence words) as granules of the same tag.  The others are workers: they
+    // solve their elements, fetch the theta-free inputs of their first element of the next iteration (Prefetch: the loads
+    // travel while the slowest worker -- the one with an element more -- is still solving, and through the step) and wait
+    // for theta.  (With the step on every workgroup -- the first version -- the step's arrays needed the LDS that now
+    // receives the prefetched normals.)
+    const int nworkers = (int)gridDim.x - 1;
+    const bool stepper = (int)blockIdx.x == nworkers;
+    Prefetch<Place::EPT> pf;
+    pf.p = -1;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+#ifdef MUSE_STAMPS   // diagnostic build: the last iteration's times (100 MHz clock, comparable across the chip) of worker 0 (one
+                     // of those with an element more), a worker in the middle and the stepper, behind the problems' rows
+    auto loop_stamp = [&](int k) {
+        LoopLds<Place> m(smem);
+        const int b = (int)blockIdx.x, row = b == 0 ? 0 : (b == nworkers / 2 ? 1 : (b == nworkers ? 2 : -1));
+        if (tid == 0 && m.a->stamps && row >= 0) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            m.a->stamps[(size_t)(m.a->nproblems + row) * 16 + k] = t;
+        }
+    };
+#else
+    auto loop_stamp = [](int) {};
+#endif
     for (int iter = 1;; ++iter) {
+        int err = STEP_OK, converged = 0;
         __syncthreads();
-        if (tid == 0) {
-            LoopLds<Place> m(smem);
-            BatchArgs& a = *m.a;   // (mutable here: the step re-writes theta and the per-iteration fields)
-            const LoopArgs& L = *m.L;
-            a.z0_mode = (iter > 1 || L.z0_warm) ? Z0_WARM : Z0_ZERO;
-            // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
-            // standard normals, the later ones load them instead of running the generator again
-            if (iter > 1 && a.ncache) a.ncache_mode = 2;   // (the first iteration's mode is the host's: 1, or 2 when the cache holds them)
-            a.scores = L.scores_out + (int64_t)(iter - 1) * a.nproblems * a.ntheta;
-            a.info = L.info_out + (int64_t)(iter - 1) * L.info_stride;
-            a.gran_tag = L.tag_base + (unsigned)iter;
-            m.flags[0] = m.flags[1] = m.flags[2] = 0;
-            if constexpr (Place::kXgLds) {  // the dummy slot and the pad element (N odd) hold 0 while problems run
-                m.lds_x[a.ld] = 0.0;
-                m.lds_g[a.ld] = 0.0;
-                m.lds_x[a.ld + 1] = 0.0;
-                m.lds_g[a.ld + 1] = 0.0;
-                if (a.N < a.ld) {
-                    m.lds_x[a.N] = 0.0;
-                    m.lds_g[a.N] = 0.0;
+        if (!stepper) {
+            if (tid == 0) {
+                LoopLds<Place> m(smem);
+                BatchArgs& a = *m.a;   // (mutable here: theta and the per-iteration fields are re-written between iterations)
+                const LoopArgs& L = *m.L;
+                a.z0_mode = (iter > 1 || L.z0_warm) ? Z0_WARM : Z0_ZERO;
+                // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
+                // standard normals (or finds them: the host's mode), the later ones load them instead of running the generator
+                if (iter > 1 && a.ncache) a.ncache_mode = 2;
+                a.scores = L.scores_out + (int64_t)(iter - 1) * a.nproblems * a.ntheta;
+                a.info = L.info_out + (int64_t)(iter - 1) * L.info_stride;
+                a.gran_tag = L.tag_base + (unsigned)iter;
+                if constexpr (Place::kXgLds) {  // the dummy slot and the pad element (N odd) hold 0 while problems run
+                    m.lds_x[a.ld] = 0.0;
+                    m.lds_g[a.ld] = 0.0;
+                    m.lds_x[a.ld + 1] = 0.0;
+                    m.lds_g[a.ld + 1] = 0.0;
+                    if (a.N < a.ld && pf.p < 0) {   // (a prefetched vector brings its pad element along; begin() masks it)
+                        m.lds_x[a.N] = 0.0;
+                        m.lds_g[a.N] = 0.0;
+                    }
                 }
             }
-        }
-        __syncthreads();
-        {
-            LoopLds<Place> m(smem);
-            const BatchArgs& a = *m.a;
-            double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
-            for (int p = (int)blockIdx.x; p < a.nproblems; p += (int)gridDim.x) {
-                Solver<Model, Place> sv(a, tid, m.red, m.shs);
-                sv.pk[0] = pk0;
-                sv.pk[1] = pk1;
-                sv.run(p, wg_scratch, m.lds_x, m.lds_g);
-                __syncthreads();
+            __syncthreads();
+            loop_stamp(0);
+            {
+                LoopLds<Place> m(smem);
+                const BatchArgs& a = *m.a;
+                double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+                {   // the first problem (peeled: the prefetched values are live up to its begin() and nowhere beyond)
+                    Solver<Model, Place> sv(a, tid, m.red, m.shs);
+                    sv.pk[0] = pk0;
+                    sv.pk[1] = pk1;
+                    sv.run((int)blockIdx.x, wg_scratch, m.lds_x, m.lds_g, pf);
+                    __syncthreads();
+                }
+                loop_stamp(1);
+                for (int p = (int)blockIdx.x + nworkers; p < a.nproblems; p += nworkers) {
+                    Solver<Model, Place> sv(a, tid, m.red, m.shs);
+                    sv.pk[0] = pk0;
+                    sv.pk[1] = pk1;
+                    sv.run(p, wg_scratch, m.lds_x, m.lds_g);
+                    __syncthreads();
+                }
+                loop_stamp(2);
+                if constexpr (Place::kXgLds) {
+                    if (iter < m.L->maxsteps && a.ncache_mode != 0 && !(a.debug & 4)) prefetch_issue<T>(a, tid, (int)blockIdx.x, m.lds_x, m.lds_g, pf);
+                }
+                loop_stamp(3);
             }
-        }
-        // ---- the exchange: this iteration's scores of every element, as 32-bit halves, into the step's score array
-        {
-            LoopLds<Place> m(smem);
-            const BatchArgs& a = *m.a;
-            typedef __attribute__((address_space(1))) unsigned long long gu64;
-            const gu64* gran = (const gu64*)a.gran;
-            const unsigned tag = a.gran_tag;
-            const int ngran = 2 * a.ntheta * a.nproblems;
-            unsigned* gsw = reinterpret_cast<unsigned*>(m.stepbuf);
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-            unsigned spins = 0;
-            unsigned long long t_wait0 = 0;
-            bool expired = false;
-            for (int q0 = 0; q0 < ngran; q0 += T) {
-                const int q = q0 + tl;
-                const bool live = q < ngran;
-                unsigned long long gv = 0;
-                for (;;) {
-                    bool ok = true;
-                    if (live) {
-                        gv = __hip_atomic_load(gran + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (unsigned)(gv >> 32) == tag;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || expired) break;
-                    __builtin_amdgcn_s_sleep(4);
-                    // bounded by TIME (s_memrealtime, 100 MHz; looked at every 256 sweeps): workgroups that are not all resident
-                    // must not hang the GPU -- 4 seconds
-                    if ((++spins & 0xffu) == 0) {
-                        unsigned long long now;
-                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-                        if (t_wait0 == 0) t_wait0 = now;
-                        else if (now - t_wait0 > 400000000ull) {
-                            __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            expired = true;
+            // ---- wait for the stepper's granules: theta_next [nt], then {err, converged} as one double
+            {
+                LoopLds<Place> m(smem);
+                BatchArgs& a = *m.a;
+                const int nt = a.ntheta;
+                const gu64* gran = (const gu64*)a.gran + (int64_t)2 * nt * a.nproblems;
+                const unsigned tag = a.gran_tag;
+                const int ngran = 2 * (nt + 1);
+                unsigned* out = reinterpret_cast<unsigned*>(m.rec);   // (the record area is the stepper's; a worker parks theta here)
+                if (tid < 64) {
+                    int tl = tid;
+                    asm volatile("" : "+v"(tl));
+                    const bool live = tl < ngran;
+                    unsigned long long gv = 0, t_wait0 = 0;
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = true;
+                        if (live) {
+                            gv = __hip_atomic_load(gran + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (unsigned)(gv >> 32) == tag;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((++spins & 0xffu) == 0) {   // bounded by TIME (4 s): workgroups that are not all resident must not hang the GPU
+                            unsigned long long now;
+                            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                            if (t_wait0 == 0) t_wait0 = now;
+                            else if (now - t_wait0 > 400000000ull) {
+                                __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (tl == 0) m.flags[2] = 1;
+                                break;
+                            }
                         }
                     }
+                    if (live) out[tl] = (unsigned)(gv & 0xffffffffull);
                 }
-                if (live) gsw[q] = (unsigned)(gv & 0xffffffffull);
+                __syncthreads();
+                loop_stamp(4);
+                const double* th = m.rec;
+                const unsigned long long ec = (unsigned long long)__double_as_longlong(th[nt]);
+                err = m.flags[2] ? (int)STEP_TIMEOUT : __builtin_amdgcn_readfirstlane((int)(ec & 0xffffffffull));
+                converged = __builtin_amdgcn_readfirstlane((int)(ec >> 32));
+                if (err != STEP_OK || converged || iter == m.L->maxsteps) break;
+                if (tid == 0) make_map_theta(nt, a.bnd, th, a.cur);
+                // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
             }
-            if (expired && (tl & 63) == 0) m.flags[2] = 1;
-        }
-        __syncthreads();
-        // ---- the step (step.hpp).  stepbuf: scores [nprob][nt] (data element first), small[24] = {-, mean[8], var[8]}, StepWork
-        int err, converged;
-        {
+        } else {
+            // ---- the stepper.  ONE wavefront does everything (the others wait at the barrier below): lane l takes the
+            // simulations s = l, l + 64, ... -- it polls each score's two granules (one 16-byte load) until both carry this
+            // iteration's tag, in the order in which its partial sum adds them, so that when the last element's score lands
+            // one addition per lane, the tree and the few scalar operations of the step are all that is left to do.
+            // stepbuf: gs [nprob][nt] (data element first), small[24] = {-, mean[8], var[8]}, StepWork
             LoopLds<Place> m(smem);
             BatchArgs& a = *m.a;
             const LoopArgs& L = *m.L;
@@ -454,56 +501,113 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             double* gs = m.stepbuf;
             double* small = gs + (int64_t)a.nproblems * nt;
             StepWork& w = *reinterpret_cast<StepWork*>(small + 24);
-            {
-                const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
-                for (int k = wave; k < nt; k += NW) {
-                    double mk, vk;
-                    step_moments_wave(tid & 63, k, nt, S, gs + nt, mk, vk);
-                    if ((tid & 63) == 0) {
+            if (tid == 0) {
+                a.gran_tag = L.tag_base + (unsigned)iter;
+                m.flags[0] = m.flags[1] = m.flags[2] = 0;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const unsigned tag = a.gran_tag;
+                const rsrc_t grs = make_rsrc(a.gran, (int64_t)(2 * nt * a.nproblems + 2 * (kMaxTheta + 1)) * 8);
+                bool expired = false;
+                auto score = [&](int row, int k) -> double {   // element `row`'s component k, once both of its granules are this iteration's
+                    unsigned spins = 0;
+                    unsigned long long t_wait0 = 0;
+                    for (;;) {
+                        double lo, hi;
+                        load_f64x2<kCoherent>(grs, 2 * (row * nt + k), lo, hi);
+                        const unsigned long long glo = (unsigned long long)__double_as_longlong(lo), ghi = (unsigned long long)__double_as_longlong(hi);
+                        if (((unsigned)(glo >> 32) == tag && (unsigned)(ghi >> 32) == tag) || expired)
+                            return __longlong_as_double((long long)((ghi << 32) | (glo & 0xffffffffull)));
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 0xffu) == 0) {   // bounded by TIME (4 s): workgroups that are not all resident must not hang the GPU
+                            unsigned long long now;
+                            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                            if (t_wait0 == 0) t_wait0 = now;
+                            else if (now - t_wait0 > 400000000ull) {
+                                __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                expired = true;
+                            }
+                        }
+                    }
+                };
+                int lane = tid;
+                asm volatile("" : "+v"(lane));
+                for (int k = 0; k < nt; ++k) {   // step.hpp's step_moments_wave, with the poll in its first pass
+                    double mk = 0.0;
+                    for (int sidx = lane; sidx < S; sidx += 64) {
+                        const double v = score(1 + sidx, k);
+                        gs[(int64_t)(1 + sidx) * nt + k] = v;
+                        mk += v;
+                    }
+                    mk = wave_total<false>(mk);
+                    mk /= S;
+                    double vk = 0.0;
+                    for (int sidx = lane; sidx < S; sidx += 64) {
+                        const double dlt = gs[(int64_t)(1 + sidx) * nt + k] - mk;
+                        vk += dlt * dlt;
+                    }
+                    vk = wave_total<false>(vk);
+                    vk /= (S - 1);
+                    if (lane == 0) {
                         small[8 + k] = mk;
                         small[16 + k] = vk;
                     }
                 }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int k = 0; k < nt; ++k) w.theta[k] = a.cur.t.theta[k];
-                int e = m.flags[2] ? (int)STEP_TIMEOUT : step_record(L.sp, w.theta, gs, small + 8, small + 16, w.rec, w.theta_next, w);
-                int cv = 0;
-                if (e == STEP_OK) {
-                    unsigned long long now;
-                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-                    w.rec[7 * nt + nt * nt] = (double)(now - *m.t_prev) * 1e-8;   // seconds of this iteration
-                    *m.t_prev = now;
-                    // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
-                    if (iter >= 2 && iter < L.maxsteps) {
-                        const int c = step_converged(nt, w.rec, m.rec, L.sp.theta_rtol);
-                        if (c < 0) e = STEP_DOMAIN;
-                        cv = c > 0;
+                if (lane < nt) gs[lane] = score(0, lane);   // the data element's score
+                if (__builtin_amdgcn_ballot_w64(expired) != 0ull && lane == 0) m.flags[2] = 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wavefront: its LDS writes above are visible to its reads below)
+                loop_stamp(4);
+                if (lane == 0) {
+                    for (int k = 0; k < nt; ++k) w.theta[k] = a.cur.t.theta[k];
+                    int e = m.flags[2] ? (int)STEP_TIMEOUT : step_record(L.sp, w.theta, gs, small + 8, small + 16, w.rec, w.theta_next, w);
+                    int cv = 0;
+                    if (e == STEP_OK) {
+                        unsigned long long now;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                        w.rec[7 * nt + nt * nt] = (double)(now - *m.t_prev) * 1e-8;   // seconds of this iteration
+                        *m.t_prev = now;
+                        // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
+                        if (iter >= 2 && iter < L.maxsteps) {
+                            const int c = step_converged(nt, w.rec, m.rec, L.sp.theta_rtol);
+                            if (c < 0) e = STEP_DOMAIN;
+                            cv = c > 0;
+                        }
                     }
+                    m.flags[0] = e;
+                    m.flags[1] = cv;
+                    // the words the workers wait for
+                    w.theta_next[nt] = __longlong_as_double((long long)(((unsigned long long)(unsigned)cv << 32) | (unsigned)e));
                 }
-                m.flags[0] = e;
-                m.flags[1] = cv;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 2 * (nt + 1)) {   // theta_next [nt] and the {err, converged} word, two tagged granules each
+                    gu64* gran = (gu64*)a.gran + (int64_t)2 * nt * a.nproblems;
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(w.theta_next[lane >> 1]);
+                    const unsigned half = (lane & 1) ? (unsigned)(b >> 32) : (unsigned)(b & 0xffffffffull);
+                    __hip_atomic_store(gran + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                loop_stamp(5);
+                const int e1 = m.flags[0];
+                if (e1 == STEP_OK) {
+                    for (int k = lane; k < (int)H; k += 64) {
+                        const double v = w.rec[k];
+                        L.hist_out[(int64_t)(iter - 1) * H + k] = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int k = lane; k < (int)H; k += 64) m.rec[k] = w.rec[k];
+                    if (lane < nt) L.theta_out[lane] = w.theta_next[lane];
+                }
+                if (lane == 0) {
+                    L.status[0] = e1 == STEP_OK ? iter : iter - 1;
+                    L.status[1] = e1;
+                    L.status[2] = m.flags[1];
+                    if (e1 == STEP_OK) make_map_theta(nt, a.bnd, w.theta_next, a.cur);   // (the stepper's own copy: the next record's theta)
+                }
             }
             __syncthreads();
             err = __builtin_amdgcn_readfirstlane(m.flags[0]);
             converged = __builtin_amdgcn_readfirstlane(m.flags[1]);
-            if (err == STEP_OK) {
-                for (int k = tid; k < (int)H; k += T) {
-                    const double v = w.rec[k];
-                    m.rec[k] = v;
-                    if (blockIdx.x == 0) L.hist_out[(int64_t)(iter - 1) * H + k] = v;
-                }
-                if (blockIdx.x == 0 && tid < nt) L.theta_out[tid] = w.theta_next[tid];
-            }
-            if (blockIdx.x == 0 && tid == 0) {
-                L.status[0] = err == STEP_OK ? iter : iter - 1;
-                L.status[1] = err;
-                L.status[2] = converged;
-            }
             if (err != STEP_OK || converged || iter == L.maxsteps) break;
-            if (tid == 0) make_map_theta(nt, a.bnd, w.theta_next, a.cur);
-            // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
         }
     }
 }

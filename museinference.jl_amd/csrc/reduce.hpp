@@ -69,7 +69,11 @@ __device__ __forceinline__ double lanes_total(double v) {  // butterfly over the
     return uniform(v);
 }
 
-template <int T, int KS, int KM>
+// RAW: the barrier alone (s_waitcnt lgkmcnt(0) + s_barrier) instead of __syncthreads(), whose fence also drains the
+// vector-memory counter -- every store of the pass (the MAP going out in a solve's last pass: 80 KB per workgroup) and
+// every LDS-DMA prefetch in flight would have to complete before the reduction could.  For passes whose threads only ever
+// re-read their own elements (the elementwise models); the stencil model's passes read what other threads stored.
+template <int T, int KS, int KM, bool RAW = false>
 __device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], double (&m)[KM > 0 ? KM : 1],
                                                 double* red, int& parity, int tid) {
     constexpr int NW = T / 64, K = KS + KM;

@@ -71,7 +71,7 @@ struct StepWork {
     double gprior[kMaxTheta], hprior[kMaxTheta];
     double Hlike[kMaxTheta * kMaxTheta], Hinv_like_inv[kMaxTheta * kMaxTheta], Hpost[kMaxTheta * kMaxTheta];
     double rec[7 * kMaxTheta + kMaxTheta * kMaxTheta + 1];
-    double theta[kMaxTheta], theta_next[kMaxTheta];
+    double theta[kMaxTheta], theta_next[kMaxTheta + 1];   // (+1: the loop kernel's stepper appends its status word)
 };
 
 // inverse of a small dense matrix (n <= kMaxTheta) by Gauss-Jordan with partial pivoting; false if singular
@@ -186,6 +186,21 @@ MUSE_HD int step_record(const StepParams& sp, const double* theta, const double*
         h[4 * nt + k] = h[2 * nt + k] + gprior[k];  // g_post
         h[5 * nt + k] = -1.0 / var[k];              // diag H^-1_like
         h[6 * nt + k] = hprior[k];
+    }
+    if (nt == 1) {
+        // one component: the statements below on 1 x 1 matrices, written out -- the same IEEE operations in the same order
+        // (small_inverse of [d] is the singularity test and ONE division 1 / d), without the dense code's dependent chain
+        // of memory accesses (the device-resident loop runs this on one lane between two iterations)
+        const double hl = h[5];
+        if (!(fabs(hl) > 0.0)) return STEP_SINGULAR_LIKE;
+        const double ip = 1.0 / hl + hprior[0];
+        if (!(fabs(ip) > 0.0)) return STEP_SINGULAR_POST;
+        const double hp = 1.0 / ip;
+        h[7] = hp;
+        double stp = 0.0;
+        stp += hp * h[4];
+        theta_next[0] = h[0] - sp.alpha * stp;
+        return STEP_OK;
     }
     // H^-1_post = inv(inv(H^-1_like) + H_prior): both diagonal here, kept general through the dense inverse
     for (int a_ = 0; a_ < nt * nt; ++a_) Hlike[a_] = 0.0;

@@ -34,11 +34,12 @@ HOT = [
 
 
 # the device-resident muse! loop (muse_loop_kernel): the same budget as the map kernel of the placement
-# (what is tolerated is a value stored once at the kernel's entry and re-loaded once per ITERATION, at the step)
+# (what is tolerated: values stored at the kernel's entry and re-loaded once per PROBLEM, between two problems -- none inside
+# an element loop, a reduction or the line search)
 HOT_LOOP = [
-    ("FunnelModel<1>, PlaceResident<512, 10, true>", 2),
-    ("NoiseModel, PlaceResident<512, 10, true>", 2),
-    ("FunnelModel<4>, PlaceResident<512, 10, true>", 4),
+    ("FunnelModel<1>, PlaceResident<512, 10, true>", 8),
+    ("NoiseModel, PlaceResident<512, 10, true>", 8),
+    ("FunnelModel<4>, PlaceResident<512, 10, true>", 12),
 ]
 
 

@@ -16,5 +16,10 @@ for dev in ((False,) if HOST_ONLY else (False, True, False, True)):
         n, theta, hist, gs, info = prob.run_muse(0, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7,
                                                  device_loop=dev)
         best = min(best, (time.perf_counter() - t0) / n)
+    # the same loop ten times as long: the difference is the iterations' own time, without what a call costs once
+    t0 = time.perf_counter()
+    n2 = prob.run_muse(0, [1.0] * nth, nsims=nsims, maxsteps=300, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=dev)[0]
+    slope = (time.perf_counter() - t0 - best * n) / max(1, n2 - n)
     print(f"N={N} nsims={nsims} ntheta={nth} device_loop={dev}: {1e6 * best:.1f} us per outer iteration ({n} iterations), "
-          f"device-side iteration time {1e6 * float(np.median(hist[5:, -1])):.1f} us", flush=True)
+          f"device-side iteration time {1e6 * float(np.median(hist[5:, -1])):.1f} us, marginal {1e6 * slope:.1f} us per iteration "
+          f"(from a {n2}-iteration run)", flush=True)

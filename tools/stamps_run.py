@@ -16,13 +16,22 @@ DEV = len(sys.argv) > 5 and sys.argv[5] == "dev"    # the device-resident loop (
 xdata, _ = M.HipMuseProblem(None, model="funnel", ntheta=NTH, N=N).sample_x_z(M.SimRng(0, M.DATA_SIM), [0.0] * NTH)
 prob = M.HipMuseProblem(xdata, model="funnel", ntheta=NTH, prior=M.GaussianPrior(0.0, 3.0))
 n = S + 1
+if os.environ.get("MUSE_LOOP_DEBUG"):   # bit 2 (4): the loop kernel does not prefetch
+    lib.muse_debug_flags(prob._ctx, int(os.environ["MUSE_LOOP_DEBUG"]))
 for _ in range(2):
     prob.run_muse(0, [1.0] * NTH, nsims=S, maxsteps=ITERS, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=DEV)
-lib.muse_debug_stamps(prob._ctx, C.c_int64(n), None)
+lib.muse_debug_stamps(prob._ctx, C.c_int64(n + 8), None)
 nit, theta, hist, gs, info = prob.run_muse(0, [1.0] * NTH, nsims=S, maxsteps=ITERS, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=DEV)
-out = np.zeros((n, 16), dtype=np.uint64)
-lib.muse_debug_stamps(prob._ctx, C.c_int64(n), out.ctypes.data_as(C.c_void_p))
+out_all = np.zeros((n + 8, 16), dtype=np.uint64)
+lib.muse_debug_stamps(prob._ctx, C.c_int64(n + 8), out_all.ctypes.data_as(C.c_void_p))
+out = out_all[:n]
 o = out.astype(np.int64)
+if DEV:   # the loop kernel's own stamps of its last iteration (100 MHz clock -> us), relative to worker 0's iteration start
+    lp = out_all[n:n + 3].astype(np.int64)
+    t0 = lp[0, 0]
+    for nm, r in (("worker 0 (an element more)", lp[0]), ("a worker in the middle", lp[1]), ("the stepper", lp[2])):
+        print(f"  loop stamps, {nm:28s}: " + "  ".join(f"{k}:{(r[k] - t0) / 100.0:7.2f}" for k in range(6) if r[k] > 0),
+              " [0 iteration start, 1 first problem done, 2 problems done, 3 prefetch issued, 4 theta received / sweep complete, 5 theta published]")
 st = o[:, :8]
 print(f"N={N} ntheta={NTH} nsims={S}: iteration {nit} of {'muse_run_device' if DEV else 'muse_run'}; iterations/f_calls of its solves: "
       f"{info[-1]['iterations'].mean():.2f} / {info[-1]['f_calls'].mean():.2f}")
@@ -51,4 +60,10 @@ for s0 in st[:, 0]:
     k = np.searchsorted(ends, s0) - 1
     if k >= 0 and 0 < s0 - ends[k] < 20000: gaps.append(s0 - ends[k])
 if gaps: print("between two problems of a workgroup (end stamp -> next start stamp): median", np.median(gaps), "cycles over", len(gaps))
+if DEV:
+    nw = min(255, n)   # (workers of the loop kernel on a 256-CU part)
+    for wk in (0, 1, 100):
+        ps = [q for q in range(wk, n, nw)]
+        print(f"  worker {wk}: problems {ps}: " + " | ".join(
+            f"p{q}: begin {st[q,1]-st[q,0]} solve {st[q,6]-st[q,1]} total {st[q,7]-st[q,0]} (start +{st[q,0]-st[ps[0],0]})" for q in ps))
 print("iteration wall times from the history records (us):", np.round(1e6 * hist[:, -1], 1))
