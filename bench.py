@@ -211,12 +211,77 @@ def cpu_baseline(model, N, theta, seed, cpu_seconds=30.0):
     t0 = time.perf_counter()
     O.map_and_score_batch(model, N, seed, 0, nall, theta, atol=1e-2, z0_mode=0, nthreads=cores)
     tall = time.perf_counter() - t0
-    return {
+    out = {
         "value": nall / tall, "unit": "sims/s", "cores": cores, "kind": "port",
         "sample": f"{nall} sims of the same workload (oracle/muse_oracle.c, gcc -O3, OpenMP over sims, "
                   f"{cores} threads, {tall:.2f} s wall); 1 thread: {1.0 / t1:.1f} sims/s on {n1} sims",
         "value_1thread": 1.0 / t1,
     }
+    # A second figure, against code a CPU user would actually run (-O3 -march=native): the same source built on
+    # THIS machine with contraction and re-association allowed and the generator written for SIMD lanes (oracle/Makefile,
+    # target `fast`).  Not a checker: its scores are compared with the strict build's at a tolerance, never the other way.
+    try:
+        g_ref, _, i_ref = O.map_and_score_batch(model, N, seed, 0, 16, theta, atol=1e-2, z0_mode=0, nthreads=1)
+        with O.fast_build():
+            g_f, _, i_f = O.map_and_score_batch(model, N, seed, 0, 16, theta, atol=1e-2, z0_mode=0, nthreads=1)
+            t0 = time.perf_counter()
+            O.map_and_score_batch(model, N, seed, 0, n1, theta, atol=1e-2, z0_mode=0, nthreads=1)
+            t1f = (time.perf_counter() - t0) / n1
+            O.map_and_score_batch(model, N, seed, 0, 4 * cores, theta, atol=1e-2, z0_mode=0, nthreads=cores)
+            nallf = int(max(8 * cores, 0.5 * cpu_seconds / max(t1f, 1e-9)))
+            t0 = time.perf_counter()
+            O.map_and_score_batch(model, N, seed, 0, nallf, theta, atol=1e-2, z0_mode=0, nthreads=cores)
+            tallf = time.perf_counter() - t0
+        rel = float(np.max(np.abs(g_f - g_ref) / np.maximum(np.abs(g_ref), 1e-300)))
+        out["vectorised"] = {
+            "value": nallf / tallf, "value_1thread": 1.0 / t1f, "unit": "sims/s", "cores": cores,
+            "flags": "-O3 -march=native -ffp-contract=fast -fassociative-math -fno-signed-zeros -fno-trapping-math -fno-math-errno",
+            "max_rel_score_difference_vs_strict_build": rel, "same_evaluation_counts": bool(np.array_equal(i_f["f_calls"], i_ref["f_calls"])),
+            "sample": f"{nallf} sims, {cores} threads, {tallf:.2f} s wall",
+        }
+        if not (rel < 1e-9):
+            out["vectorised"]["note"] = "scores differ from the strict build beyond 1e-9: figure not comparable"
+    except Exception as e:  # noqa: BLE001 -- a second figure, never at the cost of the line
+        out["vectorised"] = {"skipped": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, ngpus=8):
+    """What ONE rank of an 8-GPU job runs per outer iteration of muse! (a DEPENDENT map sequence, src/muse.jl:159-232): the
+    native sharded loop (muse_run_sharded) at nsims/8 + 1 elements, measured on this one GPU with a one-rank shared-memory
+    communicator -- the gathered map, the hand-off through the segment, the step on the host.  The ratio to the whole job's
+    iteration on one GPU is the speed-up 8 GPUs can give that loop at best (the exchange with 8 ranks costs at least what it
+    costs with one)."""
+    share = max(2, nsims // ngpus)
+    out = {"elements_per_rank": share + 1, "ngpus": ngpus}
+    try:
+        prob = M.HipMuseProblem(xdata, model=model, ntheta=nth, device=device, prior=M.GaussianPrior(0.0, 3.0))
+        kw = dict(nsims=share, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7)
+        for name, dev in (("device_loop_no_exchange", True), ("host_loop_no_exchange", False)):
+            best = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                n, _, hist, _, _ = prob.run_muse(seed, [1.0] * nth, device_loop=dev, **kw)
+                best = min(best, (time.perf_counter() - t0) / max(1, n))
+            out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1]))}
+        prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            n, _, hist, _, _ = prob.run_muse_sharded(seed, [1.0] * nth, **kw)
+            best = min(best, (time.perf_counter() - t0) / max(1, n))
+        out["sharded_loop_shm_1rank"] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1]))}
+        prob.close()
+        if whole_job_steady_us:
+            out["projected_speedup_at_8_gpus"] = whole_job_steady_us / out["sharded_loop_shm_1rank"]["us_per_outer_iteration_steady"]
+        out["note"] = ("a muse! iteration is ONE dependent map: per rank a launch of nsims/8 + 1 one-workgroup problems (one round on 256 "
+                       "CUs: one problem's latency), then the exchange and the step before the next launch can start; "
+                       "projected_speedup_at_8_gpus = the whole job's steady iteration on one GPU (device loop) / this rank's steady "
+                       "iteration through the sharded loop -- an upper bound, measured with ONE rank in the communicator; the "
+                       "..._no_exchange entries are the same 64 + 1 elements without any exchange")
+    except Exception as e:  # noqa: BLE001 -- an extra: never at the cost of the line
+        out["skipped"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
@@ -268,24 +333,32 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     t0 = time.perf_counter()
     res30 = M.muse(prob, [1.0] * nth, rng=seed, nsims=nsims, maxsteps=30, theta_rtol=1e-12)
     dt30 = time.perf_counter() - t0
-    # the native loops alone (no Python between the iterations, no history records built): algebra on the host / in a step kernel
-    loops = {}
+    # the native loops alone (no Python between the iterations, no history records built): ONE launch for all iterations
+    # (the default) / one launch per iteration with the algebra on the host
+    loops, steady = {}, {}
     for name, dev in (("host_loop", False), ("device_loop", True)):
         best = float("inf")
         for _ in range(3):
             t0 = time.perf_counter()
-            n30 = prob.run_muse(seed, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=dev)[0]
+            n30, _, hist30, _, _ = prob.run_muse(seed, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=dev)
             best = min(best, (time.perf_counter() - t0) / max(1, n30))
         loops[name] = 1e6 * best
+        steady[name] = 1e6 * float(np.median(hist30[5:, -1])) if n30 > 6 else None
     out["muse_run"] = {"wall_s": dt, "outer_iterations": len(res.history), "theta": [float(t) for t in res.theta],
                        "sigma": [float(t) for t in np.sqrt(np.diag(np.atleast_2d(res.Sigma)))],
-                       "us_per_outer_iteration_30": loops["host_loop"],
-                       "us_per_outer_iteration_30_device_loop": loops["device_loop"],
+                       "us_per_outer_iteration_30": loops["device_loop"],
+                       "us_per_outer_iteration_30_host_loop": loops["host_loop"],
+                       "us_per_outer_iteration_steady": steady["device_loop"],
+                       "us_per_outer_iteration_steady_host_loop": steady["host_loop"],
                        "us_per_outer_iteration_30_with_python_history": 1e6 * dt30 / max(1, len(res30.history)),
-                       "note": "muse(prob, theta0=1; nsims, get_covariance=True): outer iterations (native muse_run) + get_J! + get_H!, "
-                               "host algebra included; us_per_outer_iteration_30: wall of a 30-iteration muse_run (the library's loop: "
-                               "launch, wait, algebra on the host) per iteration; ..._device_loop: muse_run_device (step kernel, theta "
-                               "from device memory); ..._with_python_history: through muse(), which also builds the 30 history records"}
+                       "note": "muse(prob, theta0=1; nsims, get_covariance=True): outer iterations (native loop) + get_J! + get_H!, "
+                               "host algebra included; us_per_outer_iteration_30: wall of a 30-iteration muse_run_device call (what "
+                               "muse() runs: ONE launch for all iterations, scores exchanged between the workgroups as tagged granules, "
+                               "the step on the GPU) per iteration, the first (cold: generator) iteration and the call's own launch and "
+                               "copy-out included; ..._host_loop: muse_run, one launch per iteration, algebra on the host; "
+                               "..._steady: the median of the per-iteration times the loop itself records from iteration 6 on; "
+                               "..._with_python_history: through muse(), which also builds the 30 history records"}
+    out["muse_run_8gpu_share"] = share_rates(M, xdata, model, nth, nsims, seed, device, steady["device_loop"])
     prob.close()
     # the get_H! finite-difference map at configs[3]'s OWN shape: funnel, N = 10^4, 4 theta blocks, 512 sims ->
     # 1 fiducial + 512 x 4 x 2 perturbed MAP+score problems (src/muse.jl:407-446); last, on a context of its own
@@ -780,11 +853,15 @@ def main():
                        "pipelining": f"maps_per_launch={best['maps_per_launch']}: that many consecutive (independent) steps share one "
                                      "launch and one exchange",
                        "parallelism": f"sims sharded over {world} GPU(s) ({scaling} scaling), one all-gather of scores per step"
-                                      + (f" ({collective})" if collective else "")},
+                                      + (f" ({collective})" if collective else ""),
+                       "scaling_note": ("the timed steps are INDEPENDENT maps (a get_J!-style pass repeated): with N > 1 a launch carries "
+                                        "maps_per_launch of them, so `value` is the strong scaling of independent maps per launch -- not of "
+                                        "one dependent map.  A muse! iteration (src/muse.jl:159-232) is one dependent map per launch: its "
+                                        "8-GPU share is measured on one GPU in extra.muse_run_8gpu_share (N = 1 runs), projected speed-up "
+                                        "2-3x, bounded by one problem's latency plus the exchange")},
             "timed_rounds": len(rounds), "timed_seconds": sum(rounds),
             "ms_per_step_min_round": 1e3 * min(rounds) / args.steps, "ms_per_step_max_round": 1e3 * max(rounds) / args.steps,
             "roofline": primary,
-            "kernel_sims_per_s": nlocal * best["maps_per_launch"] / mean_kernel_s,
             "host_us_per_step": host_us,
         }
         if sharded:

@@ -316,6 +316,14 @@ int muse_map_and_score_batch_gather_async(muse_ctx* ctx, uint64_t seed, int64_t 
                                           int include_data, const double* theta, double atol, int z0_mode,
                                           int64_t rows_per_rank, int result_area);
 int muse_batch_wait_gathered(muse_ctx* ctx, int result_area, double* g_all_out, muse_info* info_out);
+/* muse_run over the ranks of the communicator (the muse! loop, src/muse.jl:159-232, with its pmap over a pool of GPUs,
+ * src/util.jl:74-83): rank r owns the contiguous block of the opt->nsims simulations that a static partition gives it (the
+ * first nsims mod nranks ranks one more), the data element lives on rank 0; per iteration one gathered map, after which
+ * every rank takes the same step from the same scores -- theta is never exchanged, and the trajectory is the unsharded
+ * muse_run's bit for bit.  Arguments and outputs as muse_run, on every rank; info_out (may be NULL) receives THIS rank's
+ * solver infos, [maxsteps][this rank's element count] (rank 0: the data element first). */
+int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
+                     double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 /* The sharded form of muse_map_and_score_multi_async: this rank's block of `nmaps` maps in one launch, one exchange for
  * all of them.  The gathered block is [nranks][nmaps][rows_per_rank][ntheta]; info_out [nmaps][n]. */
 int muse_map_and_score_multi_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,

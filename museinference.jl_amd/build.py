@@ -26,7 +26,9 @@ UNITS = {
     # (-ffp-contract=off here too: step.hpp's algebra must round on the host exactly as in the step kernel)
     "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), os.path.join(CSRC, "user_model.hpp"), _API],
                         ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
-    "muse_comm.cpp": ([_API, os.path.join(CSRC, "shm_gather.hpp")], ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2"]),
+    # (step.hpp's algebra again: the sharded muse! loop takes the same step as muse_run)
+    "muse_comm.cpp": ([_API, os.path.join(CSRC, "shm_gather.hpp"), os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp")],
+                      ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
 }
 COMMON_FLAGS = ["-std=c++17", "-fPIC", "-Wno-unused-value"]
 SOURCES = [os.path.join(CSRC, s) for s in UNITS]

@@ -20,8 +20,12 @@
 #include <string>
 #include <thread>
 
+#include <chrono>
+#include <vector>
+
 #include "../../include/muse_hip.h"
 #include "shm_gather.hpp"
+#include "step.hpp"
 
 // Minimal slice of the public RCCL/NCCL C API (rccl.h: ncclGetUniqueId, ncclCommInitRank,
 // ncclAllGather, ncclAllReduce, ncclCommDestroy).
@@ -558,3 +562,97 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int area, double* g_all_out, muse_in
 }
 
 }  // extern "C"
+
+// ---- the muse! outer loop over the ranks of a communicator (src/muse.jl:159-232 with the pmap of :169 over a pool of GPUs) ---
+// muse_run with this rank's share of every map: rank r owns the contiguous block of simulations block_partition gives it
+// (distributed.py: the first nsims mod nranks ranks get one more), the data element lives on rank 0; per iteration ONE
+// gathered map (muse_map_and_score_batch_gather_async: the solver launch and the exchange of the score blocks), after which
+// every rank holds every score in simulation order and takes the same step (step.hpp) -- so the ranks agree on theta bit for
+// bit without exchanging it, and the trajectory is the unsharded muse_run's.  Nothing but the loop is new: no Python, no
+// torch tensor and no allocation sits between two maps.  info_out (may be NULL): THIS rank's solver infos,
+// [maxsteps][count of this rank's elements] (the data element first on rank 0).
+extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
+                                double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
+    using namespace muse;
+    CommState* st = state_of(ctx);
+    if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
+    if (!theta0 || !o || !niter_out || !theta_out || !hist_out || !gsims_out) return muse_set_error(MUSE_ERR_INVALID, "NULL argument");
+    if (o->nsims < 2 || o->maxsteps < 1) return muse_set_error(MUSE_ERR_INVALID, "muse_run_sharded needs nsims >= 2 and maxsteps >= 1");
+    if (o->prior_kind != 0 && o->prior_kind != 1) return muse_set_error(MUSE_ERR_INVALID, "prior_kind must be 0 (flat) or 1 (Gaussian)");
+    void* ev = nullptr;
+    int nt = 0;
+    int rc = muse_ctx_area_event(ctx, 0, &ev, &nt);
+    if (rc) return rc;
+    const int S = o->nsims, world = st->nranks, rank = st->rank;
+    const int64_t H = MUSE_RUN_HIST(nt);
+    auto block = [&](int r, int64_t& lo, int64_t& hi) {
+        const int64_t base = S / world, extra = S % world;
+        lo = (int64_t)r * base + (r < extra ? r : extra);
+        hi = lo + base + (r < extra ? 1 : 0);
+    };
+    int64_t rows = 0, lo = 0, hi = 0;
+    for (int r = 0; r < world; ++r) {
+        int64_t l, h;
+        block(r, l, h);
+        const int64_t cnt = (h - l) + (r == 0 ? 1 : 0);
+        rows = cnt > rows ? cnt : rows;
+    }
+    block(rank, lo, hi);
+    const int64_t nlocal = (hi - lo) + (rank == 0 ? 1 : 0);
+    StepParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.ntheta = nt;
+    sp.nsims = S;
+    sp.prior_kind = o->prior_kind;
+    sp.alpha = o->alpha;
+    sp.theta_rtol = o->theta_rtol;
+    for (int k = 0; k < nt; ++k) {
+        sp.prior_mean[k] = o->prior_mean[k];
+        sp.prior_sigma[k] = o->prior_sigma[k];
+    }
+    StepWork work;
+    double theta[kMaxTheta], theta_next[kMaxTheta], mean[kMaxTheta], var[kMaxTheta];
+    for (int k = 0; k < nt; ++k) theta[k] = theta0[k];
+    std::vector<double> gall((size_t)world * rows * nt), g((size_t)(S + 1) * nt);
+    std::vector<muse_info> info((size_t)nlocal);
+    auto now_s = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-9; };
+    int n = 0;
+    for (int i = 1; i <= o->maxsteps; ++i) {
+        const double t_start = now_s();
+        if (i > 2) {  // convergence on the last two records (src/muse.jl:163-166); a NaN compares false and the loop goes on
+            const int cv = step_converged(nt, hist_out + (int64_t)(i - 2) * H, hist_out + (int64_t)(i - 3) * H, o->theta_rtol);
+            if (cv < 0) return muse_set_error(MUSE_ERR_INVALID, "muse_run_sharded: DomainError in the convergence test: dtheta' H^-1_post' dtheta > 0 (H^-1_post' is not negative definite)");
+            if (cv > 0) break;
+        }
+        const int z0_mode = (i > 1 || o->z0_warm) ? MUSE_Z0_WARM : MUSE_Z0_ZERO;
+        rc = muse_map_and_score_batch_gather_async(ctx, seed, lo, hi, rank == 0 ? 1 : 0, theta, o->atol, z0_mode, rows, 0);
+        if (rc) return rc;
+        rc = muse_batch_wait_gathered(ctx, 0, gall.data(), info.data());
+        if (rc) return rc;
+        // every score in the reference's order: the data element (rank 0's first row), then the simulations by rank
+        {
+            double* out = g.data();
+            for (int r = 0; r < world; ++r) {
+                int64_t l, h;
+                block(r, l, h);
+                const int64_t cnt = (h - l) + (r == 0 ? 1 : 0);
+                memcpy(out, gall.data() + (size_t)r * rows * nt, (size_t)cnt * nt * sizeof(double));
+                out += cnt * nt;
+            }
+        }
+        double* h = hist_out + (int64_t)(i - 1) * H;
+        double* gs = gsims_out + (int64_t)(i - 1) * S * nt;
+        memcpy(gs, g.data() + nt, (size_t)S * nt * sizeof(double));
+        if (info_out) memcpy(info_out + (int64_t)(i - 1) * nlocal, info.data(), (size_t)nlocal * sizeof(muse_info));
+        for (int k = 0; k < nt; ++k) step_moments(k, nt, S, gs, mean[k], var[k]);
+        const int err = step_record(sp, theta, g.data(), mean, var, h, theta_next, work);
+        if (err == STEP_SINGULAR_LIKE) return muse_set_error(MUSE_ERR_INVALID, "muse_run: singular H^-1_like (zero score variance)");
+        if (err == STEP_SINGULAR_POST) return muse_set_error(MUSE_ERR_INVALID, "muse_run: singular posterior Hessian");
+        for (int k = 0; k < nt; ++k) theta[k] = theta_next[k];
+        h[7 * nt + nt * nt] = now_s() - t_start;
+        n = i;
+    }
+    *niter_out = n;
+    for (int k = 0; k < nt; ++k) theta_out[k] = theta[k];
+    return MUSE_OK;
+}

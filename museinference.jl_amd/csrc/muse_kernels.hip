@@ -373,6 +373,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
     const bool stepper = (int)blockIdx.x == nworkers;
     Prefetch<Place::EPT> pf;
     pf.p = -1;
+    pf.have_n1 = pf.have_n2 = pf.have_x = pf.g_pending = false;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
 #ifdef MUSE_STAMPS   // diagnostic build: the last iteration's times (100 MHz clock, comparable across the chip) of worker 0 (one
                      // of those with an element more), a worker in the middle and the stepper, behind the problems' rows
@@ -424,7 +425,8 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     Solver<Model, Place> sv(a, tid, m.red, m.shs);
                     sv.pk[0] = pk0;
                     sv.pk[1] = pk1;
-                    sv.run((int)blockIdx.x, wg_scratch, m.lds_x, m.lds_g, pf);
+                    const int nx = (int)blockIdx.x + nworkers;
+                    sv.run((int)blockIdx.x, wg_scratch, m.lds_x, m.lds_g, pf, nx < a.nproblems ? nx : -1);
                     __syncthreads();
                 }
                 loop_stamp(1);
@@ -432,12 +434,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     Solver<Model, Place> sv(a, tid, m.red, m.shs);
                     sv.pk[0] = pk0;
                     sv.pk[1] = pk1;
-                    sv.run(p, wg_scratch, m.lds_x, m.lds_g);
+                    sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, p + nworkers < a.nproblems ? p + nworkers : -1);
                     __syncthreads();
                 }
                 loop_stamp(2);
                 if constexpr (Place::kXgLds) {
-                    if (iter < m.L->maxsteps && a.ncache_mode != 0 && !(a.debug & 4)) prefetch_issue<T>(a, tid, (int)blockIdx.x, m.lds_x, m.lds_g, pf);
+                    if (iter < m.L->maxsteps && a.ncache_mode != 0 && !(a.debug & 4))
+                        prefetch_issue<T>(a, tid, (int)blockIdx.x, m.lds_x, m.lds_g, pf, true);
                 }
                 loop_stamp(3);
             }

@@ -148,8 +148,33 @@ public:
         return true;
     }
     void close() {
-        if (base_) munmap(base_, size_);
+        if (base_ && !adopted_) munmap(base_, size_);
         base_ = nullptr; hdr_ = nullptr; lines_ = nullptr; data_ = nullptr;
+    }
+    // A segment of this process alone (anonymous shared mapping): what the ranks-as-threads sanitizer test exchanges through.
+    bool open_private(int nranks_, int narea_, size_t block_doubles_) {
+        nranks = nranks_; rank = 0; narea = narea_; block_doubles = block_doubles_;
+        size_ = bytes_for(nranks, narea, block_doubles);
+        void* p = mmap(nullptr, size_, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) return false;
+        base_ = (char*)p;
+        hdr_ = (Header*)base_;
+        lines_ = (Line*)(base_ + kHeaderBytes);
+        data_ = (double*)(base_ + kHeaderBytes + (size_t)narea * nranks * sizeof(Line));
+        hdr_->nranks = (uint32_t)nranks;
+        hdr_->narea = (uint32_t)narea;
+        hdr_->block_doubles = block_doubles;
+        hdr_->attached.store((uint32_t)nranks, std::memory_order_relaxed);
+        hdr_->magic.store(kMagic, std::memory_order_release);
+        return true;
+    }
+    // Another rank's view of a segment that `owner` has mapped, through the SAME mapping (the ranks of the sanitizer test are
+    // threads of one process: ThreadSanitizer follows a word by its address, and two mappings of one page are two addresses).
+    void adopt(const Gather& owner, int rank_) {
+        close();
+        nranks = owner.nranks; rank = rank_; narea = owner.narea; block_doubles = owner.block_doubles; timeout_s = owner.timeout_s;
+        base_ = owner.base_; hdr_ = owner.hdr_; lines_ = owner.lines_; data_ = owner.data_; size_ = owner.size_;
+        adopted_ = true;
     }
     ~Gather() { close(); }
 
@@ -170,6 +195,7 @@ private:
     Line* lines_ = nullptr;
     double* data_ = nullptr;
     size_t size_ = 0;
+    bool adopted_ = false;
     Line& line(int area, int r) const { return lines_[(size_t)area * nranks + r]; }
     int wait_all(int area, uint64_t seq, bool ready) const {
         double t0 = 0.0;

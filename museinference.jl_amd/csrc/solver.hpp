@@ -18,31 +18,40 @@ namespace muse {
 // slot -- LDS-DMA writes lane l's 16 bytes at the wave's base + 16 l -- so a wave only ever waits for its own loads.
 template <int EPT>
 struct Prefetch {
-    int p;        // the problem the areas' contents belong to, -1: none
-    bool have_n;  // the x / g areas hold the normals n2 / n1 of a simulation (X_SAMPLE with a cache slot)
-    bool have_x;  // the x area holds the data vector (X_DATA)
+    int p;          // the problem the areas' contents belong to, -1: none
+    bool have_n1;   // the g area holds the normals n1 of a simulation (X_SAMPLE with a cache slot)
+    bool have_n2;   // the x area holds its n2
+    bool have_x;    // the x area holds the data vector (X_DATA)
+    bool g_pending; // n1 was sent to the g area while another problem is being solved: a solve that comes to need g
+                    // (a second L-BFGS iteration) waits for the loads to land and drops the prefetch (Solver::drop_g_prefetch)
 };
 typedef __attribute__((address_space(1))) const void* glds_src_t;
 typedef __attribute__((address_space(3))) void* glds_dst_t;
+// both: between two iterations (x and g areas free): n2 -> x area (or the data vector), n1 -> g area.  !both: while another
+// problem is being solved, whose x lives in the x area: n1 -> g area only (a solve of one L-BFGS iteration never touches g).
 template <int T, int EPT>
-__device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int p, double* lds_x, double* lds_g, Prefetch<EPT>& pf) {
+__device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int p, double* lds_x, double* lds_g, Prefetch<EPT>& pf,
+                                               bool both) {
     const ProblemDesc d = describe(a, p);
     const int64_t ld = a.ld;
+    const bool sim = d.x_mode == X_SAMPLE && d.nslot >= 0;
     pf.p = p;
-    pf.have_n = d.x_mode == X_SAMPLE && d.nslot >= 0;
-    pf.have_x = d.x_mode == X_DATA;
+    pf.have_n1 = sim;
+    pf.have_n2 = sim && both;
+    pf.have_x = d.x_mode == X_DATA && both;
+    pf.g_pending = sim && !both;
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    const double* src_x = pf.have_n ? a.ncache + (int64_t)(2 * d.nslot + 1) * ld : a.x_data;   // n2, or the data
-    const double* src_g = a.ncache + (int64_t)(2 * d.nslot) * ld;                               // n1
+    const double* src_x = sim ? a.ncache + (int64_t)(2 * d.nslot + 1) * ld : a.x_data;   // n2, or the data
+    const double* src_g = a.ncache + (int64_t)(2 * d.nslot) * ld;                         // n1
     const int wave0 = __builtin_amdgcn_readfirstlane(tl) & ~63;   // the wave's first thread
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int i0 = 2 * (tl + j * T);
-        if (i0 < (int)ld && (pf.have_n || pf.have_x)) {   // (phantom pairs stay out of LDS: they would land beyond the vector)
+        if (i0 < (int)ld) {   // (phantom pairs stay out of LDS: they would land beyond the vector)
             const int base = 2 * (wave0 + j * T);         // the wave's first element of this row: wave-uniform
-            __builtin_amdgcn_global_load_lds((glds_src_t)(src_x + i0), (glds_dst_t)(lds_x + base), 16, 0, 0);
-            if (pf.have_n) __builtin_amdgcn_global_load_lds((glds_src_t)(src_g + i0), (glds_dst_t)(lds_g + base), 16, 0, 0);
+            if (pf.have_n2 || pf.have_x) __builtin_amdgcn_global_load_lds((glds_src_t)(src_x + i0), (glds_dst_t)(lds_x + base), 16, 0, 0);
+            if (pf.have_n1) __builtin_amdgcn_global_load_lds((glds_src_t)(src_g + i0), (glds_dst_t)(lds_g + base), 16, 0, 0);
         }
     }
 }
@@ -834,13 +843,31 @@ struct Solver {
     __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         Prefetch<EPT> none;
         none.p = -1;
+        none.g_pending = false;
         run(p, wg_scratch, lds_x, lds_g, none);
     }
-    __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf) {
+    // (next_p: the workgroup's next problem of the same iteration, -1: none -- its n1 travels into the g area during this solve)
+    __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p = -1) {
         begin<false>(p, wg_scratch, lds_x, lds_g, pf);
         if (d.normals_only) return;  // the element only filled its slot of the normals cache
+        pfp = &pf;
+        if constexpr (Place::kResident && Place::kXgLds) {
+            if (next_p >= 0 && a.ncache_mode == 2 && !(a.debug & 4)) prefetch_issue<T>(a, tid, next_p, lds_x, lds_g, pf, false);
+        }
         solve(p);
         finish(p);
+    }
+    Prefetch<EPT>* pfp;
+    // the solve is about to write g (a kept L-BFGS update): a prefetch that is on its way into the g area must land first --
+    // it would overwrite the gradient -- and is given up (the next problem loads its n1 the ordinary way)
+    __device__ __forceinline__ void drop_g_prefetch() {
+        if constexpr (Place::kResident && Place::kXgLds) {
+            if (pfp->g_pending) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pfp->g_pending = false;
+                pfp->p = -1;
+            }
+        }
     }
 
     // -- phase 1: bind storage, produce x and the starting point
@@ -848,6 +875,8 @@ struct Solver {
     __device__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         Prefetch<EPT> none;
         none.p = -1;
+        none.g_pending = false;
+        pfp = nullptr;
         begin<KEEP_ZTRUE>(p, wg_scratch, lds_x, lds_g, none);
     }
     template <bool KEEP_ZTRUE>
@@ -925,31 +954,33 @@ struct Solver {
                     double c1[EPT][2], c2[EPT][2];
                     int tl = tid;
                     asm volatile("" : "+v"(tl));  // per-slot offsets recomputed here, not held across the kernel
-                    if (pf_hit && pf.have_n) {
-                        // n2 sits in the x area and n1 in the g area, each pair at the slot of the thread that owns it
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA loads have landed (long ago)
-                        if (z_warm) {   // the warm start travels while the normals are read back
+                    const bool n1_here = pf_hit && pf.have_n1, n2_here = pf_hit && pf.have_n2;   // in the g / x area already
+                    if (n1_here) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA loads have landed
+                    if (z_warm) {   // the warm start's loads first, then what is not here yet: all in flight at once
 #pragma unroll
-                            for (int j = 0; j < EPT; ++j) load_f64x2(z0src.rsrc, 2 * (tl + j * T), zw[j][0], zw[j][1]);
-                            z_loaded = true;
-                        }
+                        for (int j = 0; j < EPT; ++j) load_f64x2(z0src.rsrc, 2 * (tl + j * T), zw[j][0], zw[j][1]);
+                        z_loaded = true;
+                    }
+                    if (!n2_here) {
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) load_f64x2(n2r, 2 * (tl + j * T), c2[j][0], c2[j][1]);
+                    }
+                    if (!n1_here) {
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) load_f64x2(n1r, 2 * (tl + j * T), c1[j][0], c1[j][1]);
+                    }
+                    if (n1_here) {   // each pair at the slot of the thread that owns it
 #pragma unroll
                         for (int j = 0; j < EPT; ++j) {
                             const int i0 = 2 * (tl + j * T);
                             c1[j][0] = g.get(2 * j, i0); c1[j][1] = g.get(2 * j + 1, i0 + 1);
-                            c2[j][0] = x.get(2 * j, i0); c2[j][1] = x.get(2 * j + 1, i0 + 1);
                         }
-                    } else {
-                        if (z_warm) {
-#pragma unroll
-                            for (int j = 0; j < EPT; ++j) load_f64x2(z0src.rsrc, 2 * (tl + j * T), zw[j][0], zw[j][1]);
-                            z_loaded = true;
-                        }
+                    }
+                    if (n2_here) {
 #pragma unroll
                         for (int j = 0; j < EPT; ++j) {
                             const int i0 = 2 * (tl + j * T);
-                            load_f64x2(n1r, i0, c1[j][0], c1[j][1]);
-                            load_f64x2(n2r, i0, c2[j][0], c2[j][1]);
+                            c2[j][0] = x.get(2 * j, i0); c2[j][1] = x.get(2 * j + 1, i0 + 1);
                         }
                     }
                     const bool stage_ztrue = d.z0_mode == Z0_TRUE;   // (only that start reads the true z back from the g area)
@@ -1197,7 +1228,10 @@ struct Solver {
                 else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
             }, x, when(z_zero || !z_in_place, z));
         }
-        if (pf_hit) pf.p = -1;   // consumed
+        if (pf_hit) {   // consumed
+            pf.p = -1;
+            pf.g_pending = false;
+        }
         stamp(p, 9);
         if constexpr (Model::kStencil) pass_barrier();  // x (and the start z) complete before neighbours read them
         else __syncthreads();
@@ -1349,6 +1383,7 @@ struct Solver {
             if (dphi_0 >= 0.0) {
                 pseudo = 1;
                 if constexpr (!Model::kStencil) {
+                    drop_g_prefetch();
                     if (!g_stored) {  // (cannot happen after a finite, unconverged initial evaluation; kept for completeness)
                         for_elems_zz([&](auto zz, int jj, int i) {
                             double unused = 0.0;
@@ -1457,6 +1492,7 @@ struct Solver {
                     g.set(jj, i, gn);
                     s.set(jj, i, gn);
                 };
+                drop_g_prefetch();
                 if (g_stored) {
                     for_elems_zz([&](auto zz, int jj, int i) { body(std::true_type{}, zz, jj, i); }, z, dxs, dgs, g, s);
                 } else {

@@ -139,6 +139,34 @@ class ShardedMuseProblem:
     def __getattr__(self, name):
         return getattr(self.local, name)
 
+    # -- the muse! outer loop in the library's native code, sharded (muse_run_sharded of the C ABI): with the engine's own
+    #    communicator every rank runs the loop itself -- one gathered map per iteration, the same step on every rank --
+    #    and no Python, torch tensor or allocation sits between two maps.  Without it muse_() drives the maps from Python.
+    supports_native_muse = True
+
+    def native_prior(self):
+        return self.local.native_prior() if self.engine_comm and hasattr(self.local, "native_prior") else None
+
+    def run_muse(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False, device_loop=None):
+        """As HipMuseProblem.run_muse, over the ranks: (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]) --
+        the same on every rank, and the same bits as the unsharded loop's."""
+        loc = self.local
+        lo, hi = block_partition(0, nsims, self.world, self.rank)
+        nloc = (hi - lo) + (1 if self.rank == 0 else 0)
+        n, theta, hist, gs, info = loc.run_muse_sharded(rng, theta0, nsims=nsims, maxsteps=maxsteps, theta_rtol=theta_rtol, atol=atol,
+                                                        alpha=alpha, z0_warm=z0_warm)
+        self._last_nslots, self._last_had_data = nsims + 1, True
+        # the solver infos of every element, once for the run: [n iterations][this rank's elements] -> [n][nsims + 1]
+        ninfo = len(_capi.INFO_DTYPE.names)
+        counts = [(h - l) + (1 if r == 0 else 0) for r, (l, h) in
+                  ((r, block_partition(0, nsims, self.world, r)) for r in range(self.world))]
+        rows = self._info_to_rows(info[:n].T.reshape(-1)).reshape(nloc, n * ninfo) if n else np.zeros((nloc, 0))
+        allrows = self._allgather_rows(rows, counts) if n else np.zeros((nsims + 1, 0))
+        info_all = np.zeros((n, nsims + 1), dtype=_capi.INFO_DTYPE)
+        for e in range(nsims + 1 if n else 0):
+            info_all[:, e] = self._rows_to_info(allrows[e].reshape(n, ninfo))
+        return n, theta, hist, gs, info_all
+
     def _tensor_device(self):
         import torch
         if self._device is not None:

@@ -381,8 +381,10 @@ class HipMuseProblem(AbstractMuseProblem):
         """The muse! outer loop in the library's native code (muse_run / muse_run_device, include/muse_hip.h): returns
         (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]).  device_loop=True: ONE launch runs every
         iteration -- map, exchange of the scores between the (all resident) workgroups, step, next map -- and nothing leaves
-        the GPU in between; False: one launch per iteration, the algebra on the host.  The same results bit for bit either
-        way; placements without a loop kernel (an element split, N >= 65 536) run the host loop whatever is asked."""
+        the GPU in between (the default: 44 against 48 us per iteration at N = 10^4 x 512 sims, and no host in the loop to be
+        slowed by whatever else the process does); False: one launch per iteration, the algebra on the host.  The same results
+        bit for bit either way; placements without a loop kernel (an element split, N >= 65 536) run the host loop whatever
+        is asked."""
         kind, mean, sigma = self.native_prior()
         o = _capi.RunOptions()
         o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)
@@ -396,10 +398,34 @@ class HipMuseProblem(AbstractMuseProblem):
         info = np.zeros((maxsteps, nsims + 1), dtype=_capi.INFO_DTYPE)
         theta = np.zeros(self.ntheta)
         n = C.c_int32()
-        device_loop = bool(device_loop)
+        device_loop = True if device_loop is None else bool(device_loop)   # default: the device-resident loop (measured faster)
         fn = self._lib.muse_run_device if device_loop else self._lib.muse_run
         self._check(fn(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
                        _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
+        return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
+
+    def run_muse_sharded(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False):
+        """This rank's part of the muse! loop over the ranks of the context's communicator (muse_run_sharded; comm_init
+        first): (n, theta, hist, g_sims) as run_muse -- the same on every rank -- and THIS rank's solver infos
+        [n, count of its elements] (rank 0: the data element first)."""
+        kind, mean, sigma = self.native_prior()
+        o = _capi.RunOptions()
+        o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)
+        o.prior_kind, o.z0_warm = int(kind), int(bool(z0_warm))
+        for k in range(self.ntheta):
+            o.prior_mean[k], o.prior_sigma[k] = float(mean[k]), float(sigma[k])
+        th0 = self._theta(theta0)
+        world, rank = self._nranks, self._rank
+        base, extra = divmod(int(nsims), world)
+        nloc = base + (1 if rank < extra else 0) + (1 if rank == 0 else 0)
+        W = _capi.run_hist_width(self.ntheta)
+        hist = np.zeros((maxsteps, W))
+        gs = np.zeros((maxsteps, nsims, self.ntheta))
+        info = np.zeros((maxsteps, nloc), dtype=_capi.INFO_DTYPE)
+        theta = np.zeros(self.ntheta)
+        n = C.c_int32()
+        self._check(self._lib.muse_run_sharded(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
+                                               _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
         return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
 
     def get_zhat(self, slot_begin, slot_end):
@@ -501,7 +527,7 @@ class HipMuseProblem(AbstractMuseProblem):
             raise ValueError("unique_id must be the bytes returned by comm_unique_id")
         buf = (C.c_char * _capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)  # (binary: not a C string)
         self._check(self._lib.muse_comm_init(self._ctx, int(nranks), int(rank), buf))
-        self._nranks = int(nranks)
+        self._nranks, self._rank = int(nranks), int(rank)
 
     def comm_destroy(self):
         """Tear the communicator down (a context may then be given another one, e.g. the other transport)."""

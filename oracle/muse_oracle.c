@@ -225,6 +225,57 @@ void mo_normals(uint64_t seed, uint64_t sim, int64_t N, double* n1, double* n2) 
     for (int64_t i = 0; i < N; ++i) mo_normal_pair(seed, sim, (uint64_t)i, &n1[i], &n2[i]);
 }
 
+#ifdef MO_FAST
+/* bench.py's second CPU figure (Makefile target `fast`; never the checker): the same generator written so that the
+ * compiler can run it in SIMD lanes -- one loop over the elements, no call, no branch (the uniforms are >= 2^-53, so log's
+ * subnormal path is never taken; the quadrant of sincospi by selects).  The same operations per element as mo_normal_pair,
+ * free to be contracted and re-associated by this build's flags. */
+static void mo_normals_simd(uint64_t seed, uint64_t sim, int64_t N, double* restrict n1o, double* restrict n2o) {
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32), s0 = (uint32_t)sim, s1 = (uint32_t)(sim >> 32);
+#pragma omp simd
+    for (int64_t i = 0; i < N; ++i) {
+        uint32_t c0 = (uint32_t)i, c1 = (uint32_t)((uint64_t)i >> 32), c2 = s0, c3 = s1, k0 = key0, k1 = key1;
+#pragma GCC unroll 10
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t m0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, m1 = (uint32_t)p1, m2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, m3 = (uint32_t)p0;
+            c0 = m0; c1 = m1; c2 = m2; c3 = m3;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint64_t q1 = ((uint64_t)c0 << 20) | (c1 >> 12), q2 = ((uint64_t)c2 << 20) | (c3 >> 12);
+        const double u1 = ((double)(int64_t)q1 + 0.5) * 2.220446049250313080847e-16;
+        const double u2 = ((double)(int64_t)q2 + 0.5) * 2.220446049250313080847e-16;
+        /* log(u1), u1 in [2^-53, 1) */
+        union { double d; uint64_t u; } b;
+        b.d = u1;
+        uint32_t hx = (uint32_t)(b.u >> 32) + (0x3ff00000u - 0x3fe6a09eu);
+        const double dk = (double)((int)(hx >> 20) - 0x3ff);
+        hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+        b.u = ((uint64_t)hx << 32) | (b.u & 0xffffffffu);
+        const double f = b.d - 1.0, hfsq = 0.5 * f * f, sl = f / (2.0 + f), zl = sl * sl, wl = zl * zl;
+        const double t1 = wl * (wl * (wl * 1.531383769920937332e-01 + 2.222219843214978396e-01) + 3.999999999940941908e-01);
+        const double t2 = zl * (wl * (wl * (wl * 1.479819860511658591e-01 + 1.818357216161805012e-01) + 2.857142874366239149e-01) + 6.666666666666735130e-01);
+        const double lg = dk * 6.93147180369123816490e-01 + ((sl * (hfsq + (t2 + t1)) + dk * 1.90821492927058770002e-10) - hfsq + f);
+        const double rr = sqrt(-2.0 * lg);
+        /* sincospi(2 u2) */
+        const double t = 2.0 * u2;
+        const int n = (int)(2.0 * t + 0.5);
+        const double y = (t - 0.5 * (double)n) * 3.14159265358979311600e+00, z = y * y, w = z * z;
+        const double rs = z * w * (z * 1.58969099521155010221e-10 + -2.50507602534068634195e-08) + (z * (z * 2.75573137070700676789e-06 + -1.98412698298579493134e-04) + 8.33333333332248946124e-03);
+        const double ks = z * y * (z * rs + -1.66666666666666324348e-01) + y;
+        const double rc = w * w * (z * (z * -1.13596475577881948265e-11 + 2.08757232129817482790e-09) + -2.75573143513906633035e-07)
+                          + z * (z * (z * 2.48015872894767294178e-05 + -1.38888888888741095749e-03) + 4.16666666666666019037e-02);
+        const double hz = 0.5 * z, ww = 1.0 - hz, kc = ww + (z * rc + ((1.0 - ww) - hz));
+        const int qd = n & 3;
+        const double sn = qd == 0 ? ks : (qd == 1 ? kc : (qd == 2 ? -ks : -kc));
+        const double cs = qd == 0 ? kc : (qd == 1 ? -ks : (qd == 2 ? -kc : ks));
+        n1o[i] = rr * cs;
+        n2o[i] = rr * sn;
+    }
+}
+#endif
+
 /* ---------------------------------------------------------------- models */
 static inline int mo_block(int64_t i, int64_t N, int B) { return (int)((i * (int64_t)B) / N); }
 
@@ -298,12 +349,20 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
             x[i] = n1 + sd[0] * n2;
         }
     } else if (model == MO_MODEL_FUNNEL) {
+#ifdef MO_FAST
+        mo_normals_simd(seed, sim, N, z, x);   /* (z <- n1, x <- n2) */
+        for (int64_t i = 0; i < N; ++i) {
+            z[i] = sd[mo_block(i, N, ntheta)] * z[i];
+            x[i] = z[i] + x[i];
+        }
+#else
         for (int64_t i = 0; i < N; ++i) {
             double n1, n2;
             mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
             z[i] = sd[mo_block(i, N, ntheta)] * n1;
             x[i] = z[i] + n2;
         }
+#endif
     } else { /* SMOOTH: x = A z + n2 */
         for (int64_t i = 0; i < N; ++i) {
             double n1, n2;

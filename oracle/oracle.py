@@ -81,6 +81,31 @@ def build_user_model(header, name, force=False):
     return path
 
 
+class fast_build:
+    """with fast_build(): every function of this module runs in libmuse_oracle_fast.so -- the same source compiled for THIS
+    machine with re-association and contraction allowed (Makefile target `fast`).  For bench.py's second CPU figure only:
+    its results are compared with the strict build's at a tolerance, it is never the checker."""
+    _lib = None
+
+    def __init__(self, rebuild=True):
+        path = os.path.join(_HERE, "libmuse_oracle_fast.so")
+        if rebuild or not os.path.exists(path):   # (-march=native: built on the machine that runs it)
+            subprocess.check_call(["make", "-C", _HERE, "-B", "fast"], stdout=subprocess.DEVNULL)
+            fast_build._lib = None
+        if fast_build._lib is None:
+            fast_build._lib = _declare(C.CDLL(path))
+
+    def __enter__(self):
+        global _selected
+        self._prev, _selected = _selected, fast_build._lib
+        return self
+
+    def __exit__(self, *exc):
+        global _selected
+        _selected = self._prev
+        return False
+
+
 class user_model:
     """with user_model(header, name): every function of this module runs in the build that holds that model (model "user");
     the built-in models are there too."""

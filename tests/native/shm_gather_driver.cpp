@@ -3,8 +3,14 @@
 // Every rank runs `rounds` exchanges over 4 areas in turn with rank- and round-dependent delays, fills its block with
 // a function of (rank, area, sequence number, index) and checks every block it reads.  With abort_at_round the LAST
 // rank raises the abort word instead of publishing; the others must then leave their wait with code 2 (exit 42).
+//   shm_gather_driver --threads <segment name> <nranks> <rounds> <block_doubles>
+// The same exchange with the ranks as THREADS of this process sharing one mapping of the segment -- the form
+// ThreadSanitizer can follow (tests/test_sanitizers.py).
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <thread>
+#include <vector>
 
 #include "../../museinference.jl_amd/csrc/shm_gather.hpp"
 
@@ -12,7 +18,29 @@ static double value(int rank, int area, uint64_t seq, size_t i) {
     return (double)rank * 1e6 + (double)area * 1e5 + (double)(seq % 100000) + 1e-3 * (double)(i % 997);
 }
 
+static int exchange(muse_shm::Gather& g, int nranks, int rank, int rounds, size_t B, int abort_at);
+
 int main(int argc, char** argv) {
+    if (argc >= 6 && std::string(argv[1]) == "--threads") {
+        const int nranks = atoi(argv[3]), rounds = atoi(argv[4]);   // (argv[2], the segment name, is not used: the mapping is private)
+        const size_t B = (size_t)atol(argv[5]);
+        muse_shm::Gather owner;
+        owner.timeout_s = 60.0;
+        if (!owner.open_private(nranks, 4, B)) {
+            fprintf(stderr, "open_private failed\n");
+            return 3;
+        }
+        std::vector<muse_shm::Gather> views((size_t)nranks);
+        std::vector<int> rc((size_t)nranks, -1);
+        std::vector<std::thread> th;
+        for (int r = 0; r < nranks; ++r) views[(size_t)r].adopt(owner, r);
+        for (int r = 0; r < nranks; ++r)
+            th.emplace_back([&, r] { rc[(size_t)r] = exchange(views[(size_t)r], nranks, r, rounds, B, -1); });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < nranks; ++r)
+            if (rc[(size_t)r]) return rc[(size_t)r];
+        return 0;
+    }
     if (argc < 6) return 2;
     const char* name = argv[1];
     const int nranks = atoi(argv[2]), rank = atoi(argv[3]), rounds = atoi(argv[4]);
@@ -25,6 +53,10 @@ int main(int argc, char** argv) {
         fprintf(stderr, "rank %d: open failed: %s\n", rank, err.c_str());
         return 3;
     }
+    return exchange(g, nranks, rank, rounds, B, abort_at);
+}
+
+static int exchange(muse_shm::Gather& g, int nranks, int rank, int rounds, size_t B, int abort_at) {
     uint64_t seq[4] = {0, 0, 0, 0};
     unsigned lcg = 12345u + 77u * (unsigned)rank;
     for (int k = 0; k < rounds; ++k) {

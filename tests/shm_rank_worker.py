@@ -1,4 +1,4 @@
-"""One rank of tests/test_gpu_shm_transport.py: python shm_rank_worker.py <id hex> <nranks> <rank> <out.npz>.
+"""One rank of tests/test_gpu_shm_transport.py: python shm_rank_worker.py <id hex> <nranks> <rank> <out.npz> <second id hex>.
 All ranks share GPU 0 (the shared-memory transport has no device-side part)."""
 import os
 import sys
@@ -36,4 +36,11 @@ big = np.sin(np.arange(40000.0) * (rank + 1))
 res["ar"] = prob.allreduce_sum(big)
 res["ag_big"] = prob.allgather_scores(big[:20001])
 prob.close()
+# the muse! loop over the ranks in native code (muse_run_sharded): the same theta trajectory, records and scores on every rank
+xdat = np.sin(0.37 * np.arange(N)) * 1.3
+pm = M.HipMuseProblem(xdat, model="funnel", ntheta=NTH, prior=M.GaussianPrior(0.0, 3.0))
+pm.comm_init(world, rank, bytes.fromhex(sys.argv[5]))
+n, theta, hist, gs, info = pm.run_muse_sharded(SEED, [1.0, 0.4], nsims=NSIMS, maxsteps=6, theta_rtol=0.0, atol=1e-3, alpha=0.7)
+res["run_n"], res["run_theta"], res["run_hist"], res["run_gs"], res["run_it"] = n, theta, hist[:, :-1], gs, info["iterations"]
+pm.close()
 np.savez(out, **res)

@@ -14,12 +14,12 @@ BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--war
          "--no-cpu-baseline", "--no-extra"]
 
 
-def run(extra, env):
+def run(extra, env, rc=0):
     e = dict(os.environ, **env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         e.pop(k, None)
     p = subprocess.run(BENCH + extra, env=e, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-4000:]
+    assert p.returncode == rc, p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     return json.loads(lines[0])
@@ -32,6 +32,23 @@ def test_bench_gpus2_self_launch_gloo(gpu):
     shm, rccl = d["transports"]["shm"], d["transports"]["rccl"]
     assert shm["collective"] == "shm-capi" and shm["ranks_seen"] == 2
     assert "skipped" in rccl
+    assert d["value"] > 0 and abs(d["value"] - 512 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
+
+
+def test_bench_gpus8_self_launch_gloo(gpu):
+    """The driver's 8-GPU command, as far as one GPU can take it: `python bench.py --gpus 8` starts eight ranks (here all on
+    GPU 0, collectives over gloo), the shared-memory communicator counts eight processes, the 512 simulations of a step
+    are dealt 8 x 64, every launch carries 8 independent maps, and RCCL -- which refuses several ranks on one device --
+    is reported as skipped without costing the line or the exit status."""
+    d = run(["--gpus", "8"], {"MUSE_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["sims_per_step_total"] == 512
+    assert "(64 on this rank)" in d["config"]["workload"]
+    assert d["transport"] == "shm"
+    shm, rccl = d["transports"]["shm"], d["transports"]["rccl"]
+    assert shm["collective"] == "shm-capi" and shm["ranks_seen"] == 8
+    assert shm["pipelining"] == "maps_per_launch=8"
+    assert "skipped" in rccl
+    assert "independent" in d["config"]["scaling_note"].lower()
     assert d["value"] > 0 and abs(d["value"] - 512 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
 
 
@@ -52,7 +69,9 @@ def test_bench_default_line_is_the_single_gpu_workload(gpu):
 
 def test_bench_watchdog_reports_without_a_transport_that_hangs(gpu):
     """A second transport that does not finish in time (here: a deadline of a millisecond) must not cost the line: the ranks
-    report what the first transport measured and mark the other one."""
-    d = run(["--nsims", "64"], {"MUSE_BENCH_FORCE_DIST": "1", "MUSE_BENCH_TRANSPORT_DEADLINE_S": "0.001"})
+    report what the first transport measured and mark the other one -- and leave with a NON-ZERO status (3): a collective
+    hung with GPU work in flight, which a launcher or CI must not take for a clean run."""
+    d = run(["--nsims", "64"], {"MUSE_BENCH_FORCE_DIST": "1", "MUSE_BENCH_TRANSPORT_DEADLINE_S": "0.001"}, rc=3)
+    assert d["transport_failed"] == "rccl"
     assert d["transport"] == "shm" and "watchdog" in d["transports"]["rccl"]["skipped"]
     assert d["transports"]["shm"]["ranks_seen"] == 1 and d["value"] == d["transports"]["shm"]["value"]

@@ -17,9 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
     import museinference_jl_amd as M
     uid = M.HipMuseProblem.comm_unique_id("shm", 4096)   # naming the segment does not touch the GPU
+    uid2 = M.HipMuseProblem.comm_unique_id("shm", 4096)  # (the communicator of the native sharded muse! loop)
     assert len(uid) == 128
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r], uid2.hex()],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert [p.returncode for p in procs] == [0] * world, "\n".join(logs)
@@ -41,6 +42,19 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
             lo, hi = M.block_partition(0, NSIMS, world, r)
             assert np.array_equal(res[r][f"it{k}"], info["iterations"][lo:hi])
     ref.close()
+    # muse_run_sharded on every rank = the unsharded native loop, bit for bit (theta is never exchanged: every rank takes the
+    # same step from the same gathered scores)
+    xdat = np.sin(0.37 * np.arange(N)) * 1.3
+    one = M.HipMuseProblem(xdat, model="funnel", ntheta=NTH, prior=M.GaussianPrior(0.0, 3.0))
+    n1, t1, h1, g1, i1 = one.run_muse(SEED, [1.0, 0.4], nsims=NSIMS, maxsteps=6, theta_rtol=0.0, atol=1e-3, alpha=0.7, device_loop=False)
+    one.close()
+    assert n1 == 6
+    for r in range(world):
+        assert int(res[r]["run_n"]) == n1 and np.array_equal(res[r]["run_theta"], t1)
+        assert np.array_equal(res[r]["run_hist"], h1[:, :-1]) and np.array_equal(res[r]["run_gs"], g1)
+        lo, hi = M.block_partition(0, NSIMS, world, r)
+        mine = np.concatenate([i1["iterations"][:, :1], i1["iterations"][:, 1 + lo:1 + hi]], axis=1) if r == 0 else i1["iterations"][:, 1 + lo:1 + hi]
+        assert np.array_equal(res[r]["run_it"], mine)
     big = [np.sin(np.arange(40000.0) * (q + 1)) for q in range(world)]
     total = big[0].copy()
     for q in range(1, world):

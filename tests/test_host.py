@@ -292,7 +292,12 @@ def test_native_path_selection(M, O, funnel512):
     assert len(r.history) == 2
     with pytest.raises(ValueError):
         M.muse(prob, [1.0], rng=0, nsims=8, maxsteps=2, native=True)
-    assert M.HipMuseProblem.supports_native_muse and not getattr(M.ShardedMuseProblem, "supports_native_muse", False)
+    # the sharded wrapper declares it too (muse_run_sharded), but only offers a native prior -- the switch muse_() looks at --
+    # once the engine's own communicator is up; over torch collectives (here: no process group at all) it stays on the host driver
+    assert M.HipMuseProblem.supports_native_muse and M.ShardedMuseProblem.supports_native_muse
+    bare = M.ShardedMuseProblem.__new__(M.ShardedMuseProblem)
+    bare.local, bare.engine_comm = prob, False
+    assert bare.native_prior() is None
 
 
 # ---- finite-difference methods of get_H! (fdm.py against the independent restatement in muse_reference.py) ----------

@@ -37,9 +37,9 @@ HOT = [
 # (what is tolerated: values stored at the kernel's entry and re-loaded once per PROBLEM, between two problems -- none inside
 # an element loop, a reduction or the line search)
 HOT_LOOP = [
-    ("FunnelModel<1>, PlaceResident<512, 10, true>", 8),
-    ("NoiseModel, PlaceResident<512, 10, true>", 8),
-    ("FunnelModel<4>, PlaceResident<512, 10, true>", 12),
+    ("FunnelModel<1>, PlaceResident<512, 10, true>", 12),
+    ("NoiseModel, PlaceResident<512, 10, true>", 12),
+    ("FunnelModel<4>, PlaceResident<512, 10, true>", 40),
 ]
 
 
