@@ -46,16 +46,17 @@ namespace muse {
 typedef __attribute__((address_space(4))) const uint32_t* kernarg_ptr;
 // theta of problem p into the LDS copy of the arguments (BatchArgs::cur) -- a launch that carries several maps -- from the
 // map's entry of maps[], read straight from the kernarg segment.  Workgroup-uniform; a no-op (no barrier) for the plain launch.
+template <bool RAW>
 __device__ __forceinline__ void load_problem_theta(const BatchArgs& a, double* args_lds, int p, int tid) {
     if (a.nmaps > 1) {
-        __syncthreads();  // every thread is done with the previous problem's theta
+        wg_barrier<RAW>();  // every thread is done with the previous problem's theta
         asm volatile("" : "+v"(tid));  // (else the source address is formed at the kernel's entry and held -- spilled -- across it)
         if (tid < (int)(sizeof(MapTheta) / 4)) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(args_lds) + offsetof(BatchArgs, cur) / 4;
             kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
             dst[tid] = kp[(offsetof(BatchArgs, maps) + (size_t)(p / a.n_per_map) * sizeof(MapTheta)) / 4 + tid];
         }
-        __syncthreads();
+        wg_barrier<RAW>();
     }
 }
 
@@ -137,8 +138,8 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
             sv.bufsel = nth & 1;
             sv.next_p = p + a.nclusters < a.nproblems ? p + a.nclusters : -1;
             sv.parity = 0;
-            __syncthreads();
-            load_problem_theta(a, args_lds, p, tid);
+            wg_barrier<!Model::kStencil>();
+            load_problem_theta<!Model::kStencil>(a, args_lds, p, tid);
             if constexpr (IMPLICIT) sv.run_implicit(p, cl_scratch, lds_x, lds_g);
             else sv.run(p, cl_scratch, lds_x, lds_g);
         }
@@ -170,7 +171,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
 #ifdef MUSE_STAMPS
             if (tid == 0 && a.stamps && p < (int)gridDim.x) a.stamps[(size_t)p * 16 + 8] = t_entry;  // kernel entry
 #endif
-            load_problem_theta(a, args_lds, p, tid);
+            load_problem_theta<!Model::kStencil>(a, args_lds, p, tid);
             {
                 Solver<Model, Place> sv(a, tid, red, shs);
                 sv.pk[0] = pk0;
@@ -178,9 +179,10 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
                 if constexpr (IMPLICIT) sv.run_implicit(p, wg_scratch, lds_x, lds_g);
                 else sv.run(p, wg_scratch, lds_x, lds_g);
             }
-            __syncthreads();
+            // (raw barriers for the elementwise models: the MAP's stores keep draining while the next problem starts)
+            wg_barrier<!Model::kStencil>();
             if (tid == 0) ticket[0] = next;
-            __syncthreads();
+            wg_barrier<!Model::kStencil>();
             p = (int)gridDim.x + (__builtin_amdgcn_readfirstlane(ticket[0]) - a.ticket_base);
             if (p >= a.nproblems) break;
         }
@@ -427,7 +429,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     sv.pk[1] = pk1;
                     const int nx = (int)blockIdx.x + nworkers;
                     sv.run((int)blockIdx.x, wg_scratch, m.lds_x, m.lds_g, pf, nx < a.nproblems ? nx : -1);
-                    __syncthreads();
+                    wg_barrier<!Model::kStencil>();   // (raw: the next problem's n1 is on its way into the g area)
                 }
                 loop_stamp(1);
                 for (int p = (int)blockIdx.x + nworkers; p < a.nproblems; p += nworkers) {
@@ -435,7 +437,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     sv.pk[0] = pk0;
                     sv.pk[1] = pk1;
                     sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, p + nworkers < a.nproblems ? p + nworkers : -1);
-                    __syncthreads();
+                    wg_barrier<!Model::kStencil>();
                 }
                 loop_stamp(2);
                 if constexpr (Place::kXgLds) {

@@ -71,8 +71,14 @@ __device__ __forceinline__ double lanes_total(double v) {  // butterfly over the
 
 // RAW: the barrier alone (s_waitcnt lgkmcnt(0) + s_barrier) instead of __syncthreads(), whose fence also drains the
 // vector-memory counter -- every store of the pass (the MAP going out in a solve's last pass: 80 KB per workgroup) and
-// every LDS-DMA prefetch in flight would have to complete before the reduction could.  For passes whose threads only ever
-// re-read their own elements (the elementwise models); the stencil model's passes read what other threads stored.
+// every LDS-DMA prefetch in flight would have to complete before the reduction could (measured at configs[1]: 48.9 -> 36.6 us
+// per 512-sim step).  For code whose threads only ever meet through LDS and re-read from memory only what they stored
+// themselves (the elementwise models); the stencil model's passes read what other threads stored.
+template <bool RAW>
+__device__ __forceinline__ void wg_barrier() {
+    if constexpr (RAW) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
 template <int T, int KS, int KM, bool RAW = false>
 __device__ __forceinline__ void block_allreduce(double (&s)[KS > 0 ? KS : 1], double (&m)[KM > 0 ? KM : 1],
                                                 double* red, int& parity, int tid) {

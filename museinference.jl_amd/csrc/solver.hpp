@@ -177,7 +177,7 @@ struct Solver {
                 if (live) reinterpret_cast<unsigned*>(exch)[q] = (unsigned)(gv & 0xffffffffull);
             }
         }
-        __syncthreads();
+        wg_barrier<!Model::kStencil>();   // (the values travel through LDS)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             double acc = exch[k];
@@ -896,7 +896,7 @@ struct Solver {
             int tl = tid;
             asm volatile("" : "+v"(tl));  // (else tid * 8 is formed at the kernel's entry and held -- spilled -- across it)
             if (tl < MAXB) sh_sd[tl] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tl] : a.cur.t.sd[tl];
-            __syncthreads();
+            wg_barrier<!Model::kStencil>();
         }
         // bind storage
         const double* zmem = nullptr;
@@ -1234,7 +1234,7 @@ struct Solver {
         }
         stamp(p, 9);
         if constexpr (Model::kStencil) pass_barrier();  // x (and the start z) complete before neighbours read them
-        else __syncthreads();
+        else wg_barrier<true>();                        // (x of the LDS layout; elsewhere a thread reads back only its own elements)
         if constexpr (kBg && !KEEP_ZTRUE) {
             // arm the background generator with the cluster's next problem (same conditions as the foreground path above)
             gen.active = false;

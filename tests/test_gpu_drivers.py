@@ -364,14 +364,20 @@ def test_native_outer_loop_equals_host_driver(gpu, M, O, model, N, nth, theta0, 
     a, b = res[False], res[True]
     assert len(a.history) == len(b.history) >= 3
     for ha, hb in zip(a.history, b.history):
+        # (absolute tolerances relative to the scores' size: g_like' = g_dat' - mean(g_sims') is the difference of two numbers
+        #  of that size, and the two loops sum the mean in different orders -- numpy pairwise, the library's 64-leaf tree)
+        gscale = max(1.0, float(np.max(np.abs(np.asarray(ha["g_like_sims"])))))
         for k in ("θ", "θunreg", "θ′", "g_like_dat′", "g_like′", "g_prior′", "g_post′", "H⁻¹_post′", "H_prior′",
                   "H⁻¹_like′", "H⁻¹_like_sims′", "g_like_sims", "g_like_sims′"):
-            np.testing.assert_allclose(np.asarray(hb[k]), np.asarray(ha[k]), rtol=1e-12, atol=1e-13, err_msg=k)
+            np.testing.assert_allclose(np.asarray(hb[k]), np.asarray(ha[k]), rtol=1e-12, atol=1e-13 * gscale, err_msg=k)
         assert np.array_equal(hb["ẑ_history_sims"]["iterations"], ha["ẑ_history_sims"]["iterations"])
         assert hb["ẑ_history_dat"]["f_calls"] == ha["ẑ_history_dat"]["f_calls"]
     for k in ("theta", "J", "H", "Sigma"):
-        np.testing.assert_allclose(getattr(b, k), getattr(a, k), rtol=1e-10, err_msg=k)
-    np.testing.assert_allclose(np.array(b.gs), np.array(a.gs), rtol=1e-12, atol=1e-13)
+        # (relative to the matrix: the off-diagonal entries of a block model's H are differences of nearly equal numbers,
+        #  10^-12 of the diagonal, and the two loops' thetas differ in the last bits)
+        scale = float(np.max(np.abs(np.asarray(getattr(a, k)))))
+        np.testing.assert_allclose(getattr(b, k), getattr(a, k), rtol=1e-10, atol=1e-10 * scale, err_msg=k)
+    np.testing.assert_allclose(np.array(b.gs), np.array(a.gs), rtol=1e-12, atol=1e-13 * max(1.0, float(np.max(np.abs(np.array(a.gs))))))
 
 
 def test_native_outer_loop_options(gpu, M, O):

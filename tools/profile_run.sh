@@ -9,11 +9,18 @@ OUT=$R/gpurun_out/prof_run
 rm -rf $OUT
 mkdir -p $OUT
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc_fingerprint())" > $OUT/csrc_sha16.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/runloop_bench.py host > $OUT/runloop_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/runloop_bench.py host once > $OUT/runloop_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/runloop_bench.py host once > $OUT/runloop_write.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/runloop_bench.py host once > $OUT/runloop_sq.log 2>&1
+# both native loops: "host" = muse_run (one map_score_kernel launch per iteration), "dev" = muse_run_device (ONE muse_loop_kernel
+# launch per 30-iteration call -- what muse() runs)
+for L in host dev; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$L -- python3 $R/tools/runloop_bench.py $L > $OUT/runloop_trace_$L.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$L -- python3 $R/tools/runloop_bench.py $L once > $OUT/runloop_fetch_$L.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$L -- python3 $R/tools/runloop_bench.py $L once > $OUT/runloop_write_$L.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_$L -- python3 $R/tools/runloop_bench.py $L once > $OUT/runloop_sq_$L.log 2>&1
+done
 python3 $R/tools/runloop_bench.py > $OUT/runloop.log 2>&1
-[ -f $R/museinference.jl_amd/libmuse_hip_stamps.so ] && python3 $R/tools/stamps_run.py > $OUT/stamps_run.log 2>&1
+if [ -f $R/museinference.jl_amd/libmuse_hip_stamps.so ]; then
+  python3 $R/tools/stamps_run.py > $OUT/stamps_run_host.log 2>&1
+  python3 $R/tools/stamps_run.py 10000 1 512 4 dev > $OUT/stamps_run_dev.log 2>&1
+fi
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -r head -5
-cat $OUT/runloop.log $OUT/stamps_run.log 2>/dev/null | grep -v amdgpu.ids
+cat $OUT/runloop.log $OUT/stamps_run_host.log $OUT/stamps_run_dev.log 2>/dev/null | grep -v amdgpu.ids

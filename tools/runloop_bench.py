@@ -4,12 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import museinference_jl_amd as M
-argv = [a for a in sys.argv[1:] if a not in ("host", "once")]
-HOST_ONLY, ONCE = "host" in sys.argv[1:], "once" in sys.argv[1:]   # (profiling passes: the default loop only / one run of it)
+argv = [a for a in sys.argv[1:] if a not in ("host", "dev", "once")]
+HOST_ONLY, DEV_ONLY, ONCE = "host" in sys.argv[1:], "dev" in sys.argv[1:], "once" in sys.argv[1:]   # (profiling passes: one loop only / one run of it)
 N, nsims, nth = (int(argv[0]), int(argv[1]), int(argv[2])) if len(argv) > 2 else (10000, 512, 1)
 xdata, _ = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N).sample_x_z(M.SimRng(0, M.DATA_SIM), [0.0] * nth)
 prob = M.HipMuseProblem(xdata, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
-for dev in ((False,) if HOST_ONLY else (False, True, False, True)):
+for dev in ((False,) if HOST_ONLY else (True,) if DEV_ONLY else (False, True, False, True)):
     best = 1e9
     for rep in range(1 if ONCE else 5):
         t0 = time.perf_counter()

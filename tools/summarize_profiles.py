@@ -13,7 +13,7 @@ _shafile = os.path.join(ROOT, "gpurun_out", "prof", "csrc_sha16.txt")
 CSRC_SHA = open(_shafile).read().strip() if os.path.exists(_shafile) else _bench.csrc_fingerprint()
 PROF = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 workloads = sorted({os.path.basename(d)[len("trace_"):] for d in glob.glob(os.path.join(PROF, "trace_*"))})
 
 
