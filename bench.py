@@ -394,6 +394,7 @@ def user_model_rates(M, device, N=10000, nsims=512):
                 continue
             model = M.ElementwiseModel.packaged(name)
         prob = M.HipMuseProblem(None, model=model, ntheta=1, N=N, device=device)
+        prob.set_normals_cache(False)   # (every step draws its simulations; the steps of run() use distinct ranges anyway)
         prob.set_concurrency(2)
         AREAS = 4
         outs = [(np.empty((nsims, 1)), np.zeros(nsims, dtype=M._capi.INFO_DTYPE)) for _ in range(AREAS)]
@@ -540,6 +541,10 @@ def main():
         nsims = args.nsims
     seed = 0
     prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=local_rank)
+    # The timed steps repeat ONE map (the same simulations, cold start) to time sample -> MAP -> score: the engine's cache of
+    # the standard normals of repeated simulations would turn every step after the second into a load instead of a draw --
+    # work skipped inside the timed region.  Off: every step runs the generator.
+    prob.set_normals_cache(False)
     if args.placement >= 0:
         prob.set_placement(args.placement)
     # consecutive steps on alternating lanes (streams): a launch starts on the compute units the previous one has left

@@ -121,6 +121,15 @@ int muse_set_element_split(muse_ctx* ctx, int split);
  * and -- stencil model in a cluster -- whether the search direction is kept in LDS.  For reports (bench.py's roofline
  * accounts the bytes of the placement that ran); any pointer may be NULL. */
 int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element, int* resident, int* direction_in_lds);
+/* The normals cache of plain maps.  A simulation's stream depends only on (seed, simulation index) (split_rng,
+ * src/util.jl:87-92), and the reference's loops draw the same streams again and again -- every iteration of muse!
+ * (src/muse.jl:134,169), get_J! after it (:506), every grid point of get_H! (:430).  The native loops and the
+ * finite-difference batch keep a stream's standard normals in device memory after the first draw and load them instead of
+ * running the generator again (the same doubles: bit-identical results).  Plain maps do the same on their own when a map
+ * asks for a simulation range the context has just been asked for: the second time the normals are stored beside the
+ * solve, from the third time on they are loaded (LDS-resident placement, one lane; at most MUSE_NCACHE_MAX_MB, default
+ * 8192).  enabled = 0 switches that off for plain maps (a benchmark that repeats one map to time the generator). */
+int muse_set_normals_cache(muse_ctx* ctx, int enabled);
 /* Concurrency of the batched maps: with n > 1 result area r runs on lane r mod n -- a stream, a workgroup scratch, a
  * ticket counter and a cluster state of its own -- so that consecutive launches (enqueued on different result areas) overlap:
  * a launch starts on the compute units the previous one has already left instead of behind its last workgroup and a

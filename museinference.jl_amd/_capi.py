@@ -76,6 +76,7 @@ SIGNATURES = {
     "muse_map_and_score_multi_gather_async": (_i, [_vp, _u64, _i64, _i64, _i, _i, _vp, _d, _i, _i64, _i]),
     "muse_run": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_run_device": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
+    "muse_set_normals_cache": (_i, [_vp, _i]),
     "muse_run_sharded": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_get_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),

@@ -107,6 +107,7 @@ struct muse_ctx {
     // nc_count == 0), and the simulation range of the last plain map (a range is cached when it is asked for AGAIN)
     uint64_t nc_seed = 0, nc_seen_seed = 0;
     int64_t nc_sim0 = 0, nc_count = 0, nc_seen_sim0 = 0, nc_seen_count = 0;
+    bool nc_auto = true;                 // muse_set_normals_cache: plain maps may store / load the normals of repeated simulations
     double* cl_part = nullptr;           // [cl_cap][kClusterSlotDoubles]
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
@@ -664,6 +665,12 @@ int muse_synchronize(muse_ctx* c) {
         return MUSE_OK;
     });
 }
+int muse_set_normals_cache(muse_ctx* c, int enabled) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    c->nc_auto = enabled != 0;
+    if (!c->nc_auto) c->nc_seen_count = 0;
+    return MUSE_OK;
+}
 int muse_set_concurrency(muse_ctx* c, int nlanes) {
     int rc = muse_synchronize(c);
     if (rc) return rc;
@@ -944,7 +951,7 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             a.ncache_mode = 1;
             c->nc_seed = seed; c->nc_sim0 = sim_begin; c->nc_count = nsim;
         }
-    } else if (o.ncache_mode == 0 && o.nmaps == 1 && nsim > 0 && c->cur_lane == 0 && ncache_applies(c)) {
+    } else if (o.ncache_mode == 0 && c->nc_auto && o.nmaps == 1 && nsim > 0 && c->cur_lane == 0 && ncache_applies(c)) {
         // A map over simulations the context has drawn before -- every iteration of a muse! loop the HOST drives (muse.py:
         // the same streams at a new theta, src/muse.jl:134,169), a get_J! pass after it: the second time a range is asked
         // for its normals are stored beside the solve, from the third time on they are loaded instead of generated (the

@@ -489,7 +489,8 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 err = m.flags[2] ? (int)STEP_TIMEOUT : __builtin_amdgcn_readfirstlane((int)(ec & 0xffffffffull));
                 converged = __builtin_amdgcn_readfirstlane((int)(ec >> 32));
                 if (err != STEP_OK || converged || iter == m.L->maxsteps) break;
-                if (tid == 0) make_map_theta(nt, a.bnd, th, a.cur);
+                if (tid < kMaxTheta) make_map_theta_component(tid, nt, th, a.cur);   // (a lane per component: two exponentials each)
+                if (tid == 0) make_map_theta_const(nt, a.bnd, th, a.cur);
                 // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
             }
         } else {
@@ -538,46 +539,115 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 };
                 int lane = tid;
                 asm volatile("" : "+v"(lane));
-                for (int k = 0; k < nt; ++k) {   // step.hpp's step_moments_wave, with the poll in its first pass
-                    double mk = 0.0;
-                    for (int sidx = lane; sidx < S; sidx += 64) {
-                        const double v = score(1 + sidx, k);
-                        gs[(int64_t)(1 + sidx) * nt + k] = v;
-                        mk += v;
+                constexpr int MAXB = Model::MAXB;
+                // step.hpp's step_moments_wave for every component at once, with the poll in its first pass: a lane asks for ALL
+                // components of a simulation together (their granules are neighbours), so that after the last score has
+                // landed nothing is left but the sums -- polled one component after the other, every component paid a
+                // lane's eight dependent round trips again
+                double mk[MAXB], vk[MAXB];
+#pragma unroll
+                for (int k = 0; k < MAXB; ++k) mk[k] = vk[k] = 0.0;
+                for (int sidx = lane; sidx < S; sidx += 64) {
+                    double v[MAXB];
+                    {   // all components of the simulation: their loads in flight together, until every granule carries the tag
+                        unsigned spins = 0;
+                        unsigned long long t_wait0 = 0;
+                        for (;;) {
+                            bool all = true;
+#pragma unroll
+                            for (int k = 0; k < MAXB; ++k) {
+                                double lo = 0.0, hi = 0.0;
+                                if (k < nt) load_f64x2<kCoherent>(grs, 2 * ((1 + sidx) * nt + k), lo, hi);
+                                const unsigned long long glo = (unsigned long long)__double_as_longlong(lo), ghi = (unsigned long long)__double_as_longlong(hi);
+                                all = all && (k >= nt || ((unsigned)(glo >> 32) == tag && (unsigned)(ghi >> 32) == tag));
+                                v[k] = __longlong_as_double((long long)((ghi << 32) | (glo & 0xffffffffull)));
+                            }
+                            if (all || expired) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 0xffu) == 0) {   // bounded by TIME (4 s)
+                                unsigned long long now;
+                                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                                if (t_wait0 == 0) t_wait0 = now;
+                                else if (now - t_wait0 > 400000000ull) {
+                                    __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    expired = true;
+                                }
+                            }
+                        }
                     }
-                    mk = wave_total<false>(mk);
-                    mk /= S;
-                    double vk = 0.0;
-                    for (int sidx = lane; sidx < S; sidx += 64) {
-                        const double dlt = gs[(int64_t)(1 + sidx) * nt + k] - mk;
-                        vk += dlt * dlt;
-                    }
-                    vk = wave_total<false>(vk);
-                    vk /= (S - 1);
-                    if (lane == 0) {
-                        small[8 + k] = mk;
-                        small[16 + k] = vk;
-                    }
+#pragma unroll
+                    for (int k = 0; k < MAXB; ++k)
+                        if (k < nt) {
+                            gs[(int64_t)(1 + sidx) * nt + k] = v[k];
+                            mk[k] += v[k];
+                        }
                 }
-                if (lane < nt) gs[lane] = score(0, lane);   // the data element's score
+#pragma unroll
+                for (int k = 0; k < MAXB; ++k)
+                    if (k < nt) {
+                        mk[k] = wave_total<false>(mk[k]);
+                        mk[k] /= S;
+                    }
+                for (int sidx = lane; sidx < S; sidx += 64) {
+#pragma unroll
+                    for (int k = 0; k < MAXB; ++k)
+                        if (k < nt) {
+                            const double dlt = gs[(int64_t)(1 + sidx) * nt + k] - mk[k];
+                            vk[k] += dlt * dlt;
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < MAXB; ++k)
+                    if (k < nt) {
+                        vk[k] = wave_total<false>(vk[k]);
+                        vk[k] /= (S - 1);
+                        if (lane == 0) {
+                            small[8 + k] = mk[k];
+                            small[16 + k] = vk[k];
+                        }
+                    }
+                if (lane < nt) {
+                    gs[lane] = score(0, lane);   // the data element's score
+                    w.theta[lane] = a.cur.t.theta[lane];
+                }
                 if (__builtin_amdgcn_ballot_w64(expired) != 0ull && lane == 0) m.flags[2] = 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wavefront: its LDS writes above are visible to its reads below)
                 loop_stamp(4);
+                // ---- the step, one lane per component (step.hpp: step_record's pieces; every lane the same statements the host
+                //      loop runs for that component, the sums over components in component order)
+                int e = m.flags[2] ? (int)STEP_TIMEOUT : (int)STEP_OK;
+                if (e == STEP_OK) {
+                    if (lane < nt) step_component(L.sp, lane, w.theta, gs, small + 8, small + 16, w.rec, w);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (__builtin_amdgcn_ballot_w64(lane < nt && !step_like_ok(nt, lane, w.rec)) != 0ull) e = STEP_SINGULAR_LIKE;
+                }
+                if (e == STEP_OK) {
+                    bool ok = true;
+                    if (lane < nt) ok = step_post_diag(nt, lane, w.rec, w);
+                    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) e = STEP_SINGULAR_POST;
+                }
+                int cv = 0;
+                if (e == STEP_OK) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane < nt) step_row(L.sp, lane, w.rec, w.theta_next, w);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
+                    if (iter >= 2 && iter < L.maxsteps) {
+                        if (lane < nt) small[lane] = step_converged_term(nt, lane, w.rec, m.rec);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        double q = 0.0;
+                        for (int k = 0; k < nt; ++k) q += small[k];
+                        const int c = step_converged_from(q, L.sp.theta_rtol);
+                        if (c < 0) e = STEP_DOMAIN;
+                        cv = c > 0;
+                    }
+                }
                 if (lane == 0) {
-                    for (int k = 0; k < nt; ++k) w.theta[k] = a.cur.t.theta[k];
-                    int e = m.flags[2] ? (int)STEP_TIMEOUT : step_record(L.sp, w.theta, gs, small + 8, small + 16, w.rec, w.theta_next, w);
-                    int cv = 0;
                     if (e == STEP_OK) {
                         unsigned long long now;
                         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
                         w.rec[7 * nt + nt * nt] = (double)(now - *m.t_prev) * 1e-8;   // seconds of this iteration
                         *m.t_prev = now;
-                        // the test at the top of iteration iter + 1 > 2, on this record and the previous one (src/muse.jl:163-166)
-                        if (iter >= 2 && iter < L.maxsteps) {
-                            const int c = step_converged(nt, w.rec, m.rec, L.sp.theta_rtol);
-                            if (c < 0) e = STEP_DOMAIN;
-                            cv = c > 0;
-                        }
                     }
                     m.flags[0] = e;
                     m.flags[1] = cv;
@@ -592,8 +662,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     __hip_atomic_store(gran + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 loop_stamp(5);
-                const int e1 = m.flags[0];
-                if (e1 == STEP_OK) {
+                if (e == STEP_OK) {
                     for (int k = lane; k < (int)H; k += 64) {
                         const double v = w.rec[k];
                         L.hist_out[(int64_t)(iter - 1) * H + k] = v;
@@ -603,10 +672,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     if (lane < nt) L.theta_out[lane] = w.theta_next[lane];
                 }
                 if (lane == 0) {
-                    L.status[0] = e1 == STEP_OK ? iter : iter - 1;
-                    L.status[1] = e1;
-                    L.status[2] = m.flags[1];
-                    if (e1 == STEP_OK) make_map_theta(nt, a.bnd, w.theta_next, a.cur);   // (the stepper's own copy: the next record's theta)
+                    L.status[0] = e == STEP_OK ? iter : iter - 1;
+                    L.status[1] = e;
+                    L.status[2] = cv;
+                }
+                if (e == STEP_OK) {   // (the stepper's own copy of theta: the next record's)
+                    if (lane < kMaxTheta) make_map_theta_component(lane, nt, w.theta_next, a.cur);
+                    if (lane == 0) make_map_theta_const(nt, a.bnd, w.theta_next, a.cur);
                 }
             }
             __syncthreads();

@@ -50,17 +50,22 @@ MUSE_HD double muse_exp(double x) {
     return (y * s.d) * 9.33263618503218878990e-302;  // 2^-1000
 }
 
-MUSE_HD void make_map_theta(int ntheta, const int64_t* bnd, const double* theta, MapTheta& m) {
-    for (int k = 0; k < kMaxTheta; ++k) m.t.theta[k] = m.t.sd[k] = m.t.iv[k] = 0.0;
+// (component k's entries -- on the device one lane per component -- and the constant term, a sum in component order)
+MUSE_HD void make_map_theta_component(int k, int ntheta, const double* theta, MapTheta& m) {
+    const bool live = k < ntheta;
+    m.t.theta[k] = live ? theta[k] : 0.0;
+    m.t.sd[k] = live ? muse_exp(0.5 * theta[k]) : 0.0;
+    m.t.iv[k] = live ? muse_exp(-theta[k]) : 0.0;
+}
+MUSE_HD void make_map_theta_const(int ntheta, const int64_t* bnd, const double* theta, MapTheta& m) {
     double cst = 0.0;
-    for (int k = 0; k < ntheta; ++k) {
-        m.t.theta[k] = theta[k];
-        m.t.sd[k] = muse_exp(0.5 * theta[k]);
-        m.t.iv[k] = muse_exp(-theta[k]);
-        cst += (double)(bnd[k + 1] - bnd[k]) * theta[k];
-    }
+    for (int k = 0; k < ntheta; ++k) cst += (double)(bnd[k + 1] - bnd[k]) * theta[k];
     m.f_const = cst;
     m.pad_ = 0.0;
+}
+MUSE_HD void make_map_theta(int ntheta, const int64_t* bnd, const double* theta, MapTheta& m) {
+    for (int k = 0; k < kMaxTheta; ++k) make_map_theta_component(k, ntheta, theta, m);
+    make_map_theta_const(ntheta, bnd, theta, m);
 }
 
 // Work space of one step.  The caller places it: on the device in LDS -- a lane's local arrays indexed at run time live in
@@ -162,73 +167,82 @@ inline void step_moments(int k, int ntheta, int S, const double* gs, double& mea
 // One record of the history and the next iterate, from theta (where the map ran), the data element's score g_dat and the
 // moments of the simulation scores: h = [theta, g_like_dat, g_like, g_prior, g_post, diag H^-1_like, diag H_prior]
 // (ntheta each), H^-1_post (ntheta x ntheta); theta_next = theta - alpha H^-1_post g_post (src/muse.jl:183-208,224).
+// In pieces per component, so that the device-resident loop can give every component a lane of its own (the pieces of one
+// component touch nothing another component's pieces write, except where a barrier is noted); step_record is the pieces in
+// component order -- the host loop's form, and the definition.
+MUSE_HD void step_component(const StepParams& sp, int k, const double* theta, const double* g_dat, const double* mean, const double* var,
+                            double* h, StepWork& w) {
+    const int nt = sp.ntheta;
+    if (sp.prior_kind == 1) {
+        const double sg2 = sp.prior_sigma[k] * sp.prior_sigma[k];
+        w.gprior[k] = -(theta[k] - sp.prior_mean[k]) / sg2;
+        w.hprior[k] = -1.0 / sg2;
+    } else {
+        w.gprior[k] = 0.0;
+        w.hprior[k] = 0.0;
+    }
+    h[k] = theta[k];
+    h[nt + k] = g_dat[k];                         // g_like_dat
+    h[2 * nt + k] = g_dat[k] - mean[k];           // g_like  = g_dat - mean(g_sims)
+    h[3 * nt + k] = w.gprior[k];
+    h[4 * nt + k] = h[2 * nt + k] + w.gprior[k];  // g_post
+    h[5 * nt + k] = -1.0 / var[k];                // diag H^-1_like
+    h[6 * nt + k] = w.hprior[k];
+}
+// H^-1_post = inv(inv(H^-1_like) + H_prior) (src/muse.jl:208).  Both matrices are DIAGONAL here (the "sims" update and an
+// independent prior), and for a diagonal matrix the dense inverse (small_inverse above: Gauss-Jordan with partial pivoting,
+// kept as the definition and checked against this form bit for bit in tests/native/step_driver.cpp) does exactly this:
+// no row is ever exchanged or eliminated (every off-diagonal entry is a zero), pivot i fails iff !(|d_i| > 0), the
+// diagonal of the inverse is ONE division 1 / d_i, and the off-diagonal entries of row i are (+0) / d_i -- zeros that
+// carry d_i's sign.  Written out, the step is 2 nt divisions instead of two eliminations whose every access, on the
+// one lane of the device-resident loop that took the step, was a dependent LDS round trip (measured at nt = 4: 25 us).
+MUSE_HD bool step_like_ok(int nt, int k, const double* h) { return fabs(h[5 * nt + k]) > 0.0; }
+MUSE_HD bool step_post_diag(int nt, int k, const double* h, StepWork& w) {   // the diagonal of inv(H^-1_like) + H_prior; false: singular
+    w.Hinv_like_inv[k] = 1.0 / h[5 * nt + k] + w.hprior[k];
+    return fabs(w.Hinv_like_inv[k]) > 0.0;
+}
+// row a of H^-1_post and component a of the Newton-Raphson step (src/muse.jl:224); reads every component's g_post
+MUSE_HD void step_row(const StepParams& sp, int a_, double* h, double* theta_next, StepWork& w) {
+    const int nt = sp.ntheta;
+    const double dg = 1.0 / w.Hinv_like_inv[a_], off = 0.0 / w.Hinv_like_inv[a_];
+    for (int b = 0; b < nt; ++b) {
+        w.Hpost[a_ * nt + b] = a_ == b ? dg : off;
+        h[7 * nt + a_ * nt + b] = a_ == b ? dg : off;
+    }
+    double stp = 0.0;
+    for (int b = 0; b < nt; ++b) stp += w.Hpost[a_ * nt + b] * h[4 * nt + b];
+    theta_next[a_] = h[a_] - sp.alpha * stp;
+}
 MUSE_HD int step_record(const StepParams& sp, const double* theta, const double* g_dat, const double* mean, const double* var,
                         double* h, double* theta_next, StepWork& w) {
     const int nt = sp.ntheta;
-    double* gprior = w.gprior;
-    double* hprior = w.hprior;
-    double* Hlike = w.Hlike;
-    double* Hinv_like_inv = w.Hinv_like_inv;
-    double* Hpost = w.Hpost;
-    for (int k = 0; k < nt; ++k) {
-        if (sp.prior_kind == 1) {
-            const double sg2 = sp.prior_sigma[k] * sp.prior_sigma[k];
-            gprior[k] = -(theta[k] - sp.prior_mean[k]) / sg2;
-            hprior[k] = -1.0 / sg2;
-        } else {
-            gprior[k] = 0.0;
-            hprior[k] = 0.0;
-        }
-        h[k] = theta[k];
-        h[nt + k] = g_dat[k];                       // g_like_dat
-        h[2 * nt + k] = g_dat[k] - mean[k];         // g_like  = g_dat - mean(g_sims)
-        h[3 * nt + k] = gprior[k];
-        h[4 * nt + k] = h[2 * nt + k] + gprior[k];  // g_post
-        h[5 * nt + k] = -1.0 / var[k];              // diag H^-1_like
-        h[6 * nt + k] = hprior[k];
-    }
-    if (nt == 1) {
-        // one component: the statements below on 1 x 1 matrices, written out -- the same IEEE operations in the same order
-        // (small_inverse of [d] is the singularity test and ONE division 1 / d), without the dense code's dependent chain
-        // of memory accesses (the device-resident loop runs this on one lane between two iterations)
-        const double hl = h[5];
-        if (!(fabs(hl) > 0.0)) return STEP_SINGULAR_LIKE;
-        const double ip = 1.0 / hl + hprior[0];
-        if (!(fabs(ip) > 0.0)) return STEP_SINGULAR_POST;
-        const double hp = 1.0 / ip;
-        h[7] = hp;
-        double stp = 0.0;
-        stp += hp * h[4];
-        theta_next[0] = h[0] - sp.alpha * stp;
-        return STEP_OK;
-    }
-    // H^-1_post = inv(inv(H^-1_like) + H_prior): both diagonal here, kept general through the dense inverse
-    for (int a_ = 0; a_ < nt * nt; ++a_) Hlike[a_] = 0.0;
-    for (int k = 0; k < nt; ++k) Hlike[k * nt + k] = h[5 * nt + k];
-    if (!small_inverse(nt, Hlike, Hinv_like_inv, w.M)) return STEP_SINGULAR_LIKE;
-    for (int k = 0; k < nt; ++k) Hinv_like_inv[k * nt + k] += hprior[k];
-    if (!small_inverse(nt, Hinv_like_inv, Hpost, w.M)) return STEP_SINGULAR_POST;
-    for (int a_ = 0; a_ < nt * nt; ++a_) h[7 * nt + a_] = Hpost[a_];
-    for (int a_ = 0; a_ < nt; ++a_) {  // Newton-Raphson step (src/muse.jl:224)
-        double stp = 0.0;
-        for (int b = 0; b < nt; ++b) stp += Hpost[a_ * nt + b] * h[4 * nt + b];
-        theta_next[a_] = h[a_] - sp.alpha * stp;
-    }
+    for (int k = 0; k < nt; ++k) step_component(sp, k, theta, g_dat, mean, var, h, w);
+    for (int k = 0; k < nt; ++k)
+        if (!step_like_ok(nt, k, h)) return STEP_SINGULAR_LIKE;
+    bool post_ok = true;
+    for (int k = 0; k < nt; ++k) post_ok = step_post_diag(nt, k, h, w) && post_ok;
+    if (!post_ok) return STEP_SINGULAR_POST;
+    for (int a_ = 0; a_ < nt; ++a_) step_row(sp, a_, h, theta_next, w);
     return STEP_OK;
 }
 
 // The convergence test at the top of an iteration i > 2 on the last two records h1 (newer) and h0 (src/muse.jl:163-166):
-// 1 converged, 0 go on, -1 DomainError (sqrt of a negative number: H^-1_post' is not negative definite).
-MUSE_HD int step_converged(int nt, const double* h1, const double* h0, double theta_rtol) {
+// 1 converged, 0 go on, -1 DomainError (sqrt of a negative number: H^-1_post' is not negative definite).  The quadratic
+// form is a sum over the components of step_converged_term, in component order.
+MUSE_HD double step_converged_term(int nt, int a_, const double* h1, const double* h0) {
     const double* Hp = h1 + 7 * nt;
-    double q = 0.0;
-    for (int a_ = 0; a_ < nt; ++a_) {
-        double row = 0.0;
-        for (int b = 0; b < nt; ++b) row += Hp[a_ * nt + b] * (h1[b] - h0[b]);
-        q += (h1[a_] - h0[a_]) * row;
-    }
+    double row = 0.0;
+    for (int b = 0; b < nt; ++b) row += Hp[a_ * nt + b] * (h1[b] - h0[b]);
+    return (h1[a_] - h0[a_]) * row;
+}
+MUSE_HD int step_converged_from(double q, double theta_rtol) {
     if (-q < 0.0) return -1;  // a NaN compares false and the loop goes on
     return sqrt(-q) < theta_rtol ? 1 : 0;
+}
+MUSE_HD int step_converged(int nt, const double* h1, const double* h0, double theta_rtol) {
+    double q = 0.0;
+    for (int a_ = 0; a_ < nt; ++a_) q += step_converged_term(nt, a_, h1, h0);
+    return step_converged_from(q, theta_rtol);
 }
 
 }  // namespace muse

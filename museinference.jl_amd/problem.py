@@ -404,6 +404,12 @@ class HipMuseProblem(AbstractMuseProblem):
                        _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
         return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
 
+    def set_normals_cache(self, enabled):
+        """Plain maps over a simulation range the context has just been asked for store (second time) and then load (from
+        the third time on) the streams' standard normals instead of generating them again -- muse_set_normals_cache;
+        False switches that off (a benchmark that repeats one map to time the generator)."""
+        self._check(self._lib.muse_set_normals_cache(self._ctx, int(bool(enabled))))
+
     def run_muse_sharded(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False):
         """This rank's part of the muse! loop over the ranks of the context's communicator (muse_run_sharded; comm_init
         first): (n, theta, hist, g_sims) as run_muse -- the same on every rank -- and THIS rank's solver infos

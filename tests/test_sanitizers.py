@@ -56,6 +56,16 @@ def test_shm_protocol_under_address_and_ub_sanitizer(tmp_path, nranks):
     _clean(r, "ASan/UBSan, ranks as threads")
 
 
+def test_step_algebra_under_address_and_ub_sanitizer(tmp_path):
+    """csrc/step.hpp (the muse! step both native loops take on the host) with its bitwise self-check, sanitized."""
+    exe = _build(tmp_path, "step_asan", ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                                         "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                                         os.path.join(HERE, "native", "step_driver.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=600)
+    _clean(r, "step.hpp under ASan/UBSan")
+    assert "step driver ok" in r.stdout
+
+
 def test_oracle_under_address_and_ub_sanitizer(tmp_path):
     exe = _build(tmp_path, "oracle_asan", ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fopenmp",
                                            "-mavx2", "-mfma", "-ffp-contract=off", ORACLE_DRIVER, os.path.join(ROOT, "oracle", "muse_oracle.c"), "-lm"])
