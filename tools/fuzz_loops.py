@@ -1,5 +1,7 @@
-"""Randomized checks of the round-3 paths on a GPU (development aid; the committed tests hold fixed cases):
-  * muse_run_device against muse_run: the same number of iterations and the same bits (history, scores, infos, theta);
+"""Randomized checks of the round-3 and round-4 paths on a GPU (development aid; the committed tests hold fixed cases):
+  * muse_run_device (round 4: the loop kernel) against muse_run: the same number of iterations and the same bits (history,
+    scores, infos, theta), also with more elements than workers;
+  * the cross-call normals cache: sequences of plain maps on a caching context against a non-caching one (bitwise);
   * several maps in one launch against separate launches (bitwise);
   * muse_fd_values_columns against the oracle's per-simulation operators (rtol 1e-7).
 Usage: python tools/fuzz_loops.py [seconds] [seed]"""
@@ -14,20 +16,22 @@ O.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
-n = {"loop": 0, "multi": 0, "fd": 0, "lanes": 0}
+n = {"loop": 0, "multi": 0, "fd": 0, "lanes": 0, "cache": 0}
 bad = 0
 while time.time() - t0 < budget:
     model = str(rng.choice(["funnel", "noise", "smooth"]))
     N = int(rng.choice([int(rng.integers(8, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)), int(rng.integers(10000, 30000))]))
     nth = 1 if model == "noise" else min(N, int(rng.choice([1, 2, 3, 4, 8])))
     seed = int(rng.integers(1, 2**40))
-    kind = str(rng.choice(["loop", "multi", "fd", "lanes"]))
+    kind = str(rng.choice(["loop", "loop", "multi", "fd", "lanes", "cache"]))
     x = rng.standard_normal(N) * 1.3
     prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0) if rng.random() < 0.7 else None)
     ok, why = True, ""
     try:
         if kind == "loop":
             nsims = int(rng.integers(2, 200)) if N < 5000 else int(rng.integers(2, 64))
+            if rng.random() < 0.25 and N <= 10000:   # more elements than the loop kernel has workers: two and three per worker, the prefetches
+                nsims = int(rng.integers(250, 800))
             th0 = rng.uniform(-0.5, 1.5, size=nth)
             kw = dict(nsims=nsims, maxsteps=int(rng.integers(1, 12)), theta_rtol=float(rng.choice([0.0, 1e-2, 1e-1, 1.0])),
                       atol=float(rng.choice([1e-2, 1e-4])), alpha=float(rng.uniform(0.3, 1.0)), z0_warm=bool(rng.random() < 0.2))
@@ -54,6 +58,25 @@ while time.time() - t0 < budget:
                 if len(w):
                     why += f" | info differs at {w[:3].tolist()}: {a[4][tuple(w[0])]} vs {b[4][tuple(w[0])]}"
                 why += f" | th0 {th0.tolist()} prior {prob.prior}"
+        elif kind == "cache":
+            # the cross-call normals cache (round 4): a sequence of plain maps with repeated, nested and disjoint simulation ranges,
+            # cold / true-z / warm starts, on a context that caches against one that does not -- the same bits
+            ref = M.HipMuseProblem(x, model=model, ntheta=nth, prior=prob.prior)
+            ref.set_normals_cache(False)
+            ranges = [(int(a), int(a) + int(c)) for a, c in zip(rng.integers(0, 40, size=4), rng.integers(1, 70, size=4))]
+            seq = [ranges[int(rng.integers(0, len(ranges)))] for _ in range(12)]
+            if rng.random() < 0.5:
+                seq = [seq[0]] * 4 + seq   # the same range several times in a row: store, then loads
+            for (lo_, hi_) in seq:
+                th = rng.uniform(-1.0, 2.0, size=nth)
+                z0 = int(rng.choice([0, 1, 2]))
+                incl = bool(rng.random() < 0.5)
+                ga, ia = prob.map_and_score_batch(seed, lo_, hi_, th, include_data=incl, atol=1e-3, z0_mode=z0)
+                gb, ib = ref.map_and_score_batch(seed, lo_, hi_, th, include_data=incl, atol=1e-3, z0_mode=z0)
+                ok = ok and np.array_equal(ga, gb, equal_nan=True) and ia.tobytes() == ib.tobytes()
+            ok = ok and np.array_equal(prob.get_zhat(0, 1), ref.get_zhat(0, 1))
+            ref.close()
+            why = f"ranges {ranges}"
         elif kind == "multi":
             nmaps, nsims, incl = int(rng.integers(2, 9)), int(rng.integers(1, 40)) if N < 20000 else 3, bool(rng.random() < 0.5)
             split = int(rng.choice([0, 0, 2, 4]))
