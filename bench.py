@@ -804,7 +804,10 @@ def main():
                    "ops_per_element": ALG_OPS, "issue_cycles_per_wave_instruction": ISSUE_CYCLES,
                    "note": "work / peak: operation counts per element from the source (bench.py: ALG_OPS) x the measured issue cost "
                            "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
-                           "many instructions the compiled kernel spends on them"}
+                           "many instructions the compiled kernel spends on them.  The peak is the PROBE's rate -- ~10 % softer than "
+                           "the spec rates (fp64 4 cycles, 32-bit 2) and optimistic for this mix: the generator as a kernel of its own "
+                           "at eight waves per SIMD (built, measured and removed in round 4: DESIGN.md section 6) ran no faster than "
+                           "inside this kernel, i.e. the sampler -- two thirds of the launch -- already runs at the VALU's throughput"}
             valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,
                     "clock_hz": clock_hz, "clock_source": "in-kernel s_memtime / s_memrealtime" if best["clock_hz"] else "assumed",
