@@ -1262,6 +1262,120 @@ struct Solver {
         stamp(p, 1);
     }
 
+    // The two-loop recursion of the streaming clusters with the NEXT step's first trips in flight across the cluster
+    // exchange.  A step is a pass over two history vectors (A: the one the AXPY takes, B: the one the next coefficient's dot
+    // product needs) that ends in a cluster-wide reduction (~3.5 us at 16 members: workgroup reduction, granules out, sweep);
+    // the next step's coefficient needs that reduction -- its LOADS do not: which vectors it reads is known.  So before a
+    // step's reduction the first trip of the next step's A and B is issued into the accessors' trip caches (BufChunk::preload)
+    // and the pass finds them there.  The arithmetic and its order are untouched: the same bits.
+    // (the stencil model's clusters: the elementwise models' solves are one iteration long, and their longer trips would cost
+    //  32 registers of cache across the exchange)
+    static constexpr bool kPrefetchTwoLoop = !Place::kResident && Place::kCluster && Model::kStencil;
+    template <class F>
+    __device__ __forceinline__ void pass_ab(VH& A, VH& B, F&& f) {   // the element loop of a two-loop step; writes s
+        int t = tfirst;
+        asm volatile("" : "+v"(t));
+        const int n = (int)a.ld, pstr = pstride;
+#pragma unroll 1
+        for (int i0 = 2 * t; i0 < n; i0 += 2 * U * pstr) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 2 * u * pstr;
+                f(2 * u, i);
+                f(2 * u + 1, i + 1);
+            }
+            s.template flush<U>(i0, pstr);
+            A.unload();   // (only the first trip was fetched ahead)
+            B.unload();
+        }
+    }
+    __device__ double twoloop_prefetched(int upper, int lower, double dot0) {
+        if constexpr (kPrefetchTwoLoop) {
+            double dot = dot0;
+            int t0 = tfirst;
+            asm volatile("" : "+v"(t0));
+            auto fetch = [&](VH& v) { v.template preload<U>(2 * t0, pstride); };
+            VH A = hdg((upper - 1) % kM), B = A;   // (B: rebound where a step has one)
+            if (upper > lower) B = hdx((upper - 2) % kM);
+            // backward pass (q lives in s; the update pass left q = g there)
+            for (int index = upper; index >= lower; --index) {
+                const int slot = (index - 1) % kM;
+                const double al = sh_rho[slot] * dot;
+                if ((tid & 63) == 0) sh_alpha[slot] = al;  // lane 0 of EVERY wave: a wave reads back its own write (no barrier needed)
+                double sum[1] = {0.0}, mx[1] = {0.0};
+                if (index > lower) {
+                    pass_ab(A, B, [&](int jj, int i) {
+                        const double qi = fma(-al, A.get(jj, i), s.get(jj, i));
+                        s.set(jj, i, qi);
+                        sum[0] = fma(B.get(jj, i), qi, sum[0]);
+                    });
+                } else {  // last backward step: apply gamma = (dx.dg)/(dg.dg) of the newest pair
+                    const double gam = sh_gam[(upper - 1) % kM];
+                    pass_ab(A, B, [&](int jj, int i) {
+                        const double dgi = A.get(jj, i);
+                        const double si = gam * fma(-al, dgi, s.get(jj, i));
+                        s.set(jj, i, si);
+                        sum[0] = fma(dgi, si, sum[0]);
+                    });
+                }
+                // the next step's vectors, their first trips on the way before this step's exchange
+                if (index > lower) {
+                    A = hdg((index - 2) % kM);
+                    fetch(A);
+                    if (index - 1 > lower) {
+                        B = hdx((index - 3) % kM);
+                        fetch(B);
+                    }
+                } else {   // the first forward step
+                    A = hdx((lower - 1) % kM);
+                    fetch(A);
+                    if (lower < upper) {
+                        B = hdg(lower % kM);
+                        fetch(B);
+                    } else {
+                        fetch(g);
+                    }
+                }
+                reduce<1, 0>(sum, mx);
+                dot = sum[0];
+            }
+            // forward pass
+            for (int index = lower; index <= upper; ++index) {
+                const int slot = (index - 1) % kM;
+                const double beta = sh_rho[slot] * dot;
+                const double coef = sh_alpha[slot] - beta;
+                double sum[1] = {0.0}, mx[1] = {0.0};
+                if (index < upper) {
+                    pass_ab(A, B, [&](int jj, int i) {
+                        const double si = fma(A.get(jj, i), coef, s.get(jj, i));
+                        s.set(jj, i, si);
+                        sum[0] = fma(B.get(jj, i), si, sum[0]);
+                    });
+                    A = hdx(index % kM);
+                    fetch(A);
+                    if (index + 1 < upper) {
+                        B = hdg((index + 1) % kM);
+                        fetch(B);
+                    } else {
+                        fetch(g);
+                    }
+                } else {
+                    pass_ab(A, g, [&](int jj, int i) {
+                        const double si = -fma(A.get(jj, i), coef, s.get(jj, i));
+                        s.set(jj, i, si);
+                        sum[0] = fma(g.get(jj, i), si, sum[0]);
+                    });
+                }
+                reduce<1, 0>(sum, mx);
+                dot = sum[0];
+            }
+            return dot;
+        } else {
+            (void)upper; (void)lower;
+            return dot0;
+        }
+    }
+
     // -- phase 2: zhat_at_theta -- Optim LBFGS + HagerZhang on -logLike from the z prepared by begin()
     __device__ void solve(int p) {
         const int64_t ld = a.ld;
@@ -1324,6 +1438,9 @@ struct Solver {
                 }, s);
                 reduce<1, 0>(sum, mx);
                 dphi_0 = sum[0];
+            } else if constexpr (kPrefetchTwoLoop) {
+                hist_words += h;
+                dphi_0 = twoloop_prefetched(upper, lower, dot0);
             } else {
                 hist_words += h;
                 double dot = dot0;
