@@ -1319,6 +1319,7 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
         const int g = atoi(e);
         if (g >= 1 && g < nworkers) nworkers = g;
     }
+    if (getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) nworkers = (int)nprob;   // test hook: more workgroups than can be resident at once
     const int grid = nworkers + 1;
     shape.grid = grid;
     a.scratch_stride = place_scratch_vectors(pl) * c->ld;
@@ -1352,9 +1353,13 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     if (rc) return rc;
     if (trace) fprintf(stderr, "[muse_run_device] launch call %.1f us, kernel + wait %.1f us (%d iterations)\n", t_b - t_a, now_us() - t_b, r.status[0]);
     c->area_inflight[0] = false;
+    if (r.status[1] == 100) {   // a bounded wait of the loop kernel expired (it also raised the error word: clear it)
+        (void)check_error_flag(c);
+        return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident at once (another process on "
+                                  "this GPU?); muse_run gives the same results with one launch per iteration");
+    }
     rc = check_error_flag(c);
     if (rc) return rc;
-    if (r.status[1] == 100) return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident");
     if (r.status[1] != 0) return step_error(r.status[1]);
     const int n = r.status[0];
     *niter_out = n;

@@ -398,10 +398,23 @@ class HipMuseProblem(AbstractMuseProblem):
         info = np.zeros((maxsteps, nsims + 1), dtype=_capi.INFO_DTYPE)
         theta = np.zeros(self.ntheta)
         n = C.c_int32()
-        device_loop = True if device_loop is None else bool(device_loop)   # default: the device-resident loop (measured faster)
+        auto = device_loop is None
+        device_loop = True if auto else bool(device_loop)   # default: the device-resident loop (measured faster)
         fn = self._lib.muse_run_device if device_loop else self._lib.muse_run
-        self._check(fn(self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta),
-                       _capi.ptr(hist), _capi.ptr(gs), _capi.ptr(info)))
+        args = (self._ctx, _seed_of(rng), _capi.ptr(th0), C.byref(o), C.byref(n), _capi.ptr(theta), _capi.ptr(hist), _capi.ptr(gs),
+                _capi.ptr(info))
+        try:
+            self._check(fn(*args))
+        except _capi.MuseError as e:
+            # The loop kernel needs all of its workgroups resident at once; on a GPU that something else is using they may
+            # not be, its bounded waits expire and the run is reported as failed.  When the caller left the choice of loop to
+            # the library -- and the run did not start from the resident MAPs, which the aborted attempt has touched -- the
+            # host loop takes over: the same bits as the device loop would have given.
+            if not (auto and not z0_warm and "not all resident" in str(e)):
+                raise
+            warnings.warn("museinference: the device-resident muse! loop could not keep its workgroups resident (is the GPU shared?); "
+                          "running the host loop instead", RuntimeWarning)
+            self._check(self._lib.muse_run(*args))
         return n.value, theta, hist[: n.value], gs[: n.value], info[: n.value]
 
     def set_normals_cache(self, enabled):

@@ -189,6 +189,28 @@ def test_device_loop_reports_errors_like_the_host_loop(gpu, M):
     prob.close()
 
 
+def test_loop_kernel_that_cannot_stay_resident_falls_back_to_the_host_loop(gpu, M, monkeypatch):
+    """The loop kernel's workgroups meet once per iteration, so all of them must be resident.  When they cannot be (here: a
+    test hook launches one worker per element, 301 workgroups of a placement that fits 256), its bounded waits expire, the
+    call reports it -- and run_muse, left to choose the loop itself, runs the host loop instead: the same bits as an
+    undisturbed run.  The context stays usable."""
+    x = np.cos(0.1 * np.arange(10000))
+    prob = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    kw = dict(nsims=300, maxsteps=3, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+    want = prob.run_muse(5, [0.8], device_loop=False, **kw)
+    monkeypatch.setenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE", "1")
+    with pytest.raises(M.MuseError, match="not all resident"):
+        prob.run_muse(5, [0.8], device_loop=True, **kw)
+    with pytest.warns(RuntimeWarning, match="host loop"):
+        got = prob.run_muse(5, [0.8], **kw)
+    monkeypatch.delenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2][:, :-1], want[2][:, :-1])
+    assert np.array_equal(got[3], want[3])
+    again = prob.run_muse(5, [0.8], device_loop=True, **kw)     # the loop kernel itself, afterwards
+    assert again[0] == want[0] and np.array_equal(again[1], want[1]) and np.array_equal(again[3], want[3])
+    prob.close()
+
+
 # ---- row f3: checkpoint / resume / save_MAPs on the HIP path ---------------------------------------------
 def test_checkpoint_resume_and_saved_maps_on_hip(gpu, M, O, tmp_path):
     N = 3000
