@@ -25,6 +25,13 @@ struct Prefetch {
     bool g_pending; // n1 was sent to the g area while another problem is being solved: a solve that comes to need g
                     // (a second L-BFGS iteration) waits for the loads to land and drops the prefetch (Solver::drop_g_prefetch)
 };
+// Cache policy of the cached normals' loads: they are read ONCE per outer iteration by one compute unit and come back from
+// the Infinity Cache an iteration later -- `nt` (aux = 2; MI355X_MICROARCH.md, nt-weights) keeps them from displacing what
+// the same compute unit re-reads sooner from its XCD's L2: the MAPs it stored for the next iteration's warm starts.
+#ifndef MUSE_NORMALS_AUX
+#define MUSE_NORMALS_AUX 2
+#endif
+constexpr int kNormalsAux = MUSE_NORMALS_AUX;
 typedef __attribute__((address_space(1))) const void* glds_src_t;
 typedef __attribute__((address_space(3))) void* glds_dst_t;
 // both: between two iterations (x and g areas free): n2 -> x area (or the data vector), n1 -> g area.  !both: while another
@@ -50,8 +57,8 @@ __device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int 
         const int i0 = 2 * (tl + j * T);
         if (i0 < (int)ld) {   // (phantom pairs stay out of LDS: they would land beyond the vector)
             const int base = 2 * (wave0 + j * T);         // the wave's first element of this row: wave-uniform
-            if (pf.have_n2 || pf.have_x) __builtin_amdgcn_global_load_lds((glds_src_t)(src_x + i0), (glds_dst_t)(lds_x + base), 16, 0, 0);
-            if (pf.have_n1) __builtin_amdgcn_global_load_lds((glds_src_t)(src_g + i0), (glds_dst_t)(lds_g + base), 16, 0, 0);
+            if (pf.have_n2 || pf.have_x) __builtin_amdgcn_global_load_lds((glds_src_t)(src_x + i0), (glds_dst_t)(lds_x + base), 16, 0, kNormalsAux);
+            if (pf.have_n1) __builtin_amdgcn_global_load_lds((glds_src_t)(src_g + i0), (glds_dst_t)(lds_g + base), 16, 0, kNormalsAux);
         }
     }
 }
@@ -963,11 +970,11 @@ struct Solver {
                     }
                     if (!n2_here) {
 #pragma unroll
-                        for (int j = 0; j < EPT; ++j) load_f64x2(n2r, 2 * (tl + j * T), c2[j][0], c2[j][1]);
+                        for (int j = 0; j < EPT; ++j) load_f64x2<kNormalsAux>(n2r, 2 * (tl + j * T), c2[j][0], c2[j][1]);
                     }
                     if (!n1_here) {
 #pragma unroll
-                        for (int j = 0; j < EPT; ++j) load_f64x2(n1r, 2 * (tl + j * T), c1[j][0], c1[j][1]);
+                        for (int j = 0; j < EPT; ++j) load_f64x2<kNormalsAux>(n1r, 2 * (tl + j * T), c1[j][0], c1[j][1]);
                     }
                     if (n1_here) {   // each pair at the slot of the thread that owns it
 #pragma unroll
