@@ -121,6 +121,13 @@ int muse_set_element_split(muse_ctx* ctx, int split);
  * and -- stencil model in a cluster -- whether the search direction is kept in LDS.  For reports (bench.py's roofline
  * accounts the bytes of the placement that ran); any pointer may be NULL. */
 int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element, int* resident, int* direction_in_lds);
+/* Run-time constants of a user-supplied model (include/muse_model.h: a header with MUSE_MODEL_NCONST reads them through
+ * muse_const(k, i)) -- what a closure of the reference's SimpleMuseProblem captures (src/simple.jl:79-89): a known spectrum,
+ * a noise-variance map, a mask -- without compiling their values into the library: vector k < MUSE_MODEL_NCONST, `count` = N
+ * finite doubles (host or device memory).  May be called again at any time (it waits for the context's launches first).
+ * One set per model library and process is installed at a time; a context re-installs its own before it launches if another
+ * context of the library has installed others since.  Libraries whose model declares no constants refuse the call. */
+int muse_set_constants(muse_ctx* ctx, int k, const double* values, int64_t count, int mem);
 /* The normals cache of plain maps.  A simulation's stream depends only on (seed, simulation index) (split_rng,
  * src/util.jl:87-92), and the reference's loops draw the same streams again and again -- every iteration of muse!
  * (src/muse.jl:134,169), get_J! after it (:506), every grid point of get_H! (:430).  The native loops and the

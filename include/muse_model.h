@@ -40,6 +40,17 @@
  * ElementwiseModel.from_source(name, source, constants={"P": array}) writes for you -- or as a formula in i: what a closure of
  * the reference's SimpleMuseProblem would capture.  A model that does not need it ignores it.
  *
+ * RUN-TIME constants (round 4).  A table compiled into the header fixes its values at build time: a new spectrum is a new
+ * header, a 40-second build and a library of its own.  A header that says
+ *     #define MUSE_MODEL_NCONST 2                      (before including this file; at most MUSE_MODEL_MAX_CONST)
+ * may instead read  muse_const(k, i),  k < MUSE_MODEL_NCONST:  element i of constant vector k as the caller last set it --
+ * muse_set_constants(ctx, k, values, count) on the engine (muse_hip.h), mo_set_constants on the CPU checker -- and 1.0 for
+ * i >= count (the pad element and the phantom slots, as the compiled tables do) and while the vector has not been set (the
+ * engine's contract check evaluates the functions before any constant exists).  The values live in device memory and are read
+ * through one pointer per vector: one set of constants per model library and process at a time (a context that launches after
+ * another context of the same library has set its own constants re-installs its own first).
+ * ElementwiseModel.from_source(name, source, runtime_constants=["P", ...]) writes the #define and an accessor P(i) per name.
+ *
  * Requirements the engine checks when a context is created (it evaluates the functions on the host):
  *     muse_model_grad(iv, 0, 0, &acc, N) == 0 leaving acc as it was, and muse_model_score_term(0, 0, N) == 0
  *         (vectors are padded to an even length with one zero element, which must not contribute).
@@ -53,5 +64,34 @@
 #define MUSE_MODEL_H
 #ifndef MUSE_MODEL_FN
 #define MUSE_MODEL_FN static inline
+#endif
+#define MUSE_MODEL_MAX_CONST 4
+#ifdef MUSE_MODEL_NCONST
+#if MUSE_MODEL_NCONST < 1 || MUSE_MODEL_NCONST > MUSE_MODEL_MAX_CONST
+#error "MUSE_MODEL_NCONST must be in [1, MUSE_MODEL_MAX_CONST]"
+#endif
+/* the vectors: defined once per program that compiles a model header (the engine's muse_engine.cpp / muse_kernels.hip,
+ * the checker's muse_oracle.c) */
+#ifdef __cplusplus
+extern "C" {
+#endif
+extern const double* muse_host_consts[MUSE_MODEL_MAX_CONST];
+extern long muse_host_const_len[MUSE_MODEL_MAX_CONST];
+#ifdef __cplusplus
+}
+#endif
+#if defined(__HIPCC__)
+extern __device__ const double* muse_dev_consts[MUSE_MODEL_MAX_CONST];
+extern __device__ long muse_dev_const_len[MUSE_MODEL_MAX_CONST];
+#endif
+MUSE_MODEL_FN double muse_const(int k, long i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const long n = muse_dev_const_len[k];
+    return i < n ? muse_dev_consts[k][i] : 1.0;
+#else
+    const long n = muse_host_const_len[k];
+    return i < n ? muse_host_consts[k][i] : 1.0;
+#endif
+}
 #endif
 #endif

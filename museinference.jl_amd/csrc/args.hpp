@@ -249,6 +249,7 @@ hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const 
 bool loop_supported(const LaunchShape& s);
 hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid);
 hipError_t launch_loop(const LaunchShape& s, const BatchArgs& a, const LoopArgs& l, hipStream_t stream);
+hipError_t install_constants(const double* const* dev_ptrs, const long* lens, hipStream_t stream);  // a user model's run-time constants (muse_model.h)
 size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta);  // LDS of the loop kernel beside the map kernel's
 size_t loop_step_bytes(int64_t nprob, int ntheta);              // the step's own arrays (they alias x and g in the LDS-resident layout)
 constexpr int kArgsDoubles = (int)((kArgsHeadBytes + 15) / 16 * 2);  // LDS copy of the kernel arguments (without the trailing maps[])

@@ -107,6 +107,11 @@ struct muse_ctx {
     // nc_count == 0), and the simulation range of the last plain map (a range is cached when it is asked for AGAIN)
     uint64_t nc_seed = 0, nc_seen_seed = 0;
     int64_t nc_sim0 = 0, nc_count = 0, nc_seen_sim0 = 0, nc_seen_count = 0;
+    // run-time constants of a user model (include/muse_model.h: muse_const): this context's device vectors and host copies
+    double* consts_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* consts_host[4] = {nullptr, nullptr, nullptr, nullptr};
+    long consts_len[4] = {0, 0, 0, 0};
+    bool has_consts = false;
     bool nc_auto = true;                 // muse_set_normals_cache: plain maps may store / load the normals of repeated simulations
     double* cl_part = nullptr;           // [cl_cap][kClusterSlotDoubles]
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
@@ -429,6 +434,44 @@ static int settle_area(muse_ctx* c, int area) {
     });
 }
 
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_NCONST)
+// The model's run-time constants as its functions see them (include/muse_model.h): on the host through these, on the device
+// through the symbols of muse_kernels.hip -- ONE set per process and library, the set of the context that installed it last.
+extern "C" {
+const double* muse_host_consts[MUSE_MODEL_MAX_CONST] = {nullptr, nullptr, nullptr, nullptr};
+long muse_host_const_len[MUSE_MODEL_MAX_CONST] = {0, 0, 0, 0};
+}
+static muse_ctx* g_consts_owner = nullptr;
+static int install_ctx_constants(muse_ctx* c) {
+    const double* ptrs[MUSE_MODEL_MAX_CONST];
+    long lens[MUSE_MODEL_MAX_CONST];
+    for (int k = 0; k < MUSE_MODEL_MAX_CONST; ++k) {
+        ptrs[k] = c->consts_dev[k];
+        lens[k] = c->consts_len[k];
+        muse_host_consts[k] = c->consts_host[k];
+        muse_host_const_len[k] = c->consts_len[k];
+    }
+    const hipError_t e = install_constants(ptrs, lens, c->stream);
+    if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("installing the model's constants: ") + hipGetErrorString(e));
+    g_consts_owner = c;
+    return MUSE_OK;
+}
+#define MUSE_OWN_CONSTANTS(c)                                                     \
+    do {                                                                          \
+        if ((c)->has_consts && g_consts_owner != (c)) {                           \
+            const int rc_ = for_each_lane((c), [&]() -> int {                     \
+                HIPCHK(hipStreamSynchronize((c)->stream));                        \
+                return MUSE_OK;                                                   \
+            });                                                                   \
+            if (rc_) return rc_;                                                  \
+            const int rc2_ = install_ctx_constants(c);                            \
+            if (rc2_) return rc2_;                                                \
+        }                                                                         \
+    } while (0)
+#else
+#define MUSE_OWN_CONSTANTS(c) do { } while (0)
+#endif
+
 extern "C" {
 
 const char* muse_last_error(void) { return g_err.c_str(); }
@@ -563,6 +606,16 @@ int muse_ctx_destroy(muse_ctx* c) {
     free_run_buffers(c);
     hipFree(c->cl_part); hipFree(c->cl_state); hipHostFree(c->error_flag); hipHostFree(c->clock_pin);
     hipFree(c->ncache);
+    for (int k = 0; k < 4; ++k) {
+        if (c->consts_dev[k]) hipFree(c->consts_dev[k]);
+        free(c->consts_host[k]);
+    }
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_NCONST)
+    if (g_consts_owner == c) {
+        g_consts_owner = nullptr;
+        for (int k = 0; k < MUSE_MODEL_MAX_CONST; ++k) { muse_host_consts[k] = nullptr; muse_host_const_len[k] = 0; }
+    }
+#endif
     hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
     hipFree(c->small_dev); if (c->tsample_dev) hipFree(c->tsample_dev); if (c->tsample_pin) hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
@@ -580,7 +633,10 @@ int muse_ctx_destroy(muse_ctx* c) {
 static int check_ctx(muse_ctx* c) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    return use_lane(c, 0);   // every entry point works on lane 0 unless it says otherwise (map_async_impl)
+    const int rc = use_lane(c, 0);   // every entry point works on lane 0 unless it says otherwise (map_async_impl)
+    if (rc) return rc;
+    MUSE_OWN_CONSTANTS(c);           // (a user model's run-time constants: this context's, if another one installed its own since)
+    return MUSE_OK;
 }
 static hipMemcpyKind in_kind(int mem) { return mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; }
 static hipMemcpyKind out_kind(int mem) { return mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost; }
@@ -664,6 +720,36 @@ int muse_synchronize(muse_ctx* c) {
         HIPCHK(hipStreamSynchronize(c->stream));
         return MUSE_OK;
     });
+}
+int muse_set_constants(muse_ctx* c, int k, const double* values, int64_t count, int mem) {
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_NCONST)
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (k < 0 || k >= MUSE_MODEL_NCONST) return fail(MUSE_ERR_INVALID, "constant index out of range (MUSE_MODEL_NCONST of the model's header)");
+    if (!values || count != c->N) return fail(MUSE_ERR_INVALID, "a constant vector has one entry per element (count == N)");
+    rc = muse_synchronize(c);   // nothing in flight reads the vector that is about to be replaced
+    if (rc) return rc;
+    if (!c->consts_dev[k]) {
+        if (hipMalloc(&c->consts_dev[k], (size_t)count * sizeof(double)) != hipSuccess) return fail(MUSE_ERR_ALLOC, "hipMalloc(constants) failed");
+        c->consts_host[k] = (double*)malloc((size_t)count * sizeof(double));
+        if (!c->consts_host[k]) return fail(MUSE_ERR_ALLOC, "malloc(constants) failed");
+    }
+    HIPCHK(hipMemcpyAsync(c->consts_dev[k], values, (size_t)count * sizeof(double), in_kind(mem), c->stream));
+    HIPCHK(hipMemcpyAsync(c->consts_host[k], values, (size_t)count * sizeof(double),
+                          mem == MUSE_MEM_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < count; ++i)
+        if (!isfinite(c->consts_host[k][i])) {
+            c->consts_len[k] = 0;
+            return fail(MUSE_ERR_INVALID, "constants must be finite");
+        }
+    c->consts_len[k] = (long)count;
+    c->has_consts = true;
+    return install_ctx_constants(c);
+#else
+    (void)c; (void)k; (void)values; (void)count; (void)mem;
+    return fail(MUSE_ERR_INVALID, "this library's model declares no run-time constants (MUSE_MODEL_NCONST, include/muse_model.h)");
+#endif
 }
 int muse_set_normals_cache(muse_ctx* c, int enabled) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");

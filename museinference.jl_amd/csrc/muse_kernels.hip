@@ -864,6 +864,23 @@ size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta) {
 }
 size_t loop_step_bytes(int64_t nprob, int ntheta) { return ((size_t)nprob * ntheta + 24) * sizeof(double) + sizeof(StepWork); }
 
+// Run-time constants of a user model (include/muse_model.h: muse_const): the device-side vectors' pointers and lengths.
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_NCONST)
+}  // namespace muse
+__device__ const double* muse_dev_consts[MUSE_MODEL_MAX_CONST];
+__device__ long muse_dev_const_len[MUSE_MODEL_MAX_CONST];
+namespace muse {
+hipError_t install_constants(const double* const* dev_ptrs, const long* lens, hipStream_t st) {
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(muse_dev_consts), dev_ptrs, sizeof(const double*) * MUSE_MODEL_MAX_CONST, 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(muse_dev_const_len), lens, sizeof(long) * MUSE_MODEL_MAX_CONST, 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+}
+#else
+hipError_t install_constants(const double* const*, const long*, hipStream_t) { return hipErrorNotSupported; }
+#endif
+
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t st) {
     const int grid = (int)((a.N + 255) / 256 < 4096 ? (a.N + 255) / 256 : 4096);
 #ifdef MUSE_USER_MODEL_HEADER

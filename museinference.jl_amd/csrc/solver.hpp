@@ -25,11 +25,12 @@ struct Prefetch {
     bool g_pending; // n1 was sent to the g area while another problem is being solved: a solve that comes to need g
                     // (a second L-BFGS iteration) waits for the loads to land and drops the prefetch (Solver::drop_g_prefetch)
 };
-// Cache policy of the cached normals' loads: they are read ONCE per outer iteration by one compute unit and come back from
-// the Infinity Cache an iteration later -- `nt` (aux = 2; MI355X_MICROARCH.md, nt-weights) keeps them from displacing what
-// the same compute unit re-reads sooner from its XCD's L2: the MAPs it stored for the next iteration's warm starts.
+// Cache policy of the cached normals' loads.  They are read once per outer iteration by one compute unit; `nt` (aux = 2) would
+// keep them from displacing the MAPs the same compute unit stored for the next iteration's warm starts from its XCD's L2 --
+// measured (round 4, one box, interleaved): SLOWER, host loop 53.0 against 46-49 us per iteration, loop kernel 44.6 against
+// 42-46.  Plain loads stay; the knob is kept for the next idea.
 #ifndef MUSE_NORMALS_AUX
-#define MUSE_NORMALS_AUX 2
+#define MUSE_NORMALS_AUX 0
 #endif
 constexpr int kNormalsAux = MUSE_NORMALS_AUX;
 typedef __attribute__((address_space(1))) const void* glds_src_t;

@@ -41,7 +41,7 @@ class ElementwiseModel:
         return cls(name, os.path.join(_build.MODELS_DIR, name + ".h"))
 
     @classmethod
-    def from_source(cls, name, source, directory=None, constants=None):
+    def from_source(cls, name, source, directory=None, constants=None, runtime_constants=None):
         """Write `source` to <directory>/<name>_<hash>.h (default: museinference.jl_amd/models/user/, or $MUSE_MODEL_DIR/headers) and wrap it; the
         library is named after name and hash, so that an edited source gets a library of its own.
 
@@ -54,8 +54,22 @@ class ElementwiseModel:
         directory = directory or (os.path.join(_build.model_out_dir(), "headers") if os.environ.get("MUSE_MODEL_DIR")
                                   else os.path.join(_build.MODELS_DIR, "user"))
         os.makedirs(directory, exist_ok=True)
+        if constants and runtime_constants:
+            raise ValueError("give the per-element constants either as compiled tables (constants=) or at run time (runtime_constants=)")
         if constants:
             source = cls._tables(constants) + source
+        if runtime_constants:
+            # run-time constants (include/muse_model.h, muse_const): the values are set on the problem -- HipMuseProblem(...,
+            # constants={"P": array}) / set_constants -- and can be replaced without touching the library
+            names = list(runtime_constants)
+            for k in names:
+                if not re.fullmatch(r"[A-Za-z][A-Za-z0-9_]*", str(k)):
+                    raise ValueError(f"runtime_constants: {k!r} is not a C identifier")
+            if not 1 <= len(names) <= 4:
+                raise ValueError("runtime_constants: between 1 and 4 names (MUSE_MODEL_MAX_CONST)")
+            head = [f"#define MUSE_MODEL_NCONST {len(names)}", '#include "muse_model.h"']
+            head += [f"MUSE_MODEL_FN double {k}(long i) {{ return muse_const({j}, i); }}" for j, k in enumerate(names)]
+            source = "\n".join(head) + "\n" + source
         tag = hashlib.sha256(source.encode()).hexdigest()[:10]
         path = os.path.join(directory, f"{name}_{tag}.h")
         if not os.path.exists(path):
@@ -63,6 +77,7 @@ class ElementwiseModel:
                 f.write(source)
         m = cls(name, path)
         m._libname = f"{name}_{tag}"
+        m.runtime_constants = list(runtime_constants) if runtime_constants else []
         return m
 
     @staticmethod

@@ -167,7 +167,10 @@ class HipMuseProblem(AbstractMuseProblem):
     supports_native_muse = True  # muse_() may hand the whole outer loop to muse_run (class attribute: wrappers
                                  # that forward attribute access to a HipMuseProblem do not inherit it)
 
-    def __init__(self, x, model="funnel", ntheta=1, prior=None, device=0, N=None):
+    def __init__(self, x, model="funnel", ntheta=1, prior=None, device=0, N=None, constants=None):
+        """constants: {"P": array of N doubles, ...} for a user model written with run-time constants
+        (ElementwiseModel.from_source(..., runtime_constants=["P", ...]); include/muse_model.h, muse_const) -- what the
+        reference's SimpleMuseProblem closures capture; set_constants replaces a vector later, without rebuilding anything."""
         from .models import ElementwiseModel
         if isinstance(model, ElementwiseModel):     # a user's model: its own engine library, model id MUSE_MODEL_USER
             self._lib = _capi.load_library(model.library())
@@ -190,6 +193,15 @@ class HipMuseProblem(AbstractMuseProblem):
         self._ctx = ctx
         if self.x is not None:
             self._check(self._lib.muse_set_data(self._ctx, _capi.ptr(self.x), _capi.MEM_HOST))
+        for name, values in (constants or {}).items():
+            self.set_constants(name, values)
+
+    def set_constants(self, name, values):
+        """Run-time constant vector `name` (or its index) of the user model: N finite doubles (muse_set_constants)."""
+        names = getattr(self.user_model, "runtime_constants", None) or []
+        k = names.index(name) if isinstance(name, str) else int(name)
+        v = _capi.f8(values, self.N)
+        self._check(self._lib.muse_set_constants(self._ctx, k, _capi.ptr(v), v.size, _capi.MEM_HOST))
 
     def close(self):
         if getattr(self, "_ctx", None):

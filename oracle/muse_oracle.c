@@ -97,6 +97,22 @@ static double* ws_alloc(size_t n) {
 #define MUSE_MODEL_FN static inline
 #include MO_USER_MODEL_HEADER
 const char* mo_user_model_name(void) { return MUSE_MODEL_NAME; }
+#ifdef MUSE_MODEL_NCONST /* run-time constants (include/muse_model.h: muse_const): this checker's copies */
+const double* muse_host_consts[MUSE_MODEL_MAX_CONST] = {0, 0, 0, 0};
+long muse_host_const_len[MUSE_MODEL_MAX_CONST] = {0, 0, 0, 0};
+int mo_set_constants(int k, const double* values, int64_t count) {
+    if (k < 0 || k >= MUSE_MODEL_NCONST || !values || count < 1) return -1;
+    double* copy = (double*)malloc((size_t)count * sizeof(double));
+    if (!copy) return -2;
+    memcpy(copy, values, (size_t)count * sizeof(double));
+    free((void*)muse_host_consts[k]);
+    muse_host_consts[k] = copy;
+    muse_host_const_len[k] = (long)count;
+    return 0;
+}
+#else
+int mo_set_constants(int k, const double* values, int64_t count) { (void)k; (void)values; (void)count; return -3; }
+#endif
 #ifdef MUSE_MODEL_N /* a model with per-element tables is built for one N */
 #define MO_USER_CHECK_N(N) do { if ((N) != (int64_t)(MUSE_MODEL_N)) abort(); } while (0)
 #else
@@ -104,6 +120,7 @@ const char* mo_user_model_name(void) { return MUSE_MODEL_NAME; }
 #endif
 #else
 const char* mo_user_model_name(void) { return 0; }
+int mo_set_constants(int k, const double* values, int64_t count) { (void)k; (void)values; (void)count; return -3; }
 #endif
 
 #define MO_STATUS_G_CONVERGED 0

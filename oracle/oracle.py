@@ -127,6 +127,15 @@ class user_model:
         return False
 
 
+def set_constants(k, values):
+    """Run-time constant vector k of the user model whose build is selected (`with user_model(...)`): include/muse_model.h,
+    muse_const -- the checker's counterpart of muse_set_constants."""
+    v = np.ascontiguousarray(np.asarray(values, dtype=np.float64)).reshape(-1)
+    rc = lib().mo_set_constants(C.c_int(int(k)), v.ctypes.data_as(C.c_void_p), C.c_int64(v.size))
+    if rc != 0:
+        raise ValueError(f"mo_set_constants({k}) -> {rc}: the selected build's model declares no such constant")
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

@@ -469,6 +469,80 @@ def test_model_with_per_element_constants_on_the_oracle(M, O, tmp_path):
     assert other.header != model.header and other.library_name != model.library_name
 
 
+def test_runtime_constants_equal_compiled_tables_on_the_oracle(M, O, tmp_path):
+    """Run-time constants (include/muse_model.h: MUSE_MODEL_NCONST, muse_const; ElementwiseModel.from_source(...,
+    runtime_constants=["P"])): the same model source reads P(i) from a vector set at run time instead of from a table
+    compiled into the header -- the same bits on the checker, and another vector without another build."""
+    N = 3001
+    P = spectrum(N)
+    table = M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": P})
+    runtime = M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, directory=str(tmp_path), runtime_constants=["P"])
+    assert "#define MUSE_MODEL_NCONST 1" in open(runtime.header).read() and runtime.runtime_constants == ["P"]
+    th = [0.5, -0.7]
+    with O.user_model(table.header, table.library_name):
+        xt, zt = O.sample_x_z("user", N, 99, 5, th)
+        gt, zht, it = O.map_and_score_batch("user", N, 42, 0, 4, th, atol=1e-6, z0_mode=0)
+    with O.user_model(runtime.header, runtime.library_name):
+        O.set_constants(0, P)
+        xr, zr = O.sample_x_z("user", N, 99, 5, th)
+        gr, zhr, ir = O.map_and_score_batch("user", N, 42, 0, 4, th, atol=1e-6, z0_mode=0)
+        assert np.array_equal(xt, xr) and np.array_equal(zt, zr) and np.array_equal(gt, gr) and np.array_equal(zht, zhr)
+        assert it.tobytes() == ir.tobytes()
+        O.set_constants(0, 2.0 * P)
+        x2, _ = O.sample_x_z("user", N, 99, 5, th)
+        assert not np.array_equal(x2, xr)
+        with pytest.raises(ValueError):
+            O.set_constants(1, P)                      # the header declares one constant
+    with pytest.raises(ValueError):
+        M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, directory=str(tmp_path), constants={"P": P}, runtime_constants=["P"])
+    with pytest.raises(ValueError):
+        M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, directory=str(tmp_path), runtime_constants=["P q"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nth,placement,split", [(10000, 2, -1, 0), (9999, 1, -1, 4), (70001, 2, -1, 0), (2001, 1, 0, 0)])
+def test_runtime_constants_on_hip(gpu, M, O, N, nth, placement, split):
+    """The same on the engine (muse_set_constants): ONE library for every N and every P -- draw bit for bit and MAP / counts /
+    scores against the checker with the same vector, in the resident, cluster and streaming placements; the vector replaced
+    without a build; two contexts of the library with different vectors, launching in turn, each see their own; the native
+    muse! loops run on it."""
+    model = M.ElementwiseModel.from_source("spectrum", SPECTRUM_SOURCE, runtime_constants=["P"])
+    P = spectrum(N)
+    truth = [0.5, -0.7][:nth]
+    with O.user_model(model.header, model.library_name):
+        O.set_constants(0, P)
+        x, _ = O.sample_x_z("user", N, 99, M.DATA_SIM, truth)
+        prob = make(M, x, N, nth, placement, split, model=model, prior=M.GaussianPrior(0.0, 3.0))
+        with pytest.raises((M.MuseError, ValueError)):
+            prob.set_constants("P", P[:-1])            # one entry per element
+        with pytest.raises(M.MuseError):
+            prob.set_constants("P", np.where(np.arange(N) == 3, np.inf, P))
+        prob.set_constants("P", P)
+        other = make(M, x, N, nth, placement, split, model=model, prior=M.GaussianPrior(0.0, 3.0))
+        other.set_constants("P", 3.0 * P)              # installs ITS vector for the library ...
+        for vec, p in ((P, prob), (3.0 * P, other), (P, prob)):     # ... and every context still sees its own when it launches
+            O.set_constants(0, vec)
+            xs, zs = p.sample_x_z(M.SimRng(5, 3), truth)
+            xo, zo = O.sample_x_z("user", N, 5, 3, truth)
+            assert np.array_equal(xs, xo) and np.array_equal(zs, zo)
+            n = 6
+            g, info = p.map_and_score_batch(42, 0, n, truth, include_data=True, atol=1e-6, z0_mode=0)
+            go, zo, io = O.map_and_score_batch("user", N, 42, 0, n, truth, atol=1e-6, x_data=x, z0_mode=0)
+            same = assert_same_path_or_close(info, io, p.get_zhat(0, n + 1), zo, g, go, 1e-6, truth, "funnel")
+            assert same.all()
+        other.close()
+        prob.set_constants("P", 2.0 * P)               # another spectrum: no build
+        O.set_constants(0, 2.0 * P)
+        g, info = prob.map_and_score_batch(42, 0, 4, truth, atol=1e-6, z0_mode=1)
+        go, zo, io = O.map_and_score_batch("user", N, 42, 0, 4, truth, atol=1e-6, z0_mode=1)
+        assert np.array_equal(info["f_calls"], io["f_calls"])
+        np.testing.assert_allclose(g, go, rtol=1e-9)
+    a = prob.run_muse(7, [0.0] * nth, nsims=24, maxsteps=4, theta_rtol=0.0, atol=1e-4, alpha=0.8, device_loop=False)
+    b = prob.run_muse(7, [0.0] * nth, nsims=24, maxsteps=4, theta_rtol=0.0, atol=1e-4, alpha=0.8, device_loop=True)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    prob.close()
+
+
 SPECTRUM_SIZES = (10000, 9999, 70001)     # (tests/prebuild_models.py compiles these libraries ahead of time)
 
 
