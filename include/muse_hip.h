@@ -128,6 +128,17 @@ int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element
  * One set per model library and process is installed at a time; a context re-installs its own before it launches if another
  * context of the library has installed others since.  Libraries whose model declares no constants refuse the call. */
 int muse_set_constants(muse_ctx* ctx, int k, const double* values, int64_t count, int mem);
+/* The functions of a user-supplied model's header evaluated on the HOST for one element (include/muse_model.h) -- what the
+ * reference gets from AD for free has to be checkable for hand-written derivatives (src/simple.jl:84-85): Python's
+ * check_model_consistency differentiates these values numerically.  out[10] = { muse_model_grad's return value, the objective
+ * term it adds to its accumulator (A + iv B), muse_model_score_term (B), ozz, ozx, bz, bx of muse_model_second, and z, x,
+ * dx/dsd of muse_model_sample / muse_model_dx_dsd at (sd, n1, n2) }; entries 3-6 and 9 are NaN when the header does not define
+ * MUSE_MODEL_SECOND.  The model's run-time constants are the context's; a model without them needs no context (ctx may be
+ * NULL, and no GPU is touched).  Built-in models: MUSE_ERR_INVALID. */
+int muse_model_eval(muse_ctx* ctx, double iv, double sd, double x, double z, double n1, double n2, int64_t i, double* out);
+/* 1 when the library's model supplies second derivatives (the built-in models; a user header with MUSE_MODEL_SECOND), i.e.
+ * when muse_implicit_H_* accept it; 0 otherwise. */
+int muse_model_has_second(void);
 /* The normals cache of plain maps.  A simulation's stream depends only on (seed, simulation index) (split_rng,
  * src/util.jl:87-92), and the reference's loops draw the same streams again and again -- every iteration of muse!
  * (src/muse.jl:134,169), get_J! after it (:506), every grid point of get_H! (:430).  The native loops and the
@@ -281,7 +292,8 @@ int muse_fd_values_columns(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int6
  *   H = H1 - dFdtheta^T A^{-1} dFdtheta1, A = Hessian_z logLike at (x, zhat, theta0), A^{-1} by conjugate
  *   gradients (IterativeSolvers.cg defaults: x0 = 0, reltol sqrt(eps), maxiter = cg_maxiter, reference 100);
  *   zhat from zero(z) to `atol` (the reference hard-codes 1e-1 here, src/muse.jl:344).  The reference takes the
- *   derivative operands by nested AD; for the compiled-in models they are closed forms.
+ *   derivative operands by nested AD; for the compiled-in models they are closed forms, for a user-supplied model the
+ *   header's muse_model_second / muse_model_dx_dsd (include/muse_model.h; a header without them is refused).
  * Hs_out [nsims][ntheta][ntheta] host; cg_iters_out [nsims][ntheta] host (may be NULL; the
  * metadata[:implicit_diff_cg_hists] of src/muse.jl:405). */
 int muse_implicit_H_batch(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, const double* theta0,

@@ -57,8 +57,22 @@
  * Nothing differentiates the header: that muse_model_grad IS the derivative of the objective term and that muse_model_score_term
  * IS its B is the author's statement -- museinference_jl_amd.check_model_consistency(prob, theta) checks both against finite
  * differences of logLike through the problem's own operators (what AD guarantees in the reference, src/simple.jl:84-85).
- * Not supported for user models: the implicit-differentiation get_H! (muse_implicit_H_*: it needs second
- * derivatives) -- the finite-difference branch (muse_fd_*) is model-agnostic.
+ *
+ * SECOND DERIVATIVES (round 4, optional).  The implicit-differentiation get_H! (src/muse.jl:335-405; muse_implicit_H_* of
+ * muse_hip.h) differentiates the gradients once more: the reference does so by nested AD, a header says them.  A header that
+ * says   #define MUSE_MODEL_SECOND 1   also defines, with o_i(x, z) = 1/2 [A(x, z) + iv B(x, z)] the element's objective term,
+ *     MUSE_MODEL_FN void   muse_model_second(double iv, double x, double z, double* ozz, double* ozx, double* bz, double* bx, long i);
+ *         *ozz = d2 o / dz2,  *ozx = d2 o / dz dx,  *bz = dB / dz,  *bx = dB / dx        (finite at x = z = 0, i >= N)
+ *     MUSE_MODEL_FN double muse_model_dx_dsd(double sd, double n1, double n2, long i);
+ *         d x / d sd of muse_model_sample at fixed normals (the reference re-draws x(theta) from a copy of the rng, src/muse.jl:353-371)
+ * from which the engine forms, elementwise (k = the element's block, t_i = dx_i / dtheta_k = 1/2 sd_k dx/dsd),
+ *     Hessian_z logLike w        = -ozz_i w_i                      (src/muse.jl:373-379; CG as in the reference although it is diagonal)
+ *     d/dtheta_k grad_z logLike  = 1/2 iv_k bz_i                   (:361-365)
+ *     d/dtheta_k grad_z logLike(x(theta), zhat, theta0) = -ozx_i t_i      (:366-371)
+ *     H1[k][k] = 1/2 iv_k sum_{i in k} bx_i t_i                    (:353-358)
+ * (the funnel: ozz = 1 + iv, ozx = -1, bz = 2 z, bx = 0, dx/dsd = n1).  Without MUSE_MODEL_SECOND the implicit entries refuse
+ * the model and get_H! runs by finite differences (muse_fd_*: model-agnostic).  muse_model_eval of muse_hip.h evaluates the
+ * header's functions on the host for one element -- what check_model_consistency differentiates numerically.
  */
 #ifndef MUSE_MODEL_H
 #define MUSE_MODEL_H

@@ -78,6 +78,8 @@ SIGNATURES = {
     "muse_run_device": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_set_normals_cache": (_i, [_vp, _i]),
     "muse_set_constants": (_i, [_vp, _i, _vp, _i64, _i]),
+    "muse_model_eval": (_i, [_vp, _d, _d, _d, _d, _d, _d, _i64, _vp]),
+    "muse_model_has_second": (_i, []),
     "muse_run_sharded": (_i, [_vp, _u64, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "muse_get_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),
     "muse_set_zhat": (_i, [_vp, _i64, _i64, _vp, _i]),

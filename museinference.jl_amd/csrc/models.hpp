@@ -73,6 +73,15 @@ struct UserModel {  // include/muse_model.h: the three functions of the user's h
         return muse_model_grad(iv, x, z, &facc, (long)i);
     }
     __device__ static __forceinline__ double score_term(double x, double z, int i) { return muse_model_score_term(x, z, (long)i); }
+#ifdef MUSE_MODEL_SECOND  // (include/muse_model.h: the operands of the implicit-differentiation get_H!, Solver::run_implicit)
+    __device__ static __forceinline__ void second(double iv, double x, double z, double& ozz, double& ozx, double& bz, double& bx, int i) {
+        muse_model_second(iv, x, z, &ozz, &ozx, &bz, &bx, (long)i);
+    }
+    // dx_i / dtheta_k at fixed normals: sd = exp(theta / 2)
+    __device__ static __forceinline__ double dx_dtheta(double sd, double n1, double n2, int i) {
+        return 0.5 * (sd * muse_model_dx_dsd(sd, n1, n2, (long)i));
+    }
+#endif
 };
 #endif
 

@@ -510,6 +510,12 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
         if (!(g0 == 0.0 && acc == 1.25 && muse_model_score_term(0.0, 0.0, (long)N) == 0.0))
             return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": muse_model_grad(iv, 0, 0, &acc, N) must return 0 and leave acc "
                                           "unchanged, muse_model_score_term(0, 0, N) must be 0 (include/muse_model.h)");
+#ifdef MUSE_MODEL_SECOND
+        double s4[4];
+        muse_model_second(0.7, 0.0, 0.0, &s4[0], &s4[1], &s4[2], &s4[3], (long)N);
+        if (!(isfinite(s4[0]) && isfinite(s4[1]) && isfinite(s4[2]) && isfinite(s4[3])))
+            return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": muse_model_second(iv, 0, 0, ..., N) must be finite (include/muse_model.h)");
+#endif
     }
 #endif
     int ndev = 0;
@@ -749,6 +755,39 @@ int muse_set_constants(muse_ctx* c, int k, const double* values, int64_t count, 
 #else
     (void)c; (void)k; (void)values; (void)count; (void)mem;
     return fail(MUSE_ERR_INVALID, "this library's model declares no run-time constants (MUSE_MODEL_NCONST, include/muse_model.h)");
+#endif
+}
+int muse_model_has_second(void) {
+#if defined(MUSE_USER_MODEL_HEADER) && !defined(MUSE_MODEL_SECOND)
+    return 0;
+#else
+    return 1;
+#endif
+}
+int muse_model_eval(muse_ctx* c, double iv, double sd, double x, double z, double n1, double n2, int64_t i, double* out) {
+#ifdef MUSE_USER_MODEL_HEADER
+#ifdef MUSE_MODEL_NCONST
+    int rc = check_ctx(c);   // (the model's run-time constants become this context's)
+    if (rc) return rc;
+#else
+    (void)c;                 // a model without run-time constants needs no context (and no GPU) for this
+#endif
+    if (!out || i < 0) return fail(MUSE_ERR_INVALID, "bad argument");
+    double acc = 0.0;
+    out[0] = muse_model_grad(iv, x, z, &acc, (long)i);
+    out[1] = acc;
+    out[2] = muse_model_score_term(x, z, (long)i);
+    muse_model_sample(sd, n1, n2, &out[7], &out[8], (long)i);
+#ifdef MUSE_MODEL_SECOND
+    muse_model_second(iv, x, z, &out[3], &out[4], &out[5], &out[6], (long)i);
+    out[9] = muse_model_dx_dsd(sd, n1, n2, (long)i);
+#else
+    out[3] = out[4] = out[5] = out[6] = out[9] = NAN;
+#endif
+    return MUSE_OK;
+#else
+    (void)c; (void)iv; (void)sd; (void)x; (void)z; (void)n1; (void)n2; (void)i; (void)out;
+    return fail(MUSE_ERR_INVALID, "muse_model_eval evaluates a user-supplied model's header; this library holds the built-in models");
 #endif
 }
 int muse_set_normals_cache(muse_ctx* c, int enabled) {
@@ -1686,9 +1725,9 @@ static int implicit_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t 
                          const double* theta0, double atol, int cg_maxiter, double* cols_out, int32_t* cg_iters_out) {
     const int nt = c->ntheta;
     const int64_t ne = e_end - e_begin;
-    if (c->model == MUSE_MODEL_USER)
-        return fail(MUSE_ERR_INVALID, "the implicit-differentiation H needs second derivatives, which a user model does not "
-                                      "supply (include/muse_model.h): use the finite-difference entries");
+    if (!muse_model_has_second())
+        return fail(MUSE_ERR_INVALID, "the implicit-differentiation H needs second derivatives, which this model's header does not "
+                                      "supply (MUSE_MODEL_SECOND, include/muse_model.h): use the finite-difference entries");
     if (ne == 0) return MUSE_OK;
     if (ne > 0x7fffffff) return fail(MUSE_ERR_INVALID, "batch too large");
     const int64_t s_lo = sim_begin + e_begin / nt, s_hi = sim_begin + (e_end - 1) / nt + 1;

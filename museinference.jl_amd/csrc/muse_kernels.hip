@@ -748,7 +748,14 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
 #ifdef MUSE_INSPECT  // development aid (tools/regs.py --check): instantiate ONE kernel, for a quick look at its assembly
     return launch_one<MUSE_INSPECT>(s, a, st);
 #elif defined(MUSE_USER_MODEL_HEADER)  // a library built from a user's model header holds that model only (user_model.hpp)
-    if (s.model != MUSE_MODEL_USER || s.implicit) return hipErrorInvalidValue;
+    if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+    if (s.implicit) {
+#ifdef MUSE_MODEL_SECOND
+        return s.ntheta == 1 ? launch_place_implicit<UserModel<1>>(s, a, st) : launch_place_implicit<UserModel<kMaxTheta>>(s, a, st);
+#else
+        return hipErrorInvalidValue;  // (muse_engine.cpp refuses the call before it gets here)
+#endif
+    }
     return s.ntheta == 1 ? launch_place<UserModel<1>>(s, a, st) : launch_place<UserModel<kMaxTheta>>(s, a, st);
 #else
     const int nt = s.ntheta;

@@ -1153,7 +1153,7 @@ struct Solver {
                             Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt, i);
                             zt = valid ? zt : 0.0;
                             xt = valid ? xt : 0.0;
-                            if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
+                            if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, keep_value(valid, zt, sdk(jj, i), np, i));
                             x.set(jj, i, xt);
                             const double z0v = ztrue_start ? zt : 0.0;
                             if (Place::kResident || ztrue_start) z.set(jj, i, z0v);  // registers: always defined
@@ -1194,7 +1194,7 @@ struct Solver {
                     }
                     zt = valid ? zt : 0.0;
                     xt = valid ? xt : 0.0;
-                    if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, zt);
+                    if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, keep_value(valid, zt, sdk(jj, i), np, i));
                     x.set(jj, i, xt);
                     if (d.z0_mode == Z0_ZERO) z.set(jj, i, 0.0);
                     else if (d.z0_mode == Z0_TRUE) z.set(jj, i, zt);
@@ -1707,6 +1707,13 @@ struct Solver {
         stamp(p, 6);
     }
 
+    // What the implicit-differentiation H keeps of the draw in its extra vector: the simulation's true z (compiled-in models: x's
+    // derivative in theta follows from it) or, for a user-supplied model, dx_i / dtheta_k itself (include/muse_model.h).
+    __device__ __forceinline__ double keep_value(bool valid, double zt, double sd, const NormalPair& np, int i) const {
+        if constexpr (Model::kId == MUSE_MODEL_USER) return valid ? Model::dx_dtheta(sd, np.n1, np.n2, i) : 0.0;
+        else return zt;
+    }
+
     // ------------------------------------------------------------------------------------------
     // get_H! implicit-differentiation branch for one simulation (src/muse.jl:335-405):
     //   H = H1 - dFdtheta^T A^{-1} dFdtheta1,  A = Hessian_z logLike at (x, zhat, theta0),
@@ -1764,12 +1771,20 @@ struct Solver {
                     const double zt = ztrue.get(jj, i);  // unconditional: the pair load is issued at the even element
                     double bi;
                     if constexpr (Model::kId == MUSE_MODEL_NOISE) bi = iv0 * (0.5 * (x.get(jj, i) - zt));
+                    else if constexpr (Model::kId == MUSE_MODEL_USER) {
+                        // zt is dx_i / dtheta_k here (keep_value); the element's d2 o / dz2 goes to t1 for the CG passes
+                        double ozz, ozx, bz, bx;
+                        Model::second(ivk(jj, i), x.get(jj, i), z.get(jj, i), ozz, ozx, bz, bx, i);
+                        t1.set(jj, i, ozz);
+                        const double bb = -(ozx * zt);
+                        bi = blk(jj, i) == j ? bb : 0.0;
+                    }
                     else bi = blk(jj, i) == j ? 0.5 * zt : 0.0;
                     v.set(jj, i, 0.0);
                     r.set(jj, i, bi);
                     pp.set(jj, i, bi);
                     sum[0] = fma(bi, bi, sum[0]);
-                }, v, r, pp);
+                }, v, r, pp, when(Model::kId == MUSE_MODEL_USER, t1));
             }
             reduce<1, 0>(sum, mx);
             double rr = sum[0];
@@ -1792,6 +1807,7 @@ struct Solver {
                         const double pi = pp.get(jj, i);
                         double api;
                         if constexpr (Model::kId == MUSE_MODEL_NOISE) api = -((iv0 + 1.0) * pi);
+                        else if constexpr (Model::kId == MUSE_MODEL_USER) api = -(t1.get(jj, i) * pi);
                         else api = -(pi + ivk(jj, i) * pi);
                         Ap.set(jj, i, api);
                         s1[0] = fma(pi, api, s1[0]);
@@ -1822,6 +1838,7 @@ struct Solver {
             double acc[KA];
 #pragma unroll
             for (int b = 0; b < KA; ++b) acc[b] = 0.0;
+            double h1u[1] = {0.0};  // user model: sum_{i in block j} bx_i dx_i/dtheta_j
             for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                 const double zi = z.get(jj, i), vi = v.get(jj, i);
                 if constexpr (Model::kId == MUSE_MODEL_NOISE) {
@@ -1829,6 +1846,15 @@ struct Solver {
                     const double dd = xi - zi;
                     acc[0] = fma(-iv0 * dd, vi, acc[0]);
                     acc[1] = fma(dd, 0.5 * (xi - ztrue.get(jj, i)), acc[1]);
+                } else if constexpr (Model::kId == MUSE_MODEL_USER) {
+                    const double ivi = ivk(jj, i), tx = ztrue.get(jj, i);
+                    double ozz, ozx, bz, bx;
+                    Model::second(ivi, x.get(jj, i), zi, ozz, ozx, bz, bx, i);
+                    const double t = 0.5 * (ivi * bz);
+                    const int k = blk(jj, i);
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
+                    h1u[0] = (k == j) ? fma(bx, tx, h1u[0]) : h1u[0];
                 } else {
                     const double t = ivk(jj, i) * zi;
                     if constexpr (MAXB == 1) {
@@ -1841,12 +1867,14 @@ struct Solver {
                 }
             });
             reduce<KA, 0>(acc, mx);
+            if constexpr (Model::kId == MUSE_MODEL_USER) reduce<1, 0>(h1u, mx);
             if (tid == 0 && crank == 0) {
 #pragma unroll
                 for (int b = 0; b < MAXB; ++b) {
                     if (b < nth) {
                         double h1 = 0.0;
                         if constexpr (Model::kId == MUSE_MODEL_NOISE) h1 = iv0 * acc[1];
+                        if constexpr (Model::kId == MUSE_MODEL_USER) h1 = b == j ? 0.5 * (a.cur.t.iv[j] * h1u[0]) : 0.0;
                         a.scores[(psim * nth + b) * nth + j] = h1 - acc[b];
                     }
                 }

@@ -122,6 +122,9 @@ def check_model_consistency(prob, theta, rng=0, n_probe=6, step=1e-5, rtol=2e-5)
         grad_theta logLike       against central differences of logLike in every theta_k
                                  (the family identity of include/muse_model.h: the score assembled from B is the derivative),
 
+        the second derivatives of a header with MUSE_MODEL_SECOND (what the implicit-differentiation get_H! builds on) against
+                                 central differences of the header's own first-order functions (_check_second, "second"),
+
     and returns {"grad_z": worst residual, "grad_theta": worst residual, "noise_floor": ...} -- residuals relative to the larger
     of the gradient's size and 1; noise_floor: what the rounding of logLike (a sum of N terms) alone puts into such a
     difference quotient.  Raises AssertionError when a residual exceeds rtol + noise_floor.  Works on any problem with
@@ -153,7 +156,39 @@ def check_model_consistency(prob, theta, rng=0, n_probe=6, step=1e-5, rtol=2e-5)
         floor = max(floor, 4 * eps * abs(f0) / step / scale)
         res_t = max(res_t, abs((fp - fm) / (2 * step) - s[k]) / scale)
     out = {"grad_z": float(res_z), "grad_theta": float(res_t), "noise_floor": float(floor)}
+    if getattr(prob, "user_model", None) is not None and getattr(prob, "has_second_derivatives", False):
+        out["second"] = _check_second(prob.model_eval, theta, np.asarray(x), z, n_probe, rtol)
     for name in ("grad_z", "grad_theta"):
         assert out[name] <= rtol + floor, (f"model consistency: {name} differs from the finite difference of logLike by {out[name]:.3g} "
                                            f"(relative; tolerance {rtol:g} + noise floor {floor:.3g})")
     return out
+
+
+def _check_second(model_eval, theta, x, z, n_probe, rtol, h=1e-5):
+    """The second-derivative functions of a header with MUSE_MODEL_SECOND (include/muse_model.h) against central differences of
+    the header's own first-order functions, element by element on the host (model_eval: HipMuseProblem.model_eval): ozz = d grad / dz,
+    ozx = d grad / dx, bz = dB / dz, bx = dB / dx, dx_dsd = d x(sd, n1, n2) / d sd.  Returns the worst residual (relative to the
+    larger of the value's size and 1) and raises AssertionError beyond rtol."""
+    import numpy as np
+    N, nt = z.size, theta.size
+    worst = 0.0
+    rs = np.random.RandomState(7)
+    for i in np.unique(np.linspace(0, N - 1, n_probe).astype(int)):
+        k = int(i * nt // N)
+        iv, sd = float(np.exp(-theta[k])), float(np.exp(0.5 * theta[k]))
+        xi, zi = float(x[i]), float(z[i])
+        n1, n2 = rs.randn(2)
+        e = model_eval(iv, sd, xi, zi, n1, n2, i)
+        hz, hx, hs = h * max(1.0, abs(zi)), h * max(1.0, abs(xi)), h * sd
+        zp, zm = model_eval(iv, sd, xi, zi + hz, n1, n2, i), model_eval(iv, sd, xi, zi - hz, n1, n2, i)
+        xp, xm = model_eval(iv, sd, xi + hx, zi, n1, n2, i), model_eval(iv, sd, xi - hx, zi, n1, n2, i)
+        sp, sm = model_eval(iv, sd + hs, xi, zi, n1, n2, i), model_eval(iv, sd - hs, xi, zi, n1, n2, i)
+        pairs = {"ozz": (zp["grad"] - zm["grad"]) / (2 * hz), "ozx": (xp["grad"] - xm["grad"]) / (2 * hx),
+                 "bz": (zp["B"] - zm["B"]) / (2 * hz), "bx": (xp["B"] - xm["B"]) / (2 * hx),
+                 "dx_dsd": (sp["x"] - sm["x"]) / (2 * hs)}
+        for name, fd in pairs.items():
+            res = abs(fd - e[name]) / max(1.0, abs(e[name]))
+            assert res <= rtol, (f"model consistency: {name} of element {i} is {e[name]:.9g}, the finite difference of the header's "
+                                 f"own functions gives {fd:.9g}")
+            worst = max(worst, res)
+    return float(worst)

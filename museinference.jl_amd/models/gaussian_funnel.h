@@ -5,6 +5,7 @@
  * that they run at the same speed. */
 #include "muse_model.h"
 #define MUSE_MODEL_NAME "gaussian_funnel"
+#define MUSE_MODEL_SECOND 1
 
 MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) {
     (void)i;
@@ -21,4 +22,20 @@ MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) {
     (void)i;
     (void)x;
     return z * z;
+}
+
+/* second derivatives (the implicit-differentiation get_H!): o = 1/2 [(x - z)^2 + iv z^2], B = z^2, x = sd n1 + n2 */
+MUSE_MODEL_FN void muse_model_second(double iv, double x, double z, double* ozz, double* ozx, double* bz, double* bx, long i) {
+    (void)i;
+    (void)x;
+    *ozz = 1.0 + iv;
+    *ozx = -1.0;
+    *bz = 2.0 * z;
+    *bx = 0.0;
+}
+MUSE_MODEL_FN double muse_model_dx_dsd(double sd, double n1, double n2, long i) {
+    (void)i;
+    (void)sd;
+    (void)n2;
+    return n1;
 }

@@ -203,6 +203,21 @@ class HipMuseProblem(AbstractMuseProblem):
         v = _capi.f8(values, self.N)
         self._check(self._lib.muse_set_constants(self._ctx, k, _capi.ptr(v), v.size, _capi.MEM_HOST))
 
+    @property
+    def has_second_derivatives(self):
+        """Whether the implicit-differentiation get_H! accepts this problem's model: the built-in models, and a user-supplied
+        header that defines MUSE_MODEL_SECOND (include/muse_model.h)."""
+        return bool(self._lib.muse_model_has_second())
+
+    def model_eval(self, iv, sd, x, z, n1, n2, i=0):
+        """The functions of a user-supplied model's header at one element, evaluated on the host (muse_model_eval): a dict with
+        grad (d(-logLike)/dz_i), term (A + iv B), B, ozz, ozx, bz, bx (muse_model_second) and z, x, dx_dsd of the draw at
+        (sd, n1, n2).  What check_model_consistency differentiates numerically."""
+        out = np.empty(10)
+        self._check(self._lib.muse_model_eval(self._ctx, float(iv), float(sd), float(x), float(z), float(n1), float(n2), int(i),
+                                              _capi.ptr(out)))
+        return dict(zip(("grad", "term", "B", "ozz", "ozx", "bz", "bx", "z", "x", "dx_dsd"), out.tolist()))
+
     def close(self):
         if getattr(self, "_ctx", None):
             self._lib.muse_ctx_destroy(self._ctx)

@@ -973,7 +973,9 @@ int mo_fd_jacobian(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim,
  *                  A_hess w = -(iv + 1) w
  * H_out[i][j] row-major; cg_iters_out[ntheta] (may be NULL). */
 static void mo_hess_apply(int model, int64_t N, int ntheta, const double* iv, const double* w, double* out, double* tmp) {
-    if (model == MO_MODEL_NOISE) {
+    if (model == MO_MODEL_USER) { /* tmp holds the elements' d2 o / dz2 (mo_implicit_H) */
+        for (int64_t i = 0; i < N; ++i) out[i] = -(tmp[i] * w[i]);
+    } else if (model == MO_MODEL_NOISE) {
         for (int64_t i = 0; i < N; ++i) out[i] = -((iv[0] + 1.0) * w[i]);
     } else if (model == MO_MODEL_FUNNEL) {
         for (int64_t i = 0; i < N; ++i) out[i] = -(w[i] + iv[mo_block(i, N, ntheta)] * w[i]);
@@ -993,9 +995,32 @@ int mo_implicit_H(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, 
     for (int k = 0; k < ntheta; ++k) iv[k] = mo_exp(-theta0[k]);
     mo_sample_x_z(model, N, ntheta, seed, (uint64_t)sim, theta0, x, zt);
     mo_zhat_at_theta(model, N, ntheta, x, z0, theta0, atol, zh, NULL);
+    /* a user-supplied model (include/muse_model.h, MUSE_MODEL_SECOND): the operands from the header's second derivatives --
+     *   tx_i = dx_i/dtheta_k = 1/2 sd_k dx/dsd (kept in zt's place), A_hess w = -ozz w, dFdth1[:,k] = -ozx tx 1_k,
+     *   dFdth[:,k] = 1/2 iv_k bz 1_k, H1[k][k] = 1/2 iv_k sum_k bx tx */
+    double *uz = NULL, *ux = NULL, *ubz = NULL, *ubx = NULL;
+    if (model == MO_MODEL_USER) {
+#if defined(MO_USER_MODEL_HEADER) && defined(MUSE_MODEL_SECOND)
+        uz = (double*)malloc(nb); ux = (double*)malloc(nb); ubz = (double*)malloc(nb); ubx = (double*)malloc(nb);
+        for (int64_t i = 0; i < N; ++i) {
+            const int k = mo_block(i, N, ntheta);
+            const double sdk = mo_exp(0.5 * theta0[k]);
+            double n1, n2;
+            mo_normal_pair(seed, (uint64_t)sim, (uint64_t)i, &n1, &n2);
+            zt[i] = 0.5 * (sdk * muse_model_dx_dsd(sdk, n1, n2, (long)i));
+            muse_model_second(iv[k], x[i], zh[i], &uz[i], &ux[i], &ubz[i], &ubx[i], (long)i);
+        }
+#else
+        free(x); free(zt); free(zh); free(z0); free(b); free(v); free(r); free(pp); free(Ap); free(tmp);
+        return -1; /* the header has no second derivatives */
+#endif
+    }
     for (int j = 0; j < ntheta; ++j) {
         /* right-hand side dFdth1[:, j] */
-        if (model == MO_MODEL_NOISE) {
+        if (model == MO_MODEL_USER) {
+            for (int64_t i = 0; i < N; ++i) b[i] = mo_block(i, N, ntheta) == j ? -(ux[i] * zt[i]) : 0.0;
+            memcpy(tmp, uz, nb);
+        } else if (model == MO_MODEL_NOISE) {
             for (int64_t i = 0; i < N; ++i) b[i] = iv[0] * (0.5 * (x[i] - zt[i]));
         } else {
             for (int64_t i = 0; i < N; ++i) tmp[i] = mo_block(i, N, ntheta) == j ? 0.5 * zt[i] : 0.0;
@@ -1027,7 +1052,14 @@ int mo_implicit_H(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, 
         /* H[:, j] = H1[:, j] - dFdth^T v */
         for (int i2 = 0; i2 < ntheta; ++i2) {
             double acc = 0.0, h1 = 0.0;
-            if (model == MO_MODEL_NOISE) {
+            if (model == MO_MODEL_USER) {
+                for (int64_t i = 0; i < N; ++i) {
+                    const int k = mo_block(i, N, ntheta);
+                    if (k == i2) acc = fma(0.5 * (iv[i2] * ubz[i]), v[i], acc);
+                    if (k == j && i2 == j) h1 = fma(ubx[i], zt[i], h1);
+                }
+                h1 = 0.5 * (iv[i2] * h1);
+            } else if (model == MO_MODEL_NOISE) {
                 for (int64_t i = 0; i < N; ++i) {
                     const double d = x[i] - zh[i];
                     acc = fma(-iv[0] * d, v[i], acc);
@@ -1042,6 +1074,7 @@ int mo_implicit_H(int model, int64_t N, int ntheta, uint64_t seed, int64_t sim, 
         }
     }
     free(x); free(zt); free(zh); free(z0); free(b); free(v); free(r); free(pp); free(Ap); free(tmp);
+    free(uz); free(ux); free(ubz); free(ubx);
     return 0;
 }
 

@@ -24,6 +24,7 @@ def models():
     P = 30.0 / (1.0 + np.arange(10000) % 250) ** 1.7 + 0.02          # (examples/spectrum.py's table)
     out.append(M.ElementwiseModel.from_source("known_spectrum", spec_src, constants={"P": P}))
     out.append(M.ElementwiseModel.from_source("spectrum", T.SPECTRUM_SOURCE, runtime_constants=["P"]))   # (one library for every N and P)
+    out.append(M.ElementwiseModel.from_source("noise_second", T.NOISE_SECOND_SOURCE))
     out += [M.ElementwiseModel.from_source("softprior", soft), M.ElementwiseModel.from_source("badpad", bad),
             M.ElementwiseModel.from_source("saturating", example)]
     return out

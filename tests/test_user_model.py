@@ -230,9 +230,6 @@ def test_cubic_model_fd_jacobian_multi_map_and_refusal(gpu, M, O):
         for m, th in enumerate(thetas):
             g1, i1 = prob.map_and_score_batch(5, 0, 20, th, atol=1e-4, z0_mode=0)
             assert np.array_equal(gm[20 * m:20 * (m + 1)], g1) and np.array_equal(im[20 * m:20 * (m + 1)], i1)
-        with pytest.raises(M.MuseError) as e:
-            prob.implicit_H_batch(9, 0, 2, theta)
-        assert "second derivatives" in str(e.value)
         prob.close()
 
 
@@ -270,6 +267,7 @@ def test_check_model_consistency_on_hip(gpu, M):
         prob = M.HipMuseProblem(None, model=M.ElementwiseModel.packaged("cubic"), ntheta=nth, N=N)
         res = M.check_model_consistency(prob, theta, rng=3)
         assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"], res
+        assert prob.has_second_derivatives and res["second"] <= 2e-5, res    # (cubic.h defines MUSE_MODEL_SECOND)
         prob.close()
 
 
@@ -292,6 +290,137 @@ def test_funnel_as_user_model_equals_the_built_in_funnel(gpu, M):
         assert np.array_equal(a.get_zhat(0, n), b.get_zhat(0, n))
         a.close()
         b.close()
+
+
+NOISE_SECOND_SOURCE = '''
+#include "muse_model.h"
+#define MUSE_MODEL_NAME "noise_second"
+#define MUSE_MODEL_SECOND 1
+/* the built-in noise model (z ~ N(0,1), x ~ N(z, e^theta): A = z^2, B = (x - z)^2) with its second derivatives -- the member
+   of the family whose B depends on x, i.e. whose implicit-differentiation H has an H1 term */
+MUSE_MODEL_FN void muse_model_sample(double sd, double n1, double n2, double* z, double* x, long i) { (void)i; *z = n1; *x = n1 + sd * n2; }
+MUSE_MODEL_FN double muse_model_grad(double iv, double x, double z, double* acc, long i) {
+    (void)i;
+    const double r = x - z, t = iv * r;
+    *acc = fma(z, z, fma(t, r, *acc));
+    return z - t;
+}
+MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) { (void)i; const double r = x - z; return r * r; }
+MUSE_MODEL_FN void muse_model_second(double iv, double x, double z, double* ozz, double* ozx, double* bz, double* bx, long i) {
+    (void)i;
+    *ozz = iv + 1.0;
+    *ozx = -iv;
+    *bz = -2.0 * (x - z);
+    *bx = 2.0 * (x - z);
+}
+MUSE_MODEL_FN double muse_model_dx_dsd(double sd, double n1, double n2, long i) { (void)i; (void)sd; (void)n1; return n2; }
+'''
+
+
+def test_implicit_H_of_a_user_model_on_the_oracle(O):
+    """get_H! implicit-differentiation branch (src/muse.jl:335-405) for a header with second derivatives (cubic.h): the CPU
+    checker's H from muse_model_second / muse_model_dx_dsd against central differences of the same map (tight MAPs)."""
+    theta = [0.3, -0.2]
+    with O.user_model(CUBIC, "cubic"):
+        H, its = O.implicit_H("user", 2000, 5, 0, theta, atol=1e-12)
+        assert np.all(its >= 5) and H[0, 1] == 0.0 and H[1, 0] == 0.0     # (elementwise model: blocks do not couple)
+        _, zfid, _ = O.map_and_score_batch("user", 2000, 5, 0, 1, theta, atol=1e-12, z0_mode=0)
+        Hfd = O.fd_jacobian("user", 2000, 5, 0, theta, [1e-4] * 2, zfid[0], atol=1e-12)
+        np.testing.assert_allclose(H, Hfd, rtol=1e-7, atol=1e-6)
+    with O.user_model(os.path.join(HERE, "models", "wrong_score.h"), "wrong_score"):   # a header without them
+        assert O.lib().mo_implicit_H(3, 100, 1, 1, 0, O._p(np.zeros(1)), ctypes.c_double(0.1), 10, O._p(np.zeros(1)), None) == -1
+
+
+def test_second_derivative_check_on_the_host(M):
+    """muse_model_eval (the header's functions for one element, on the host: no GPU, no context for a model without run-time
+    constants) and the check built on it: cubic.h's second derivatives pass, a wrong one is caught."""
+    from museinference_jl_amd import models as MM
+    lib = M._capi.load_library(M.ElementwiseModel.packaged("cubic").library())
+    assert lib.muse_model_has_second() == 1 and M.load_library().muse_model_has_second() == 1
+
+    def ev(iv, sd, x, z, n1, n2, i=0):
+        out = np.empty(10)
+        assert lib.muse_model_eval(None, iv, sd, x, z, n1, n2, int(i), M._capi.ptr(out)) == 0
+        return dict(zip(("grad", "term", "B", "ozz", "ozx", "bz", "bx", "z", "x", "dx_dsd"), out.tolist()))
+    e = ev(0.7, 1.2, 0.9, 0.4, -0.3, 0.8)
+    hp, r = 1 + 0.3 * 0.16, 0.9 - h(0.4)
+    np.testing.assert_allclose([e["grad"], e["B"], e["ozz"], e["ozx"], e["bz"], e["bx"]],
+                               [0.7 * 0.4 - r * hp, 0.16, 0.7 + hp * hp - r * 0.24, -hp, 0.8, 0.0], rtol=1e-14)
+    zs = 1.2 * -0.3
+    np.testing.assert_allclose([e["z"], e["x"], e["dx_dsd"]], [zs, h(zs) + 0.8, (1 + 0.3 * zs * zs) * -0.3], rtol=1e-14)
+    rs = np.random.RandomState(2)
+    x, z, theta = rs.randn(600), 0.7 * rs.randn(600), np.array([0.4, -0.3])
+    assert MM._check_second(ev, theta, x, z, 8, 2e-5) <= 2e-5
+    for wrong in ("ozz", "ozx", "bz", "dx_dsd"):
+        def bad(*a, _w=wrong):
+            d = ev(*a)
+            d[_w] = 1.05 * d[_w] + 0.01
+            return d
+        with pytest.raises(AssertionError) as err:
+            MM._check_second(bad, theta, x, z, 8, 2e-5)
+        assert wrong in str(err.value)
+    main = M.load_library()
+    assert main.muse_model_eval(None, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, M._capi.ptr(np.empty(10))) == -1   # built-in models: refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nth,theta,split", [(3000, 2, [0.4, -0.2], 0), (10000, 1, [0.3], 0), (9999, 3, [0.5, 0.0, -0.4], 0),
+                                                (70001, 2, [0.3, 0.1], 0)])
+def test_implicit_H_of_the_cubic_model_against_the_oracle(gpu, M, O, N, nth, theta, split):
+    """Row f1 for a user-supplied model: get_H! by implicit differentiation through the header's second derivatives -- per-sim H
+    and CG iteration counts against the CPU checker's build of the same header, whole simulations and column ranges, and
+    (tight MAP) against central differences of the same map."""
+    with O.user_model(CUBIC, "cubic"):
+        prob = make(M, None, N, nth, -1, split)
+        Hs, its = prob.implicit_H_batch(5, 0, 3, theta, atol=1e-1, cg_maxiter=100)
+        for s in range(3):
+            Ho, io = O.implicit_H("user", N, 5, s, theta, atol=1e-1, cg_maxiter=100)
+            assert np.all(np.abs(its[s] - io) <= 1), (its[s], io)     # (the CG stop compares tree-ordered with sequential sums)
+            np.testing.assert_allclose(Hs[s], Ho, rtol=1e-7, atol=1e-7 * np.abs(Ho).max())
+        cols, ci = prob.implicit_H_columns(5, 0, 1, 2 * nth, theta)           # columns 1 .. 2 nth - 1 of the (sim, column) list
+        want = np.concatenate([Hs[s].T for s in range(2)])[1:2 * nth]
+        assert np.array_equal(cols, want) or np.allclose(cols, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+        Ht, _ = prob.implicit_H_batch(5, 0, 1, theta, atol=1e-10)
+        _, zfid, _ = O.map_and_score_batch("user", N, 5, 0, 1, theta, atol=1e-12, z0_mode=0)
+        Hfd = O.fd_jacobian("user", N, 5, 0, theta, [1e-4] * nth, zfid[0], atol=1e-12)
+        np.testing.assert_allclose(Ht[0], Hfd, rtol=2e-6, atol=2e-6 * np.abs(Hfd).max())
+        prob.close()
+
+
+@pytest.mark.gpu
+def test_implicit_H_of_built_in_models_written_as_user_models(gpu, M):
+    """The funnel and the noise model written as headers with second derivatives give the built-in models' implicit-differentiation
+    H (closed forms in the kernel) -- the noise model being the member with an H1 term (B depends on x)."""
+    cases = [("funnel", M.ElementwiseModel.packaged("gaussian_funnel"), 10000, 3, [1.0, 0.0, -1.0]),
+             ("funnel", M.ElementwiseModel.packaged("gaussian_funnel"), 70001, 1, [0.5]),
+             ("noise", M.ElementwiseModel.from_source("noise_second", NOISE_SECOND_SOURCE), 3001, 1, [0.4]),
+             ("noise", M.ElementwiseModel.from_source("noise_second", NOISE_SECOND_SOURCE), 66001, 1, [-0.3])]
+    for name, model, N, nth, theta in cases:
+        a = M.HipMuseProblem(None, model=name, ntheta=nth, N=N)
+        b = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+        Ha, ia = a.implicit_H_batch(5, 0, 4, theta)
+        Hb, ib = b.implicit_H_batch(5, 0, 4, theta)
+        assert np.array_equal(ia, ib), (name, N, ia, ib)
+        np.testing.assert_allclose(Hb, Ha, rtol=1e-11, atol=1e-11 * np.abs(Ha).max())
+        a.close()
+        b.close()
+
+
+@pytest.mark.gpu
+def test_get_H_implicit_diff_on_a_user_model(gpu, M, O):
+    """muse() + get_H!(implicit_diff=true) (src/muse.jl:335-405) on the non-Gaussian user model: the same H, within Monte-Carlo and
+    finite-difference accuracy, as the finite-difference branch on the same streams."""
+    with O.user_model(CUBIC, "cubic"):
+        x, _ = O.sample_x_z("user", 4000, 9, M.DATA_SIM, [0.2, -0.3])
+    prob = M.HipMuseProblem(x, model=M.ElementwiseModel.packaged("cubic"), ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+    res = M.muse(prob, [0.0, 0.0], rng=2, nsims=40, maxsteps=6)
+    M.get_H_(res, prob, nsims=8, implicit_diff=True)
+    a = res.H.copy()
+    assert len(res.metadata["implicit_diff_cg_hists"]) == 8
+    res.Hs, res.H = [], None
+    M.get_H_(res, prob, nsims=8)
+    np.testing.assert_allclose(a, res.H, rtol=0.05, atol=0.05 * np.abs(res.H).max())
+    prob.close()
 
 
 @pytest.mark.gpu
@@ -322,6 +451,12 @@ MUSE_MODEL_FN double muse_model_score_term(double x, double z, long i) { (void)i
     _, gz = prob.logLike_and_grad_z_logLike(x, zh, [0.2])
     assert np.abs(gz).max() <= 1e-6
     np.testing.assert_allclose(g[0], 0.5 * (np.exp(-0.2) * np.sum((x - zh) ** 2) - 4000), rtol=1e-10)
+    # a header without MUSE_MODEL_SECOND: the implicit-differentiation H is refused (the finite-difference branch is not)
+    assert not prob.has_second_derivatives
+    with pytest.raises(M.MuseError) as e:
+        prob.implicit_H_batch(9, 0, 2, [0.2])
+    assert "second derivatives" in str(e.value)
+    assert np.isnan(prob.model_eval(1.0, 1.0, 0.3, 0.2, 0.1, 0.4)["ozz"])
     prob.close()
     bad = src.replace('"softprior"', '"badpad"').replace("return r * r;", "return r * r + 1.0;")
     with pytest.raises(M.MuseError) as e:
