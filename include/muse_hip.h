@@ -55,7 +55,13 @@ extern "C" {
 #define MUSE_MEM_HOST 0
 #define MUSE_MEM_DEVICE 1
 
+/* ntheta: 1 .. MUSE_MAX_THETA in every placement and entry point (per-block coefficients and sums in the launch's LDS argument
+ * block and in registers); MUSE_MAX_THETA + 1 .. MUSE_MAX_THETA_EXT in the streaming placements (per-block tables read from the
+ * kernel-argument segment, block sums eight at a time): batched maps, the per-simulation operators, both get_H! branches, the
+ * exchange between ranks -- not the native muse! loops (muse_run*: MUSE_ERR_INVALID; a host loop over the batched maps, as the
+ * reference's muse! is one, takes their place) nor several maps per launch.  The reference has no bound (src/muse.jl:296-333). */
 #define MUSE_MAX_THETA 8
+#define MUSE_MAX_THETA_EXT 64
 
 /* error codes */
 #define MUSE_OK 0

@@ -12,6 +12,7 @@ namespace muse {
 constexpr int kM = 10;         // L-BFGS memory (Optim.LBFGS default m)
 constexpr int kMaxIter = 1000;  // Optim.Options default iterations
 constexpr int kMaxTheta = MUSE_MAX_THETA;
+constexpr int kBigTheta = MUSE_MAX_THETA_EXT;  // ntheta in (kMaxTheta, kBigTheta]: the "big" tier (BigTheta below)
 constexpr int kResultAreas = 4;
 constexpr int kMaxCluster = 16;
 constexpr int kClusterSlotDoubles = 2 * kMaxCluster * 8 * 2;  // two parities x members x 8 values x 2 granules
@@ -39,6 +40,12 @@ struct MapTheta {
 };
 static_assert(sizeof(MapTheta) % 16 == 0, "copied in 4-byte words into a 16-byte aligned LDS block");
 constexpr int kMaxMaps = 8;  // independent maps (each with a theta of its own) that ONE launch can carry
+// ntheta > kMaxTheta: the per-block coefficients of the MAP's theta and the block boundaries, read by the kernel straight from
+// the kernel-argument segment (they share the place of maps[]: such a launch carries one map); BatchArgs::cur then holds
+// f_const only, and a finite-difference batch's sampling entries (tsample) are kBigTheta doubles each
+struct BigTheta {
+    double sd[kBigTheta], iv[kBigTheta];
+};
 
 enum { X_SAMPLE = 0, X_DATA = 1, X_GIVEN = 2 };
 enum { Z0_ZERO = MUSE_Z0_ZERO, Z0_TRUE = MUSE_Z0_TRUE, Z0_WARM = MUSE_Z0_WARM, Z0_COPY = 3 };
@@ -135,8 +142,12 @@ struct BatchArgs {
     unsigned long long* gran;
     unsigned int gran_tag;         // this iteration's tag
     int pad1_;
-    alignas(16) MapTheta maps[kMaxMaps];  // LAST, read from the kernarg segment only (never copied to LDS): theta of every map, nmaps > 1
+    union {  // LAST, read from the kernarg segment only (never copied to LDS)
+        alignas(16) MapTheta maps[kMaxMaps];  // theta of every map, nmaps > 1
+        BigTheta big;                         // ntheta > kMaxTheta
+    };
 };
+static_assert(sizeof(BigTheta) <= sizeof(MapTheta) * kMaxMaps, "the big tier's tables take the place of maps[]");
 constexpr size_t kArgsHeadBytes = offsetof(BatchArgs, maps);  // what the kernel keeps in LDS
 static_assert(kArgsHeadBytes % 16 == 0 && offsetof(BatchArgs, cur) % 8 == 0, "LDS copy of the argument block");
 static_assert(sizeof(BatchArgs) <= 4096, "kernarg segment");

@@ -583,6 +583,7 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
     int nt = 0;
     int rc = muse_ctx_area_event(ctx, 0, &ev, &nt);
     if (rc) return rc;
+    if (nt > kMaxTheta) return muse_set_error(MUSE_ERR_INVALID, "the native muse! loops take ntheta <= MUSE_MAX_THETA");
     const int S = o->nsims, world = st->nranks, rank = st->rank;
     const int64_t H = MUSE_RUN_HIST(nt);
     auto block = [&](int r, int64_t& lo, int64_t& hi) {

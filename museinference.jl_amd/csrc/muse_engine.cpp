@@ -70,7 +70,7 @@ struct muse_ctx {
     int nlanes = 1, cur_lane = 0;
     int model = 0, ntheta = 1, device = 0, placement = -1, num_cus = 0;
     int64_t N = 0, ld = 0;
-    int64_t bnd[kMaxTheta + 1] = {0};
+    int64_t bnd[kBigTheta + 1] = {0};
     hipStream_t stream = nullptr, own_stream = nullptr;
     double* x_data = nullptr;
     bool has_data = false;
@@ -176,10 +176,11 @@ static int choose_place(const muse_ctx* c) {
     // cluster mode: for the stencil model the neighbours owned by other workgroups become visible through
     // the agent-scope release/acquire of the cluster reduction that ends every pass (pass_barrier where a
     // pass has no reduction)
-    if (c->split >= 2 && c->split <= 8 && c->model != MUSE_MODEL_SMOOTH && c->placement != 0 && c->N <= kMaxResidentN)
+    const bool big = c->ntheta > kMaxTheta;  // the big tier (args.hpp, BigTheta) runs in the streaming placements
+    if (c->split >= 2 && c->split <= 8 && c->model != MUSE_MODEL_SMOOTH && c->placement != 0 && c->N <= kMaxResidentN && !big)
         return c->split == 2 ? P_CR2 : (c->split == 4 ? P_CR4 : P_CR8);
     if (use_cluster(c)) return P_C256;
-    if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN) return small ? P_S256 : P_S512;
+    if (c->model == MUSE_MODEL_SMOOTH || c->placement == 0 || c->N > kMaxResidentN || big) return small ? P_S256 : P_S512;
     if (small) return P_R256x1;
     if (c->N <= 4096) return P_R512x4;
     return P_R512x10;
@@ -496,7 +497,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
                                             "header, include/muse_model.h)"
                                           : "this library was built from a user's model header and holds MUSE_MODEL_USER only");
     if (N < 1) return fail(MUSE_ERR_INVALID, "N must be >= 1");
-    if (ntheta < 1 || ntheta > kMaxTheta) return fail(MUSE_ERR_INVALID, "ntheta must be in [1, MUSE_MAX_THETA]");
+    if (ntheta < 1 || ntheta > kBigTheta) return fail(MUSE_ERR_INVALID, "ntheta must be in [1, MUSE_MAX_THETA_EXT]");
     if (model == MUSE_MODEL_NOISE && ntheta != 1) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_NOISE has ntheta = 1");
     if (ntheta > N) return fail(MUSE_ERR_INVALID, "ntheta must be <= N");
     if (model == MUSE_MODEL_SMOOTH && N < 5) return fail(MUSE_ERR_INVALID, "MUSE_MODEL_SMOOTH needs N >= 5");
@@ -532,7 +533,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     c->ntheta = ntheta;
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
-    for (int k = 0; k <= kMaxTheta; ++k) {
+    for (int k = 0; k <= kBigTheta; ++k) {
         const int kk = k < ntheta ? k : ntheta;
         c->bnd[k] = ((int64_t)kk * N + ntheta - 1) / ntheta;
     }
@@ -546,7 +547,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     HIPCHK(hipHostMalloc(&c->clock_pin, 64, hipHostMallocDefault));
     memset(c->clock_pin, 0, 64);
     HIPCHK(hipMalloc(&c->tmp, (size_t)3 * c->ld * sizeof(double)));
-    HIPCHK(hipMalloc(&c->small_dev, 16 * sizeof(double)));
+    HIPCHK(hipMalloc(&c->small_dev, (size_t)(1 + kBigTheta) * sizeof(double)));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     for (int r = 0; r < kResultAreas; ++r) HIPCHK(hipEventCreateWithFlags(&c->area_done[r], hipEventDisableTiming));
@@ -889,6 +890,11 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     }
     make_thetaset(c, theta, a.cur.t);
     a.cur.f_const = theta_const(c, theta);
+    if (c->ntheta > kMaxTheta)  // the big tier: every block's coefficients, where the kernel reads them from the kernarg segment
+        for (int k = 0; k < c->ntheta; ++k) {
+            a.big.sd[k] = muse_exp(0.5 * theta[k]);
+            a.big.iv[k] = muse_exp(-theta[k]);
+        }
     a.nmaps = 1;
     a.fid_slot = -1;
     a.nstd = 0x7fffffff;  // no normals-only elements
@@ -929,7 +935,7 @@ int muse_logLike_and_grad_z(muse_ctx* c, const double* x, const double* z, const
     double* gdev = c->tmp + 2 * c->ld;
     rc = run_loglike(c, x, z, theta, grad_out ? gdev : nullptr, mem);
     if (rc) return rc;
-    double small[1 + kMaxTheta];
+    double small[1 + kBigTheta];
     HIPCHK(hipMemcpyAsync(small, c->small_dev, sizeof(small), hipMemcpyDeviceToHost, c->stream));
     if (grad_out) HIPCHK(hipMemcpyAsync(grad_out, gdev, (size_t)c->N * sizeof(double), out_kind(mem), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -943,7 +949,7 @@ int muse_grad_theta(muse_ctx* c, const double* x, const double* z, const double*
     if (!x || !z || !theta || !g_out) return fail(MUSE_ERR_INVALID, "NULL argument");
     rc = run_loglike(c, x, z, theta, nullptr, mem);
     if (rc) return rc;
-    double small[1 + kMaxTheta];
+    double small[1 + kBigTheta];
     HIPCHK(hipMemcpyAsync(small, c->small_dev, sizeof(small), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->ntheta; ++k) g_out[k] = small[1 + k];
@@ -1020,6 +1026,8 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     if (z0_mode < MUSE_Z0_ZERO || z0_mode > MUSE_Z0_WARM) return fail(MUSE_ERR_INVALID, "bad z0_mode");
     if (area < 0 || area >= kResultAreas) return fail(MUSE_ERR_INVALID, "bad result_area");
     if (o.nmaps < 1 || o.nmaps > kMaxMaps) return fail(MUSE_ERR_INVALID, "nmaps must be in [1, MUSE_MAX_MAPS]");
+    if (o.nmaps > 1 && c->ntheta > kMaxTheta)
+        return fail(MUSE_ERR_INVALID, "several maps per launch take ntheta <= MUSE_MAX_THETA (the big tier's tables take the place of maps[])");
     if (include_data && !c->has_data) return fail(MUSE_ERR_NODATA, "include_data set but muse_set_data was not called");
     const int64_t n = (sim_end - sim_begin) + (include_data ? 1 : 0);
     const int64_t stride = o.map_stride > 0 ? o.map_stride : n;
@@ -1195,6 +1203,9 @@ int muse_map_and_score_batch(muse_ctx* c, uint64_t seed, int64_t sim_begin, int6
 static int check_run_args(muse_ctx* c, const double* theta0, const muse_run_options* o, int32_t* niter_out, double* theta_out,
                           double* hist_out, double* gsims_out) {
     if (!theta0 || !o || !niter_out || !theta_out || !hist_out || !gsims_out) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (c->ntheta > kMaxTheta)
+        return fail(MUSE_ERR_INVALID, "the native muse! loops take ntheta <= MUSE_MAX_THETA: run the loop over the batched maps "
+                                      "(muse_map_and_score_batch) for more components");
     if (o->nsims < 2 || o->maxsteps < 1) return fail(MUSE_ERR_INVALID, "muse_run needs nsims >= 2 and maxsteps >= 1");
     if (o->prior_kind != 0 && o->prior_kind != 1) return fail(MUSE_ERR_INVALID, "prior_kind must be 0 (flat) or 1 (Gaussian)");
     if (!c->has_data) return fail(MUSE_ERR_NODATA, "muse_run needs the observed data (muse_set_data)");
@@ -1566,7 +1577,10 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     const int64_t nprep = nfid + ((cached && fid_mode == 0) ? nsims : 0);
     rc = ensure_results(c, 1, n > nprep ? n : nprep);
     if (rc) return rc;
-    rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G));
+    // a sampling entry: exp(theta/2) of every block -- a SampleSd, or kBigTheta doubles in the big tier (solver.hpp, begin)
+    const int ts_stride = nt > kMaxTheta ? kBigTheta : kMaxTheta;
+    static_assert(sizeof(SampleSd) == kMaxTheta * sizeof(double) && kBigTheta % kMaxTheta == 0, "sampling entries");
+    rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G) * (size_t)(ts_stride / kMaxTheta));
     if (rc) return rc;
     {
         BatchArgs a;
@@ -1600,9 +1614,8 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         auto fill = [&](int64_t entry, int j, double off) {
             for (int k = 0; k < nt; ++k) th[k] = theta0[k];
             th[j] = theta0[j] + off;
-            MapTheta m;
-            make_map_theta(nt, c->bnd, th.data(), m);
-            memcpy(c->tsample_pin[entry].sd, m.t.sd, sizeof(SampleSd));
+            double* sd = reinterpret_cast<double*>(c->tsample_pin) + entry * ts_stride;
+            for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? muse_exp(0.5 * th[k]) : 0.0;   // (make_map_theta_component's sd)
         };
         if (per_unit) {
             for (int64_t e = 0; e < ne; ++e)
@@ -1612,7 +1625,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
                 for (int g = 0; g < G; ++g) fill((int64_t)j * G + g, j, offsets[(int64_t)j * G + g]);
         }
     }
-    HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)(per_unit ? n : (int64_t)nt * G) * sizeof(SampleSd),
+    HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)(per_unit ? n : (int64_t)nt * G) * ts_stride * sizeof(double),
                           hipMemcpyHostToDevice, c->stream));
     {
         BatchArgs a;

@@ -193,13 +193,25 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
 // ------------------------------------------------------------------------------------------------
 // Per-simulation operator kernels (API parity with the reference's per-sim interface; not the
 // performance path).
+// The per-block tables of a launch whatever its tier (args.hpp, BigTheta): BatchArgs is the first kernel parameter.
+__device__ __forceinline__ const BigTheta* kernarg_big() {
+    return reinterpret_cast<const BigTheta*>(reinterpret_cast<const char*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) +
+                                             offsetof(BatchArgs, big));
+}
+__device__ __forceinline__ int any_block(const BatchArgs& a, int64_t i) {
+    if (a.ntheta > kMaxTheta) return block_of_big((int)a.N, a.ntheta, 1.0 / (double)a.N, (int)i);
+    return a.ntheta > 1 ? block_of(a, i) : 0;
+}
+__device__ __forceinline__ double any_sd(const BatchArgs& a, int k) { return a.ntheta > kMaxTheta ? kernarg_big()->sd[k] : a.cur.t.sd[k]; }
+__device__ __forceinline__ double any_iv(const BatchArgs& a, int k) { return a.ntheta > kMaxTheta ? kernarg_big()->iv[k] : a.cur.t.iv[k]; }
+
 template <int MODEL>
 __global__ void __launch_bounds__(256) sample_kernel(BatchArgs a, uint64_t sim, double* __restrict__ x,
                                                      double* __restrict__ z) {
     const int64_t N = a.N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = a.ntheta > 1 ? block_of(a, i) : 0;
-        const double sdk = a.cur.t.sd[k];
+        const int k = any_block(a, i);
+        const double sdk = any_sd(a, k);
         const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
         if (MODEL == MUSE_MODEL_NOISE) {
             z[i] = np.n1;
@@ -218,9 +230,9 @@ __global__ void __launch_bounds__(256) sample_kernel(BatchArgs a, uint64_t sim, 
 __global__ void __launch_bounds__(256) sample_user_kernel(BatchArgs a, uint64_t sim, double* __restrict__ x, double* __restrict__ z) {
     const int64_t N = a.N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = a.ntheta > 1 ? block_of(a, i) : 0;
+        const int k = any_block(a, i);
         const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
-        UserModel<1>::sample(a.cur.t.sd[k], np.n1, np.n2, z[i], x[i], (int)i);
+        UserModel<1>::sample(any_sd(a, k), np.n1, np.n2, z[i], x[i], (int)i);
     }
 }
 #endif
@@ -239,7 +251,8 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
                                                        const double* __restrict__ zin, double* __restrict__ gout,
                                                        double* __restrict__ out /* [0]=logLike, [1..]=score */) {
     __shared__ double red[2 * 16 * 8];
-    constexpr int T = 1024, MAXB = Model::MAXB;
+    constexpr bool kBig = Model::MAXB > kMaxTheta;       // (the big tier: block sums eight at a time, as Solver::finish)
+    constexpr int T = 1024, MAXB = kBig ? 8 : Model::MAXB;
     const int tid = threadIdx.x;
     int parity = 0;
     const int64_t N = a.N;
@@ -251,8 +264,8 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     auto wrap = [&](int i) { return i < 0 ? i + Ni : (i >= Ni ? i - Ni : i); };
     // vectors are padded to the even length ld with a zero pad element (phantom zero, see for_elems)
     for_elems<T, 0, 1>(a.ld, tid, T, [&](int, int i) {
-        const int k = MAXB > 1 ? block_of(a, i) : 0;
-        const double ivk = a.cur.t.iv[k];
+        const int k = MAXB > 1 ? any_block(a, i) : 0;
+        const double ivk = any_iv(a, k);
         double gi;
         if constexpr (Model::kStencil) {
             const bool valid = i < Ni;
@@ -275,10 +288,30 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     });
     block_allreduce<T, 2, 0>(sum, mx, red, parity, tid);
     block_allreduce<T, MAXB, 0>(acc, mx, red, parity, tid);
+    auto count = [&](int k) {  // elements of block k: bnd[k] = ceil(k N / ntheta)
+        const int64_t nt = a.ntheta;
+        return (double)(((int64_t)(k + 1) * N + nt - 1) / nt - ((int64_t)k * N + nt - 1) / nt);
+    };
     if (tid == 0) {
         out[0] = -(0.5 * (sum[0] + a.cur.f_const));
         for (int b = 0; b < MAXB; ++b)
-            if (b < a.ntheta) out[1 + b] = 0.5 * (a.cur.t.iv[b] * acc[b] - (double)(a.bnd[b + 1] - a.bnd[b]));
+            if (b < a.ntheta) out[1 + b] = 0.5 * (any_iv(a, b) * acc[b] - count(b));
+    }
+    if constexpr (kBig) {
+        for (int c = 8; c < a.ntheta; c += 8) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[b] = 0.0;
+            for_elems<T, 0, 1>(a.ld, tid, T, [&](int, int i) {
+                const int k = any_block(a, i) - c;
+                const double t = Model::score_term(xin[i], zin[i], i);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[b] += (k == b) ? t : 0.0;
+            });
+            block_allreduce<T, 8, 0>(acc, mx, red, parity, tid);
+            if (tid == 0)
+                for (int b = 0; b < 8; ++b)
+                    if (c + b < a.ntheta) out[1 + c + b] = 0.5 * (any_iv(a, c + b) * acc[b] - count(c + b));
+        }
     }
 }
 
@@ -736,6 +769,21 @@ static hipError_t launch_place(const LaunchShape& s, const BatchArgs& a, hipStre
         }
     }
 }
+// The big tier (ntheta > kMaxTheta) runs in the streaming policy only.
+template <class Model>
+static hipError_t launch_place_big(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
+    if constexpr (Model::kStencil) {
+        if (s.place == P_C256 && s.lds_s) return launch_one<Model, PlaceStreaming<256, true, kStencilU, true, true>>(s, a, st);
+        if (s.place == P_C256) return launch_one<Model, PlaceStreaming<256, true, kStencilU, true>>(s, a, st);
+        if (s.place == P_S512) return launch_one<Model, PlaceStreaming<512, false, kStencilU>>(s, a, st);
+        if (s.place == P_S256) return launch_one<Model, PlaceStreaming<256, false, kStencilU>>(s, a, st);
+    } else {
+        if (s.place == P_C256) return launch_one<Model, PlaceStreaming<256, true, kStreamU>>(s, a, st);
+        if (s.place == P_S512) return launch_one<Model, PlaceStreaming<512, false, kStreamU>>(s, a, st);
+        if (s.place == P_S256) return launch_one<Model, PlaceStreaming<256, false, kStreamU>>(s, a, st);
+    }
+    return hipErrorInvalidValue;
+}
 // The implicit-differentiation H runs in the streaming policy only (single workgroup, or a cluster for large N).
 template <class Model>
 static hipError_t launch_place_implicit(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
@@ -749,8 +797,10 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
     return launch_one<MUSE_INSPECT>(s, a, st);
 #elif defined(MUSE_USER_MODEL_HEADER)  // a library built from a user's model header holds that model only (user_model.hpp)
     if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+    if (s.ntheta > kMaxTheta && !s.implicit) return launch_place_big<UserModel<kBigTheta>>(s, a, st);
     if (s.implicit) {
 #ifdef MUSE_MODEL_SECOND
+        if (s.ntheta > kMaxTheta) return launch_place_implicit<UserModel<kBigTheta>>(s, a, st);
         return s.ntheta == 1 ? launch_place_implicit<UserModel<1>>(s, a, st) : launch_place_implicit<UserModel<kMaxTheta>>(s, a, st);
 #else
         return hipErrorInvalidValue;  // (muse_engine.cpp refuses the call before it gets here)
@@ -759,6 +809,13 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
     return s.ntheta == 1 ? launch_place<UserModel<1>>(s, a, st) : launch_place<UserModel<kMaxTheta>>(s, a, st);
 #else
     const int nt = s.ntheta;
+    if (nt > kMaxTheta) {  // the big tier (args.hpp, BigTheta): streaming placements only
+        if (s.model == MUSE_MODEL_FUNNEL)
+            return s.implicit ? launch_place_implicit<FunnelModel<kBigTheta>>(s, a, st) : launch_place_big<FunnelModel<kBigTheta>>(s, a, st);
+        if (s.model == MUSE_MODEL_SMOOTH)
+            return s.implicit ? launch_place_implicit<SmoothModel<kBigTheta>>(s, a, st) : launch_place_big<SmoothModel<kBigTheta>>(s, a, st);
+        return hipErrorInvalidValue;
+    }
     if (s.implicit) {
         if (s.model == MUSE_MODEL_NOISE) return launch_place_implicit<NoiseModel>(s, a, st);
         if (s.model == MUSE_MODEL_FUNNEL)
@@ -908,11 +965,14 @@ hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x,
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t st) {
 #ifdef MUSE_USER_MODEL_HEADER
     if (model != MUSE_MODEL_USER) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(loglike_kernel<UserModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
+    if (a.ntheta > kMaxTheta) hipLaunchKernelGGL(loglike_kernel<UserModel<kBigTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
+    else hipLaunchKernelGGL(loglike_kernel<UserModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     return hipGetLastError();
 #endif
     if (model == MUSE_MODEL_NOISE) hipLaunchKernelGGL(loglike_kernel<NoiseModel>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
+    else if (model == MUSE_MODEL_FUNNEL && a.ntheta > kMaxTheta) hipLaunchKernelGGL(loglike_kernel<FunnelModel<kBigTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     else if (model == MUSE_MODEL_FUNNEL) hipLaunchKernelGGL(loglike_kernel<FunnelModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
+    else if (a.ntheta > kMaxTheta) hipLaunchKernelGGL(loglike_kernel<SmoothModel<kBigTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     else hipLaunchKernelGGL(loglike_kernel<SmoothModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     return hipGetLastError();
 }

@@ -68,6 +68,15 @@ __device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int 
 template <class Model, class Place>
 struct Solver {
     static constexpr int T = Place::T, EPT = Place::EPT, U = Place::U, MAXB = Model::MAXB;
+    // The big tier (kMaxTheta < ntheta <= kBigTheta, streaming placements only): the per-block coefficients come from the
+    // kernel-argument segment (BatchArgs::big) or a finite-difference batch's sampling entry instead of the LDS argument block,
+    // the block of an element from arithmetic instead of a compare chain, the block sums eight at a time (block_sums_big).
+    static constexpr bool kBig = MAXB > kMaxTheta;
+    static constexpr int KB = kBig ? 1 : MAXB;  // per-block accumulators a thread holds
+    static_assert(!kBig || !Place::kResident, "the big tier runs in the streaming placements");
+    const double* big_sd;  // [ntheta] sd of the theta this problem is DRAWN at
+    const double* big_iv;  // [ntheta] exp(-theta) of the MAP's theta
+    double big_rcpN;
     const BatchArgs& a;
     const int tid;
     double* red;
@@ -248,6 +257,7 @@ struct Solver {
     unsigned pk[2];
     __device__ __forceinline__ int blk(int jj, int i) const {
         if constexpr (MAXB == 1) return 0;
+        else if constexpr (kBig) return block_of_big((int)a.N, a.ntheta, big_rcpN, i);
         else if constexpr (Place::kResident) {
             // (laundered: the extraction and everything derived from it -- the lane masks k == b of the score sums, 20 slots x
             // MAXB of them, the LDS addresses of the per-block coefficients -- is otherwise hoisted to the kernel's entry, held
@@ -260,14 +270,17 @@ struct Solver {
     }
     __device__ __forceinline__ double ivk(int jj, int i) const {
         if constexpr (MAXB == 1) return iv0;
+        else if constexpr (kBig) return big_iv[blk(jj, i)];
         else return a.cur.t.iv[blk(jj, i)];
     }
     __device__ __forceinline__ double sdk(int jj, int i) const {
         if constexpr (MAXB == 1) return sd0;
+        else if constexpr (kBig) return big_sd[blk(jj, i)];
         else return sh_sd[blk(jj, i)];
     }
     __device__ __forceinline__ double sdk_at(int i) const {  // element index only (rolled loops)
         if constexpr (MAXB == 1) return sd0;
+        else if constexpr (kBig) return big_sd[blk(0, i)];
         else return sh_sd[block_of<MAXB>(a, i)];
     }
     __device__ __forceinline__ void pack_blocks() {
@@ -899,7 +912,14 @@ struct Solver {
         stamp(p, 0);
         iv0 = a.cur.t.iv[0];
         sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.cur.t.sd[0];
-        if constexpr (MAXB > 1) {
+        if constexpr (kBig) {
+            // (generic pointers into the kernarg segment: BatchArgs is the kernel's only parameter)
+            const BigTheta* bt = reinterpret_cast<const BigTheta*>(
+                reinterpret_cast<const char*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(BatchArgs, big));
+            big_iv = bt->iv;
+            big_sd = d.tsample >= 0 ? reinterpret_cast<const double*>(a.tsample) + (int64_t)d.tsample * kBigTheta : bt->sd;
+            big_rcpN = 1.0 / (double)a.N;
+        } else if constexpr (MAXB > 1) {
             // FD batches sample at a theta that differs from the MAP theta
             int tl = tid;
             asm volatile("" : "+v"(tl));  // (else tid * 8 is formed at the kernel's entry and held -- spilled -- across it)
@@ -1555,9 +1575,9 @@ struct Solver {
             if (!keep) {
                 // ---- the solve ends with this step (whatever x_converged says): z += alpha s, and in the same
                 //      pass what finish() would compute from the final z -- the score terms and the zhat store
-                double acc[MAXB];
+                double acc[KB];  // (big tier: ONE sum over all blocks -- the NaN channel below; finish() forms the block sums)
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) acc[b] = 0.0;
+                for (int b = 0; b < KB; ++b) acc[b] = 0.0;
                 VH zout;
                 const bool store = Place::kResident && d.zslot >= 0;  // streaming: z already lives in its zhat slot
                 if (store) zout.bind(a.zhat + d.zslot * ld, ld);
@@ -1570,31 +1590,31 @@ struct Solver {
                         if (store) zout.set(jj, i, zn);
                     }
                     const double t = Model::score_term(x.get(jj, i), zn, i);
-                    if constexpr (MAXB == 1) {
+                    if constexpr (KB == 1) {
                         acc[0] += t;
                     } else {
                         const int k = blk(jj, i);
 #pragma unroll
-                        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
+                        for (int b = 0; b < KB; ++b) acc[b] += (k == b) ? t : 0.0;
                     }
                 }, z);
                 if (iterations == 1) stamp(p, 14);
-                if constexpr (MAXB + 1 <= 8) {
-                    reduce<MAXB, 1>(acc, mx);
+                if constexpr (KB + 1 <= 8) {
+                    reduce<KB, 1>(acc, mx);
                     if (iterations == 1) stamp(p, 15);
                 } else {
                     double none[1] = {0.0};
                     reduce<0, 1>(none, mx);
-                    reduce<MAXB, 0>(acc, none);
+                    reduce<KB, 0>(acc, none);
                 }
                 bool any_nan = false;  // a NaN step shows up in the score sums (NaN channel of the maximum)
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
+                for (int b = 0; b < KB; ++b) {
                     score_acc[b] = acc[b];
                     any_nan = any_nan || acc[b] != acc[b];
                 }
                 mx[0] = nan_if(any_nan, mx[0]);
-                score_ready = true;
+                score_ready = !kBig;
             } else if constexpr (!Model::kStencil) {
                 auto body = [&](auto have_g, auto zz, int jj, int i) {
                     const double zo = decltype(zz)::value ? 0.0 : z.get(jj, i), si = s.get(jj, i);
@@ -1834,50 +1854,62 @@ struct Solver {
                 it += 1;
             }
             // ---- H[:, j] = H1[:, j] - dFdtheta^T v ----------------------------------------------------
-            constexpr int KA = Model::kId == MUSE_MODEL_NOISE ? 2 : MAXB;  // noise: [dFdtheta^T v, H1 sum]
-            double acc[KA];
-#pragma unroll
-            for (int b = 0; b < KA; ++b) acc[b] = 0.0;
+            // (big tier: eight rows of the column per pass, as finish() forms its block sums)
+            constexpr int NB = kBig ? 8 : MAXB;
+            constexpr int KA = Model::kId == MUSE_MODEL_NOISE ? 2 : NB;  // noise: [dFdtheta^T v, H1 sum]
             double h1u[1] = {0.0};  // user model: sum_{i in block j} bx_i dx_i/dtheta_j
-            for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
-                const double zi = z.get(jj, i), vi = v.get(jj, i);
-                if constexpr (Model::kId == MUSE_MODEL_NOISE) {
-                    const double xi = x.get(jj, i);
-                    const double dd = xi - zi;
-                    acc[0] = fma(-iv0 * dd, vi, acc[0]);
-                    acc[1] = fma(dd, 0.5 * (xi - ztrue.get(jj, i)), acc[1]);
-                } else if constexpr (Model::kId == MUSE_MODEL_USER) {
-                    const double ivi = ivk(jj, i), tx = ztrue.get(jj, i);
-                    double ozz, ozx, bz, bx;
-                    Model::second(ivi, x.get(jj, i), zi, ozz, ozx, bz, bx, i);
-                    const double t = 0.5 * (ivi * bz);
-                    const int k = blk(jj, i);
+#pragma unroll 1
+            for (int c = 0; c < (kBig ? nth : 1); c += 8) {
+                double acc[KA];
 #pragma unroll
-                    for (int b = 0; b < MAXB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
-                    h1u[0] = (k == j) ? fma(bx, tx, h1u[0]) : h1u[0];
-                } else {
-                    const double t = ivk(jj, i) * zi;
-                    if constexpr (MAXB == 1) {
-                        acc[0] = fma(t, vi, acc[0]);
+                for (int b = 0; b < KA; ++b) acc[b] = 0.0;
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
+                    const double zi = z.get(jj, i), vi = v.get(jj, i);
+                    if constexpr (Model::kId == MUSE_MODEL_NOISE) {
+                        const double xi = x.get(jj, i);
+                        const double dd = xi - zi;
+                        acc[0] = fma(-iv0 * dd, vi, acc[0]);
+                        acc[1] = fma(dd, 0.5 * (xi - ztrue.get(jj, i)), acc[1]);
+                    } else if constexpr (Model::kId == MUSE_MODEL_USER) {
+                        const double ivi = ivk(jj, i), tx = ztrue.get(jj, i);
+                        double ozz, ozx, bz, bx;
+                        Model::second(ivi, x.get(jj, i), zi, ozz, ozx, bz, bx, i);
+                        const double t = 0.5 * (ivi * bz);
+                        const int kf = blk(jj, i), k = kf - c;
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
+                        h1u[0] = (kf == j && c == 0) ? fma(bx, tx, h1u[0]) : h1u[0];
                     } else {
-                        const int k = blk(jj, i);
+                        const double t = ivk(jj, i) * zi;
+                        if constexpr (MAXB == 1) {
+                            acc[0] = fma(t, vi, acc[0]);
+                        } else {
+                            const int k = blk(jj, i) - c;
 #pragma unroll
-                        for (int b = 0; b < MAXB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
+                            for (int b = 0; b < NB; ++b) acc[b] = (k == b) ? fma(t, vi, acc[b]) : acc[b];
+                        }
+                    }
+                });
+                reduce<KA, 0>(acc, mx);
+                if constexpr (Model::kId == MUSE_MODEL_USER) {
+                    if (c == 0) reduce<1, 0>(h1u, mx);
+                }
+                if (tid == 0 && crank == 0) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (c + b < nth) {
+                            double h1 = 0.0;
+                            if constexpr (Model::kId == MUSE_MODEL_NOISE) h1 = iv0 * acc[1];
+                            if constexpr (Model::kId == MUSE_MODEL_USER) {
+                                const double ivj = kBig ? big_iv[j] : a.cur.t.iv[j];
+                                h1 = c + b == j ? 0.5 * (ivj * h1u[0]) : 0.0;
+                            }
+                            a.scores[(psim * nth + c + b) * nth + j] = h1 - acc[b];
+                        }
                     }
                 }
-            });
-            reduce<KA, 0>(acc, mx);
-            if constexpr (Model::kId == MUSE_MODEL_USER) reduce<1, 0>(h1u, mx);
+            }
             if (tid == 0 && crank == 0) {
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
-                    if (b < nth) {
-                        double h1 = 0.0;
-                        if constexpr (Model::kId == MUSE_MODEL_NOISE) h1 = iv0 * acc[1];
-                        if constexpr (Model::kId == MUSE_MODEL_USER) h1 = b == j ? 0.5 * (a.cur.t.iv[j] * h1u[0]) : 0.0;
-                        a.scores[(psim * nth + b) * nth + j] = h1 - acc[b];
-                    }
-                }
                 muse_info inf;
                 inf.iterations = it;
                 inf.f_calls = f_calls;
@@ -1893,7 +1925,44 @@ struct Solver {
     // -- phase 3: zhat out, score grad_theta logLike(x, zhat, theta), solver info
     __device__ void finish(int p) {
         const int64_t ld = a.ld;
-        {
+        if constexpr (kBig) {
+            // the big tier: the block sums of the score terms eight blocks at a time -- a pass over z (and x) and one
+            // reduction per chunk, the summation tree of a block being that of the small tiers
+            const int nth = a.ntheta;
+#pragma unroll 1
+            for (int c = 0; c < nth; c += 8) {
+                double acc[8], mx[1] = {0.0};
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[b] = 0.0;
+                for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
+                    const double t = Model::score_term(x.get(jj, i), z.get(jj, i), i);
+                    const int k = blk(jj, i) - c;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) acc[b] += (k == b) ? t : 0.0;
+                });
+                reduce<8, 0>(acc, mx);
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+                const int kk = c + tl;
+                if (tl < 8 && kk < nth && crank == 0) {
+                    double mine = acc[0];
+#pragma unroll
+                    for (int b = 1; b < 8; ++b) mine = (tl == b) ? acc[b] : mine;
+                    const long long lo = ((long long)kk * a.N + nth - 1) / nth, hi = ((long long)(kk + 1) * a.N + nth - 1) / nth;
+                    a.scores[d.row * nth + kk] = 0.5 * (big_iv[kk] * mine - (double)(hi - lo));
+                }
+            }
+            if (tid == 0 && crank == 0) {
+                muse_info inf;
+                inf.iterations = iterations;
+                inf.f_calls = f_calls;
+                inf.status = (status <= MUSE_STATUS_F_CONVERGED && !isfinite(f)) ? MUSE_STATUS_NONFINITE : status;
+                inf.hist_words = hist_words;
+                inf.f_min = f;
+                inf.gnorm = gmax;
+                a.info[p] = inf;
+            }
+        } else {
             double acc[MAXB], mx[1] = {0.0};
             if (score_ready) {  // the solve's last pass already did both (see solve())
 #pragma unroll
@@ -1952,7 +2021,7 @@ struct Solver {
         stamp(p, 7);
     }
     double last_phi;
-    double score_acc[MAXB];  // per-block sums of the score terms when the solve's last pass computed them
+    double score_acc[KB];  // per-block sums of the score terms when the solve's last pass computed them
     bool score_ready;
 };
 

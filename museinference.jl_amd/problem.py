@@ -397,6 +397,8 @@ class HipMuseProblem(AbstractMuseProblem):
     def native_prior(self):
         """(kind, mean[nθ], sigma[nθ]) if the prior is one muse_run evaluates itself, else None."""
         from .priors import FlatPrior, GaussianPrior
+        if self.ntheta > _capi.MAX_THETA:        # (the big tier of muse_hip.h: the loop over the batched maps runs in muse.py)
+            return None
         if type(self.prior) is FlatPrior:
             return 0, np.zeros(self.ntheta), np.ones(self.ntheta)
         if type(self.prior) is GaussianPrior:
@@ -412,7 +414,11 @@ class HipMuseProblem(AbstractMuseProblem):
         slowed by whatever else the process does); False: one launch per iteration, the algebra on the host.  The same results
         bit for bit either way; placements without a loop kernel (an element split, N >= 65 536) run the host loop whatever
         is asked."""
-        kind, mean, sigma = self.native_prior()
+        native = self.native_prior()
+        if native is None:
+            raise _capi.MuseError(-1, "the native muse! loops take a flat or Gaussian prior and ntheta <= MUSE_MAX_THETA "
+                                                     "(muse() runs its loop over the batched maps otherwise)")
+        kind, mean, sigma = native
         o = _capi.RunOptions()
         o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)
         o.prior_kind, o.z0_warm = int(kind), int(bool(z0_warm))
@@ -456,7 +462,11 @@ class HipMuseProblem(AbstractMuseProblem):
         """This rank's part of the muse! loop over the ranks of the context's communicator (muse_run_sharded; comm_init
         first): (n, theta, hist, g_sims) as run_muse -- the same on every rank -- and THIS rank's solver infos
         [n, count of its elements] (rank 0: the data element first)."""
-        kind, mean, sigma = self.native_prior()
+        native = self.native_prior()
+        if native is None:
+            raise _capi.MuseError(-1, "the native muse! loops take a flat or Gaussian prior and ntheta <= MUSE_MAX_THETA "
+                                                     "(muse() runs its loop over the batched maps otherwise)")
+        kind, mean, sigma = native
         o = _capi.RunOptions()
         o.nsims, o.maxsteps, o.theta_rtol, o.atol, o.alpha = int(nsims), int(maxsteps), float(theta_rtol), float(atol), float(alpha)
         o.prior_kind, o.z0_warm = int(kind), int(bool(z0_warm))

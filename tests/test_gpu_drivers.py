@@ -132,7 +132,7 @@ def test_c_abi_errors(gpu, M):
     with pytest.raises(M.MuseError):
         M.HipMuseProblem(None, model="noise", ntheta=2, N=8)       # noise has one theta
     with pytest.raises(M.MuseError):
-        M.HipMuseProblem(None, model="funnel", ntheta=9, N=80)     # > MUSE_MAX_THETA
+        M.HipMuseProblem(None, model="funnel", ntheta=65, N=80)    # > MUSE_MAX_THETA_EXT
     p = M.HipMuseProblem(None, model="funnel", N=64)
     with pytest.raises(M.MuseError) as e:
         p.map_and_score_batch(0, 0, 4, [0.0], include_data=True)   # no data set
