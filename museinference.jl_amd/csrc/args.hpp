@@ -248,6 +248,8 @@ struct LoopArgs {
 struct LaunchShape {
     int model, ntheta, place, grid;
     bool implicit;
+    bool big;    // the big tier's instantiation (BigTheta): ntheta > kMaxTheta, or 2..kMaxTheta components of an elementwise model in a
+                 // streaming placement (muse_engine.cpp, tier_big: the same bits, 2.4x faster than the small tiers' streaming passes)
     bool lds_s;  // stencil model in a cluster: the search direction in LDS (vec.hpp, LdsMirror)
     size_t lds;
     void* done_event;  // hipEvent_t (or null) that the launch itself signals on completion: no separate event packet

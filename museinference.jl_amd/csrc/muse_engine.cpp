@@ -185,6 +185,16 @@ static int choose_place(const muse_ctx* c) {
     if (c->N <= 4096) return P_R512x4;
     return P_R512x10;
 }
+// Which instantiation a launch of placement `pl` gets: the big tier's (args.hpp, BigTheta: tables from the kernarg segment, blocks
+// by arithmetic, block sums in chunks) for more than kMaxTheta components -- and for 2..kMaxTheta components of an elementwise
+// model whenever the placement streams and the launch carries one map: the results are the small tier's bit for bit (the same
+// per-thread order, the same trees), the streaming passes much cheaper (funnel, N = 10^5, 8 components, 128 sims: 0.68 -> 0.28 ms;
+// the small tier's compare chain and selected accumulations in every trip).  The stencil model gains nothing (2.32 / 2.38 ms).
+static bool tier_big(const muse_ctx* c, int pl, int nmaps) {
+    if (c->ntheta > kMaxTheta) return true;
+    static const bool off = getenv("MUSE_DEBUG_NO_BIG_TIER") != nullptr;  // tuning aid (A/B)
+    return !off && c->ntheta > 1 && c->model != MUSE_MODEL_SMOOTH && nmaps <= 1 && (pl == P_S256 || pl == P_S512 || pl == P_C256);
+}
 static bool ncache_applies(const muse_ctx* c) {
     static const bool off = getenv("MUSE_DEBUG_NO_NCACHE") != nullptr;  // tuning aid
     return !off && choose_place(c) == P_R512x10;
@@ -370,6 +380,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     {
         LaunchShape shape;
         shape.model = c->model; shape.ntheta = c->ntheta; shape.place = pl; shape.grid = grid; shape.implicit = implicit; shape.lds = lds;
+        shape.big = tier_big(c, pl, a.nmaps);
         shape.lds_s = !implicit && pl == P_C256 && stencil_lds_s(c, a.csize);
         shape.done_event = c->launch_done;
         c->launch_done_used = c->launch_done != nullptr;
@@ -890,8 +901,8 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     }
     make_thetaset(c, theta, a.cur.t);
     a.cur.f_const = theta_const(c, theta);
-    if (c->ntheta > kMaxTheta)  // the big tier: every block's coefficients, where the kernel reads them from the kernarg segment
-        for (int k = 0; k < c->ntheta; ++k) {
+    if (c->ntheta > 1 && c->model != MUSE_MODEL_NOISE)  // the big tier (tier_big): every block's coefficients, where its kernels read
+        for (int k = 0; k < c->ntheta; ++k) {           // them from the kernarg segment (a launch of several maps overwrites them: maps[])
             a.big.sd[k] = muse_exp(0.5 * theta[k]);
             a.big.iv[k] = muse_exp(-theta[k]);
         }
@@ -1381,6 +1392,7 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     const int pl = choose_place(c);
     LaunchShape shape;
     shape.model = c->model; shape.ntheta = nt; shape.place = pl; shape.grid = 0; shape.implicit = false; shape.lds_s = false;
+    shape.big = false;  // (the loop kernel runs the resident placements)
     shape.done_event = nullptr;
     const bool xg_lds = pl == P_R512x10;
     shape.lds = place_lds(c, pl) + loop_extra_lds(xg_lds, nprob, nt);
@@ -1578,7 +1590,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     rc = ensure_results(c, 1, n > nprep ? n : nprep);
     if (rc) return rc;
     // a sampling entry: exp(theta/2) of every block -- a SampleSd, or kBigTheta doubles in the big tier (solver.hpp, begin)
-    const int ts_stride = nt > kMaxTheta ? kBigTheta : kMaxTheta;
+    const int ts_stride = tier_big(c, choose_place(c), 1) ? kBigTheta : kMaxTheta;
     static_assert(sizeof(SampleSd) == kMaxTheta * sizeof(double) && kBigTheta % kMaxTheta == 0, "sampling entries");
     rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G) * (size_t)(ts_stride / kMaxTheta));
     if (rc) return rc;

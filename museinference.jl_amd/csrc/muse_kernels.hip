@@ -797,10 +797,10 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
     return launch_one<MUSE_INSPECT>(s, a, st);
 #elif defined(MUSE_USER_MODEL_HEADER)  // a library built from a user's model header holds that model only (user_model.hpp)
     if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
-    if (s.ntheta > kMaxTheta && !s.implicit) return launch_place_big<UserModel<kBigTheta>>(s, a, st);
+    if (s.big && !s.implicit) return launch_place_big<UserModel<kBigTheta>>(s, a, st);
     if (s.implicit) {
 #ifdef MUSE_MODEL_SECOND
-        if (s.ntheta > kMaxTheta) return launch_place_implicit<UserModel<kBigTheta>>(s, a, st);
+        if (s.big) return launch_place_implicit<UserModel<kBigTheta>>(s, a, st);
         return s.ntheta == 1 ? launch_place_implicit<UserModel<1>>(s, a, st) : launch_place_implicit<UserModel<kMaxTheta>>(s, a, st);
 #else
         return hipErrorInvalidValue;  // (muse_engine.cpp refuses the call before it gets here)
@@ -809,7 +809,7 @@ hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t s
     return s.ntheta == 1 ? launch_place<UserModel<1>>(s, a, st) : launch_place<UserModel<kMaxTheta>>(s, a, st);
 #else
     const int nt = s.ntheta;
-    if (nt > kMaxTheta) {  // the big tier (args.hpp, BigTheta): streaming placements only
+    if (s.big) {  // the big tier (args.hpp, BigTheta; muse_engine.cpp, tier_big): streaming placements only
         if (s.model == MUSE_MODEL_FUNNEL)
             return s.implicit ? launch_place_implicit<FunnelModel<kBigTheta>>(s, a, st) : launch_place_big<FunnelModel<kBigTheta>>(s, a, st);
         if (s.model == MUSE_MODEL_SMOOTH)
