@@ -1,4 +1,4 @@
-"""One rank of tests/test_gpu_shm_transport.py: python shm_rank_worker.py <id hex> <nranks> <rank> <out.npz> <second id hex>.
+"""One rank of tests/test_gpu_shm_transport.py: python shm_rank_worker.py <id hex> <nranks> <rank> <out.npz> <second id hex> <third id hex>.
 All ranks share GPU 0 (the shared-memory transport has no device-side part)."""
 import os
 import sys
@@ -36,6 +36,13 @@ big = np.sin(np.arange(40000.0) * (rank + 1))
 res["ar"] = prob.allreduce_sum(big)
 res["ag_big"] = prob.allgather_scores(big[:20001])
 prob.close()
+# the big tier (12 components > MUSE_MAX_THETA) through the same gathered map
+pb = M.HipMuseProblem(None, model="funnel", ntheta=12, N=N)
+pb.comm_init(world, rank, bytes.fromhex(sys.argv[6]))
+nb = pb.map_and_score_batch_gather_async(SEED, lo, hi, np.linspace(-0.5, 0.6, 12), rows, atol=1e-4, result_area=1)
+res["gbig"], ib = pb.batch_wait_gathered(nb, rows, 1)
+res["itbig"] = ib["iterations"]
+pb.close()
 # the muse! loop over the ranks in native code (muse_run_sharded): the same theta trajectory, records and scores on every rank
 xdat = np.sin(0.37 * np.arange(N)) * 1.3
 pm = M.HipMuseProblem(xdat, model="funnel", ntheta=NTH, prior=M.GaussianPrior(0.0, 3.0))

@@ -18,9 +18,10 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
     import museinference_jl_amd as M
     uid = M.HipMuseProblem.comm_unique_id("shm", 4096)   # naming the segment does not touch the GPU
     uid2 = M.HipMuseProblem.comm_unique_id("shm", 4096)  # (the communicator of the native sharded muse! loop)
+    uid3 = M.HipMuseProblem.comm_unique_id("shm", 4096)  # (the 12-component problem's)
     assert len(uid) == 128
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r], uid2.hex()],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r], uid2.hex(), uid3.hex()],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert [p.returncode for p in procs] == [0] * world, "\n".join(logs)
@@ -42,6 +43,16 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
             lo, hi = M.block_partition(0, NSIMS, world, r)
             assert np.array_equal(res[r][f"it{k}"], info["iterations"][lo:hi])
     ref.close()
+    refb = M.HipMuseProblem(None, model="funnel", ntheta=12, N=N)      # the big tier's score blocks travel like the others
+    gb, ib = refb.map_and_score_batch(SEED, 0, NSIMS, np.linspace(-0.5, 0.6, 12), atol=1e-4)
+    refb.close()
+    for r in range(world):
+        assert res[r]["gbig"].shape == (world, rows, 12)
+        for q in range(world):
+            lo, hi = M.block_partition(0, NSIMS, world, q)
+            assert np.array_equal(res[r]["gbig"][q, : hi - lo], gb[lo:hi]), (r, q)
+        lo, hi = M.block_partition(0, NSIMS, world, r)
+        assert np.array_equal(res[r]["itbig"], ib["iterations"][lo:hi])
     # muse_run_sharded on every rank = the unsharded native loop, bit for bit (theta is never exchanged: every rank takes the
     # same step from the same gathered scores)
     xdat = np.sin(0.37 * np.arange(N)) * 1.3
