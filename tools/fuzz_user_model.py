@@ -22,13 +22,13 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 model = M.ElementwiseModel.packaged("cubic")
 t0 = time.time()
-ncase = nsame = ntight = noff = noff_equal = nbad = 0
+ncase = nsame = ntight = noff = noff_equal = nbad = nimp = nimp_bad = 0
 maxit = 0
 with O.user_model(model.header, "cubic"):
     while time.time() - t0 < budget:
         N = int(rng.choice([int(rng.integers(5, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)),
                             int(rng.integers(10000, 30000)), int(rng.integers(65000, 80000))]))
-        nth = min(int(rng.choice([1, 2, 3, 4, 8])), N)
+        nth = min(int(rng.choice([1, 2, 3, 4, 8, 8, int(rng.integers(9, 65))])), N)   # (9..64: the big tier)
         theta = rng.uniform(-2.0, 0.8, size=nth)
         atol = float(rng.choice([1e-2, 1e-4, 1e-6]))
         z0 = int(rng.choice([0, 1]))
@@ -43,7 +43,7 @@ with O.user_model(model.header, "cubic"):
             prob.set_element_split(split)
         else:
             split = 0
-        nmaps = int(rng.choice([1, 1, 2, 3]))
+        nmaps = 1 if nth > 8 else int(rng.choice([1, 1, 2, 3]))
         if nmaps > 1:
             thetas = np.vstack([theta] + [rng.uniform(-2.0, 0.8, size=nth) for _ in range(nmaps - 1)])
             tot = prob.map_and_score_multi_async(seed, s0, s0 + n, thetas, atol=atol, z0_mode=z0, result_area=2)
@@ -52,7 +52,20 @@ with O.user_model(model.header, "cubic"):
         else:
             g, info = prob.map_and_score_batch(seed, s0, s0 + n, theta, atol=atol, z0_mode=z0)
         zh = prob.get_zhat(0, n)
+        # every fourth case: the implicit-differentiation H of one simulation (the header's second derivatives) against the checker's
+        imp = None
+        if rng.random() < 0.25 and N >= 20:
+            Hi, its = prob.implicit_H_batch(seed, s0, s0 + 1, theta, atol=1e-1, cg_maxiter=100)
+            imp = (Hi[0], its[0])
         prob.close()
+        if imp is not None:
+            Ho, io_cg = O.implicit_H("user", N, seed, s0, theta, atol=1e-1, cg_maxiter=100)
+            nimp += 1
+            scale = max(np.abs(Ho).max(), 1.0)
+            if not (np.all(np.abs(imp[1] - io_cg) <= 2) and np.all(np.abs(imp[0] - Ho) <= 1e-6 * scale)):
+                nimp_bad += 1
+                print("IMPLICIT MISMATCH", "N", N, "nth", nth, "placement", placement, "split", split, theta.tolist(), seed, s0, imp[1], io_cg,
+                      float(np.abs(imp[0] - Ho).max() / scale), flush=True)
         go, zo, io = O.map_and_score_batch("user", N, seed, s0, s0 + n, theta, atol=atol, z0_mode=z0, nthreads=8)
         ncase += 1
         maxit = max(maxit, int(io["iterations"].max()))
@@ -71,4 +84,4 @@ with O.user_model(model.header, "cubic"):
                   info["iterations"], io["iterations"], info["f_calls"], io["f_calls"], info["status"], io["status"], dz,
                   float(np.abs(g - go).max()), flush=True)
 print(f"{ncase} cases: {nsame} same path ({ntight} of them with MAPs to 1e-9), {noff} off path (converged, MAPs within 2 atol; {noff_equal} of them with equal counts), {nbad} MISMATCHES; longest solve {maxit} iterations; "
-      f"{time.time() - t0:.0f} s")
+      f"implicit-differentiation H: {nimp} cases, {nimp_bad} beyond 1e-6 or two CG iterations; {time.time() - t0:.0f} s")
