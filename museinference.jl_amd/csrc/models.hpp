@@ -2,6 +2,7 @@
 #pragma once
 #include <type_traits>
 
+#include "step.hpp"
 #include "user_model.hpp"
 #include "vec.hpp"
 
@@ -18,18 +19,7 @@ __device__ __forceinline__ int block_of(const BatchArgs& a, int i) {
     return k;
 }
 
-// ntheta > kMaxTheta (the big tier): block k = floor(i * B / N) by arithmetic -- the same blocks as the boundaries
-// bnd[k] = ceil(k N / B) of the compare chain above -- instead of up to 63 compares.  i * B < 2^34 is exact in a double, the
-// product with the rounded reciprocal is off by at most one, which the exact remainder corrects; the pad element of an
-// odd-length vector and the phantom slots behind it (i >= N) belong to the last block, as in block_of.
-__device__ __forceinline__ int block_of_big(int N, int B, double rcpN, int i) {
-    const long long ab = (long long)i * B;
-    int q = (int)((double)ab * rcpN);
-    const long long r = ab - (long long)q * N;
-    q += r >= N ? 1 : 0;
-    q -= r < 0 ? 1 : 0;
-    return q < B - 1 ? q : B - 1;
-}
+// (block_of_big, the big tier's block index by arithmetic: step.hpp -- host and device, checked exhaustively on the host)
 
 template <int MAXB_>
 struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)

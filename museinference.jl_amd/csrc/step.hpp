@@ -50,6 +50,19 @@ MUSE_HD double muse_exp(double x) {
     return (y * s.d) * 9.33263618503218878990e-302;  // 2^-1000
 }
 
+// The block of element i when ntheta > kMaxTheta (the big tier of args.hpp, BigTheta): block k = floor(i * B / N) by arithmetic -- the same blocks as the boundaries
+// bnd[k] = ceil(k N / B) of the small tiers' compare chain (models.hpp, block_of) -- instead of up to 63 compares.  i * B < 2^34 is exact in a double, the
+// product with the rounded reciprocal is off by at most one, which the exact remainder corrects; the pad element of an
+// odd-length vector and the phantom slots behind it (i >= N) belong to the last block, as in block_of.
+MUSE_HD int block_of_big(int N, int B, double rcpN, int i) {
+    const long long ab = (long long)i * B;
+    int q = (int)((double)ab * rcpN);
+    const long long r = ab - (long long)q * N;
+    q += r >= N ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q < B - 1 ? q : B - 1;
+}
+
 // (component k's entries -- on the device one lane per component -- and the constant term, a sum in component order)
 MUSE_HD void make_map_theta_component(int k, int ntheta, const double* theta, MapTheta& m) {
     const bool live = k < ntheta;

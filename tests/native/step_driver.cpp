@@ -52,10 +52,50 @@ static double rnd() {  // xorshift -> (0, 1)
     return ((double)(rng_state >> 11) + 0.5) / 9007199254740992.0;
 }
 
+// block_of_big (the big tier's block index: a double product with 1/N and an exact remainder correction) against the integer
+// definition floor(i B / N), clamped to the last block for the pad / phantom elements i >= N: every i for small N, every
+// boundary's neighbourhood and random elements for N up to 2^28 - 1 (the engine's bound for 32-bit element indices).
+static long check_blocks(int& bad) {
+    long n = 0;
+    auto one = [&](int N, int B, long long i) {
+        if (i < 0 || i > 0x7fffffff) return;
+        const long long want = i * B / N;
+        const int expect = (int)(want < B - 1 ? want : B - 1);
+        const int got = block_of_big(N, B, 1.0 / (double)N, (int)i);
+        n += 1;
+        if (got != expect && bad++ < 10) printf("block_of_big(N=%d, B=%d, i=%lld) = %d, floor = %d\n", N, B, i, got, expect);
+    };
+    for (int N = 1; N <= 400; ++N)
+        for (int B = 1; B <= (N < kBigTheta ? N : kBigTheta); ++B)
+            for (int i = 0; i <= N + 2; ++i) one(N, B, i);
+    unsigned long long lcg = 88172645463325252ull;
+    auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(lcg >> 33); };
+    const int sizes[] = {10000, 9999, 65536, 70001, 100000, 1000000, 999983, 16777216, 16777217, 134217728, 268435455, 268435399, 200000003};
+    for (int N : sizes)
+        for (int B = 2; B <= kBigTheta; ++B) {
+            for (int k = 0; k <= B; ++k) {
+                const long long bnd = ((long long)k * N + B - 1) / B;   // ceil(k N / B): the first element of block k
+                for (int d = -3; d <= 3; ++d) one(N, B, bnd + d);
+            }
+            for (int r = 0; r < 64; ++r) one(N, B, rnd() % (unsigned)N);
+            one(N, B, N); one(N, B, (long long)N + 1);
+        }
+    for (int r = 0; r < 200000; ++r) {
+        const int N = 1 + (int)(rnd() % 268435455u), B = 1 + (int)(rnd() % (unsigned)(N < kBigTheta ? N : kBigTheta));
+        const int k = (int)(rnd() % (unsigned)(B + 1));
+        const long long bnd = ((long long)k * N + B - 1) / B;
+        for (int d = -2; d <= 2; ++d) one(N, B, bnd + d);
+        one(N, B, rnd() % (unsigned)N);
+    }
+    return n;
+}
+
 int main() {
     const double special[] = {0.0, -0.0, INFINITY, -INFINITY, NAN, 1e-320, -1e-320, 1e308, -1e308, 1.0, -1.0};
     int bad = 0;
     long cases = 0;
+    const long nblocks = check_blocks(bad);
+    printf("block_of_big: %ld elements checked\n", nblocks);
     for (int nt = 1; nt <= kMaxTheta; ++nt)
         for (int rep = 0; rep < 4000; ++rep) {
             StepParams sp;

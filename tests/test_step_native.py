@@ -1,7 +1,8 @@
 """csrc/step.hpp on CPU (a g++ build of tests/native/step_driver.cpp): the diagonal closed form of the muse! step that the
 library runs -- on the host in muse_run / muse_run_sharded, on one lane of the GPU in muse_run_device -- against its
 definition with dense Gauss-Jordan inverses (src/muse.jl:208 inverts general matrices): the same bits, signed zeros,
-infinities, NaNs and error codes included; and the 64-leaf summation tree of the score moments."""
+infinities, NaNs and error codes included; the 64-leaf summation tree of the score moments; and block_of_big, the arithmetic
+block index of the big tier (ntheta > MUSE_MAX_THETA), against its integer definition."""
 import os
 import subprocess
 
@@ -15,3 +16,4 @@ def test_step_closed_form_equals_dense_definition_bitwise(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "step driver ok" in r.stdout
+    assert "block_of_big:" in r.stdout      # (the big tier's block index against floor(i B / N): tens of millions of elements)
