@@ -51,4 +51,6 @@ while time.time() - t0 < seconds:
 while pend:
     p.batch_wait(pend.pop(0), (steps - len(pend) - 1) % 4)
 p.synchronize()
-print(f"{steps} pipelined two-lane steps in {time.time() - t0:.1f} s: {1e6 * (time.time() - t0) / steps:.1f} us per step, all converged")
+print(f"{steps} pipelined two-lane steps in {time.time() - t0:.1f} s: {1e6 * (time.time() - t0) / steps:.1f} us per step, all converged "
+      f"(the loop repeats ONE step: from its third pass on the normals come from the cross-call cache, not from the generator -- "
+      f"not bench.py's step, which draws its simulations)")
