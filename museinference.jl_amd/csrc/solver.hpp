@@ -695,7 +695,7 @@ struct Solver {
     // id comparison, as the index comparisons of the published algorithm.
     // Returns true on success.  On failure (LineSearchException / failed assertion) alpha is the step
     // Optim falls back to.  On success last_phi/last_gmax are the scalars at z + alpha s.
-    __device__ bool linesearch(double c0, double phi_0, double dphi_0, double& alpha) {
+    __device__ __forceinline__ bool linesearch(double c0, double phi_0, double dphi_0, double& alpha) {
         enum { S_INIT, S_EXPAND, S_BIS, S_SEC1, S_SEC2, S_MID, S_FINAL };
         enum { CONT_BRACKET, CONT_UPD1, CONT_UPD2, CONT_UPD3 };
         alpha = 0.0;
@@ -861,14 +861,20 @@ struct Solver {
     int iterations, hist_words, status;
     double* extra;  // one more scratch vector (streaming): the simulation's true z for the implicit-diff H
 
-    __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
+    // (run / begin / solve / finish / linesearch are ALWAYS inlined: left to the inliner's budget, the library build -- a hundred
+    // instantiations in one translation unit -- kept Solver::run as a function of its own for some of them (FunnelModel<8> in every
+    // placement, the non-cluster streaming placements of every model: two call sites, the map kernel's and the loop kernel's), and
+    // the solver's state, its register-resident vectors included, then lived in memory behind `this`: FunnelModel<8> at
+    // N = 10^4 ran 189 us per 512-sim step against 67 us for FunnelModel<4>.  A single-instantiation build (tools/regs.py
+    // --check) does not show it: tools/regs.py --library reads the product's own code object.)
+    __device__ __forceinline__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         Prefetch<EPT> none;
         none.p = -1;
         none.g_pending = false;
         run(p, wg_scratch, lds_x, lds_g, none);
     }
     // (next_p: the workgroup's next problem of the same iteration, -1: none -- its n1 travels into the g area during this solve)
-    __device__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p = -1) {
+    __device__ __forceinline__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p = -1) {
         begin<false>(p, wg_scratch, lds_x, lds_g, pf);
         if (d.normals_only) return;  // the element only filled its slot of the normals cache
         pfp = &pf;
@@ -893,7 +899,7 @@ struct Solver {
 
     // -- phase 1: bind storage, produce x and the starting point
     template <bool KEEP_ZTRUE>
-    __device__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
+    __device__ __forceinline__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         Prefetch<EPT> none;
         none.p = -1;
         none.g_pending = false;
@@ -901,7 +907,7 @@ struct Solver {
         begin<KEEP_ZTRUE>(p, wg_scratch, lds_x, lds_g, none);
     }
     template <bool KEEP_ZTRUE>
-    __device__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf) {
+    __device__ __forceinline__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf) {
         d = describe(a, p);
         // the loop kernel fetched this problem's theta-free inputs ahead (LDS-resident layout only; workgroup-uniform)
         const bool pf_hit = Place::kResident && Place::kXgLds && pf.p == p;
@@ -1317,7 +1323,7 @@ struct Solver {
             B.unload();
         }
     }
-    __device__ double twoloop_prefetched(int upper, int lower, double dot0) {
+    __device__ __forceinline__ double twoloop_prefetched(int upper, int lower, double dot0) {
         if constexpr (kPrefetchTwoLoop) {
             double dot = dot0;
             int t0 = tfirst;
@@ -1405,7 +1411,7 @@ struct Solver {
     }
 
     // -- phase 2: zhat_at_theta -- Optim LBFGS + HagerZhang on -logLike from the z prepared by begin()
-    __device__ void solve(int p) {
+    __device__ __forceinline__ void solve(int p) {
         const int64_t ld = a.ld;
         const int N = (int)a.N;
         // ---- initial_state: value_gradient!!(d, z0); initial convergence -----------------------
@@ -1742,7 +1748,7 @@ struct Solver {
     // closed forms (see oracle/muse_oracle.c, mo_implicit_H, for the list).  Streaming policy only:
     // the CG vectors reuse the solver's g, s and history buffers; z_true sits in the extra vector.
     // Writes H[p] (row-major ntheta x ntheta) and the CG iteration count of column j to info[p*ntheta+j].
-    __device__ void run_implicit(int p, double* wg_scratch, double* lds_x, double* lds_g) {
+    __device__ __forceinline__ void run_implicit(int p, double* wg_scratch, double* lds_x, double* lds_g) {
         begin<true>(p, wg_scratch, lds_x, lds_g);
         solve(p);
         const int64_t ld = a.ld;
@@ -1923,7 +1929,7 @@ struct Solver {
     }
 
     // -- phase 3: zhat out, score grad_theta logLike(x, zhat, theta), solver info
-    __device__ void finish(int p) {
+    __device__ __forceinline__ void finish(int p) {
         const int64_t ld = a.ld;
         if constexpr (kBig) {
             // the big tier: the block sums of the score terms eight blocks at a time -- a pass over z (and x) and one

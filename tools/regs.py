@@ -2,6 +2,9 @@
 
   python tools/regs.py file.s           report every map_score_kernel variant of an assembly file
                                         (hipcc -S --cuda-device-only ... muse_kernels.hip -o file.s: ~2.5 min for all)
+  python tools/regs.py --library lib.so report the solver kernels of a BUILT library from its own code object, and fail if one calls a
+                                        device function or keeps the solver's state in scratch (what the library build can do and a
+                                        single-instantiation build does not show)
   python tools/regs.py --check          compile ONLY the hot instantiations (-DMUSE_INSPECT=..., a few seconds each)
                                         and fail if one of them spills vector registers to scratch
 The hot instantiations: the resident kernels of BASELINE.json configs[1] (funnel, 1 theta) and of the noise model
@@ -86,8 +89,60 @@ def check():
     return bad
 
 
+def library_report(path):
+    """Every solver kernel of a BUILT library (libmuse_hip.so, a model's library), from the metadata of its gfx950 code object: the
+    single-instantiation builds of --check do not show what the inliner does with a hundred instantiations in one translation
+    unit (round 4: Solver::run left as a function of its own for some of them -- the solver's state, its register-resident vectors
+    included, in memory behind `this`: 1 KB of scratch per lane and a 3x slower FunnelModel<8>)."""
+    import struct
+    data = open(path, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    if i < 0:
+        raise RuntimeError(path + ": no offload bundle found")
+    n, = struct.unpack_from("<Q", data, i + 24)
+    pos, blob = i + 32, None
+    for _ in range(n):
+        off, size, idlen = struct.unpack_from("<QQQ", data, pos)
+        pos += 24
+        tid = data[pos:pos + idlen].decode()
+        pos += idlen
+        if "gfx950" in tid:
+            blob = data[i + off:i + off + size]
+    if blob is None:
+        raise RuntimeError(path + ": no gfx950 code object in the bundle")
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(blob)
+        f.flush()
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    rows = []
+    for b in out.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", b).group(1)
+        if "map_score" not in name and "muse_loop" not in name:
+            continue
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1))
+        short = name.replace("_ZN4muse16map_score_kernelINS_", "").replace("_ZN4muse16muse_loop_kernelINS_", "loop:").replace("EvNS_9BatchArgsE", "")
+        rows.append((short, g("vgpr_count"), g("vgpr_spill_count"), g("sgpr_spill_count"), g("private_segment_fixed_size"),
+                     bool(re.search(r"\.uses_dynamic_stack:\s+true", b))))
+    return rows
+
+
+LIBRARY_SCRATCH_LIMIT = 512   # bytes per lane; the solver's state behind a pointer is > 1000
+
+
+def check_library(path):
+    """Kernels of a built library that call a device function (dynamic stack) or keep more than LIBRARY_SCRATCH_LIMIT bytes of
+    scratch per lane."""
+    return [r for r in library_report(path) if r[5] or r[4] > LIBRARY_SCRATCH_LIMIT]
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
         sys.exit(1 if check() else 0)
+    if len(sys.argv) > 2 and sys.argv[1] == "--library":
+        for short, vgpr, vspill, sspill, scratch, dyn in sorted(library_report(sys.argv[2]), key=lambda r: -r[4]):
+            print(f"{short:78s} vgpr {vgpr:3d} vspill {vspill:3d} sspill {sspill:3d} scratch {scratch:4d}{' CALLS' if dyn else ''}")
+        bad = check_library(sys.argv[2])
+        print(f"{len(bad)} kernels beyond {LIBRARY_SCRATCH_LIMIT} bytes of scratch or with calls")
+        sys.exit(1 if bad else 0)
     for short, vgpr, vspill, sspill, scratch in report(sys.argv[1]):
         print(f"{short:70s} vgpr {vgpr:3d} vspill {vspill:3d} sspill {sspill:3d} scratch {scratch}")
