@@ -18,7 +18,11 @@ for L in host dev; do
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_$L -- python3 $R/tools/runloop_bench.py $L once > $OUT/runloop_sq_$L.log 2>&1
 done
 python3 $R/tools/runloop_bench.py > $OUT/runloop.log 2>&1
-if [ -f $R/museinference.jl_amd/libmuse_hip_stamps.so ]; then
+STAMPS=$R/museinference.jl_amd/libmuse_hip_stamps.so   # (python museinference.jl_amd/build.py --stamps, before the gpurun call)
+for f in $R/museinference.jl_amd/csrc/* $R/include/muse_hip.h; do
+  if [ -f $STAMPS ] && [ $f -nt $STAMPS ]; then echo "libmuse_hip_stamps.so is older than $f: rebuild it (build.py --stamps); no stamp breakdown"; STAMPS=/nonexistent; fi
+done
+if [ -f $STAMPS ]; then
   python3 $R/tools/stamps_run.py > $OUT/stamps_run_host.log 2>&1
   python3 $R/tools/stamps_run.py 10000 1 512 4 dev > $OUT/stamps_run_dev.log 2>&1
 fi
