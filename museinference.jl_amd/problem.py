@@ -412,7 +412,7 @@ class HipMuseProblem(AbstractMuseProblem):
         iteration -- map, exchange of the scores between the (all resident) workgroups, step, next map -- and nothing leaves
         the GPU in between (the default: 44 against 48 us per iteration at N = 10^4 x 512 sims, and no host in the loop to be
         slowed by whatever else the process does); False: one launch per iteration, the algebra on the host.  The same results
-        bit for bit either way; placements other than the resident ones (an element split, N > 10 000) run the host loop whatever
+        bit for bit either way; placements other than the resident ones (an element split, N > 10 000) and more than one theta component run the host loop whatever
         is asked."""
         native = self.native_prior()
         if native is None:

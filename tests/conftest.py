@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# muse_run_device hands runs with more than one theta component to the host loop (the faster one there); the tests compare the
+# loop KERNEL with the host loop for every ntheta, so they ask for it whatever ntheta (read once by the library)
+os.environ.setdefault("MUSE_DEBUG_LOOP_ANY_NTHETA", "1")
 
 
 def pytest_configure(config):

@@ -5,6 +5,8 @@
   * several maps in one launch against separate launches (bitwise);
   * muse_fd_values_columns against the oracle's per-simulation operators (rtol 1e-7).
 Usage: python tools/fuzz_loops.py [seconds] [seed]"""
+import os
+os.environ.setdefault("MUSE_DEBUG_LOOP_ANY_NTHETA", "1")   # (the loop kernel whatever ntheta: muse_run_device's default hands ntheta > 1 to the host loop)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
