@@ -250,8 +250,9 @@ int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_
  * step, the history record and the convergence test for itself from the same bits; the next theta never leaves the
  * chip.  (exp(theta/2), exp(-theta) are a fixed sequence of IEEE operations on host and device, and the score moments one
  * fixed 64-leaf summation tree, for this reason.)  The loop kernel runs where it is the faster loop: the register/LDS-resident
- * placements (N <= 10 000, no element split) with one theta component; more components, the streaming placements and score
- * blocks beyond the step's LDS arrays (nsims * ntheta above ~19 000) run muse_run's loop instead -- the same bits. */
+ * placements (N <= 10 000, no element split) with one theta component or at most one element per workgroup; everything else
+ * (more elements AND more components, the streaming placements, score blocks beyond the step's LDS arrays: nsims * ntheta above
+ * ~19 000) runs muse_run's loop instead -- the same bits. */
 int muse_run_device(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
                     double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 

@@ -1402,11 +1402,12 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     // hundreds of microseconds of HBM traffic, the host's share of it nothing, and the loop kernel's static deal of the elements
     // slower than the map kernel's tickets (N = 30 000 x 512 sims: 377 against 347 us per iteration)
     const bool resident = pl == P_R256x1 || pl == P_R512x4 || pl == P_R512x10;
-    // ... and with one theta component: the loop kernels of the multi-theta instantiations carry their per-block state across the
-    // solver (37-180 spilled registers) and lose to the host loop -- measured per iteration at 512 sims, host / device:
-    // N = 10^4: 53 / 50 us (1 component), 75 / 79 (2), 89 / 97 (4), 100 / 113 (8); N = 512: 25 / 20 (1), 38 / 44 (8)
+    // ... and with one theta component, or one problem per worker: the loop kernels of the multi-theta instantiations carry their
+    // per-block state across the solver (37-180 spilled registers) and lose to the host loop when a worker has several problems --
+    // measured per iteration at 512 sims, host / device: N = 10^4: 53 / 50 us (1 component), 75 / 79 (2), 89 / 97 (4), 100 / 113 (8);
+    // N = 512: 25 / 20 (1), 38 / 44 (8) -- and win when it has one (100 sims: N = 3000 x 4 components 30.5 / 25.8, N = 512 x 8: 19.6 / 16.5)
     static const bool any_nt = getenv("MUSE_DEBUG_LOOP_ANY_NTHETA") != nullptr;   // tuning aid / tests: the loop kernel whatever ntheta
-    if (host_only || !resident || (nt > 1 && !any_nt) || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
+    if (host_only || !resident || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
         (xg_lds && loop_step_bytes(nprob, nt) > (size_t)2 * (c->ld + 2) * sizeof(double)))
         return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
     if (c->nlanes > 1) {   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
@@ -1425,7 +1426,8 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
         r.grid_max = mg;
     }
     const int max_grid = r.grid_max;
-    if (max_grid < 2) return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
+    if (max_grid < 2 || (nt > 1 && !any_nt && nprob > max_grid - 1))
+        return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
     rc = ensure_zhat(c, nprob);
     if (rc) return rc;
     BatchArgs a;
