@@ -47,8 +47,9 @@
  * muse_set_constants(ctx, k, values, count) on the engine (muse_hip.h), mo_set_constants on the CPU checker -- and 1.0 for
  * i >= count (the pad element and the phantom slots, as the compiled tables do) and while the vector has not been set (the
  * engine's contract check evaluates the functions before any constant exists).  The values live in device memory and are read
- * through one pointer per vector: one set of constants per model library and process at a time (a context that launches after
- * another context of the same library has set its own constants re-installs its own first).
+ * through one pointer per vector, and the pointers travel WITH EVERY LAUNCH (round 5: in its kernel-argument block, which
+ * muse_const reads through the kernarg segment pointer) -- contexts of one library with different constants may have launches in
+ * flight at the same time; only the host-side evaluation (muse_model_eval, the contract check) goes through one set per process.
  * ElementwiseModel.from_source(name, source, runtime_constants=["P", ...]) writes the #define and an accessor P(i) per name.
  *
  * Requirements the engine checks when a context is created (it evaluates the functions on the host):
@@ -94,14 +95,14 @@ extern long muse_host_const_len[MUSE_MODEL_MAX_CONST];
 #ifdef __cplusplus
 }
 #endif
-#if defined(__HIPCC__)
-extern __device__ const double* muse_dev_consts[MUSE_MODEL_MAX_CONST];
-extern __device__ long muse_dev_const_len[MUSE_MODEL_MAX_CONST];
-#endif
 MUSE_MODEL_FN double muse_const(int k, long i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const long n = muse_dev_const_len[k];
-    return i < n ? muse_dev_consts[k][i] : 1.0;
+    /* the launch's own vectors: every kernel of the engine takes its argument block (csrc/args.hpp, BatchArgs) as its FIRST
+     * parameter, and MUSE_KERNARG_CONSTS (csrc/user_model.hpp) is the offset of {pointers[4], lengths[4]} in it -- uniform
+     * scalar loads from the kernel-argument segment, no state shared between launches */
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + MUSE_KERNARG_CONSTS;
+    const long n = ((const long*)(ka + MUSE_MODEL_MAX_CONST * sizeof(const double*)))[k];
+    return i < n ? ((const double* const*)ka)[k][i] : 1.0;
 #else
     const long n = muse_host_const_len[k];
     return i < n ? muse_host_consts[k][i] : 1.0;

@@ -139,14 +139,22 @@ struct BatchArgs {
     // device-resident muse! loop (muse_loop_kernel): every element also publishes its score components as tagged 8-byte
     // granules {32-bit half, 32-bit tag} -- [row * ntheta + k][2], one write-through store each -- which every workgroup
     // sweeps at the end of the iteration (no fence, no barrier: solver.hpp, cluster_exchange, has the argument)
-    unsigned long long* gran;
+    unsigned long long* gran;      // (the sharded loop: this rank's rows of the NODE's score board -- pinned host memory that every
+                                   //  rank's GPU maps -- and gran_sys = 1: the stores are system-scope)
     unsigned int gran_tag;         // this iteration's tag
-    int pad1_;
-    union {  // LAST, read from the kernarg segment only (never copied to LDS)
+    int gran_sys;
+    union {  // read from the kernarg segment only (never copied to LDS)
         alignas(16) MapTheta maps[kMaxMaps];  // theta of every map, nmaps > 1
         BigTheta big;                         // ntheta > kMaxTheta
     };
+    // LAST, kernarg segment only: the run-time constants of a user-supplied model (include/muse_model.h, muse_const) -- the
+    // launching context's device vectors and their lengths.  Per LAUNCH (round 5; a process-wide __device__ symbol before:
+    // a launch of another context of the same library still in flight would have read the new owner's pointers).
+    const double* consts[4];
+    long const_len[4];
 };
+constexpr size_t kArgsConstsOffset = offsetof(BatchArgs, consts);
+static_assert(offsetof(BatchArgs, const_len) == kArgsConstsOffset + 4 * sizeof(const double*), "muse_const reads {pointers[4], lengths[4]}");
 static_assert(sizeof(BigTheta) <= sizeof(MapTheta) * kMaxMaps, "the big tier's tables take the place of maps[]");
 constexpr size_t kArgsHeadBytes = offsetof(BatchArgs, maps);  // what the kernel keeps in LDS
 static_assert(kArgsHeadBytes % 16 == 0 && offsetof(BatchArgs, cur) % 8 == 0, "LDS copy of the argument block");
@@ -235,7 +243,14 @@ struct LoopArgs {
     StepParams sp;
     int maxsteps, z0_warm;
     unsigned int tag_base;           // the granule tag of iteration i is tag_base + i (grows from run to run: nothing is reset)
-    int pad_;
+    int board;                       // 1: score_gran is the node's score board in pinned host memory (muse_run_sharded's device loop: the
+                                     // ranks' workers write their scores there, every rank's stepper polls ALL of them -- batched
+                                     // sweeps, a PCIe round trip each -- and takes the same step from the same bits)
+    const unsigned long long* score_gran;  // what the stepper polls: [nprob_total * ntheta][2] tagged granules, data element first
+    unsigned long long* theta_gran;  // this GPU's own: the stepper's theta_next [ntheta] and {err, converged}, two granules each
+    int nprob_total, pad_;           // elements of the WHOLE job (nsims + 1); BatchArgs::nproblems is this rank's share
+    int64_t scores_stride;           // doubles between two iterations' score blocks at scores_out (0: one block, overwritten)
+    double* scores_all_out;          // board mode: pinned [maxsteps][nprob_total][ntheta], written by the stepper
     double* hist_out;                // pinned [maxsteps][MUSE_RUN_HIST]
     double* scores_out;              // pinned [maxsteps][nsims + 1][ntheta]: every iteration's scores, data element first
     muse_info* info_out;             // pinned [maxsteps][nsims + 1], or a device dummy of one iteration (info_stride 0)
@@ -262,7 +277,6 @@ hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const 
 bool loop_supported(const LaunchShape& s);
 hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid);
 hipError_t launch_loop(const LaunchShape& s, const BatchArgs& a, const LoopArgs& l, hipStream_t stream);
-hipError_t install_constants(const double* const* dev_ptrs, const long* lens, hipStream_t stream);  // a user model's run-time constants (muse_model.h)
 size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta);  // LDS of the loop kernel beside the map kernel's
 size_t loop_step_bytes(int64_t nprob, int ntheta);              // the step's own arrays (they alias x and g in the LDS-resident layout)
 constexpr int kArgsDoubles = (int)((kArgsHeadBytes + 15) / 16 * 2);  // LDS copy of the kernel arguments (without the trailing maps[])

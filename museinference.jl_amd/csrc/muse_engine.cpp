@@ -127,6 +127,8 @@ struct muse_ctx {
     int64_t stamps_cap = 0;
     unsigned long long* clock_pin = nullptr;  // pinned [4]: {s_memtime, s_memrealtime} at entry and exit of workgroup 0 (profiling launches)
     struct RunBuffers* run = nullptr;  // buffers of the device-resident muse! loop (muse_run_device)
+    bool loop_unfit = false;   // a loop kernel of this context could not keep its workgroups resident (a shared GPU): the later
+                               // calls of muse_run_device go straight to muse_run instead of spinning into the bounded waits again
     int comm_reserve_cus = 0;  // compute units left to a device-side collective that runs beside the solver (muse_comm.cpp)
     void* comm = nullptr;  // ncclComm_t (muse_comm.cpp)
     double* comm_buf = nullptr;
@@ -447,42 +449,35 @@ static int settle_area(muse_ctx* c, int area) {
 }
 
 #if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_NCONST)
-// The model's run-time constants as its functions see them (include/muse_model.h): on the host through these, on the device
-// through the symbols of muse_kernels.hip -- ONE set per process and library, the set of the context that installed it last.
+// The model's run-time constants as its functions see them (include/muse_model.h).  On the DEVICE every launch carries the
+// launching context's pointers in its own argument block (BatchArgs::consts: set_launch_constants below) -- no state is shared
+// between launches, so contexts of one library with different constants may have maps in flight at the same time.  On the HOST
+// (muse_model_eval, the contract check of muse_ctx_create) the functions read these: ONE set per process and library, the set
+// of the context that entered the library last (check_ctx); host evaluation is synchronous, nothing is in flight across it.
 extern "C" {
 const double* muse_host_consts[MUSE_MODEL_MAX_CONST] = {nullptr, nullptr, nullptr, nullptr};
 long muse_host_const_len[MUSE_MODEL_MAX_CONST] = {0, 0, 0, 0};
 }
 static muse_ctx* g_consts_owner = nullptr;
-static int install_ctx_constants(muse_ctx* c) {
-    const double* ptrs[MUSE_MODEL_MAX_CONST];
-    long lens[MUSE_MODEL_MAX_CONST];
+static void own_host_constants(muse_ctx* c) {
+    if (!c->has_consts || g_consts_owner == c) return;
     for (int k = 0; k < MUSE_MODEL_MAX_CONST; ++k) {
-        ptrs[k] = c->consts_dev[k];
-        lens[k] = c->consts_len[k];
         muse_host_consts[k] = c->consts_host[k];
         muse_host_const_len[k] = c->consts_len[k];
     }
-    const hipError_t e = install_constants(ptrs, lens, c->stream);
-    if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("installing the model's constants: ") + hipGetErrorString(e));
     g_consts_owner = c;
-    return MUSE_OK;
 }
-#define MUSE_OWN_CONSTANTS(c)                                                     \
-    do {                                                                          \
-        if ((c)->has_consts && g_consts_owner != (c)) {                           \
-            const int rc_ = for_each_lane((c), [&]() -> int {                     \
-                HIPCHK(hipStreamSynchronize((c)->stream));                        \
-                return MUSE_OK;                                                   \
-            });                                                                   \
-            if (rc_) return rc_;                                                  \
-            const int rc2_ = install_ctx_constants(c);                            \
-            if (rc2_) return rc2_;                                                \
-        }                                                                         \
-    } while (0)
+#define MUSE_OWN_CONSTANTS(c) own_host_constants(c)
 #else
 #define MUSE_OWN_CONSTANTS(c) do { } while (0)
 #endif
+// the launching context's constants into a launch's argument block (all zero for a model without any: muse_const is never called)
+static void set_launch_constants(const muse_ctx* c, BatchArgs& a) {
+    for (int k = 0; k < 4; ++k) {
+        a.consts[k] = c->consts_dev[k];
+        a.const_len[k] = c->consts_len[k];
+    }
+}
 
 extern "C" {
 
@@ -718,6 +713,9 @@ static int check_error_flag(muse_ctx* c) {
         if (c->area_inflight[r]) c->area_failed[r] = true;
         c->area_inflight[r] = false;
     }
+    // a launch that raised the error word may have left its share of the normals cache unwritten: nothing is held any more
+    c->nc_count = 0;
+    c->nc_seen_count = 0;
     return fail(MUSE_ERR_HIP, "a cluster wait expired inside the solver kernel (workgroups of a cluster were not co-resident); "
                               "the cluster state was reset, result areas in flight are marked failed");
 }
@@ -763,7 +761,9 @@ int muse_set_constants(muse_ctx* c, int k, const double* values, int64_t count, 
         }
     c->consts_len[k] = (long)count;
     c->has_consts = true;
-    return install_ctx_constants(c);
+    g_consts_owner = nullptr;   // (the host copies are re-read below)
+    own_host_constants(c);
+    return MUSE_OK;
 #else
     (void)c; (void)k; (void)values; (void)count; (void)mem;
     return fail(MUSE_ERR_INVALID, "this library's model declares no run-time constants (MUSE_MODEL_NCONST, include/muse_model.h)");
@@ -909,6 +909,7 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     a.nmaps = 1;
     a.fid_slot = -1;
     a.nstd = 0x7fffffff;  // no normals-only elements
+    set_launch_constants(c, a);
 }
 
 int muse_sample_x_z(muse_ctx* c, uint64_t seed, int64_t sim, const double* theta, double* x_out, double* z_out,
@@ -1093,7 +1094,6 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             a.ncache_sim0 = sim_begin;
             a.ncache_count = (int)nsim;
             a.ncache_mode = 1;
-            c->nc_seed = seed; c->nc_sim0 = sim_begin; c->nc_count = nsim;
         }
     } else if (o.ncache_mode == 0 && c->nc_auto && o.nmaps == 1 && nsim > 0 && c->cur_lane == 0 && ncache_applies(c)) {
         // A map over simulations the context has drawn before -- every iteration of a muse! loop the HOST drives (muse.py:
@@ -1116,7 +1116,6 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             a.ncache_sim0 = sim_begin;
             a.ncache_count = (int)nsim;
             a.ncache_mode = 1;
-            c->nc_seed = seed; c->nc_sim0 = sim_begin; c->nc_count = nsim;
         }
         c->nc_seen_seed = seed; c->nc_seen_sim0 = sim_begin; c->nc_seen_count = nsim;
     }
@@ -1125,9 +1124,14 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     static const bool no_ext = getenv("MUSE_DEBUG_NO_EXT_LAUNCH") != nullptr;
     c->launch_done = (c->timing || c->prof_on || no_ext) ? nullptr : c->area_done[area];
     c->launch_done_used = false;
+    // A storing launch overwrites the cache: whatever it held is gone the moment the launch is issued, and the new range is
+    // claimed only once the launch HAS been issued -- a launch that fails leaves no tag behind under which a later map would
+    // load slots that were never written (a launch that is issued and then raises the error word: check_error_flag).
+    if (a.ncache_mode == 1) c->nc_count = 0;
     rc = launch_batch(c, a);
     c->launch_done = nullptr;
     if (rc) return rc;
+    if (a.ncache_mode == 1) { c->nc_seed = seed; c->nc_sim0 = sim_begin; c->nc_count = nsim; }
     c->area_inflight[area] = true;
     c->res_rows[area] = rows;
     if (c->launch_done_used) {
@@ -1407,7 +1411,7 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     // measured per iteration at 512 sims, host / device: N = 10^4: 53 / 50 us (1 component), 75 / 79 (2), 89 / 97 (4), 100 / 113 (8);
     // N = 512: 25 / 20 (1), 38 / 44 (8) -- and win when it has one (100 sims: N = 3000 x 4 components 30.5 / 25.8, N = 512 x 8: 19.6 / 16.5)
     static const bool any_nt = getenv("MUSE_DEBUG_LOOP_ANY_NTHETA") != nullptr;   // tuning aid / tests: the loop kernel whatever ntheta
-    if (host_only || !resident || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
+    if (host_only || c->loop_unfit || !resident || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
         (xg_lds && loop_step_bytes(nprob, nt) > (size_t)2 * (c->ld + 2) * sizeof(double)))
         return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
     if (c->nlanes > 1) {   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
@@ -1444,6 +1448,7 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     a.nmaps = 1;
     a.n_per_map = (int)nprob;
     a.map_stride = nprob;
+    bool storing = false;
     {
         const bool held = ncache_holds(c, seed, 0, S);   // (an earlier run, or maps of the host driver, drew these streams)
         if (held || ensure_ncache(c, S)) {
@@ -1451,7 +1456,10 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
             a.ncache_sim0 = held ? c->nc_sim0 : 0;
             a.ncache_count = held ? (int)c->nc_count : S;
             a.ncache_mode = held ? 2 : 1;   // of the FIRST iteration; the later ones load
-            if (!held) { c->nc_seed = seed; c->nc_sim0 = 0; c->nc_count = S; }
+            // (a storing run overwrites the cache now and claims its range when it has ENDED well: an aborted loop -- workers
+            //  that never ran their first iteration, a bounded wait that expired -- must not leave a tag behind)
+            storing = !held;
+            if (storing) c->nc_count = 0;
         }
     }
     a.gran = r.gran;
@@ -1513,13 +1521,17 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     c->area_inflight[0] = false;
     if (r.status[1] == 100) {   // a bounded wait of the loop kernel expired (it also raised the error word: clear it)
         (void)check_error_flag(c);
+        if (!getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;   // (the test hook provokes the failure on purpose)
         return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident at once (another process on "
-                                  "this GPU?); muse_run gives the same results with one launch per iteration");
+                                  "this GPU?); muse_run gives the same results with one launch per iteration, and later calls of "
+                                  "muse_run_device on this context take that loop by themselves");
     }
     rc = check_error_flag(c);
     if (rc) return rc;
     if (r.status[1] != 0) return step_error(r.status[1]);
     const int n = r.status[0];
+    // every worker ran its elements' first iteration (the stepper saw all of their scores) and the launch has completed
+    if (storing && n >= 1) { c->nc_seed = seed; c->nc_sim0 = 0; c->nc_count = S; }
     *niter_out = n;
     for (int k = 0; k < nt; ++k) theta_out[k] = r.theta_out[k];
     for (int i = 0; i < n; ++i) {
@@ -1618,7 +1630,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             a.ncache_sim0 = s_lo;
             a.ncache_count = (int)nsims;
             a.ncache_mode = 1;
-            c->nc_seed = seed; c->nc_sim0 = s_lo; c->nc_count = nsims;
+            c->nc_count = 0;   // (overwritten from here on; claimed below once the whole call has ended well)
         }
         a.include_data = 0;
         a.z0_mode = MUSE_Z0_ZERO;
@@ -1679,6 +1691,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = check_error_flag(c);
     if (rc) return rc;
+    if (cached) { c->nc_seed = seed; c->nc_sim0 = s_lo; c->nc_count = nsims; }   // both launches have completed
     if (f_out) memcpy(f_out, c->scores_pin[1], (size_t)n * nt * sizeof(double));
     if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
     return MUSE_OK;

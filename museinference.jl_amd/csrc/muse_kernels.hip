@@ -409,6 +409,8 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
     Prefetch<Place::EPT> pf;
     pf.p = -1;
     pf.have_n1 = pf.have_n2 = pf.have_x = pf.g_pending = false;
+    typename Place::VZ zkeep;   // the MAP of the worker's last solve, carried in registers into the next iteration (see below)
+    zkeep.clear();
     typedef __attribute__((address_space(1))) unsigned long long gu64;
 #ifdef MUSE_STAMPS   // diagnostic build: the last iteration's times (100 MHz clock, comparable across the chip) of worker 0 (one
                      // of those with an element more), a worker in the middle and the stepper, behind the problems' rows
@@ -424,10 +426,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
 #else
     auto loop_stamp = [](int) {};
 #endif
+    // (two loops, one per role -- round 5: in ONE loop with the roles as its branches, whatever a worker carries in registers from
+    //  one iteration to the next -- the kept MAP -- was also live through the stepper's branch)
+    if (!stepper) {
     for (int iter = 1;; ++iter) {
         int err = STEP_OK, converged = 0;
         __syncthreads();
-        if (!stepper) {
+        {
             if (tid == 0) {
                 LoopLds<Place> m(smem);
                 BatchArgs& a = *m.a;   // (mutable here: theta and the per-iteration fields are re-written between iterations)
@@ -455,27 +460,48 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             {
                 LoopLds<Place> m(smem);
                 const BatchArgs& a = *m.a;
+                // test hook (muse_debug_flags bit 4): every second worker leaves before its first solve -- a loop that dies with part of
+                // the normals cache unwritten (tests/test_gpu_rows.py: the cache must not be taken for valid afterwards)
+                if ((a.debug & 16) && ((int)blockIdx.x & 1)) return;
                 double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+                // The worker's elements w, w + W, ... are visited in ALTERNATING order (round 5): upwards in the odd iterations,
+                // downwards in the even ones, so that an iteration begins with the element the previous one ended with -- whose
+                // MAP, the warm start it needs, is still in the z registers (Solver::run, keep_z: no load, no clear).  A
+                // worker with ONE element (the per-GPU share of a sharded job) never loads a warm start at all.  The solves are
+                // independent of one another, so the order changes no bit.  (MUSE_DEBUG bit 3: the old order, always reloading.)
+                const int cnt = (a.nproblems - (int)blockIdx.x + nworkers - 1) / nworkers;   // >= 1: the grid is <= nproblems + 1
+                const bool alternate = Solver<Model, Place>::kKeepZ && !(a.debug & 8);
+                const bool up = !alternate || (iter & 1);
+                const int step = up ? nworkers : -nworkers;
+                int p = up ? (int)blockIdx.x : (int)blockIdx.x + (cnt - 1) * nworkers;
                 {   // the first problem (peeled: the prefetched values are live up to its begin() and nowhere beyond)
                     Solver<Model, Place> sv(a, tid, m.red, m.shs);
                     sv.pk[0] = pk0;
                     sv.pk[1] = pk1;
-                    const int nx = (int)blockIdx.x + nworkers;
-                    sv.run((int)blockIdx.x, wg_scratch, m.lds_x, m.lds_g, pf, nx < a.nproblems ? nx : -1);
+                    const int nx = cnt > 1 ? p + step : -1;
+                    if (__builtin_expect(alternate && iter > 1 && sv.can_keep(p), 1)) {
+                        if constexpr (Solver<Model, Place>::kKeepZ) sv.z = zkeep;
+                        sv.run_kept(p, wg_scratch, m.lds_x, m.lds_g, pf, nx);
+                    } else {
+                        sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, nx);
+                    }
+                    if constexpr (Solver<Model, Place>::kKeepZ) zkeep = sv.z;
                     wg_barrier<!Model::kStencil>();   // (raw: the next problem's n1 is on its way into the g area)
                 }
                 loop_stamp(1);
-                for (int p = (int)blockIdx.x + nworkers; p < a.nproblems; p += nworkers) {
+                for (int k = 1; k < cnt; ++k) {
+                    p += step;
                     Solver<Model, Place> sv(a, tid, m.red, m.shs);
                     sv.pk[0] = pk0;
                     sv.pk[1] = pk1;
-                    sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, p + nworkers < a.nproblems ? p + nworkers : -1);
+                    sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, k + 1 < cnt ? p + step : -1);
+                    if constexpr (Solver<Model, Place>::kKeepZ) zkeep = sv.z;   // (the last one's stays: the next iteration's first)
                     wg_barrier<!Model::kStencil>();
                 }
                 loop_stamp(2);
-                if constexpr (Place::kXgLds) {
+                if constexpr (Place::kXgLds) {   // the next iteration's first problem: the one just solved (p), or the first again
                     if (iter < m.L->maxsteps && a.ncache_mode != 0 && !(a.debug & 4))
-                        prefetch_issue<T>(a, tid, (int)blockIdx.x, m.lds_x, m.lds_g, pf, true);
+                        prefetch_issue<T>(a, tid, alternate ? p : (int)blockIdx.x, m.lds_x, m.lds_g, pf, true);
                 }
                 loop_stamp(3);
             }
@@ -526,7 +552,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 if (tid == 0) make_map_theta_const(nt, a.bnd, th, a.cur);
                 // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
             }
-        } else {
+        }
+    }
+    } else {
+    for (int iter = 1;; ++iter) {
+        int err = STEP_OK, converged = 0;
+        __syncthreads();
+        {
             // ---- the stepper.  ONE wavefront does everything (the others wait at the barrier below): lane l takes the
             // simulations s = l, l + 64, ... -- it polls each score's two granules (one 16-byte load) until both carry this
             // iteration's tag, in the order in which its partial sum adds them, so that when the last element's score lands
@@ -720,6 +752,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             if (err != STEP_OK || converged || iter == L.maxsteps) break;
         }
     }
+    }
 }
 
 }  // namespace muse
@@ -873,20 +906,18 @@ static hipError_t loop_one(const LaunchShape& s, const LoopCall& c) {
 }
 template <class Model>
 static hipError_t loop_place(const LaunchShape& s, const LoopCall& c) {
-    if constexpr (Model::kStencil) {
-        if (s.place == P_S256) return loop_one<Model, PlaceStreaming<256, false, kStencilU>>(s, c);
-        if (s.place == P_S512) return loop_one<Model, PlaceStreaming<512, false, kStencilU>>(s, c);
-    } else {
+    // The resident placements only (round 5): muse_run_device routes every streaming placement and the stencil model to the host
+    // loop (measured slower in loop form: N = 30 000 x 512 sims 377 against 347 us per iteration), so their loop kernels were
+    // dead code that nothing launched and no test ran.
+    if constexpr (!Model::kStencil) {
         switch (s.place) {
             case P_R256x1: return loop_one<Model, PlaceResident<256, 1, false>>(s, c);
             case P_R512x4: return loop_one<Model, PlaceResident<512, 4, false>>(s, c);
             case P_R512x10: return loop_one<Model, PlaceResident<512, 10, true>>(s, c);
-            case P_S256: return loop_one<Model, PlaceStreaming<256, false, kStreamU>>(s, c);
-            case P_S512: return loop_one<Model, PlaceStreaming<512, false, kStreamU>>(s, c);
             default: break;
         }
     }
-    return hipErrorNotSupported;  // cluster placements: the host loop (muse_run) runs those
+    return hipErrorNotSupported;  // streaming and cluster placements: the host loop (muse_run) runs those
 }
 static hipError_t loop_dispatch(const LaunchShape& s, const LoopCall& c) {
 #ifdef MUSE_INSPECT_LOOP  // development aid (tools/regs.py --check): ONE loop kernel
@@ -904,9 +935,7 @@ static hipError_t loop_dispatch(const LaunchShape& s, const LoopCall& c) {
                : nt == 2 ? loop_place<FunnelModel<2>>(s, c)
                : nt <= 4 ? loop_place<FunnelModel<4>>(s, c)
                          : loop_place<FunnelModel<kMaxTheta>>(s, c);
-    return nt <= 2   ? loop_place<SmoothModel<2>>(s, c)
-           : nt <= 4 ? loop_place<SmoothModel<4>>(s, c)
-                     : loop_place<SmoothModel<kMaxTheta>>(s, c);
+    return hipErrorNotSupported;  // the stencil model streams
 #endif
 }
 bool loop_supported(const LaunchShape& s) {
@@ -927,23 +956,6 @@ size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta) {
     return (size_t)kLoopPersistDoubles * sizeof(double) + (xg_lds ? 0 : step);
 }
 size_t loop_step_bytes(int64_t nprob, int ntheta) { return ((size_t)nprob * ntheta + 24) * sizeof(double) + sizeof(StepWork); }
-
-// Run-time constants of a user model (include/muse_model.h: muse_const): the device-side vectors' pointers and lengths.
-#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_NCONST)
-}  // namespace muse
-__device__ const double* muse_dev_consts[MUSE_MODEL_MAX_CONST];
-__device__ long muse_dev_const_len[MUSE_MODEL_MAX_CONST];
-namespace muse {
-hipError_t install_constants(const double* const* dev_ptrs, const long* lens, hipStream_t st) {
-    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(muse_dev_consts), dev_ptrs, sizeof(const double*) * MUSE_MODEL_MAX_CONST, 0, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return e;
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(muse_dev_const_len), lens, sizeof(long) * MUSE_MODEL_MAX_CONST, 0, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(st);
-}
-#else
-hipError_t install_constants(const double* const*, const long*, hipStream_t) { return hipErrorNotSupported; }
-#endif
 
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t st) {
     const int grid = (int)((a.N + 255) / 256 < 4096 ? (a.N + 255) / 256 : 4096);

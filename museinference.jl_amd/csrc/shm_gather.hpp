@@ -150,6 +150,7 @@ public:
     void close() {
         if (base_ && !adopted_) munmap(base_, size_);
         base_ = nullptr; hdr_ = nullptr; lines_ = nullptr; data_ = nullptr;
+        adopted_ = false;   // (a later open() maps a segment of this object's own; the owner of an adopted view must outlive it)
     }
     // A segment of this process alone (anonymous shared mapping): what the ranks-as-threads sanitizer test exchanges through.
     bool open_private(int nranks_, int narea_, size_t block_doubles_) {

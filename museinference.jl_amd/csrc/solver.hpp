@@ -884,6 +884,127 @@ struct Solver {
         solve(p);
         finish(p);
     }
+    // The loop kernel's first problem of an outer iteration > 1 (LDS-resident layout): the problem this workgroup solved LAST in
+    // the previous iteration (it visits its elements in alternating order), so its warm start -- the MAP that solve ended with --
+    // is still in the z registers, which the caller carried over: nothing is cleared or loaded for z.  The registers hold exactly
+    // what that solve's last pass stored into the problem's slot (phantom slots: zeros, as an out-of-range load returns), so the
+    // results are the same bits.  A path of its own, beside begin() instead of inside it: with z live through ALL of begin() --
+    // the generator loop, the staging of a true-z start -- the register allocator spilled it (40 -> 111 spilled registers).
+    static constexpr bool kKeepZ = Place::kResident && Place::kXgLds && !Model::kStencil && MAXB == 1;   // (several components: the per-block state beside a kept z spilled)
+    // (workgroup-uniform) can problem p start from kept registers: a warm start whose x comes from cached normals or from the data
+    __device__ __forceinline__ bool can_keep(int p) const {
+        if constexpr (!kKeepZ) return false;
+        const ProblemDesc dd = describe(a, p);
+        return dd.z0_mode == Z0_WARM && !dd.normals_only && dd.tsample < 0 &&
+               ((dd.x_mode == X_SAMPLE && dd.nslot >= 0 && a.ncache_mode == 2) || dd.x_mode == X_DATA);
+    }
+    __device__ __forceinline__ void run_kept(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p = -1) {
+        begin_kept(p, wg_scratch, lds_x, lds_g, pf);
+        pfp = &pf;
+        if constexpr (Place::kResident && Place::kXgLds) {
+            if (next_p >= 0 && a.ncache_mode == 2 && !(a.debug & 4)) prefetch_issue<T>(a, tid, next_p, lds_x, lds_g, pf, false);
+        }
+        solve(p);
+        finish(p);
+    }
+    __device__ __forceinline__ void begin_kept(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf) {
+        if constexpr (kKeepZ) {
+            d = describe(a, p);
+            const bool pf_hit = pf.p == p;
+            const int64_t N = a.N, ld = a.ld;
+            init_done = false;
+            z_zero = false;
+            have_trial = false;
+            stamp(p, 0);
+            iv0 = a.cur.t.iv[0];
+            sd0 = a.cur.t.sd[0];
+            if constexpr (MAXB > 1) {
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+                if (tl < MAXB) sh_sd[tl] = a.cur.t.sd[tl];
+                wg_barrier<true>();
+            }
+            hist = wg_scratch;
+            x.bind(lds_x, ld);
+            g.bind(lds_g, ld);
+            if (d.x_mode == X_SAMPLE) {
+                // (begin()'s cached-normals path without its warm-start loads)
+                const rsrc_t n1r = make_rsrc(a.ncache + (int64_t)(2 * d.nslot) * ld, ld * 8);
+                const rsrc_t n2r = make_rsrc(a.ncache + (int64_t)(2 * d.nslot + 1) * ld, ld * 8);
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+                const bool n1_here = pf_hit && pf.have_n1, n2_here = pf_hit && pf.have_n2;
+                if (n1_here && n2_here) {
+                    // both vectors are in LDS (the usual case: fetched while the workgroup waited for theta): pair by pair, in
+                    // place -- nothing but the pair in hand is live beside the kept z
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA loads have landed
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) {
+                        const int i0 = 2 * (tl + j * T);
+                        const double a0 = g.get(2 * j, i0), a1 = g.get(2 * j + 1, i0 + 1);
+                        const double b0 = x.get(2 * j, i0), b1 = x.get(2 * j + 1, i0 + 1);
+                        double zt0, xt0, zt1, xt1;
+                        Model::sample(sdk(2 * j, i0), a0, b0, zt0, xt0, i0);
+                        Model::sample(sdk(2 * j + 1, i0 + 1), a1, b1, zt1, xt1, i0 + 1);
+                        const bool valid1 = i0 + 1 < (int)N;
+                        x.set(2 * j, i0, xt0);
+                        x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
+                    }
+                } else {
+                    double c1[EPT][2], c2[EPT][2];
+                    if (n1_here) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!n2_here) {
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) load_f64x2<kNormalsAux>(n2r, 2 * (tl + j * T), c2[j][0], c2[j][1]);
+                    }
+                    if (!n1_here) {
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) load_f64x2<kNormalsAux>(n1r, 2 * (tl + j * T), c1[j][0], c1[j][1]);
+                    }
+                    if (n1_here) {
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) {
+                            const int i0 = 2 * (tl + j * T);
+                            c1[j][0] = g.get(2 * j, i0); c1[j][1] = g.get(2 * j + 1, i0 + 1);
+                        }
+                    }
+                    if (n2_here) {
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) {
+                            const int i0 = 2 * (tl + j * T);
+                            c2[j][0] = x.get(2 * j, i0); c2[j][1] = x.get(2 * j + 1, i0 + 1);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) {
+                        const int i0 = 2 * (tl + j * T);
+                        double zt0, xt0, zt1, xt1;
+                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
+                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
+                        const bool valid1 = i0 + 1 < (int)N;
+                        x.set(2 * j, i0, xt0);
+                        x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
+                    }
+                }
+            } else {   // the data element
+                if (pf_hit && pf.have_x) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    VH xs;
+                    xs.bind(a.x_data, ld);
+                    for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { x.set(jj, i, xs.get(jj, i)); }, x);
+                }
+            }
+            s.clear();
+            if (pf_hit) {   // consumed
+                pf.p = -1;
+                pf.g_pending = false;
+            }
+            stamp(p, 9);
+            wg_barrier<true>();
+            stamp(p, 1);
+        }
+    }
     Prefetch<EPT>* pfp;
     // the solve is about to write g (a kept L-BFGS update): a prefetch that is on its way into the g area must land first --
     // it would overwrite the gradient -- and is given up (the next problem loads its n1 the ordinary way)
@@ -2009,8 +2130,13 @@ struct Solver {
                     typedef __attribute__((address_space(1))) unsigned long long gu64;
                     gu64* gq = (gu64*)a.gran + (d.row * a.ntheta + tl) * 2;
                     const unsigned long long b = (unsigned long long)__double_as_longlong(sc), tg = (unsigned long long)a.gran_tag << 32;
-                    __hip_atomic_store(gq, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(gq + 1, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.gran_sys) {   // the node's board in host memory: other GPUs' steppers read it
+                        __hip_atomic_store(gq, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(gq + 1, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else {
+                        __hip_atomic_store(gq, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(gq + 1, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             if (tid == 0 && crank == 0) {

@@ -11,6 +11,9 @@
 #else
 #define MUSE_MODEL_FN static inline
 #endif
+// where a launch's run-time constants sit in its kernel-argument block (args.hpp, BatchArgs::consts; muse_model.h, muse_const)
+#include "args.hpp"
+#define MUSE_KERNARG_CONSTS (muse::kArgsConstsOffset)
 #include MUSE_USER_MODEL_HEADER
 #ifndef MUSE_MODEL_NAME
 #error "the model header must #define MUSE_MODEL_NAME (include/muse_model.h)"

@@ -211,6 +211,33 @@ def test_loop_kernel_that_cannot_stay_resident_falls_back_to_the_host_loop(gpu, 
     prob.close()
 
 
+def test_aborted_loop_leaves_no_normals_cache_tag_behind(gpu, M):
+    """A device-resident loop whose FIRST iteration stores the simulations' standard normals (the cross-call normals cache) and
+    that dies before all of them are written -- a test hook makes every second worker leave before its first solve; the stepper's
+    bounded wait then expires -- must not leave the cache tagged as holding the range: the maps that follow over the same
+    simulations (the second stores, the third loads) equal those of a fresh context bit for bit.  (Round 4 claimed the tag when
+    the launch was ENQUEUED: the next map loaded slots that had never been written.)"""
+    x = np.sin(0.05 * np.arange(10000))
+    prob = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    kw = dict(nsims=40, maxsteps=3, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+    assert prob._lib.muse_debug_flags(prob._ctx, 16) == 0
+    with pytest.raises(M.MuseError):
+        prob.run_muse(9, [0.7], device_loop=True, **kw)
+    assert prob._lib.muse_debug_flags(prob._ctx, 0) == 0
+    fresh = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    fresh.set_normals_cache(False)
+    want, winfo = fresh.map_and_score_batch(9, 0, 40, [0.7], include_data=True, atol=1e-2, z0_mode=M.Z0_ZERO)
+    for _ in range(4):   # (plain maps: seen, stored, loaded, loaded)
+        got, info = prob.map_and_score_batch(9, 0, 40, [0.7], include_data=True, atol=1e-2, z0_mode=M.Z0_ZERO)
+        assert np.array_equal(got, want) and np.array_equal(info, winfo)
+    # ... and the native loops afterwards are the undisturbed ones (the failed call is remembered: the host loop runs)
+    a = prob.run_muse(9, [0.7], **kw)
+    b = fresh.run_muse(9, [0.7], device_loop=False, **kw)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    prob.close()
+    fresh.close()
+
+
 # ---- row f3: checkpoint / resume / save_MAPs on the HIP path ---------------------------------------------
 def test_checkpoint_resume_and_saved_maps_on_hip(gpu, M, O, tmp_path):
     N = 3000

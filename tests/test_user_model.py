@@ -665,6 +665,21 @@ def test_runtime_constants_on_hip(gpu, M, O, N, nth, placement, split):
             go, zo, io = O.map_and_score_batch("user", N, 42, 0, n, truth, atol=1e-6, x_data=x, z0_mode=0)
             same = assert_same_path_or_close(info, io, p.get_zhat(0, n + 1), zo, g, go, 1e-6, truth, "funnel")
             assert same.all()
+        # The pointers travel with every LAUNCH (round 5; a process-wide device symbol before): maps of the two contexts enqueued
+        # back to back, none waited for until all are in flight, give what each context gives alone.
+        alone = {}
+        for name, p in (("prob", prob), ("other", other)):
+            p.set_normals_cache(False)
+            alone[name] = p.map_and_score_batch(17, 0, 24, truth, include_data=True, atol=1e-6, z0_mode=0)
+        pend = []
+        for k in range(3):
+            for name, p in (("prob", prob), ("other", other)):
+                pend.append((name, p, k, p.map_and_score_batch_async(17, 0, 24, truth, include_data=True, atol=1e-6, z0_mode=0,
+                                                                     result_area=k)))
+        for name, p, k, n in pend:
+            g, info = p.batch_wait(n, k)
+            assert np.array_equal(g, alone[name][0]) and np.array_equal(info, alone[name][1]), (name, k)
+        assert not np.array_equal(alone["prob"][0], alone["other"][0])
         other.close()
         prob.set_constants("P", 2.0 * P)               # another spectrum: no build
         O.set_constants(0, 2.0 * P)
