@@ -46,6 +46,8 @@ WORKLOADS = {
     "noise_1e6": ("noise", 1000000, 1, [0.5], 128),        # configs[2]
     "funnel4_1e4": ("funnel", 10000, 4, [1.0] * 4, 512),   # configs[3] (s/J pass)
     "smooth_1e5": ("smooth", 100000, 8, [1.0] * 8, 128),   # configs[4], per-GPU share
+    "cfg5_smooth_1e5": ("smooth", 100000, 8, [1.0] * 8, 1024),   # configs[4], the whole job (shards under --gpus N)
+    "cfg4_fd_H": ("funnel", 10000, 4, [1.0] * 4, 512),     # configs[3], get_H! by finite differences (shards under --gpus N)
 }
 
 
@@ -126,6 +128,71 @@ def algorithmic_valu(info, N, clock_hz):
     cyc = fp64 * ISSUE_CYCLES["fp64"] + ALG_OPS["sampler_mul64"] * ISSUE_CYCLES["mul64"] + ALG_OPS["sampler_int32"] * ISSUE_CYCLES["int32"]
     elems = float(N)
     return float(cyc.sum() * elems / 64.0), float(fp64.sum() * elems)
+
+
+def roofline_object(workload, model, N, info, pinfo, kernel_ms, launch_s, clock_hz_measured, lanes, ms_per_launch_pipelined, prow_ok=True):
+    """The `roofline` object of a launch of `workload`: the solver kernel against the bound that binds the placement it ran in
+    (module docstring).  launch_s: the time a launch is charged with -- its own duration between HIP events, unless the pipelined
+    step is shorter (the event pair costs a launch ~3 us, and with two lanes a launch's own duration includes waiting for the
+    compute units the launch before it still holds, while launches complete once per step)."""
+    mean_kernel_s = float(kernel_ms.mean()) * 1e-3
+    placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
+                                                      if model == "smooth" else "streaming")
+    comp_bytes = compulsory_bytes(info, N, placement)
+    prow, why = profile_row(workload) if prow_ok else (None, "profiles/ hold the 1-GPU, unsplit, unsharded launch")
+    traffic = measured_traffic(workload) if prow is not None else None
+    hbm = {"bound": "hbm", "achieved": comp_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": comp_bytes / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+           "compulsory_bytes_per_launch": comp_bytes, "launch_s_used": launch_s,
+           "traffic_GBps": None if traffic is None else traffic / launch_s / 1e9}
+    clock_hz = clock_hz_measured or CLOCK_HZ
+    valu = None
+    if placement == "resident":
+        alg_cycles, alg_fp64 = algorithmic_valu(info, N, clock_hz)
+        alg = {"fp64_ops_per_launch": alg_fp64, "issue_cycles_per_launch": alg_cycles,
+               "frac_of_issue_peak": alg_cycles / (N_SIMD * launch_s * clock_hz),
+               "fp64_TFLOPs_fma_equiv": 2.0 * alg_fp64 / launch_s / 1e12,
+               "ops_per_element": ALG_OPS, "issue_cycles_per_wave_instruction": ISSUE_CYCLES,
+               "note": "work / peak: operation counts per element from the source (bench.py: ALG_OPS) x the measured issue cost "
+                       "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
+                       "many instructions the compiled kernel spends on them.  The peak is the PROBE's rate -- ~10 % softer than "
+                       "the spec rates (fp64 4 cycles, 32-bit 2) and optimistic for this mix: the generator as a kernel of its own "
+                       "at eight waves per SIMD (built, measured and removed in round 4: DESIGN.md section 6) ran no faster than "
+                       "inside this kernel, i.e. the sampler -- two thirds of the launch -- already runs at the VALU's throughput"}
+        valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,
+                "clock_hz": clock_hz, "clock_source": "in-kernel s_memtime / s_memrealtime" if clock_hz_measured else "assumed",
+                "launch_s_used": launch_s}
+        if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
+            # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
+            # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
+            # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
+            busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
+            valu["utilisation"] = {"valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
+                                   "frac": busy / (N_SIMD * launch_s * clock_hz),
+                                   "note": "VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (1024 SIMDs x launch "
+                                           "time x measured clock): how busy the kernel's OWN instruction stream keeps the SIMDs "
+                                           "(round 2 quoted this figure, against an assumed 2.4 GHz, as the roofline fraction)"}
+    primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
+    primary.update({
+        "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
+        "lanes": lanes, "ms_per_launch_pipelined": ms_per_launch_pipelined,
+        "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
+        "algorithmic_bytes_d3": algorithmic_bytes(info, N),
+        "hbm": hbm, "valu": valu,
+        "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
+        "profile_note": why,
+        "note": ("resident placement: z, s, x, g never leave registers/LDS, the HBM leg only carries zhat out (and the "
+                 "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes). "
+                 "frac = algorithmic work / issue peak (valu.algorithmic); valu.utilisation is how busy the compiled kernel keeps "
+                 "the SIMDs.  BASELINE.json's '>= 40 % of the HBM roofline' can be neither met nor missed by this placement: it "
+                 "moves 1 word per element where SURVEY 8.d3's accounting assumes 22 (hbm.frac is that one word / 8 TB/s)"
+                 if placement == "resident" else
+                 "streaming placement: achieved = compulsory bytes of the passes the solves made / kernel time"),
+        "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
+                    "hist_pairs_mean": float(info["hist_words"].mean())},
+    })
+    return primary
 
 
 def csrc_fingerprint():
@@ -246,7 +313,87 @@ def cpu_baseline(model, N, theta, seed, cpu_seconds=30.0):
     return out
 
 
-def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, ngpus=8):
+def pipelined_steps(M, prob, seed, sim_lo, sim_hi, theta, K, areas=4, outs=None):
+    """K independent cold-start maps over [sim_lo, sim_hi), software-pipelined over the result areas (and the lanes the context
+    was given); returns the last step's (scores, infos)."""
+    n = sim_hi - sim_lo
+    if outs is None:
+        outs = [(np.empty((n, prob.ntheta)), np.zeros(n, dtype=M._capi.INFO_DTYPE)) for _ in range(areas)]
+    pend, last = [], None
+    for k in range(K):
+        prob.map_and_score_batch_async(seed, sim_lo, sim_hi, theta, atol=1e-2, z0_mode=M.Z0_ZERO, result_area=k % areas)
+        pend.append(k % areas)
+        if len(pend) > areas - 1:
+            a = pend.pop(0)
+            last = prob.batch_wait(n, a, out=outs[a])
+    while pend:
+        a = pend.pop(0)
+        last = prob.batch_wait(n, a, out=outs[a])
+    return last
+
+
+def quick_workload(M, name, device, seconds=0.3, seed=0):
+    """One of the other BASELINE workloads, timed briefly inside the default run so that it is in the driver's line: the same
+    pipelined cold-start steps as the headline's timed region (normals cache off, two lanes except the stencil model), for about
+    `seconds`, then a short leg with HIP events around every launch for the roofline object (bound, frac, traffic from profiles/)."""
+    model, N, nth, theta, nsims = WORKLOADS[name]
+    prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=device)
+    try:
+        prob.set_normals_cache(False)
+        lanes = 1 if model == "smooth" else 2
+        if lanes > 1:
+            prob.set_concurrency(lanes)
+        outs = [(np.empty((nsims, nth)), np.zeros(nsims, dtype=M._capi.INFO_DTYPE)) for _ in range(4)]
+        pipelined_steps(M, prob, seed, 0, nsims, theta, 3, outs=outs)
+        prob.synchronize()
+        t0 = time.perf_counter()
+        pipelined_steps(M, prob, seed, 0, nsims, theta, 4, outs=outs)
+        prob.synchronize()
+        t_step = (time.perf_counter() - t0) / 4
+        K = int(max(8, min(4000, seconds / max(t_step, 1e-6))))
+        t0 = time.perf_counter()
+        g, info = pipelined_steps(M, prob, seed, 0, nsims, theta, K, outs=outs)
+        prob.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        nprof = 8 if t_step > 5e-4 else 32
+        prob.profile_begin(nprof + 8)
+        pipelined_steps(M, prob, seed, 0, nsims, theta, nprof, outs=outs)
+        kernel_ms = prob.profile_end()
+        try:
+            clock_hz = prob.profile_clock_hz()
+        except M.MuseError:
+            clock_hz = None
+        assert np.all(info["status"] == 0), "a MAP solve did not converge"
+        pinfo = prob.placement_info()
+        launch_s = min(float(kernel_ms.mean()) * 1e-3, dt)
+        roof = roofline_object(name, model, N, info, pinfo, kernel_ms, launch_s, clock_hz, lanes, 1e3 * dt)
+        return {"ms_per_step": 1e3 * dt, "sims_per_s": nsims / dt, "steps_timed": K, "nsims": nsims, "N": N, "ntheta": nth,
+                "bound": roof["bound"], "frac": roof["frac"], "traffic": roof["traffic"], "achieved": roof["achieved"],
+                "unit": roof["unit"], "kernel_ms_mean": roof["kernel_ms_mean"], "lanes": lanes, "placement": roof["placement"],
+                "compulsory_bytes_per_launch": roof["hbm"]["compulsory_bytes_per_launch"], "profile": roof["profile"],
+                "per_sim": roof["per_sim"]}
+    finally:
+        prob.close()
+
+
+def iteration_regimes(hist, info):
+    """The per-iteration times a native loop records (hist[:, -1], seconds), grouped by what its solves did: "line_search" --
+    (nearly) every element's solve took a line search (f_calls = 3: what every iteration of a run with the reference's default
+    theta_rtol looks like) -- and "converged_at_start" -- theta has stopped moving, the warm starts pass the gradient test at once
+    (f_calls = 1), which only a run driven far past convergence (theta_rtol = 1e-12, as these timing runs are) ever reaches.  The
+    first iteration (cold start: the generator) belongs to neither."""
+    out = {}
+    fc = info["f_calls"].mean(axis=1)
+    t = 1e6 * hist[:, -1]
+    for name, sel in (("line_search", fc >= 2.5), ("converged_at_start", fc <= 1.05)):
+        sel = sel.copy()
+        sel[0] = False
+        if sel.any():
+            out[name] = {"us_per_outer_iteration": float(np.median(t[sel])), "iterations": int(sel.sum())}
+    return out
+
+
+def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, ngpus=8, whole_job_regimes=None):
     """What ONE rank of an 8-GPU job runs per outer iteration of muse! (a DEPENDENT map sequence, src/muse.jl:159-232): the
     native sharded loop (muse_run_sharded) at nsims/8 + 1 elements, measured on this one GPU with a one-rank shared-memory
     communicator -- the gathered map, the hand-off through the segment, the step on the host.  The ratio to the whole job's
@@ -261,24 +408,45 @@ def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, 
             best = float("inf")
             for _ in range(3):
                 t0 = time.perf_counter()
-                n, _, hist, _, _ = prob.run_muse(seed, [1.0] * nth, device_loop=dev, **kw)
+                n, _, hist, _, info = prob.run_muse(seed, [1.0] * nth, device_loop=dev, **kw)
                 best = min(best, (time.perf_counter() - t0) / max(1, n))
-            out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1]))}
+            out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])),
+                         "by_regime": iteration_regimes(hist, info)}
         prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
-        best = float("inf")
-        for _ in range(3):
-            t0 = time.perf_counter()
-            n, _, hist, _, _ = prob.run_muse_sharded(seed, [1.0] * nth, **kw)
-            best = min(best, (time.perf_counter() - t0) / max(1, n))
-        out["sharded_loop_shm_1rank"] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1]))}
+        for name, env in (("sharded_loop_shm_1rank", None), ("sharded_host_loop_shm_1rank", "1")):
+            # the sharded loop as the library runs it -- ONE persistent launch per rank, the ranks' scores meeting on the node's board
+            # in pinned host memory (round 5) -- and, for comparison, the host-driven loop of round 4 (gathered map, step on the host)
+            if env is None:
+                os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
+            else:
+                os.environ["MUSE_DEBUG_SHARDED_HOST_LOOP"] = env
+            best = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                n, _, hist, _, info = prob.run_muse_sharded(seed, [1.0] * nth, **kw)
+                best = min(best, (time.perf_counter() - t0) / max(1, n))
+            out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])),
+                         "by_regime": iteration_regimes(hist, info)}
+        os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
         prob.close()
         if whole_job_steady_us:
             out["projected_speedup_at_8_gpus"] = whole_job_steady_us / out["sharded_loop_shm_1rank"]["us_per_outer_iteration_steady"]
-        out["note"] = ("a muse! iteration is ONE dependent map: per rank a launch of nsims/8 + 1 one-workgroup problems (one round on 256 "
-                       "CUs: one problem's latency), then the exchange and the step before the next launch can start; "
-                       "projected_speedup_at_8_gpus = the whole job's steady iteration on one GPU (device loop) / this rank's steady "
-                       "iteration through the sharded loop -- an upper bound, measured with ONE rank in the communicator; the "
-                       "..._no_exchange entries are the same 64 + 1 elements without any exchange")
+        if whole_job_regimes:
+            proj = {}
+            for reg, w in whole_job_regimes.items():
+                sh = out["sharded_loop_shm_1rank"]["by_regime"].get(reg)
+                if sh:
+                    proj[reg] = {"whole_job_us": w["us_per_outer_iteration"], "share_us": sh["us_per_outer_iteration"],
+                                 "projected_speedup_at_8_gpus": w["us_per_outer_iteration"] / sh["us_per_outer_iteration"]}
+            out["projected_by_regime"] = proj
+        out["note"] = ("a muse! iteration is ONE dependent map: per rank nsims/8 + 1 one-workgroup problems (one round on 256 CUs: one "
+                       "problem's latency), then the exchange and the step before the next map can start.  sharded_loop_shm_1rank: "
+                       "muse_run_sharded as the library runs it -- a persistent loop kernel per rank, scores exchanged through the "
+                       "node's board in pinned host memory, no host between two maps -- measured with ONE rank in the communicator (an "
+                       "upper bound for 8: the board costs a PCIe round trip whoever writes it).  projected_speedup_at_8_gpus = the whole "
+                       "job's steady iteration on one GPU / this rank's steady iteration, both the median from iteration 6 on of a "
+                       "30-iteration run -- which mixes two regimes (iteration_regimes): projected_by_regime compares like with like; "
+                       "line_search is what every iteration of a run with the reference's default theta_rtol is")
     except Exception as e:  # noqa: BLE001 -- an extra: never at the cost of the line
         out["skipped"] = f"{type(e).__name__}: {e}"
     return out
@@ -335,21 +503,23 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     dt30 = time.perf_counter() - t0
     # the native loops alone (no Python between the iterations, no history records built): ONE launch for all iterations
     # (the default) / one launch per iteration with the algebra on the host
-    loops, steady = {}, {}
+    loops, steady, regimes = {}, {}, {}
     for name, dev in (("host_loop", False), ("device_loop", True)):
         best = float("inf")
         for _ in range(3):
             t0 = time.perf_counter()
-            n30, _, hist30, _, _ = prob.run_muse(seed, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=dev)
+            n30, _, hist30, _, info30 = prob.run_muse(seed, [1.0] * nth, nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7, device_loop=dev)
             best = min(best, (time.perf_counter() - t0) / max(1, n30))
         loops[name] = 1e6 * best
         steady[name] = 1e6 * float(np.median(hist30[5:, -1])) if n30 > 6 else None
+        regimes[name] = iteration_regimes(hist30, info30)
     out["muse_run"] = {"wall_s": dt, "outer_iterations": len(res.history), "theta": [float(t) for t in res.theta],
                        "sigma": [float(t) for t in np.sqrt(np.diag(np.atleast_2d(res.Sigma)))],
                        "us_per_outer_iteration_30": loops["device_loop"],
                        "us_per_outer_iteration_30_host_loop": loops["host_loop"],
                        "us_per_outer_iteration_steady": steady["device_loop"],
                        "us_per_outer_iteration_steady_host_loop": steady["host_loop"],
+                       "by_regime": regimes["device_loop"], "by_regime_host_loop": regimes["host_loop"],
                        "us_per_outer_iteration_30_with_python_history": 1e6 * dt30 / max(1, len(res30.history)),
                        "note": "muse(prob, theta0=1; nsims, get_covariance=True): outer iterations (native loop) + get_J! + get_H!, "
                                "host algebra included; us_per_outer_iteration_30: wall of a 30-iteration muse_run_device call (what "
@@ -358,7 +528,8 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
                                "copy-out included; ..._host_loop: muse_run, one launch per iteration, algebra on the host; "
                                "..._steady: the median of the per-iteration times the loop itself records from iteration 6 on; "
                                "..._with_python_history: through muse(), which also builds the 30 history records"}
-    out["muse_run_8gpu_share"] = share_rates(M, xdata, model, nth, nsims, seed, device, steady["device_loop"])
+    out["muse_run_8gpu_share"] = share_rates(M, xdata, model, nth, nsims, seed, device, steady["device_loop"],
+                                             whole_job_regimes=regimes["device_loop"])
     prob.close()
     # the get_H! finite-difference map at configs[3]'s OWN shape: funnel, N = 10^4, 4 theta blocks, 512 sims ->
     # 1 fiducial + 512 x 4 x 2 perturbed MAP+score problems (src/muse.jl:407-446); last, on a context of its own
@@ -373,6 +544,111 @@ def extra_rates(M, sampler, model, N, nth, theta, nsims, seed, device):
     out["get_H_fd_configs3"] = {"maps_per_s": (1 + 2 * 4 * 512) / best, "ms_per_call": 1e3 * best, "nsims": 512, "ntheta": 4,
                                 "maps_per_call": 1 + 2 * 4 * 512}
     p4.close()
+    return out
+
+
+# ---- the workloads BASELINE.json puts on 8 GPUs (configs[3], configs[4]) --------------------------------------------------------------
+# cfg4_fd_H: get_H!'s finite-difference map (src/muse.jl:407-446) of the 4-theta funnel at N = 10^4 over 512 sims: 1 fiducial +
+#            512 x 4 x 2 perturbed MAP+score problems per call, shared over the ranks as contiguous blocks of the flattened
+#            (sim, column) list (the reference's rule of mapping over the longer axis, src/muse.jl:327-333, across ranks), one
+#            exchange of the column blocks per call.
+# cfg5_smooth_1e5: the s/J map (src/muse.jl:508-525) of the hierarchical linear-Gaussian field, N = 10^5, 8 theta, 1024 sims, shared
+#            over the ranks as contiguous blocks of sims, one exchange of the score blocks per map.
+FD_WORKLOAD = {"model": "funnel", "N": 10000, "ntheta": 4, "theta": [1.0] * 4, "step": [0.05] * 4, "nsims": 512}
+
+
+def fd_call(M, prob, seed, lo, hi, sharded):
+    """One get_H! finite-difference call over the (sim, column) units [lo, hi) of the 512 x 4 list, and -- sharded -- the exchange
+    of the column block through the engine's communicator.  Returns (columns, infos)."""
+    w = FD_WORKLOAD
+    cols, info = prob.fd_jacobian_columns(seed, 0, lo, hi, w["theta"], w["step"])
+    if sharded:
+        prob.allgather_scores(cols.reshape(-1))
+    return cols, info
+
+
+def fd_problems(lo, hi, nth):
+    """MAP+score problems of one call over units [lo, hi): two perturbed ones per unit and the shared fiducial one."""
+    return 2 * (hi - lo) + 1
+
+
+def scale_projection(M, device, seed=0, ngpus=8):
+    """configs[3] and configs[4] -- the workloads BASELINE.json assigns to 8 GPUs -- on ONE GPU: the whole job, and one rank's
+    share of it through a one-rank shared-memory communicator (the exchange included).  Both are maps whose elements keep every
+    compute unit busy at the 8-GPU share too, so the ratio is the speed-up 8 GPUs can give (an upper bound: an 8-rank exchange
+    costs at least what a 1-rank one does; it is one hand-off per map of tens to hundreds of microseconds to milliseconds)."""
+    out = {}
+    # ---- cfg4: FD get_H!
+    try:
+        w = FD_WORKLOAD
+        nunits = w["nsims"] * w["ntheta"]
+        prob = M.HipMuseProblem(None, model=w["model"], ntheta=w["ntheta"], N=w["N"], device=device)
+        fd_call(M, prob, seed, 0, nunits, False)
+        best = float("inf")
+        for _ in range(5):
+            t0 = time.perf_counter()
+            fd_call(M, prob, seed, 0, nunits, False)
+            best = min(best, time.perf_counter() - t0)
+        whole = best
+        lo, hi = M.block_partition(0, nunits, ngpus, 0)
+        prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
+        fd_call(M, prob, seed, lo, hi, True)
+        best = float("inf")
+        for _ in range(8):
+            t0 = time.perf_counter()
+            fd_call(M, prob, seed, lo, hi, True)
+            best = min(best, time.perf_counter() - t0)
+        prob.close()
+        out["cfg4_fd_H"] = {"whole_job_ms": 1e3 * whole, "share_ms": 1e3 * best, "projected_speedup_at_8_gpus": whole / best,
+                            "problems_whole": fd_problems(0, nunits, w["ntheta"]), "problems_share": fd_problems(lo, hi, w["ntheta"]),
+                            "maps_per_s_whole": fd_problems(0, nunits, w["ntheta"]) / whole,
+                            "bound": "the share is 513 problems -- two rounds of the 256 compute units, as the whole job is eighteen -- plus the "
+                                     "call's fixed cost: two launches, the upload of the sampling thetas, one exchange"}
+    except Exception as e:  # noqa: BLE001 -- an extra: never at the cost of the line
+        out["cfg4_fd_H"] = {"skipped": f"{type(e).__name__}: {e}"}
+    # ---- cfg5: the 1024-sim map of the stencil model
+    try:
+        model, N, nth, theta, nsims = WORKLOADS["cfg5_smooth_1e5"]
+        share = nsims // ngpus
+        prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N, device=device)
+        prob.set_normals_cache(False)
+        outs = [(np.empty((nsims, nth)), np.zeros(nsims, dtype=M._capi.INFO_DTYPE)) for _ in range(4)]
+        pipelined_steps(M, prob, seed, 0, nsims, theta, 1, outs=outs)
+        prob.synchronize()
+        t0 = time.perf_counter()
+        pipelined_steps(M, prob, seed, 0, nsims, theta, 3, outs=outs)
+        prob.synchronize()
+        whole = (time.perf_counter() - t0) / 3
+        prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", share * nth))
+        outs = [(np.empty((1, share, nth)), np.zeros(share, dtype=M._capi.INFO_DTYPE)) for _ in range(4)]
+
+        def gathered(K):
+            pend = []
+            for k in range(K):
+                prob.map_and_score_batch_gather_async(seed, 0, share, theta, share, atol=1e-2, z0_mode=M.Z0_ZERO, result_area=k % 4)
+                pend.append(k % 4)
+                if len(pend) > 3:
+                    a = pend.pop(0)
+                    prob.batch_wait_gathered(share, share, a, out=outs[a])
+            while pend:
+                a = pend.pop(0)
+                prob.batch_wait_gathered(share, share, a, out=outs[a])
+        gathered(2)
+        prob.synchronize()
+        t0 = time.perf_counter()
+        gathered(12)
+        prob.synchronize()
+        part = (time.perf_counter() - t0) / 12
+        prob.close()
+        out["cfg5_smooth_1e5"] = {"whole_job_ms": 1e3 * whole, "share_ms": 1e3 * part, "projected_speedup_at_8_gpus": whole / part,
+                                  "sims_whole": nsims, "sims_share": share, "sims_per_s_whole": nsims / whole,
+                                  "bound": "HBM on both sides: 1024 and 128 sims are 64 and 8 rounds of the 16 clusters a GPU holds; the "
+                                           "exchange is one 8 KB hand-off per 2 ms map"}
+    except Exception as e:  # noqa: BLE001
+        out["cfg5_smooth_1e5"] = {"skipped": f"{type(e).__name__}: {e}"}
+    out["note"] = ("whole job on one GPU / one rank's share of it (1/8 of the units, through a one-rank shared-memory communicator, "
+                   "exchange included): what 8 GPUs can give these maps at best; `python bench.py --gpus N --workload cfg4_fd_H | "
+                   "cfg5_smooth_1e5` measures the same on N GPUs")
     return out
 
 
@@ -423,6 +699,99 @@ def user_model_rates(M, device, N=10000, nsims=512):
                    "lbfgs_history_TBps: (4 sum h_k + 2 K + 1) N doubles per sim / step time -- the (dx, dg) history is what the resident "
                    "placement keeps in HBM (meaningful for the many-iteration cubic model, not for the one-iteration funnel)")
     return out
+
+
+def main_fd(args, M, torch, dist, world, rank, local_rank, sharded, tdev):
+    """--workload cfg4_fd_H: BASELINE.json configs[3], get_H! by finite differences (src/muse.jl:407-446), 512 sims x 4 theta.  A step
+    is ONE call: the rank's block of the flattened (sim, column) list (muse_fd_jacobian_columns) and, with N > 1, the exchange of
+    the column blocks through the engine's shared-memory communicator.  The unit of `value` is one MAP+score problem."""
+    w = FD_WORKLOAD
+    nth, N, seed = w["ntheta"], w["N"], 0
+    nunits = w["nsims"] * nth
+    prob = M.HipMuseProblem(None, model=w["model"], ntheta=nth, N=N, device=local_rank)
+    lo, hi = M.block_partition(0, nunits, world, rank)
+    collective, seen = None, 1
+    if sharded:
+        uid = [M.HipMuseProblem.comm_unique_id("shm", 4096) if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        prob.comm_init(world, rank, uid[0])
+        collective, seen = "shm-capi", prob.comm_ranks_seen()
+
+    def barrier():
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+        prob.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        cols, info = fd_call(M, prob, seed, lo, hi, sharded)
+    barrier()
+    rounds = []
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cols, info = fd_call(M, prob, seed, lo, hi, sharded)
+        barrier()
+        dt = time.perf_counter() - t0
+        if sharded:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        rounds.append(dt)
+        more = 1 if (sum(rounds) < args.min_seconds and len(rounds) < 100000) else 0
+        if sharded:
+            flag = torch.tensor([more if rank == 0 else 0], dtype=torch.int32, device=tdev)
+            dist.broadcast(flag, src=0)
+            more = int(flag.item())
+        if not more:
+            break
+    dt = sum(rounds) / len(rounds)
+    # roofline leg: HIP events around every solver launch of a few calls; a call is two launches -- the fiducial MAP with the
+    # normals-only elements that fill the cache, then the perturbed problems (the dominant one)
+    ncalls = 16
+    prob.profile_begin(2 * ncalls + 8)
+    for _ in range(ncalls):
+        fd_call(M, prob, seed, lo, hi, sharded)
+    barrier()
+    kernel_ms = prob.profile_end()
+    fid_ms, fd_ms = kernel_ms[0::2], kernel_ms[1::2]
+    assert np.all(info["status"] == 0), "a MAP solve did not converge in the timed region"
+    nprob_job = 2 * nunits + 1                      # what the job needs; every rank repeats the one shared fiducial MAP
+    nprob_rank = 2 * (hi - lo)
+    # compulsory HBM bytes of the perturbed launch (resident placement): a problem reads its simulation's cached normals n1, n2 and
+    # the fiducial MAP it starts from; its MAP is not stored (only the score leaves): 3 words per element
+    comp = 3 * 8 * N * nprob_rank
+    launch_s = float(fd_ms.mean()) * 1e-3
+    pinfo = prob.placement_info()
+    roof = {"bound": "hbm", "achieved": comp / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": comp / launch_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "map_score_kernel (BATCH_FD)", "placement": "resident" if pinfo["resident"] else "streaming",
+            "compulsory_bytes_per_launch": comp, "kernel_ms_mean": float(fd_ms.mean()), "fiducial_launch_ms_mean": float(fid_ms.mean()),
+            "launches_timed": int(fd_ms.size),
+            "note": "the perturbed problems' launch: per problem the simulation's cached normals (2 words per element) and the fiducial MAP "
+                    "(1) are read, one L-BFGS iteration runs on chip, nothing but the score is written; a mixed bound -- 3 words per "
+                    "element against ~60 fp64 operations",
+            "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean())}}
+    out = {
+        "metric": "MC sims/sec (MAP+score)", "value": nprob_job * args.steps / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg4_fd_H: BASELINE.json configs[3], get_H! by finite differences (central_fdm(3,1), src/muse.jl:407-446) of the "
+                               f"{nth}-theta funnel, N={N}, {w['nsims']} sims: {nprob_job} MAP+score problems per step (one 'sim' of the metric = "
+                               f"one MAP+score problem), {nprob_rank + 1} on this rank",
+                   "theta": w["theta"], "step": w["step"],
+                   "parallelism": f"the flattened (sim, column) list in {world} contiguous block(s) (src/muse.jl:327-333 across ranks), one exchange "
+                                  "of the column blocks per call" + (f" ({collective}, {seen} ranks seen)" if collective else "")},
+        "timed_rounds": len(rounds), "timed_seconds": sum(rounds), "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w["model"], N, w["theta"], seed, cpu_seconds=15.0)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    prob.close()
+    if sharded:
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def parse_args(argv=None):
@@ -536,6 +905,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "cfg4_fd_H":   # configs[3]: a step is a get_H! call, not a map
+        return main_fd(args, M, torch, dist, world, rank, local_rank, sharded, tdev)
     model, N, nth, theta, nsims = WORKLOADS[args.workload]
     if args.nsims > 0:
         nsims = args.nsims
@@ -779,68 +1150,10 @@ def main():
         dt, rounds, host_us, kernel_ms, info, split, collective, pinfo = (best[k] for k in (
             "dt", "rounds", "host_us", "kernel_ms", "info", "split", "collective", "pinfo"))
 
-        mean_kernel_s = float(kernel_ms.mean()) * 1e-3
-        placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
-                                                          if model == "smooth" else "streaming")
-        comp_bytes = compulsory_bytes(info, N, placement)
-        prow, why = profile_row(args.workload) if (world == 1 and split == 1 and not sharded) else (None, "profiles/ hold the 1-GPU, unsplit, unsharded launch")
-        traffic = measured_traffic(args.workload) if prow is not None else None
-        # The time a launch is charged with: its own duration between HIP events, unless the pipelined step is shorter --
-        # the event pair costs a launch ~3 us (it cannot overlap the next launch's start), and with two lanes a launch's own
-        # duration (events and rocprofv3 agree on it: kernel_ms_mean) includes waiting for the compute units the launch
-        # before it still holds, while launches complete once per step.
-        launch_s = min(mean_kernel_s, dt / best["launches"]) if world == 1 else mean_kernel_s
-        hbm = {"bound": "hbm", "achieved": comp_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": comp_bytes / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-               "compulsory_bytes_per_launch": comp_bytes, "launch_s_used": launch_s,
-               "traffic_GBps": None if traffic is None else traffic / launch_s / 1e9}
-        clock_hz = best["clock_hz"] or CLOCK_HZ
-        valu = None
-        if placement == "resident":
-            alg_cycles, alg_fp64 = algorithmic_valu(info, N, clock_hz)
-            alg = {"fp64_ops_per_launch": alg_fp64, "issue_cycles_per_launch": alg_cycles,
-                   "frac_of_issue_peak": alg_cycles / (N_SIMD * launch_s * clock_hz),
-                   "fp64_TFLOPs_fma_equiv": 2.0 * alg_fp64 / launch_s / 1e12,
-                   "ops_per_element": ALG_OPS, "issue_cycles_per_wave_instruction": ISSUE_CYCLES,
-                   "note": "work / peak: operation counts per element from the source (bench.py: ALG_OPS) x the measured issue cost "
-                           "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
-                           "many instructions the compiled kernel spends on them.  The peak is the PROBE's rate -- ~10 % softer than "
-                           "the spec rates (fp64 4 cycles, 32-bit 2) and optimistic for this mix: the generator as a kernel of its own "
-                           "at eight waves per SIMD (built, measured and removed in round 4: DESIGN.md section 6) ran no faster than "
-                           "inside this kernel, i.e. the sampler -- two thirds of the launch -- already runs at the VALU's throughput"}
-            valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,
-                    "clock_hz": clock_hz, "clock_source": "in-kernel s_memtime / s_memrealtime" if best["clock_hz"] else "assumed",
-                    "launch_s_used": launch_s}
-            if prow is not None and prow.get("SQ_ACTIVE_INST_VALU"):
-                # VALU-active time of one launch: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs
-                # (MI355X_MICROARCH.md, cycle constants: SQ_ACTIVE_INST_* are in quad-cycles); the instruction stream of a
-                # launch is fixed by its inputs, so the counter of the profiled launch is this launch's.
-                busy = 4.0 * float(prow["SQ_ACTIVE_INST_VALU"])
-                valu["utilisation"] = {"valu_active_cycles_per_launch": busy, "valu_insts_per_launch": float(prow["SQ_INSTS_VALU"]),
-                                       "frac": busy / (N_SIMD * launch_s * clock_hz),
-                                       "note": "VALU-active cycles (rocprofv3 SQ_ACTIVE_INST_VALU of profiles/) / (1024 SIMDs x launch "
-                                               "time x measured clock): how busy the kernel's OWN instruction stream keeps the SIMDs "
-                                               "(round 2 quoted this figure, against an assumed 2.4 GHz, as the roofline fraction)"}
-        primary = dict(valu if (placement == "resident" and valu is not None) else hbm)
-        primary.update({
-            "kernel": "map_score_kernel", "placement": placement, "placement_info": pinfo, "kernel_ms_mean": 1e3 * mean_kernel_s,
-            "lanes": lanes, "ms_per_launch_pipelined": 1e3 * dt / best["launches"],
-            "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
-            "algorithmic_bytes_d3": algorithmic_bytes(info, N),
-            "hbm": hbm, "valu": valu,
-            "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
-            "profile_note": why,
-            "note": ("resident placement: z, s, x, g never leave registers/LDS, the HBM leg only carries zhat out (and the "
-                     "L-BFGS pairs of solves with K > 1); the binding resource is fp64 VALU issue (sampler + evaluation passes). "
-                     "frac = algorithmic work / issue peak (valu.algorithmic); valu.utilisation is how busy the compiled kernel keeps "
-                     "the SIMDs.  BASELINE.json's '>= 40 % of the HBM roofline' can be neither met nor missed by this placement: it "
-                     "moves 1 word per element where SURVEY 8.d3's accounting assumes 22 (hbm.frac is that one word / 8 TB/s)"
-                     if placement == "resident" else
-                     "streaming placement: achieved = compulsory bytes of the passes the solves made / kernel time"),
-            "per_sim": {"f_calls_mean": float(info["f_calls"].mean()), "iterations_mean": float(info["iterations"].mean()),
-                        "hist_pairs_mean": float(info["hist_words"].mean())},
-        })
+        prow_ok = world == 1 and split == 1 and not sharded
+        launch_s = min(float(kernel_ms.mean()) * 1e-3, dt / best["launches"]) if world == 1 else float(kernel_ms.mean()) * 1e-3
+        primary = roofline_object(args.workload, model, N, info, pinfo, kernel_ms, launch_s, best["clock_hz"], lanes,
+                                  1e3 * dt / best["launches"], prow_ok)
 
         out = {
             "metric": "MC sims/sec (MAP+score)",
@@ -915,6 +1228,15 @@ def main():
     best_t = out.get("transport")
     if rank == 0 and world == 1 and not sharded and not args.no_extra:
         out["extra"] = extra_rates(M, prob, model, N, nth, theta, nsims, seed, local_rank)
+        if args.workload == "funnel_1e4":
+            # the other BASELINE workloads, briefly, so that they are in the driver's line too (each <= ~0.3 s of timed steps)
+            out["extra"]["workloads"] = {}
+            for name in ("funnel4_1e4", "noise_1e6", "smooth_1e5"):
+                try:
+                    out["extra"]["workloads"][name] = quick_workload(M, name, local_rank)
+                except Exception as e:  # noqa: BLE001 -- an extra: never at the cost of the line
+                    out["extra"]["workloads"][name] = {"skipped": f"{type(e).__name__}: {e}"}
+            out["extra"]["scale_projection"] = scale_projection(M, local_rank)
         if args.workload == "funnel_1e4":
             try:
                 out["extra"]["user_model"] = user_model_rates(M, local_rank)

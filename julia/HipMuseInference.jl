@@ -105,11 +105,38 @@ end
 # muse! for this problem type: the reference's own loop (src/muse.jl:159-236) with the pmap replaced by
 # one batched launch; dispatch on the problem type as src/turing.jl:248-256 does for PPL models.
 function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=nothing, maxsteps=50, θ_rtol=1e-1,
-               ∇z_logLike_atol=1e-2, nsims=100, α=0.7, get_covariance=false, kwargs...)
+               ∇z_logLike_atol=1e-2, nsims=100, α=0.7, get_covariance=false, native_prior=nothing, kwargs...)
     seed = UInt64(something(rng, result.rng, rand(UInt32)))
     result.rng = seed
     θ = standardizeθ(prob, something(result.θ, θ₀))
     history = result.history
+    if native_prior !== nothing && isempty(history) && isempty(kwargs) && prob.nθ <= 8
+        # The plain option set (untransformed θ, "sims" Jacobian update, constant α, a prior the library evaluates itself:
+        # native_prior = (kind, mean, sigma), kind 0 flat / 1 independent Gaussian): the whole loop runs in the library --
+        # muse_run_device, ONE persistent launch for every iteration; it falls back to muse_run (one launch per iteration)
+        # by itself where the loop kernel does not apply.  Same bits either way, and the same as the loop below.
+        kind, mean, sigma = native_prior
+        θ, hist, gs = muse_run_device(prob, seed, θ; nsims, maxsteps, θ_rtol, ∇z_logLike_atol, α, prior_kind=kind,
+                                      prior_mean=mean, prior_sigma=sigma)
+        nθ = prob.nθ
+        for i in 1:size(hist, 2)          # MUSE_RUN_HIST record -> the reference's history record (src/muse.jl:211-221)
+            h = hist[:, i]
+            θi, g_dat, g_like′, g_prior′, g_post′ = (h[(k-1)*nθ+1:k*nθ] for k in 1:5)
+            H⁻¹_like′ = Diagonal(h[5nθ+1:6nθ]); H_prior′ = Diagonal(h[6nθ+1:7nθ])
+            H⁻¹_post′ = reshape(h[7nθ+1:7nθ+nθ^2], nθ, nθ)'
+            g_like_sims = [gs[:, s, i] for s in 1:nsims]
+            push!(history, (;θ=θi, θunreg=θi, θ′=θi, θunreg′=θi, g_like_sims, g_like_dat′=g_dat, g_like_sims′=g_like_sims,
+                            g_like′, g_prior′, g_post′, H⁻¹_post′, H_prior′, H⁻¹_like′, H⁻¹_like_sims′=H⁻¹_like′,
+                            ẑ_history_dat=nothing, ẑ_history_sims=nothing, t=h[end], ẑ_dat=nothing, ẑ_sims=fill(nothing, nsims)))
+        end
+        result.θ = θ
+        result.gs = history[end].g_like_sims
+        if get_covariance
+            get_J!(result, prob; rng=seed, nsims, ∇z_logLike_atol)
+            get_H!(result, prob; rng=seed, nsims=max(1, nsims ÷ 10), ∇z_logLike_atol)
+        end
+        return result
+    end
     for i = (length(history)+1):maxsteps
         if i > 2
             Δθ = history[end].θ′ - history[end-1].θ′
@@ -177,6 +204,62 @@ function muse_run(prob::HipMuseProblem, seed::Integer, θ₀; nsims=100, maxstep
                 (Ptr{Cvoid}, UInt64, Ptr{Float64}, Ref{MuseRunOptions}, Ref{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
                 prob.ctx, seed, standardizeθ(prob, θ₀), opt, n, θ, hist, gs, C_NULL))
     θ, hist[:, 1:n[]], gs[:, :, 1:n[]]
+end
+
+# muse_run_device: the same signature -- ONE persistent launch runs every iteration (map, exchange of the scores between the
+# workgroups, step on the GPU, next map); muse_run_sharded: this rank's share of the loop over the ranks of the context's
+# communicator (comm_init first) -- a persistent launch per rank whose scores meet on the node's board in pinned host memory,
+# or the host-driven loop where that does not apply.  Every rank gets the same (θ, history, scores).
+function _native_loop(sym::Symbol, prob::HipMuseProblem, seed::Integer, θ₀; nsims=100, maxsteps=50, θ_rtol=1e-1, ∇z_logLike_atol=1e-2,
+                      α=0.7, prior_kind=0, prior_mean=ntuple(_ -> 0.0, 8), prior_sigma=ntuple(_ -> 1.0, 8), z0_warm=false)
+    nθ = prob.nθ; W = 7nθ + nθ^2 + 1
+    opt = Ref(MuseRunOptions(nsims, maxsteps, θ_rtol, ∇z_logLike_atol, α, prior_kind, z0_warm, prior_mean, prior_sigma))
+    n = Ref{Int32}(0); θ = Vector{Float64}(undef, nθ)
+    hist = Matrix{Float64}(undef, W, maxsteps); gs = Array{Float64}(undef, nθ, nsims, maxsteps)
+    args = (prob.ctx, UInt64(seed), standardizeθ(prob, θ₀), opt, n, θ, hist, gs, C_NULL)
+    if sym === :muse_run_device
+        check(ccall((:muse_run_device, libmuse_hip), Cint, (Ptr{Cvoid}, UInt64, Ptr{Float64}, Ref{MuseRunOptions}, Ref{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), args...))
+    else
+        check(ccall((:muse_run_sharded, libmuse_hip), Cint, (Ptr{Cvoid}, UInt64, Ptr{Float64}, Ref{MuseRunOptions}, Ref{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), args...))
+    end
+    θ, hist[:, 1:n[]], gs[:, :, 1:n[]]
+end
+muse_run_device(prob::HipMuseProblem, seed::Integer, θ₀; kw...) = _native_loop(:muse_run_device, prob, seed, θ₀; kw...)
+muse_run_sharded(prob::HipMuseProblem, seed::Integer, θ₀; kw...) = _native_loop(:muse_run_sharded, prob, seed, θ₀; kw...)
+
+# What a SimpleMuseProblem closure captures (src/simple.jl:79-89: a spectrum, a noise map, a mask) for a user-supplied model
+# whose header declares run-time constants (include/muse_model.h, muse_const): vector k, one entry per element.
+set_constants(prob::HipMuseProblem, k::Integer, values::Vector{Float64}) =
+    check(ccall((:muse_set_constants, libmuse_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Cint), prob.ctx, k, values, length(values), MEM_HOST))
+# plain maps over simulations the context has drawn before load their standard normals instead of generating them: off / on
+set_normals_cache(prob::HipMuseProblem, enabled::Bool) =
+    check(ccall((:muse_set_normals_cache, libmuse_hip), Cint, (Ptr{Cvoid}, Cint), prob.ctx, enabled))
+# A user-supplied model's header evaluated for one element on the host -- (grad, objective term, score term, ozz, ozx, bz, bx, z, x,
+# dx/dsd): what a consistency check differentiates numerically where the reference has AD (src/simple.jl:84-85)
+model_has_second() = ccall((:muse_model_has_second, libmuse_hip), Cint, ()) != 0
+function model_eval(prob::HipMuseProblem, iv, sd, x, z, n1, n2, i::Integer)
+    out = Vector{Float64}(undef, 10)
+    check(ccall((:muse_model_eval, libmuse_hip), Cint, (Ptr{Cvoid}, Float64, Float64, Float64, Float64, Float64, Float64, Int64, Ptr{Float64}),
+                prob.ctx, iv, sd, x, z, n1, n2, i, out))
+    out
+end
+
+# get_H! by implicit differentiation (src/muse.jl:335-405): H = H1 - dFdθᵀ A⁻¹ dFdθ1 with conjugate gradients on the device, for
+# whole simulations (nθ × nθ per sim) or for a range of the flattened (sim, column) list (a worker's block, src/muse.jl:327-333)
+function implicit_H_batch(prob::HipMuseProblem, seed::Integer, sims::UnitRange, θ₀; atol=1e-1, cg_maxiter=100)
+    n = length(sims)
+    Hs = Array{Float64}(undef, prob.nθ, prob.nθ, n); its = Matrix{Int32}(undef, prob.nθ, n)
+    check(ccall((:muse_implicit_H_batch, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Int32}),
+                prob.ctx, UInt64(seed), first(sims), last(sims) + 1, standardizeθ(prob, θ₀), atol, cg_maxiter, Hs, its))
+    [permutedims(Hs[:, :, s]) for s in 1:n], its          # (the C ABI is row-major [sim][i][j])
+end
+function implicit_H_columns(prob::HipMuseProblem, seed::Integer, sim_begin, col_begin, col_end, θ₀; atol=1e-1, cg_maxiter=100)
+    cols = Matrix{Float64}(undef, prob.nθ, col_end - col_begin); its = Vector{Int32}(undef, col_end - col_begin)
+    check(ccall((:muse_implicit_H_columns, libmuse_hip), Cint,
+                (Ptr{Cvoid}, UInt64, Int64, Int64, Int64, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Int32}),
+                prob.ctx, UInt64(seed), sim_begin, col_begin, col_end, standardizeθ(prob, θ₀), atol, cg_maxiter, cols, its))
+    cols, its
 end
 
 # One process per GPU (e.g. MPI.jl ranks or Distributed workers pinned to devices): after

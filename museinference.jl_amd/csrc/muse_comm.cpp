@@ -58,6 +58,14 @@ struct CommState {
     int rank = 0;
     // shared-memory transport (null: RCCL).  Area kAreas of the segment carries the synchronous collectives.
     muse_shm::Gather* shm = nullptr;
+    // The node's score board of the sharded DEVICE loop (muse_run_sharded): a region of the shared segment that this process
+    // has registered with the HIP runtime, so that its GPU reads and writes it in place.  Every rank's workers store their
+    // scores there as tagged granules; every rank's stepper polls all of them.  No host is in the loop between two maps.
+    unsigned long long* board_dev = nullptr;   // this GPU's pointer to it (null: not available -- the host loop runs)
+    void* board_host = nullptr;
+    size_t board_granules = 0;
+    unsigned int board_tag = 0;      // the last tag used (the same on every rank: every rank makes the same calls)
+    bool dev_loop_off = false;       // the device loop failed once on some rank (a shared GPU): host loop from then on, on every rank
     uint64_t seq[kAreas + 1] = {0};   // sequence number of the last exchange per area (the same on every rank)
     size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced PER MAP for the gather in flight
     int nmaps[kAreas] = {1, 1, 1, 1}; // maps of the gather in flight (block per rank: [nmaps][rows_per_rank][ntheta])
@@ -123,6 +131,10 @@ int muse_internal_map_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int
 int muse_ctx_set_comm_reserve(muse_ctx* ctx, int cus);
 int muse_set_error(int code, const char* msg);
 int muse_wait_event(void* event);
+int muse_internal_loop_usable(muse_ctx* ctx, int nsims, int64_t nlocal);
+int muse_internal_run_loop_shard(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* o, int64_t sim_lo, int64_t sim_hi,
+                                 int include_data, void* board_dev, unsigned int tag_base, int32_t* niter_out, double* theta_out,
+                                 double* hist_out, double* gsims_out, muse_info* info_out);
 }
 
 static CommState* state_of(muse_ctx* ctx, void** stream_out = nullptr) {
@@ -197,6 +209,7 @@ struct ShmId {
 };
 static_assert(sizeof(ShmId) == MUSE_UNIQUE_ID_BYTES, "the id travels in the same 128 bytes as RCCL's");
 constexpr size_t kShmDefaultBlock = 16384;
+constexpr size_t kBoardBytes = 256 * 1024;   // the score board: 32 768 granules -- (nsims + 1) * ntheta <= 16 384
 
 #define SHMCHK(st, expr, what)                                                                            \
     do {                                                                                                  \
@@ -298,7 +311,7 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
             muse_shm::Gather* g = new muse_shm::Gather();
             if (const char* t = getenv("MUSE_SHM_TIMEOUT_S")) g->timeout_s = atof(t) > 0 ? atof(t) : g->timeout_s;
             std::string err;
-            if (!g->open(sid.name, nranks, rank, kAreas + 1, (size_t)sid.block_doubles, err)) {
+            if (!g->open(sid.name, nranks, rank, kAreas + 1, (size_t)sid.block_doubles, err, kBoardBytes)) {
                 delete g;
                 return muse_set_error(MUSE_ERR_RCCL, ("shared-memory transport: " + err).c_str());
             }
@@ -307,6 +320,19 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
             st->nranks = nranks;
             st->rank = rank;
             st->device = device;
+            // the score board: mapped into this GPU's address space where the runtime allows it (else: the host loop)
+            if (!getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(device) == hipSuccess && g->extra() &&
+                hipHostRegister(g->extra(), g->extra_bytes(), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, g->extra(), 0) == hipSuccess && dp) {
+                    st->board_host = g->extra();
+                    st->board_dev = (unsigned long long*)dp;
+                    st->board_granules = g->extra_bytes() / sizeof(unsigned long long);
+                } else {
+                    (void)hipHostUnregister(g->extra());
+                }
+            }
+            (void)hipGetLastError();
             *slot = st;
             return MUSE_OK;
         }
@@ -351,6 +377,11 @@ int muse_comm_destroy(muse_ctx* ctx) {
     if (rc) return rc;
     if (CommState* st = (CommState*)*slot) {
         if (st->shm) {
+            if (st->board_host) {
+                hipSetDevice(device);
+                (void)hipDeviceSynchronize();   // (nothing of this process may still be polling the board)
+                (void)hipHostUnregister(st->board_host);
+            }
             delete st->shm;
             delete st;
             *slot = nullptr;
@@ -600,6 +631,35 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
     }
     block(rank, lo, hi);
     const int64_t nlocal = (hi - lo) + (rank == 0 ? 1 : 0);
+    // ---- the device loop: ONE persistent launch per rank runs every iteration; the ranks' scores meet on the node's board (pinned host
+    // memory that every GPU maps), every rank's stepper takes the same step from the same bits -- no host between two maps.  Every
+    // rank must take the same loop: the decision is the minimum over the ranks of what each can do.
+    if (st->shm) {
+        const bool want = st->board_dev && !st->dev_loop_off && !getenv("MUSE_DEBUG_SHARDED_HOST_LOOP") &&
+                          (uint64_t)(S + 1) * (uint64_t)nt * 2 <= st->board_granules && st->board_tag < 0x70000000u &&
+                          muse_internal_loop_usable(ctx, S, nlocal) != 0;
+        double flag[1] = {want ? 1.0 : 0.0};
+        rc = shm_allgather(st, flag, 1, flag, true);
+        if (rc) return rc;
+        if (flag[0] == (double)world) {
+            const unsigned int tag_base = st->board_tag;
+            st->board_tag += (unsigned)o->maxsteps + 1;
+            rc = muse_internal_run_loop_shard(ctx, seed, theta0, o, lo, hi, rank == 0 ? 1 : 0, st->board_dev, tag_base, niter_out, theta_out,
+                                              hist_out, gsims_out, info_out);
+            // a rank whose workgroups were not all resident (rc 1001) stalls every rank's stepper: all of them time out -- but
+            // make the outcome a collective decision anyway
+            double bad[1] = {rc == 1001 ? 1.0 : 0.0};
+            const int rc2 = shm_allgather(st, bad, 1, bad, true);
+            if (rc < 0) return rc;
+            if (rc2) return rc2;
+            if (bad[0] == 0.0) return MUSE_OK;
+            st->dev_loop_off = true;
+            if (o->z0_warm)   // (the aborted attempt has touched the resident MAPs the run was to start from)
+                return muse_set_error(MUSE_ERR_HIP, "muse_run_sharded: the workgroups of the loop kernel were not all resident at once on "
+                                                    "some rank; later calls run the host loop");
+            // ... a cold start is simply run again, by the host loop below: the same bits
+        }
+    }
     StepParams sp;
     memset(&sp, 0, sizeof sp);
     sp.ntheta = nt;

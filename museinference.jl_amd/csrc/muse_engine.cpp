@@ -1314,6 +1314,8 @@ struct RunBuffers {
     unsigned int tag = 0;                 // the last granule tag used (tags grow from run to run: nothing is reset)
     muse_info* info_dummy = nullptr;      // device [info_cap]: where the solver infos go when the caller does not want them
     int64_t info_cap = 0;
+    double* scores_dummy = nullptr;       // device [scores_dummy_cap]: the workers' own score block of a SHARDED loop (its stepper
+    int64_t scores_dummy_cap = 0;         // writes every rank's scores to the pinned block instead)
     // pinned
     double* hist = nullptr;
     double* scores = nullptr;
@@ -1324,10 +1326,18 @@ struct RunBuffers {
     int grid_place = -1, grid_max = 0;    // the occupancy query's answer for (placement, LDS bytes): asked once
     size_t grid_lds = 0;
 };
-static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, bool want_info) {
+// S: simulations of the whole job; nlocal: elements this context solves (S + 1 unless the loop is sharded over ranks)
+static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, int64_t nlocal, bool want_info) {
     if (!c->run) c->run = new RunBuffers();
     RunBuffers& r = *c->run;
     const int nt = c->ntheta;
+    if (nlocal * nt > r.scores_dummy_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (r.scores_dummy) HIPCHK(hipFree(r.scores_dummy));
+        r.scores_dummy = nullptr; r.scores_dummy_cap = 0;
+        HIPCHK(hipMalloc(&r.scores_dummy, (size_t)(nlocal * nt) * sizeof(double)));
+        r.scores_dummy_cap = nlocal * nt;
+    }
     if (!r.theta_out) {
         HIPCHK(hipHostMalloc(&r.theta_out, kMaxTheta * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&r.status, 64, hipHostMallocDefault));
@@ -1344,15 +1354,15 @@ static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, bool want_info) 
         HIPCHK(hipMemsetAsync(r.gran, 0, (size_t)r.gran_cap * sizeof(unsigned long long), c->stream));  // tag 0 is never used
         r.tag = 0;
     }
-    if (S + 1 > r.info_cap) {
+    if (nlocal > r.info_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (r.info_dummy) HIPCHK(hipFree(r.info_dummy));
         r.info_dummy = nullptr; r.info_cap = 0;
-        HIPCHK(hipMalloc(&r.info_dummy, (size_t)(S + 1) * sizeof(muse_info)));
-        r.info_cap = S + 1;
+        HIPCHK(hipMalloc(&r.info_dummy, (size_t)nlocal * sizeof(muse_info)));
+        r.info_cap = nlocal;
     }
     const int64_t nh = (int64_t)maxsteps * MUSE_RUN_HIST(kMaxTheta), ns = (int64_t)maxsteps * (S + 1) * nt,
-                  ni = want_info ? (int64_t)maxsteps * (S + 1) : 0;
+                  ni = want_info ? (int64_t)maxsteps * nlocal : 0;
     if (nh > r.cap_hist) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (r.hist) HIPCHK(hipHostFree(r.hist));
@@ -1379,59 +1389,87 @@ static int ensure_run_buffers(muse_ctx* c, int maxsteps, int S, bool want_info) 
 static void free_run_buffers(muse_ctx* c) {
     if (!c->run) return;
     RunBuffers& r = *c->run;
-    hipFree(r.gran); hipFree(r.info_dummy);
+    hipFree(r.gran); hipFree(r.info_dummy); hipFree(r.scores_dummy);
     hipHostFree(r.hist); hipHostFree(r.scores); hipHostFree(r.infos); hipHostFree(r.theta_out); hipHostFree(r.status);
     delete c->run;
     c->run = nullptr;
 }
 
-int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
-                    double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
-    int rc = check_ctx(c);
-    if (rc) return rc;
-    rc = check_run_args(c, theta0, o, niter_out, theta_out, hist_out, gsims_out);
-    if (rc) return rc;
-    const int nt = c->ntheta, S = o->nsims, maxsteps = o->maxsteps;
-    const int64_t H = MUSE_RUN_HIST(nt), nprob = (int64_t)S + 1;
+// One rank's share of a loop that is sharded over the ranks of a node (muse_run_sharded, muse_comm.cpp): simulations
+// [sim_lo, sim_hi) -- and the data element on the rank that has include_data -- of a job of opt->nsims simulations; every rank's
+// workers write their scores to the node's board (pinned host memory mapped by every GPU), every rank's stepper polls all of
+// them and takes the same step from the same bits.  null: the whole job on this GPU, scores exchanged through its own memory.
+struct LoopShard {
+    int64_t sim_lo, sim_hi;
+    int include_data;
+    unsigned long long* board;   // device pointer of the board: [(nsims + 1) * ntheta][2] granules, the data element's first
+    unsigned int tag_base;       // the same on every rank (the board's tags grow from run to run)
+};
+// Can this context run (its share of) the loop as ONE persistent launch?  On success *shape_out / *max_grid_out describe it.
+static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_out, int* max_grid_out) {
+    const int nt = c->ntheta;
+    const int64_t nprob_total = (int64_t)S + 1;
     const int pl = choose_place(c);
     LaunchShape shape;
     shape.model = c->model; shape.ntheta = nt; shape.place = pl; shape.grid = 0; shape.implicit = false; shape.lds_s = false;
     shape.big = false;  // (the loop kernel runs the resident placements)
     shape.done_event = nullptr;
     const bool xg_lds = pl == P_R512x10;
-    shape.lds = place_lds(c, pl) + loop_extra_lds(xg_lds, nprob, nt);
+    shape.lds = place_lds(c, pl) + loop_extra_lds(xg_lds, nprob_total, nt);
     static const bool host_only = getenv("MUSE_DEBUG_NO_LOOP_KERNEL") != nullptr;  // tuning aid
     const size_t lds_limit = 160 * 1024;
     // the loop kernel pays where an iteration is short: the resident placements (N <= 10^4).  In the streaming ones an iteration is
     // hundreds of microseconds of HBM traffic, the host's share of it nothing, and the loop kernel's static deal of the elements
     // slower than the map kernel's tickets (N = 30 000 x 512 sims: 377 against 347 us per iteration)
     const bool resident = pl == P_R256x1 || pl == P_R512x4 || pl == P_R512x10;
-    // ... and with one theta component, or one problem per worker: the loop kernels of the multi-theta instantiations carry their
-    // per-block state across the solver (37-180 spilled registers) and lose to the host loop when a worker has several problems --
-    // measured per iteration at 512 sims, host / device: N = 10^4: 53 / 50 us (1 component), 75 / 79 (2), 89 / 97 (4), 100 / 113 (8);
-    // N = 512: 25 / 20 (1), 38 / 44 (8) -- and win when it has one (100 sims: N = 3000 x 4 components 30.5 / 25.8, N = 512 x 8: 19.6 / 16.5)
-    static const bool any_nt = getenv("MUSE_DEBUG_LOOP_ANY_NTHETA") != nullptr;   // tuning aid / tests: the loop kernel whatever ntheta
     if (host_only || c->loop_unfit || !resident || place_is_cluster(pl) || !loop_supported(shape) || shape.lds > lds_limit ||
-        (xg_lds && loop_step_bytes(nprob, nt) > (size_t)2 * (c->ld + 2) * sizeof(double)))
-        return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
-    if (c->nlanes > 1) {   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
-        rc = muse_synchronize(c);
-        if (rc) return rc;
-    }
-    rc = ensure_run_buffers(c, maxsteps, S, info_out != nullptr);
-    if (rc) return rc;
+        (xg_lds && loop_step_bytes(nprob_total, nt) > (size_t)2 * (c->ld + 2) * sizeof(double)))
+        return false;
+    if (!c->run) c->run = new RunBuffers();
     RunBuffers& r = *c->run;
     if (r.grid_place != pl || r.grid_lds != shape.lds) {
         int mg = 0;
-        const hipError_t e = loop_max_grid(shape, c->num_cus, &mg);
-        if (e != hipSuccess) return fail(MUSE_ERR_HIP, std::string("loop kernel occupancy: ") + hipGetErrorString(e));
+        if (loop_max_grid(shape, c->num_cus, &mg) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         r.grid_place = pl;
         r.grid_lds = shape.lds;
         r.grid_max = mg;
     }
-    const int max_grid = r.grid_max;
-    if (max_grid < 2 || (nt > 1 && !any_nt && nprob > max_grid - 1))
-        return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
+    // ... and with one theta component, or one problem per worker: the loop kernels of the multi-theta instantiations carry their
+    // per-block state across the solver (35-114 spilled registers) and lose to the host loop when a worker has several problems --
+    // measured per iteration at 512 sims, host / device: N = 10^4: 53 / 50 us (1 component), 75 / 79 (2), 89 / 97 (4), 100 / 113 (8);
+    // N = 512: 25 / 20 (1), 38 / 44 (8) -- and win when it has one (100 sims: N = 3000 x 4 components 30.5 / 25.8, N = 512 x 8: 19.6 / 16.5)
+    static const bool any_nt = getenv("MUSE_DEBUG_LOOP_ANY_NTHETA") != nullptr;   // tuning aid / tests: the loop kernel whatever ntheta
+    if (r.grid_max < 2 || (nt > 1 && !any_nt && nlocal > r.grid_max - 1)) return false;
+    if (shape_out) *shape_out = shape;
+    if (max_grid_out) *max_grid_out = r.grid_max;
+    return true;
+}
+
+// The loop as ONE launch.  info_out: [maxsteps][nlocal] (this context's elements).  rc MUSE_LOOP_NOT_RESIDENT (internal, > 0): the
+// bounded waits of the kernel expired -- nothing has been reported to the caller yet.
+enum { MUSE_LOOP_NOT_RESIDENT = 1001 };
+static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, const LoopShard* sh,
+                           const LaunchShape& shape_in, int max_grid, int32_t* niter_out, double* theta_out, double* hist_out,
+                           double* gsims_out, muse_info* info_out) {
+    const int nt = c->ntheta, S = o->nsims, maxsteps = o->maxsteps;
+    const int64_t H = MUSE_RUN_HIST(nt), nprob_total = (int64_t)S + 1;
+    const int64_t sim_lo = sh ? sh->sim_lo : 0, sim_hi = sh ? sh->sim_hi : S;
+    const int include_data = sh ? sh->include_data : 1;
+    const int64_t nsim_local = sim_hi - sim_lo, nprob = nsim_local + include_data;
+    if (nprob < 1) return fail(MUSE_ERR_INVALID, "a rank of a sharded loop needs at least one element");
+    LaunchShape shape = shape_in;
+    const int pl = shape.place;
+    int rc = MUSE_OK;
+    if (c->nlanes > 1) {   // (every lane: the loop's workgroups must have the GPU to themselves; lane 0 afterwards)
+        rc = muse_synchronize(c);
+        if (rc) return rc;
+    }
+    rc = ensure_run_buffers(c, maxsteps, S, nprob, info_out != nullptr);
+    if (rc) return rc;
+    RunBuffers& r = *c->run;
     rc = ensure_zhat(c, nprob);
     if (rc) return rc;
     BatchArgs a;
@@ -1440,21 +1478,21 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     a.seed = seed;
     a.atol = o->atol;
     a.nproblems = (int)nprob;
-    a.include_data = 1;
+    a.include_data = include_data;
     a.z0_mode = MUSE_Z0_ZERO;   // (per iteration, set by the kernel)
     a.store_zhat = 1;
-    a.sim_begin = 0;
+    a.sim_begin = sim_lo;
     a.slot0 = 0;
     a.nmaps = 1;
     a.n_per_map = (int)nprob;
     a.map_stride = nprob;
     bool storing = false;
-    {
-        const bool held = ncache_holds(c, seed, 0, S);   // (an earlier run, or maps of the host driver, drew these streams)
-        if (held || ensure_ncache(c, S)) {
+    if (nsim_local > 0) {
+        const bool held = ncache_holds(c, seed, sim_lo, nsim_local);   // (an earlier run, or maps of the host driver, drew these streams)
+        if (held || ensure_ncache(c, nsim_local)) {
             a.ncache = c->ncache;
-            a.ncache_sim0 = held ? c->nc_sim0 : 0;
-            a.ncache_count = held ? (int)c->nc_count : S;
+            a.ncache_sim0 = held ? c->nc_sim0 : sim_lo;
+            a.ncache_count = held ? (int)c->nc_count : (int)nsim_local;
             a.ncache_mode = held ? 2 : 1;   // of the FIRST iteration; the later ones load
             // (a storing run overwrites the cache now and claims its range when it has ENDED well: an aborted loop -- workers
             //  that never ran their first iteration, a bounded wait that expired -- must not leave a tag behind)
@@ -1462,7 +1500,10 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
             if (storing) c->nc_count = 0;
         }
     }
-    a.gran = r.gran;
+    // where the workers' scores go as granules: this GPU's own buffer, or this rank's rows of the node's board
+    const int64_t row0 = sh ? (include_data ? 0 : 1 + sim_lo) : 0;
+    a.gran = sh ? sh->board + (size_t)row0 * nt * 2 : r.gran;
+    a.gran_sys = sh ? 1 : 0;
     // the common fields, as launch_batch fills them
     a.N = c->N;
     a.ld = c->ld;
@@ -1497,14 +1538,33 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     step_params(c, o, l.sp);
     l.maxsteps = maxsteps;
     l.z0_warm = o->z0_warm ? 1 : 0;
-    l.tag_base = r.tag;
-    r.tag += (unsigned)maxsteps + 1;
     l.hist_out = r.hist;
-    l.scores_out = r.scores;
     l.info_out = info_out ? r.infos : r.info_dummy;
     l.info_stride = info_out ? nprob : 0;
     l.theta_out = r.theta_out;
     l.status = r.status;
+    l.nprob_total = (int)nprob_total;
+    l.theta_gran = r.gran + (size_t)2 * nt * nprob_total;   // (behind the score granules of an unsharded loop)
+    if (sh) {
+        l.board = 1;
+        l.tag_base = sh->tag_base;
+        l.score_gran = sh->board;
+        l.scores_out = r.scores_dummy;    // the workers' own block: nowhere (the stepper writes every rank's scores)
+        l.scores_stride = 0;
+        l.scores_all_out = r.scores;
+        // (this GPU's theta granules carry the board's tags: they grow with it)
+        if (r.tag > sh->tag_base) HIPCHK(hipMemsetAsync(r.gran + (size_t)2 * nt * nprob_total, 0, (size_t)2 * (kMaxTheta + 1) * sizeof(unsigned long long), c->stream));
+        if (r.tag < sh->tag_base + (unsigned)maxsteps + 1) r.tag = sh->tag_base + (unsigned)maxsteps + 1;   // (never backwards: this
+                                                                  // GPU's own score granules of unsharded runs keep their last tags)
+    } else {
+        l.board = 0;
+        l.tag_base = r.tag;
+        r.tag += (unsigned)maxsteps + 1;
+        l.score_gran = r.gran;
+        l.scores_out = r.scores;
+        l.scores_stride = nprob * nt;
+        l.scores_all_out = nullptr;
+    }
     r.status[0] = r.status[1] = r.status[2] = 0;
     for (int k = 0; k < nt; ++k) r.theta_out[k] = theta0[k];
     static const bool trace = getenv("MUSE_DEBUG_RUN_TIMING") != nullptr;   // tuning aid: where a call's own time goes
@@ -1521,25 +1581,73 @@ int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse
     c->area_inflight[0] = false;
     if (r.status[1] == 100) {   // a bounded wait of the loop kernel expired (it also raised the error word: clear it)
         (void)check_error_flag(c);
-        if (!getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;   // (the test hook provokes the failure on purpose)
-        return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident at once (another process on "
-                                  "this GPU?); muse_run gives the same results with one launch per iteration, and later calls of "
-                                  "muse_run_device on this context take that loop by themselves");
+        return MUSE_LOOP_NOT_RESIDENT;
     }
     rc = check_error_flag(c);
     if (rc) return rc;
     if (r.status[1] != 0) return step_error(r.status[1]);
     const int n = r.status[0];
     // every worker ran its elements' first iteration (the stepper saw all of their scores) and the launch has completed
-    if (storing && n >= 1) { c->nc_seed = seed; c->nc_sim0 = 0; c->nc_count = S; }
+    if (storing && n >= 1) { c->nc_seed = seed; c->nc_sim0 = sim_lo; c->nc_count = nsim_local; }
     *niter_out = n;
     for (int k = 0; k < nt; ++k) theta_out[k] = r.theta_out[k];
     for (int i = 0; i < n; ++i) {
         memcpy(hist_out + (int64_t)i * H, r.hist + (int64_t)i * H, (size_t)H * sizeof(double));
-        memcpy(gsims_out + (int64_t)i * S * nt, r.scores + ((int64_t)i * nprob + 1) * nt, (size_t)S * nt * sizeof(double));
+        memcpy(gsims_out + (int64_t)i * S * nt, r.scores + ((int64_t)i * nprob_total + 1) * nt, (size_t)S * nt * sizeof(double));
     }
     if (info_out) memcpy(info_out, r.infos, (size_t)n * nprob * sizeof(muse_info));
     return MUSE_OK;
+}
+static int not_resident_error(muse_ctx* c) {
+    if (!getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;   // (the test hook provokes the failure on purpose)
+    return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident at once (another process on "
+                              "this GPU?); muse_run gives the same results with one launch per iteration, and later calls of "
+                              "muse_run_device on this context take that loop by themselves");
+}
+
+int muse_run_device(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int32_t* niter_out,
+                    double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    rc = check_run_args(c, theta0, o, niter_out, theta_out, hist_out, gsims_out);
+    if (rc) return rc;
+    LaunchShape shape;
+    int max_grid = 0;
+    // the cluster placements (an element split, N >= 65 536), the streaming ones and several components with several problems per
+    // worker run the host loop: the same bits either way
+    if (!loop_usable(c, o->nsims, (int64_t)o->nsims + 1, &shape, &max_grid))
+        return muse_run(c, seed, theta0, o, niter_out, theta_out, hist_out, gsims_out, info_out);
+    rc = run_loop_launch(c, seed, theta0, o, nullptr, shape, max_grid, niter_out, theta_out, hist_out, gsims_out, info_out);
+    return rc == MUSE_LOOP_NOT_RESIDENT ? not_resident_error(c) : rc;
+}
+
+// ---- for muse_comm.cpp: this rank's share of a sharded loop as ONE launch (muse_run_sharded) -------------------------------------
+int muse_internal_loop_usable(muse_ctx* c, int nsims, int64_t nlocal) {
+    if (!c || check_ctx(c) != MUSE_OK) return 0;
+    return loop_usable(c, nsims, nlocal, nullptr, nullptr) ? 1 : 0;
+}
+// rc: MUSE_OK; 1001: the kernel's bounded waits expired (workgroups not all resident) -- the caller decides with its peers; < 0: error
+int muse_internal_run_loop_shard(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int64_t sim_lo, int64_t sim_hi,
+                                 int include_data, void* board_dev, unsigned int tag_base, int32_t* niter_out, double* theta_out,
+                                 double* hist_out, double* gsims_out, muse_info* info_out) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!theta0 || !o || !niter_out || !theta_out || !hist_out || !gsims_out || !board_dev) return fail(MUSE_ERR_INVALID, "NULL argument");
+    if (c->ntheta > kMaxTheta || o->nsims < 2 || o->maxsteps < 1 || (o->prior_kind != 0 && o->prior_kind != 1) || sim_lo < 0 || sim_hi < sim_lo ||
+        sim_hi > o->nsims)
+        return fail(MUSE_ERR_INVALID, "bad arguments of a sharded loop");
+    if (include_data && !c->has_data) return fail(MUSE_ERR_NODATA, "the rank that holds the data element needs the observed data (muse_set_data)");
+    LaunchShape shape;
+    int max_grid = 0;
+    const int64_t nlocal = (sim_hi - sim_lo) + (include_data ? 1 : 0);
+    if (!loop_usable(c, o->nsims, nlocal, &shape, &max_grid)) return fail(MUSE_ERR_INVALID, "the loop kernel cannot run this share");
+    LoopShard sh;
+    sh.sim_lo = sim_lo; sh.sim_hi = sim_hi; sh.include_data = include_data ? 1 : 0;
+    sh.board = (unsigned long long*)board_dev;
+    sh.tag_base = tag_base;
+    rc = run_loop_launch(c, seed, theta0, o, &sh, shape, max_grid, niter_out, theta_out, hist_out, gsims_out, info_out);
+    if (rc == MUSE_LOOP_NOT_RESIDENT && !getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;
+    return rc;
 }
 
 int muse_get_zhat(muse_ctx* c, int64_t b, int64_t e, double* out, int mem) {

@@ -441,7 +441,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
                 // standard normals (or finds them: the host's mode), the later ones load them instead of running the generator
                 if (iter > 1 && a.ncache) a.ncache_mode = 2;
-                a.scores = L.scores_out + (int64_t)(iter - 1) * a.nproblems * a.ntheta;
+                a.scores = L.scores_out + (int64_t)(iter - 1) * L.scores_stride;
                 a.info = L.info_out + (int64_t)(iter - 1) * L.info_stride;
                 a.gran_tag = L.tag_base + (unsigned)iter;
                 if constexpr (Place::kXgLds) {  // the dummy slot and the pad element (N odd) hold 0 while problems run
@@ -510,7 +510,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 LoopLds<Place> m(smem);
                 BatchArgs& a = *m.a;
                 const int nt = a.ntheta;
-                const gu64* gran = (const gu64*)a.gran + (int64_t)2 * nt * a.nproblems;
+                const gu64* gran = (const gu64*)m.L->theta_gran;
                 const unsigned tag = a.gran_tag;
                 const int ngran = 2 * (nt + 1);
                 unsigned* out = reinterpret_cast<unsigned*>(m.rec);   // (the record area is the stepper's; a worker parks theta here)
@@ -570,7 +570,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             const int nt = a.ntheta, S = L.sp.nsims;
             const int64_t H = MUSE_RUN_HIST(nt);
             double* gs = m.stepbuf;
-            double* small = gs + (int64_t)a.nproblems * nt;
+            double* small = gs + (int64_t)L.nprob_total * nt;   // (the whole job's elements: a sharded loop's rank solves a share of them)
             StepWork& w = *reinterpret_cast<StepWork*>(small + 24);
             if (tid == 0) {
                 a.gran_tag = L.tag_base + (unsigned)iter;
@@ -579,9 +579,56 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             __syncthreads();
             if (tid < 64) {
                 const unsigned tag = a.gran_tag;
-                const rsrc_t grs = make_rsrc(a.gran, (int64_t)(2 * nt * a.nproblems + 2 * (kMaxTheta + 1)) * 8);
+                const rsrc_t grs = make_rsrc(L.score_gran, (int64_t)(2 * nt * L.nprob_total) * 8);
                 bool expired = false;
+                int lane = tid;
+                asm volatile("" : "+v"(lane));
+                // The node's board (muse_run_sharded's device loop): the scores of EVERY rank's elements, in pinned host memory.  A
+                // poll is a PCIe round trip (~2 us), so the in-order poll below -- eight dependent polls per lane at 512 simulations
+                // -- is replaced by batched sweeps: a lane's (up to) eight entries of a chunk of 512 are requested together and
+                // re-requested until all of them carry this iteration's tag; complete entries go to gs[] in LDS, from which the
+                // sums below take them in the same order as ever.  After the last score has landed: one sweep.
+                const bool board = __builtin_amdgcn_readfirstlane(L.board) != 0;
+                if (board) {
+                    const int nent = L.nprob_total * nt;
+                    for (int e0 = 0; e0 < nent; e0 += 512) {
+                        unsigned pending = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pending |= (e0 + 64 * j + lane < nent) ? (1u << j) : 0u;
+                        unsigned spins = 0;
+                        unsigned long long t_wait0 = 0;
+                        for (;;) {
+                            double lo[8], hi[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int e = (pending >> j) & 1u ? e0 + 64 * j + lane : 0x08000000;   // (done or beyond the end: out of range, no access)
+                                load_f64x2<kCoherent>(grs, 2 * e, lo[j], hi[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const unsigned long long glo = (unsigned long long)__double_as_longlong(lo[j]), ghi = (unsigned long long)__double_as_longlong(hi[j]);
+                                if (((pending >> j) & 1u) && (unsigned)(glo >> 32) == tag && (unsigned)(ghi >> 32) == tag) {
+                                    gs[e0 + 64 * j + lane] = __longlong_as_double((long long)((ghi << 32) | (glo & 0xffffffffull)));
+                                    pending &= ~(1u << j);
+                                }
+                            }
+                            if (__builtin_amdgcn_ballot_w64(pending != 0u) == 0ull || expired) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 0x3fu) == 0) {   // bounded by TIME (4 s)
+                                unsigned long long now;
+                                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                                if (t_wait0 == 0) t_wait0 = now;
+                                else if (now - t_wait0 > 400000000ull) {
+                                    __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    expired = true;
+                                }
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wavefront: its LDS writes are visible to its reads below)
+                }
                 auto score = [&](int row, int k) -> double {   // element `row`'s component k, once both of its granules are this iteration's
+                    if (board) return gs[row * nt + k];
                     unsigned spins = 0;
                     unsigned long long t_wait0 = 0;
                     for (;;) {
@@ -602,8 +649,6 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                         }
                     }
                 };
-                int lane = tid;
-                asm volatile("" : "+v"(lane));
                 constexpr int MAXB = Model::MAXB;
                 // step.hpp's step_moments_wave for every component at once, with the poll in its first pass: a lane asks for ALL
                 // components of a simulation together (their granules are neighbours), so that after the last score has
@@ -614,7 +659,10 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 for (int k = 0; k < MAXB; ++k) mk[k] = vk[k] = 0.0;
                 for (int sidx = lane; sidx < S; sidx += 64) {
                     double v[MAXB];
-                    {   // all components of the simulation: their loads in flight together, until every granule carries the tag
+                    if (board) {
+#pragma unroll
+                        for (int k = 0; k < MAXB; ++k) v[k] = k < nt ? gs[(int64_t)(1 + sidx) * nt + k] : 0.0;
+                    } else {   // all components of the simulation: their loads in flight together, until every granule carries the tag
                         unsigned spins = 0;
                         unsigned long long t_wait0 = 0;
                         for (;;) {
@@ -721,7 +769,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane < 2 * (nt + 1)) {   // theta_next [nt] and the {err, converged} word, two tagged granules each
-                    gu64* gran = (gu64*)a.gran + (int64_t)2 * nt * a.nproblems;
+                    gu64* gran = (gu64*)L.theta_gran;
                     const unsigned long long b = (unsigned long long)__double_as_longlong(w.theta_next[lane >> 1]);
                     const unsigned half = (lane & 1) ? (unsigned)(b >> 32) : (unsigned)(b & 0xffffffffull);
                     __hip_atomic_store(gran + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -735,6 +783,10 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int k = lane; k < (int)H; k += 64) m.rec[k] = w.rec[k];
                     if (lane < nt) L.theta_out[lane] = w.theta_next[lane];
+                    if (L.scores_all_out) {   // the sharded loop: every rank's stepper holds every score -- the iteration's block, data element first
+                        const int nent = L.nprob_total * nt;
+                        for (int k = lane; k < nent; k += 64) L.scores_all_out[(int64_t)(iter - 1) * nent + k] = gs[k];
+                    }
                 }
                 if (lane == 0) {
                     L.status[0] = e == STEP_OK ? iter : iter - 1;

@@ -74,11 +74,19 @@ public:
     static size_t bytes_for(int nranks, int narea, size_t block_doubles) {
         return kHeaderBytes + (size_t)narea * nranks * sizeof(Line) + (size_t)narea * nranks * block_doubles * sizeof(double);
     }
+    // An extra region behind the blocks, on a page boundary of its own (the engine registers it with the HIP runtime: the
+    // score board of the sharded device loop, which the GPUs of all ranks read and write -- muse_comm.cpp); zero-filled.
+    static size_t extra_offset(int nranks, int narea, size_t block_doubles) {
+        return (bytes_for(nranks, narea, block_doubles) + kHeaderBytes - 1) / kHeaderBytes * kHeaderBytes;
+    }
+    void* extra() const { return extra_bytes_ ? (void*)(base_ + extra_offset(nranks, narea, block_doubles)) : nullptr; }
+    size_t extra_bytes() const { return extra_bytes_; }
     // Rank 0 creates the segment (O_EXCL), the others attach (retrying until it exists and its magic is set); the
     // creator unlinks the name once everyone has attached, so that nothing outlives the processes.
-    bool open(const char* name, int nranks_, int rank_, int narea_, size_t block_doubles_, std::string& err) {
+    bool open(const char* name, int nranks_, int rank_, int narea_, size_t block_doubles_, std::string& err, size_t extra_bytes = 0) {
         nranks = nranks_; rank = rank_; narea = narea_; block_doubles = block_doubles_;
-        size_ = bytes_for(nranks, narea, block_doubles);
+        extra_bytes_ = (extra_bytes + kHeaderBytes - 1) / kHeaderBytes * kHeaderBytes;
+        size_ = extra_bytes_ ? extra_offset(nranks, narea, block_doubles) + extra_bytes_ : bytes_for(nranks, narea, block_doubles);
         const double t0 = now_s();
         int fd = -1;
         if (rank == 0) {
@@ -192,6 +200,7 @@ public:
 
 private:
     char* base_ = nullptr;
+    size_t extra_bytes_ = 0;
     Header* hdr_ = nullptr;
     Line* lines_ = nullptr;
     double* data_ = nullptr;

@@ -1,4 +1,4 @@
-"""One rank of tests/test_gpu_shm_transport.py: python shm_rank_worker.py <id hex> <nranks> <rank> <out.npz> <second id hex> <third id hex>.
+"""One rank of tests/test_gpu_shm_transport.py: python shm_rank_worker.py <id hex> <nranks> <rank> <out.npz> <second id hex> <third id hex> <fourth id hex>.
 All ranks share GPU 0 (the shared-memory transport has no device-side part)."""
 import os
 import sys
@@ -50,4 +50,23 @@ pm.comm_init(world, rank, bytes.fromhex(sys.argv[5]))
 n, theta, hist, gs, info = pm.run_muse_sharded(SEED, [1.0, 0.4], nsims=NSIMS, maxsteps=6, theta_rtol=0.0, atol=1e-3, alpha=0.7)
 res["run_n"], res["run_theta"], res["run_hist"], res["run_gs"], res["run_it"] = n, theta, hist[:, :-1], gs, info["iterations"]
 pm.close()
+# ... and at the headline's shape (N = 10^4, one component: the LDS-resident placement, the MAP kept in registers from one iteration
+# to the next), by both loops: the persistent launch per rank whose scores meet on the node's board (round 5: what the library
+# runs), and the host-driven loop (MUSE_DEBUG_SHARDED_HOST_LOOP).  A second run continues from the resident MAPs (z0_warm).
+xd1 = np.cos(0.11 * np.arange(10000)) * 1.7
+p1 = M.HipMuseProblem(xd1, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+p1.comm_init(world, rank, bytes.fromhex(sys.argv[7]))
+kw = dict(nsims=64, maxsteps=8, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+for tag, host in (("dev", False), ("host", True)):
+    if host:
+        os.environ["MUSE_DEBUG_SHARDED_HOST_LOOP"] = "1"
+    else:
+        os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
+    n, theta, hist, gs, info = p1.run_muse_sharded(SEED, [1.0], **kw)
+    res[f"s1_{tag}_n"], res[f"s1_{tag}_theta"], res[f"s1_{tag}_hist"], res[f"s1_{tag}_gs"] = n, theta, hist[:, :-1], gs
+    res[f"s1_{tag}_it"], res[f"s1_{tag}_fc"] = info["iterations"], info["f_calls"]
+    n, theta, hist, gs, info = p1.run_muse_sharded(SEED, theta, z0_warm=True, **dict(kw, maxsteps=3))
+    res[f"s1_{tag}_warm_theta"], res[f"s1_{tag}_warm_gs"] = theta, gs
+os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
+p1.close()
 np.savez(out, **res)

@@ -75,3 +75,26 @@ def test_bench_watchdog_reports_without_a_transport_that_hangs(gpu):
     assert d["transport_failed"] == "rccl"
     assert d["transport"] == "shm" and "watchdog" in d["transports"]["rccl"]["skipped"]
     assert d["transports"]["shm"]["ranks_seen"] == 1 and d["value"] == d["transports"]["shm"]["value"]
+
+
+def test_bench_gpus8_shards_the_workloads_baseline_puts_on_8_gpus(gpu):
+    """configs[3] (get_H! by finite differences, 512 sims x 4 theta) and configs[4] (the stencil model, N = 10^5, 8 theta, 1024
+    sims) as `--workload` choices of the driver's 8-GPU command: eight gloo ranks on one GPU, the flattened (sim, column) list in
+    eight blocks of 256 units / the 1024 sims in eight blocks of 128, the shared-memory communicator counting eight processes."""
+    e = {"MUSE_BENCH_BACKEND": "gloo", "MUSE_BENCH_TRANSPORT": "shm"}
+    d = run(["--gpus", "8", "--workload", "cfg4_fd_H", "--steps", "4", "--warmup", "1"], e)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and "8 ranks seen" in d["config"]["parallelism"]
+    assert "4097 MAP+score problems per step" in d["config"]["workload"] and "513 on this rank" in d["config"]["workload"]
+    assert d["value"] > 0 and abs(d["value"] - 4097 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
+    d = run(["--gpus", "8", "--workload", "cfg5_smooth_1e5", "--steps", "2", "--warmup", "1"], e)
+    assert d["n_gpus"] == 8 and d["config"]["sims_per_step_total"] == 1024 and "(128 on this rank)" in d["config"]["workload"]
+    assert d["transports"]["shm"]["ranks_seen"] == 8
+    assert d["value"] > 0 and abs(d["value"] - 1024 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
+
+
+def test_bench_single_gpu_runs_of_the_8_gpu_workloads(gpu):
+    d = run(["--workload", "cfg4_fd_H", "--steps", "8", "--warmup", "2"], {})
+    assert d["n_gpus"] == 1 and "4097 on this rank" in d["config"]["workload"] and 0 < d["roofline"]["frac"] <= 1
+    d = run(["--workload", "cfg5_smooth_1e5", "--steps", "3", "--warmup", "1"], {})
+    assert d["n_gpus"] == 1 and d["config"]["sims_per_step_total"] == 1024 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1

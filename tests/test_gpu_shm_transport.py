@@ -19,10 +19,12 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
     uid = M.HipMuseProblem.comm_unique_id("shm", 4096)   # naming the segment does not touch the GPU
     uid2 = M.HipMuseProblem.comm_unique_id("shm", 4096)  # (the communicator of the native sharded muse! loop)
     uid3 = M.HipMuseProblem.comm_unique_id("shm", 4096)  # (the 12-component problem's)
+    uid4 = M.HipMuseProblem.comm_unique_id("shm", 4096)  # (the headline-shaped sharded loop's)
     assert len(uid) == 128
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r], uid2.hex(), uid3.hex()],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    env = dict(os.environ, MUSE_DEBUG_RUN_TIMING="1")     # (the loop kernel's launches leave a line on stderr: which loop ran)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shm_rank_worker.py"), uid.hex(), str(world), str(r), outs[r], uid2.hex(), uid3.hex(),
+                               uid4.hex()], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert [p.returncode for p in procs] == [0] * world, "\n".join(logs)
     res = [np.load(o) for o in outs]
@@ -66,6 +68,25 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
         lo, hi = M.block_partition(0, NSIMS, world, r)
         mine = np.concatenate([i1["iterations"][:, :1], i1["iterations"][:, 1 + lo:1 + hi]], axis=1) if r == 0 else i1["iterations"][:, 1 + lo:1 + hi]
         assert np.array_equal(res[r]["run_it"], mine)
+    # The sharded loop at the headline's shape, as ONE persistent launch per rank -- the ranks' kernels resident side by side on this
+    # one GPU, their scores meeting on the node's board in pinned host memory -- and as the host-driven loop: both the unsharded
+    # loop's trajectory, bit for bit, on every rank; and the persistent launch is what ran (its timing line on stderr: the first
+    # sharded loop above -- N = 2000, two components, one element per worker -- and two of the three runs here).
+    xd1 = np.cos(0.11 * np.arange(10000)) * 1.7
+    one = M.HipMuseProblem(xd1, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    kw = dict(nsims=64, maxsteps=8, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+    n1, t1, h1, g1, i1 = one.run_muse(SEED, [1.0], device_loop=False, **kw)
+    n2, t2, h2, g2, i2 = one.run_muse(SEED, t1, device_loop=False, z0_warm=True, **dict(kw, maxsteps=3))
+    one.close()
+    for r in range(world):
+        lo, hi = M.block_partition(0, 64, world, r)
+        for tag in ("dev", "host"):
+            assert int(res[r][f"s1_{tag}_n"]) == n1 and np.array_equal(res[r][f"s1_{tag}_theta"], t1), (r, tag)
+            assert np.array_equal(res[r][f"s1_{tag}_hist"], h1[:, :-1]) and np.array_equal(res[r][f"s1_{tag}_gs"], g1), (r, tag)
+            mine = np.concatenate([i1[:, :1], i1[:, 1 + lo:1 + hi]], axis=1) if r == 0 else i1[:, 1 + lo:1 + hi]
+            assert np.array_equal(res[r][f"s1_{tag}_it"], mine["iterations"]) and np.array_equal(res[r][f"s1_{tag}_fc"], mine["f_calls"]), (r, tag)
+            assert np.array_equal(res[r][f"s1_{tag}_warm_theta"], t2) and np.array_equal(res[r][f"s1_{tag}_warm_gs"], g2), (r, tag)
+        assert logs[r].count("[muse_run_device]") == 3, logs[r]
     big = [np.sin(np.arange(40000.0) * (q + 1)) for q in range(world)]
     total = big[0].copy()
     for q in range(1, world):
