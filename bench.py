@@ -73,8 +73,9 @@ def compulsory_bytes(info, N, placement):
       resident  (z, s in registers, x, g in registers/LDS): zhat out; per kept iteration the pair (dx, dg) out;
                 the two-loop recursion reads 4 history vectors per pair used:        1 + 2 (K-1) + 4 H
       streaming, elementwise models: the sampler pass also makes the initial evaluation and the first trial and
-                writes x, s (2); every further trial reads z, s, x (3; z is skipped while it is the unwritten
-                zero: 2); a kept update reads z, s, x, g and writes z, dx, dg, g, s (9; the first one has neither z
+                writes x, s (2); every further trial reads z, s, x (3; from the unwritten zero start it reads s, x and
+                writes z + c s into the MAP slot -- 3 -- which is the solve's output when that trial is the accepted last step:
+                no last update pass then); a kept update reads z, s, x, g and writes z, dx, dg, g, s (9; the first one has neither z
                 nor g to read: 7); the last update reads z, s, x and writes z (4; 3 from the zero start);
                 8 words per history pair used (q is read and written once per pair in this placement)
       streaming, stencil model: sampler writes g (the true z, staged), x, z (3) and the A z pass reads g, x and
@@ -96,7 +97,10 @@ def compulsory_bytes(info, N, placement):
     else:
         first = (K == 1)  # the solve ended with its first line search: z stayed virtual until the last update
         trials = np.maximum(E - 2, 0)
-        words = np.where(first, 2 + 2 * trials + 3,
+        # (round 5: a further trial from the virtual zero also writes z + c s into the MAP slot -- 3 words instead of 2 -- and when
+        #  it is the accepted step that ends the solve, which it is for every converged one-iteration solve with E >= 3, the last
+        #  update pass is not run at all)
+        words = np.where(first, np.where(trials >= 1, 2 + 3 * trials, 2 + 3),
                          2 + 2 * np.minimum(trials, 1) + 3 * np.maximum(trials - 1, 0) + 7 + 9 * np.maximum(kept - 1, 0)
                          + 4 * (K > 0) + 8 * H)
     return int(8 * N * words.sum())

@@ -2,9 +2,10 @@
 
 The shared library is kept next to this file so that it travels with a repository snapshot to a
 GPU box (it is git-ignored, not gpurun-ignored).  hipcc cross-compiles without a GPU present.
-Three translation units, each compiled to an object of its own and rebuilt only when it (or a header it
-includes) changed: muse_kernels.hip holds ALL device code (minutes: every model x placement instantiation of
-the solver kernel), muse_engine.cpp the host side and the C ABI (seconds), muse_comm.cpp the exchange between ranks (RCCL, shared memory).
+Translation units, each compiled to an object of its own and rebuilt only when it (or a header it includes) changed:
+the device code -- muse_kernels.hip (dispatch, per-simulation operator kernels) and kernels_part.hip once per group of
+models (every model x placement instantiation of the solver and loop kernels; the groups compile side by side) --,
+muse_engine.cpp the host side and the C ABI (seconds), muse_comm.cpp the exchange between ranks (RCCL, shared memory).
 """
 import os
 import shutil
@@ -16,22 +17,28 @@ LIB_PATH = os.path.join(_HERE, "libmuse_hip.so")
 OBJ_DIR = os.path.join(_HERE, "build")
 _API = os.path.join(_HERE, "..", "include", "muse_hip.h")
 _KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "user_model.hpp", "solver.hpp",
-                                                    "step.hpp")]
+                                                    "step.hpp", "kernels.hpp")]
 # source -> (headers it depends on, extra flags)
 # -ffp-contract=off: the sampler's log/sincos sequences and the model gradients are defined in terms
 # of individually rounded IEEE operations (bit-equal to a host evaluation of the same sequence).
+_DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off"]
+KERNEL_PARTS = 8   # kernels.hpp: MUSE_PART_0 .. 7 (the groups of models whose solver / loop kernels one unit instantiates)
+# object name -> (source, headers it depends on, extra flags).  Device code: muse_kernels.hip (dispatch, per-simulation operator kernels)
+# and kernels_part.hip once per group of models (round 5: ONE unit with every instantiation took 6.5 minutes; the groups compile side
+# by side in ~1.5).
 UNITS = {
-    "muse_kernels.hip": (_KERNEL_HEADERS + [_API], ["--offload-arch=gfx950", "-O3", "-ffp-contract=off"]),
+    "muse_kernels": ("muse_kernels.hip", _KERNEL_HEADERS + [_API], _DEVICE_FLAGS),
+    **{f"kernels_part{n}": ("kernels_part.hip", _KERNEL_HEADERS + [_API], _DEVICE_FLAGS + [f"-DMUSE_PART={n}"]) for n in range(KERNEL_PARTS)},
     # host code: plain C++ against the HIP runtime API (no device pass)
     # (-ffp-contract=off here too: step.hpp's algebra must round on the host exactly as in the step kernel)
-    "muse_engine.cpp": ([os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), os.path.join(CSRC, "user_model.hpp"), _API],
+    "muse_engine": ("muse_engine.cpp", [os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), os.path.join(CSRC, "user_model.hpp"), _API],
                         ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
     # (step.hpp's algebra again: the sharded muse! loop takes the same step as muse_run)
-    "muse_comm.cpp": ([_API, os.path.join(CSRC, "shm_gather.hpp"), os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp")],
+    "muse_comm": ("muse_comm.cpp", [_API, os.path.join(CSRC, "shm_gather.hpp"), os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp")],
                       ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
 }
 COMMON_FLAGS = ["-std=c++17", "-fPIC", "-Wno-unused-value"]
-SOURCES = [os.path.join(CSRC, s) for s in UNITS]
+SOURCES = sorted({os.path.join(CSRC, u[0]) for u in UNITS.values()})
 HEADERS = _KERNEL_HEADERS + [_API, os.path.join(CSRC, "shm_gather.hpp")]
 
 
@@ -81,18 +88,26 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
     obj_dir = (os.path.join(os.path.dirname(os.path.abspath(lib_path)), "build_" + os.path.splitext(os.path.basename(lib_path))[0])
                if variant else OBJ_DIR)
     os.makedirs(obj_dir, exist_ok=True)
-    objs, procs = [], []
-    for src, (deps, flags) in UNITS.items():
+    objs, todo = [], []
+    for name, (src, deps, flags) in UNITS.items():
         path = os.path.join(CSRC, src)
-        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(obj_dir, name + ".o")
         objs.append(obj)
         if force or variant or _stale(obj, [path] + deps):
-            cmd = [hipcc] + COMMON_FLAGS + flags + list(defines) + ["-c", path, "-o", obj]
+            todo.append([hipcc] + COMMON_FLAGS + flags + list(defines) + ["-c", path, "-o", obj])
+    # the units compile side by side, MUSE_BUILD_JOBS (default: the CPUs this process may use) at a time
+    jobs = int(os.environ.get("MUSE_BUILD_JOBS", "0")) or len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+    running = []
+    while todo or running:
+        while todo and len(running) < max(1, jobs):
+            cmd = todo.pop(0)
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
-    for cmd, p in procs:  # the units compile side by side
+            running.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        cmd, p = running.pop(0)
         if p.wait() != 0:
+            for _, q in running:
+                q.kill()
             raise subprocess.CalledProcessError(p.returncode, cmd)
     tmp = lib_path + ".tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-ldl", "-lrt", "-lpthread"]

@@ -321,6 +321,13 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     if (place_is_cluster(pl) && c->comm_reserve_cus > 0 && c->num_cus > 2 * c->comm_reserve_cus)
         grid = (c->num_cus - c->comm_reserve_cus) * place_wgs_per_cu(pl);
     if (place_is_cluster(pl) && c->nlanes > 1) grid /= c->nlanes;   // ... and so do the launches of the other lanes
+    if (place_is_cluster(pl)) {
+        // ... and so do the launches of OTHER PROCESSES on this GPU, which the engine cannot see: MUSE_SHARED_GPU_RANKS=n says that n
+        // processes share the device (the development set-up of bench.py's gloo mode and of the multi-process tests: eight ranks
+        // on one GPU -- without it their cluster launches starve each other of compute units until the bounded waits expire)
+        static const int sharers = [] { const char* e = getenv("MUSE_SHARED_GPU_RANKS"); return e ? atoi(e) : 1; }();
+        if (sharers > 1) grid = grid / sharers > 0 ? grid / sharers : 1;
+    }
     a.nclusters = 0;
     if (place_is_cluster(pl)) {
         // every workgroup of a cluster must be resident at once (they wait for each other): the grid is sized from

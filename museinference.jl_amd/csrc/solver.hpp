@@ -552,18 +552,49 @@ struct Solver {
 
     //    INIT_S (resident policy, where s lives in registers): the pass also sets the steepest-descent
     //    direction s = -g and returns dphi = g . s, exactly as the separate pass would.
-    template <bool USE_S, bool STORE_G, bool INIT_S = false, bool ZZ = false>
+    //    SPEC (a line-search trial of the elementwise models, kSpec): the pass ALSO forms the sums that the solve's last pass
+    //    would form if this trial turns out to be the accepted step and the solve ends with it -- the step's norm and the score
+    //    terms at z + c s -- in the same per-thread order and through the same reduction trees (each value's tree is its own),
+    //    so that the last pass shrinks to the step and the store of the MAP, without score terms and without a reduction
+    //    (solve(), `spec_hit`): the same bits.  On a quadratic objective -- every built-in model -- HagerZhang's secant step is
+    //    accepted and ends the solve: of configs[1]'s three evaluation passes with a reduction each, two are left.  In the
+    //    streaming placements a trial from the virtual zero start also writes z + c s into the problem's MAP slot (spec_on: the
+    //    first L-BFGS iteration's trials), which then IS the last pass's output: a whole pass less over HBM.  A rejected trial's
+    //    values are dropped (a slot it wrote is overwritten by the pass that does end the solve; nothing reads it in between).
+    // STREAMING placements only (MUSE_SPEC_RESIDENT=1 builds it for the resident ones too).  Measured on one box, stamps and A/B
+    // (round 5): in the LDS-resident kernel the last pass is bound by the 80 KB store of the MAP, its arithmetic hides under the
+    // stores, and the trial -- whose arithmetic does not hide -- grows by 1.4 k cycles to save a 1.9 k reduction: 35.1 -> 34.5 k
+    // cycles per problem in the map kernel, and a LOSS in the loop kernel (24.5 -> 25.6 k: 57 more spilled registers).  In the
+    // streaming placements a whole pass over HBM disappears: noise_1e6 1.303 -> 1.048 ms per step.
+    // (one component: the per-block select chain of several components' score sums inside the trial spilled; MUSE_SPEC_MAXB)
+#ifndef MUSE_SPEC_MAXB
+#define MUSE_SPEC_MAXB 1
+#endif
+#ifndef MUSE_SPEC_RESIDENT
+#define MUSE_SPEC_RESIDENT 0
+#endif
+    static constexpr bool kSpec = !Model::kStencil && !kBig && KB <= MUSE_SPEC_MAXB && (!Place::kResident || MUSE_SPEC_RESIDENT);
+    double spec_c;          // the trial the speculative values belong to (NaN: none)
+    double spec_acc[KB], spec_mx;
+    bool spec_on;           // this line search's trials speculate (the first L-BFGS iteration: where one-iteration solves end)
+    template <bool USE_S, bool STORE_G, bool INIT_S = false, bool ZZ = false, bool SPEC = false>
     __device__ __forceinline__ void eval(double c, double& f, double& dphi, double& gmax) {
-        double sum[2] = {0.0, 0.0}, mx[1] = {0.0};
+        constexpr int KX = SPEC ? KB : 0;     // extra sums / maxima of a speculating trial
+        double sum[2 + KX] = {0.0, 0.0}, mx[1 + (SPEC ? 1 : 0)] = {0.0};
+#pragma unroll
+        for (int b = 0; b < KX; ++b) sum[2 + b] = 0.0;
+        if constexpr (SPEC) mx[1] = 0.0;
         if constexpr (!Model::kStencil) {
             pass_elems_r(reads(z, !ZZ), reads(s, USE_S), reads(x), [&](int jj, int i) {
-                double zi = ZZ ? 0.0 : z.get(jj, i);  // ZZ: z is still the (unwritten) zero start
+                const double zo = ZZ ? 0.0 : z.get(jj, i);  // ZZ: z is still the (unwritten) zero start
+                double zi = zo;
                 double si = 0.0;
                 if constexpr (USE_S) {
                     si = s.get(jj, i);
                     zi = fma(c, si, zi);
                 }
-                const double gi = Model::grad(ivk(jj, i), x.get(jj, i), zi, sum[0], i);
+                const double xi = x.get(jj, i);
+                const double gi = Model::grad(ivk(jj, i), xi, zi, sum[0], i);
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
                 if constexpr (INIT_S) {
@@ -572,7 +603,19 @@ struct Solver {
                     sum[1] = fma(gi, sd, sum[1]);
                 }
                 mx[0] = absmax(mx[0], gi);
-            }, when(STORE_G, g), when(INIT_S, s));
+                if constexpr (SPEC) {   // the sums of solve()'s last pass, should this be the accepted step (same statements, same order)
+                    mx[1] = absmax(mx[1], zi - zo);
+                    if constexpr (!Place::kResident) z.set(jj, i, zi);   // (streaming, from the virtual zero: the MAP slot itself)
+                    const double t = Model::score_term(xi, zi, i);
+                    if constexpr (KB == 1) {
+                        sum[2] += t;
+                    } else {
+                        const int k = blk(jj, i);
+#pragma unroll
+                        for (int b = 0; b < KB; ++b) sum[2 + b] += (k == b) ? t : 0.0;
+                    }
+                }
+            }, when(STORE_G, g), when(INIT_S, s), when(SPEC && !Place::kResident && spec_on, z));
         } else {
             stencil_pairs<USE_S>(c, sum[0], [](int, int) {}, [&](int u, int i0, double g0, double g1, double s0, double s1) {
                 if constexpr (STORE_G) {
@@ -588,11 +631,18 @@ struct Solver {
                 mx[0] = absmax(absmax(mx[0], g0), g1);
             }, when(STORE_G, g), when(INIT_S, s));
         }
-        reduce<2, 1>(sum, mx);
+        reduce<2 + KX, 1 + (SPEC ? 1 : 0)>(sum, mx);
         f = 0.5 * (sum[0] + a.cur.f_const);
         dphi = sum[1];
         gmax = nan_if(sum[0] != sum[0] || sum[1] != sum[1], mx[0]);
         f_calls += 1;
+        if constexpr (SPEC) {
+#pragma unroll
+            for (int b = 0; b < KB; ++b) spec_acc[b] = sum[2 + b];
+            spec_mx = mx[1];
+            // (streaming without the stores: the MAP slot was not written; MUSE_DEBUG bit 5: never a hit -- A/B runs and tests)
+            spec_c = ((Place::kResident && !(a.debug & 32)) || spec_on) ? c : __builtin_nan("");
+        }
     }
 
     // The initial evaluation of the resident elementwise layout, fused with the FIRST line-search trial: the
@@ -649,8 +699,12 @@ struct Solver {
         }
         double gm;
         if constexpr (!Place::kResident && !Model::kStencil) {
-            if (z_zero) eval<true, false, false, true>(c, phi, dphi, gm);
+            // (ONE instantiation of the trial per case: a speculating and a plain one side by side at the line search's evaluation
+            //  site cost the LDS-resident kernel 226 spilled registers; spec_on only gates the speculative STORES)
+            if (z_zero) eval<true, false, false, true, kSpec>(c, phi, dphi, gm);
             else eval<true, false>(c, phi, dphi, gm);
+        } else if constexpr (kSpec) {
+            eval<true, false, false, false, true>(c, phi, dphi, gm);
         } else {
             eval<true, false>(c, phi, dphi, gm);
         }
@@ -1679,6 +1733,8 @@ struct Solver {
             last_c = NAN;  // no trial evaluated yet in this line search
             last_phi = f;
             last_gmax = gmax;
+            spec_c = NAN;
+            spec_on = iterations == 1 && !(a.debug & 32);   // (MUSE_DEBUG bit 5: never speculate -- A/B and tests)
             double alpha;
             iter_stamp = iterations == 1 ? 0 : 99;
             stamp_p = p;
@@ -1708,6 +1764,23 @@ struct Solver {
                 VH zout;
                 const bool store = Place::kResident && d.zslot >= 0;  // streaming: z already lives in its zhat slot
                 if (store) zout.bind(a.zhat + d.zslot * ld, ld);
+                // the accepted step is a trial that speculated (eval, SPEC): its pass did all of this already
+                bool spec_hit = false;
+                if constexpr (kSpec) spec_hit = alpha == spec_c;   // (NaN: no such trial)
+                if (spec_hit) {
+                    if constexpr (kSpec) {
+#pragma unroll
+                        for (int b = 0; b < KB; ++b) acc[b] = spec_acc[b];
+                        mx[0] = spec_mx;
+                        if constexpr (Place::kResident) {   // what is left of the pass: the step itself and the MAP out -- no score terms, no reduction
+                            for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
+                                const double zn = fma(alpha, s.get(jj, i), z.get(jj, i));
+                                z.set(jj, i, zn);
+                                if (store) zout.set(jj, i, zn);
+                            });
+                        }
+                    }
+                } else {
                 for_elems_zz_r(reads(s), reads(x), [&](auto zz, int jj, int i) {
                     const double zo = decltype(zz)::value ? 0.0 : z.get(jj, i), si = s.get(jj, i);
                     const double zn = fma(alpha, si, zo);
@@ -1733,6 +1806,7 @@ struct Solver {
                     double none[1] = {0.0};
                     reduce<0, 1>(none, mx);
                     reduce<KB, 0>(acc, none);
+                }
                 }
                 bool any_nan = false;  // a NaN step shows up in the score sums (NaN channel of the maximum)
 #pragma unroll

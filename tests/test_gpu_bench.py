@@ -81,7 +81,9 @@ def test_bench_gpus8_shards_the_workloads_baseline_puts_on_8_gpus(gpu):
     """configs[3] (get_H! by finite differences, 512 sims x 4 theta) and configs[4] (the stencil model, N = 10^5, 8 theta, 1024
     sims) as `--workload` choices of the driver's 8-GPU command: eight gloo ranks on one GPU, the flattened (sim, column) list in
     eight blocks of 256 units / the 1024 sims in eight blocks of 128, the shared-memory communicator counting eight processes."""
-    e = {"MUSE_BENCH_BACKEND": "gloo", "MUSE_BENCH_TRANSPORT": "shm"}
+    # (MUSE_SHARED_GPU_RANKS: the stencil model's clusters need all of their workgroups resident at once, and eight processes'
+    #  launches on ONE GPU would starve each other -- every process sizes its cluster grid for a share of the compute units)
+    e = {"MUSE_BENCH_BACKEND": "gloo", "MUSE_BENCH_TRANSPORT": "shm", "MUSE_SHARED_GPU_RANKS": "16"}
     d = run(["--gpus", "8", "--workload", "cfg4_fd_H", "--steps", "4", "--warmup", "1"], e)
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and "8 ranks seen" in d["config"]["parallelism"]
     assert "4097 MAP+score problems per step" in d["config"]["workload"] and "513 on this rank" in d["config"]["workload"]

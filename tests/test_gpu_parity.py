@@ -137,6 +137,36 @@ def test_resident_equals_streaming_bitwise(gpu, M, model, N, nth, theta):
     assert np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("model,N,nth,theta,placement,split", [
+    ("funnel", 10000, 1, [1.0], -1, 0), ("funnel", 9999, 1, [-0.4], -1, 0), ("noise", 10000, 1, [0.5], -1, 0), ("funnel", 3000, 1, [0.3], -1, 0),
+    ("funnel", 500, 1, [0.2], -1, 0), ("funnel", 10000, 1, [1.0], 0, 0), ("noise", 70001, 1, [0.5], -1, 0), ("funnel", 10000, 1, [0.7], -1, 4),
+    ("funnel", 30000, 1, [0.1], -1, 0)])
+@pytest.mark.parametrize("z0_mode", [0, 1])
+def test_speculating_trials_change_no_bit(gpu, M, model, N, nth, theta, placement, split, z0_mode):
+    """Round 5: a line-search trial of the one-component elementwise models also forms the sums of the solve's last pass (and, in
+    the streaming placements from the virtual zero start, writes z + c s into the MAP slot), so that a solve that ends with the
+    accepted trial skips that pass (solver.hpp, eval SPEC).  With the speculation switched off (muse_debug_flags bit 5) every
+    placement -- LDS-resident, registers, streaming, streaming clusters, a register-resident element split -- returns the same
+    scores, solver records and MAPs, bit for bit."""
+    outs = []
+    for flags in (0, 32):
+        prob = M.HipMuseProblem(None, model=model, ntheta=nth, N=N)
+        if placement >= 0:
+            prob.set_placement(placement)
+        if split:
+            prob.set_element_split(split)
+        assert prob._lib.muse_debug_flags(prob._ctx, flags) == 0
+        g, info = prob.map_and_score_batch(5, 0, 40, theta, atol=1e-2, z0_mode=z0_mode)
+        z = prob.get_zhat(0, 40)
+        g2, info2 = prob.map_and_score_batch(5, 0, 40, [t + 0.05 for t in theta], atol=1e-6, z0_mode=M.Z0_WARM)   # warm starts: z is not the virtual zero
+        outs.append((g, info, z, g2, info2, prob.get_zhat(0, 40)))
+        prob.close()
+    a, b = outs
+    assert a[1]["iterations"].max() >= 1
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("model,N,nth,theta", [CASES[0], CASES[6], CASES[7], CASES[11], ("funnel", 70001, 2, [0.3, -0.2]),
                                                ("funnel", 9999, 3, [0.4, 1.1, -0.3]), ("noise", 7777, 1, [0.6])])
 @pytest.mark.parametrize("fid_mode", [0, 1])
