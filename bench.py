@@ -417,13 +417,14 @@ def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, 
             out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])),
                          "by_regime": iteration_regimes(hist, info)}
         prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
-        for name, env in (("sharded_loop_shm_1rank", None), ("sharded_host_loop_shm_1rank", "1")):
-            # the sharded loop as the library runs it -- ONE persistent launch per rank, the ranks' scores meeting on the node's board
-            # in pinned host memory (round 5) -- and, for comparison, the host-driven loop of round 4 (gathered map, step on the host)
-            if env is None:
-                os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
-            else:
-                os.environ["MUSE_DEBUG_SHARDED_HOST_LOOP"] = env
+        for name, env in (("sharded_loop_shm_1rank", {}), ("sharded_loop_host_board_shm_1rank", {"MUSE_DEBUG_HOST_BOARD": "1"}),
+                          ("sharded_host_loop_shm_1rank", {"MUSE_DEBUG_SHARDED_HOST_LOOP": "1"})):
+            # the sharded loop as the library runs it -- ONE persistent launch per rank, the ranks' scores meeting on a board per GPU in
+            # device memory that every rank maps (hipIpc; round 5) --, the same with the ONE board in pinned host memory (what runs where
+            # the ranks cannot map each other's device memory), and the host-driven loop of round 4 (gathered map, step on the host)
+            for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
             best = float("inf")
             for _ in range(3):
                 t0 = time.perf_counter()
@@ -431,7 +432,8 @@ def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, 
                 best = min(best, (time.perf_counter() - t0) / max(1, n))
             out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])),
                          "by_regime": iteration_regimes(hist, info)}
-        os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
+        for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
+            os.environ.pop(k, None)
         prob.close()
         if whole_job_steady_us:
             out["projected_speedup_at_8_gpus"] = whole_job_steady_us / out["sharded_loop_shm_1rank"]["us_per_outer_iteration_steady"]
@@ -445,9 +447,10 @@ def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, 
             out["projected_by_regime"] = proj
         out["note"] = ("a muse! iteration is ONE dependent map: per rank nsims/8 + 1 one-workgroup problems (one round on 256 CUs: one "
                        "problem's latency), then the exchange and the step before the next map can start.  sharded_loop_shm_1rank: "
-                       "muse_run_sharded as the library runs it -- a persistent loop kernel per rank, scores exchanged through the "
-                       "node's board in pinned host memory, no host between two maps -- measured with ONE rank in the communicator (an "
-                       "upper bound for 8: the board costs a PCIe round trip whoever writes it).  projected_speedup_at_8_gpus = the whole "
+                       "muse_run_sharded as the library runs it -- a persistent loop kernel per rank, scores stored into every rank's board "
+                       "in device memory (hipIpc mappings), no host between two maps -- measured with ONE rank in the communicator (an "
+                       "upper bound for 8: stores into other GPUs' boards cross xGMI; ..._host_board_...: the one board in pinned host memory, "
+                       "a PCIe round trip per iteration whoever writes it).  projected_speedup_at_8_gpus = the whole "
                        "job's steady iteration on one GPU / this rank's steady iteration, both the median from iteration 6 on of a "
                        "30-iteration run -- which mixes two regimes (iteration_regimes): projected_by_regime compares like with like; "
                        "line_search is what every iteration of a run with the reference's default theta_rtol is")

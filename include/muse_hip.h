@@ -250,9 +250,9 @@ int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_
  * step, the history record and the convergence test for itself from the same bits; the next theta never leaves the
  * chip.  (exp(theta/2), exp(-theta) are a fixed sequence of IEEE operations on host and device, and the score moments one
  * fixed 64-leaf summation tree, for this reason.)  The loop kernel runs where it is the faster loop: the register/LDS-resident
- * placements (N <= 10 000, no element split) with one theta component or at most one element per workgroup; everything else
- * (more elements AND more components, the streaming placements, score blocks beyond the step's LDS arrays: nsims * ntheta above
- * ~19 000) runs muse_run's loop instead -- the same bits.
+ * placements (N <= 10 000, no element split) with up to four theta components, or at most one element per workgroup; everything
+ * else (more elements AND five to eight components, the streaming placements, score blocks beyond the step's LDS arrays: nsims *
+ * ntheta above ~19 000) runs muse_run's loop instead -- the same bits.
  * REQUIREMENT: every workgroup of the loop kernel must be resident at once (they meet once per iteration); the grid is sized from an
  * occupancy query that assumes the GPU is this process's.  On a GPU that something else is using they may not be: every wait inside
  * the kernel is bounded (4 s), the call then returns MUSE_ERR_HIP ("not all resident") -- once: the context remembers it and its later
@@ -366,9 +366,12 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int result_area, double* g_all_out, 
  * Round 5: with the shared-memory transport and a resident placement the loop has NO host in it -- every rank runs its share as
  * ONE persistent launch (muse_run_device's loop kernel); the workers write their scores as tagged granules to a board in the
  * communicator's shared segment, which every rank's GPU maps (pinned host memory; system-scope 8-byte stores and loads), every
- * rank's stepper polls ALL the scores -- batched sweeps, one PCIe round trip each -- and takes the same step.  Whether that
- * loop runs is decided by all ranks together (the minimum of what each can do); a rank whose workgroups cannot all be resident
- * makes every rank fall back to the host-driven loop, the same bits. */
+ * rank's stepper polls ALL the scores -- batched sweeps, one PCIe round trip each -- and takes the same step.  Where the runtime
+ * lets the ranks map each other's device memory (hipIpc; decided by all ranks together when the communicator is set up) there is a
+ * board per GPU in DEVICE memory instead: a worker stores its score into every rank's board (posted writes, xGMI between GPUs) and a
+ * stepper polls its own GPU's memory -- no PCIe round trip in an iteration.  Whether the persistent loop runs is decided by all
+ * ranks together (the minimum of what each can do); a rank whose workgroups cannot all be resident makes every rank fall back to the
+ * host-driven loop, the same bits. */
 int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
                      double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 /* The sharded form of muse_map_and_score_multi_async: this rank's block of `nmaps` maps in one launch, one exchange for

@@ -152,6 +152,11 @@ struct BatchArgs {
     // a launch of another context of the same library still in flight would have read the new owner's pointers).
     const double* consts[4];
     long const_len[4];
+    // kernarg segment only: gran_sys == 2 -- the sharded loop with a board per GPU in DEVICE memory (muse_comm.cpp: every rank's board
+    // is mapped into every rank by hipIpc): an element's score granules are stored into EVERY rank's board (posted writes over xGMI),
+    // each at this rank's row offset; gran itself is not used then
+    unsigned long long* gran_peers[8];
+    int ngran_peers, pad2_;
 };
 constexpr size_t kArgsConstsOffset = offsetof(BatchArgs, consts);
 static_assert(offsetof(BatchArgs, const_len) == kArgsConstsOffset + 4 * sizeof(const double*), "muse_const reads {pointers[4], lengths[4]}");

@@ -325,29 +325,27 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 const bool up = !alternate || (iter & 1);
                 const int step = up ? nworkers : -nworkers;
                 int p = up ? (int)blockIdx.x : (int)blockIdx.x + (cnt - 1) * nworkers;
-                {   // the first problem (peeled: the prefetched values are live up to its begin() and nowhere beyond)
+                // (ONE copy of the solve in the worker's loop -- round 5; the first problem used to be peeled off, a second copy of the
+                //  whole solver in the kernel)
+                for (int k = 0; k < cnt; ++k) {
                     Solver<Model, Place> sv(a, tid, m.red, m.shs);
                     sv.pk[0] = pk0;
                     sv.pk[1] = pk1;
-                    const int nx = cnt > 1 ? p + step : -1;
-                    if (__builtin_expect(alternate && iter > 1 && sv.can_keep(p), 1)) {
-                        if constexpr (Solver<Model, Place>::kKeepZ) sv.z = zkeep;
-                        sv.run_kept(p, wg_scratch, m.lds_x, m.lds_g, pf, nx);
-                    } else {
-                        sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, nx);
+                    const int nx = k + 1 < cnt ? p + step : -1;
+                    bool kept = false;
+                    if constexpr (Solver<Model, Place>::kKeepZ) {
+                        if (__builtin_expect(k == 0 && alternate && iter > 1 && sv.can_keep(p), 1)) {
+                            sv.z = zkeep;
+                            sv.begin_kept(p, wg_scratch, m.lds_x, m.lds_g, pf);
+                            kept = true;
+                        }
                     }
-                    if constexpr (Solver<Model, Place>::kKeepZ) zkeep = sv.z;
-                    wg_barrier<!Model::kStencil>();   // (raw: the next problem's n1 is on its way into the g area)
-                }
-                loop_stamp(1);
-                for (int k = 1; k < cnt; ++k) {
-                    p += step;
-                    Solver<Model, Place> sv(a, tid, m.red, m.shs);
-                    sv.pk[0] = pk0;
-                    sv.pk[1] = pk1;
-                    sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, k + 1 < cnt ? p + step : -1);
+                    if (!kept) sv.template begin<false>(p, wg_scratch, m.lds_x, m.lds_g, pf);
+                    sv.after_begin(p, m.lds_x, m.lds_g, pf, nx);
                     if constexpr (Solver<Model, Place>::kKeepZ) zkeep = sv.z;   // (the last one's stays: the next iteration's first)
-                    wg_barrier<!Model::kStencil>();
+                    wg_barrier<!Model::kStencil>();   // (raw: the next problem's n1 is on its way into the g area)
+                    if (k == 0) loop_stamp(1);
+                    if (k + 1 < cnt) p += step;
                 }
                 loop_stamp(2);
                 if constexpr (Place::kXgLds) {   // the next iteration's first problem: the one just solved (p), or the first again

@@ -65,6 +65,13 @@ struct CommState {
     void* board_host = nullptr;
     size_t board_granules = 0;
     unsigned int board_tag = 0;      // the last tag used (the same on every rank: every rank makes the same calls)
+    // ... and, where the runtime allows it, a board per GPU in DEVICE memory instead: every rank allocates one and maps every peer's
+    // (hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles exchanged through the segment); a worker's score is stored into every
+    // rank's board -- posted writes, over xGMI between GPUs -- and a stepper polls its OWN GPU's memory: no PCIe round trip in the
+    // iteration.  A collective decision at init (every rank must have opened every handle); the host board otherwise.
+    unsigned long long* ipc_own = nullptr;
+    void* ipc_peers[8] = {nullptr};   // [rank]: the peer's board as mapped here (own: ipc_own)
+    bool ipc_ok = false;
     bool dev_loop_off = false;       // the device loop failed once on some rank (a shared GPU): host loop from then on, on every rank
     uint64_t seq[kAreas + 1] = {0};   // sequence number of the last exchange per area (the same on every rank)
     size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced PER MAP for the gather in flight
@@ -133,8 +140,8 @@ int muse_set_error(int code, const char* msg);
 int muse_wait_event(void* event);
 int muse_internal_loop_usable(muse_ctx* ctx, int nsims, int64_t nlocal);
 int muse_internal_run_loop_shard(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* o, int64_t sim_lo, int64_t sim_hi,
-                                 int include_data, void* board_dev, unsigned int tag_base, int32_t* niter_out, double* theta_out,
-                                 double* hist_out, double* gsims_out, muse_info* info_out);
+                                 int include_data, void* board_dev, void* const* peer_boards, int npeers, unsigned int tag_base,
+                                 int32_t* niter_out, double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
 }
 
 static CommState* state_of(muse_ctx* ctx, void** stream_out = nullptr) {
@@ -245,6 +252,57 @@ static int shm_allgather(CommState* st, const double* send, size_t count, double
     return MUSE_OK;
 }
 
+// A score board per GPU in device memory, every rank's mapped into every rank (CommState::ipc_*).  Collective over the segment.
+static void setup_ipc_boards(CommState* st) {
+    st->ipc_ok = false;
+    if (st->nranks > 8) return;
+    bool ok = !getenv("MUSE_DEBUG_NO_IPC_BOARD") && !getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(st->device) == hipSuccess;
+    hipIpcMemHandle_t mine;
+    memset(&mine, 0, sizeof mine);
+    if (ok) {
+        void* p = nullptr;
+        // uncached where the runtime offers it: the board is written by other GPUs and polled by this one
+        if (hipExtMallocWithFlags(&p, kBoardBytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            if (hipMalloc(&p, kBoardBytes) != hipSuccess) p = nullptr;
+        }
+        ok = p != nullptr && hipMemset(p, 0, kBoardBytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipIpcGetMemHandle(&mine, p) == hipSuccess;
+        st->ipc_own = (unsigned long long*)p;
+    }
+    (void)hipGetLastError();
+    // every rank's {ok, handle}: 1 + 8 doubles per rank (the 64 handle bytes travel as 8 doubles' bit patterns)
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle exchanged as 8 doubles");
+    double send[9], recv[9 * 8];
+    send[0] = ok ? 1.0 : 0.0;
+    memcpy(send + 1, &mine, 64);
+    if (shm_allgather(st, send, 9, recv, false) != MUSE_OK) ok = false;
+    bool all = ok;
+    for (int q = 0; q < st->nranks && all; ++q) all = recv[9 * q] == 1.0;
+    if (all) {
+        for (int q = 0; q < st->nranks; ++q) {
+            if (q == st->rank) { st->ipc_peers[q] = st->ipc_own; continue; }
+            hipIpcMemHandle_t h;
+            memcpy(&h, recv + 9 * q + 1, 64);
+            void* pp = nullptr;
+            if (hipIpcOpenMemHandle(&pp, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !pp) { all = false; (void)hipGetLastError(); break; }
+            st->ipc_peers[q] = pp;
+        }
+    }
+    double flag[1] = {all ? 1.0 : 0.0};   // did EVERY rank open EVERY handle
+    if (shm_allgather(st, flag, 1, flag, true) != MUSE_OK) flag[0] = 0.0;
+    st->ipc_ok = flag[0] == (double)st->nranks;
+    if (!st->ipc_ok) {
+        for (int q = 0; q < st->nranks; ++q)
+            if (q != st->rank && st->ipc_peers[q]) { (void)hipIpcCloseMemHandle(st->ipc_peers[q]); }
+        for (int q = 0; q < 8; ++q) st->ipc_peers[q] = nullptr;
+        if (st->ipc_own) (void)hipFree(st->ipc_own);
+        st->ipc_own = nullptr;
+        (void)hipGetLastError();
+    }
+}
+
 extern "C" {
 
 int muse_comm_unique_id(void* id_out) {
@@ -334,6 +392,7 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
             }
             (void)hipGetLastError();
             *slot = st;
+            setup_ipc_boards(st);   // (collective; failure on any rank = no device boards on every rank)
             return MUSE_OK;
         }
     }
@@ -377,10 +436,22 @@ int muse_comm_destroy(muse_ctx* ctx) {
     if (rc) return rc;
     if (CommState* st = (CommState*)*slot) {
         if (st->shm) {
-            if (st->board_host) {
+            if (st->board_host || st->ipc_own) {
                 hipSetDevice(device);
                 (void)hipDeviceSynchronize();   // (nothing of this process may still be polling the board)
-                (void)hipHostUnregister(st->board_host);
+            }
+            if (st->board_host) (void)hipHostUnregister(st->board_host);
+            if (st->ipc_ok) {
+                // (every rank closes its views before anyone frees: one more exchange; a peer that is gone already just times out)
+                for (int q = 0; q < st->nranks; ++q)
+                    if (q != st->rank && st->ipc_peers[q]) (void)hipIpcCloseMemHandle(st->ipc_peers[q]);
+                double f[1] = {1.0};
+                const double keep = st->shm->timeout_s;
+                st->shm->timeout_s = keep < 5.0 ? keep : 5.0;
+                (void)shm_allgather(st, f, 1, f, true);
+                st->shm->timeout_s = keep;
+                (void)hipFree(st->ipc_own);
+                (void)hipGetLastError();
             }
             delete st->shm;
             delete st;
@@ -635,7 +706,8 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
     // memory that every GPU maps), every rank's stepper takes the same step from the same bits -- no host between two maps.  Every
     // rank must take the same loop: the decision is the minimum over the ranks of what each can do.
     if (st->shm) {
-        const bool want = st->board_dev && !st->dev_loop_off && !getenv("MUSE_DEBUG_SHARDED_HOST_LOOP") &&
+        const bool ipc = st->ipc_ok && !getenv("MUSE_DEBUG_HOST_BOARD");   // (the same answer on every rank)
+        const bool want = (ipc || st->board_dev) && !st->dev_loop_off && !getenv("MUSE_DEBUG_SHARDED_HOST_LOOP") &&
                           (uint64_t)(S + 1) * (uint64_t)nt * 2 <= st->board_granules && st->board_tag < 0x70000000u &&
                           muse_internal_loop_usable(ctx, S, nlocal) != 0;
         double flag[1] = {want ? 1.0 : 0.0};
@@ -644,8 +716,9 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
         if (flag[0] == (double)world) {
             const unsigned int tag_base = st->board_tag;
             st->board_tag += (unsigned)o->maxsteps + 1;
-            rc = muse_internal_run_loop_shard(ctx, seed, theta0, o, lo, hi, rank == 0 ? 1 : 0, st->board_dev, tag_base, niter_out, theta_out,
-                                              hist_out, gsims_out, info_out);
+            rc = muse_internal_run_loop_shard(ctx, seed, theta0, o, lo, hi, rank == 0 ? 1 : 0, ipc ? (void*)st->ipc_own : (void*)st->board_dev,
+                                              ipc ? st->ipc_peers : nullptr, ipc ? world : 0, tag_base, niter_out, theta_out, hist_out,
+                                              gsims_out, info_out);
             // a rank whose workgroups were not all resident (rc 1001) stalls every rank's stepper: all of them time out -- but
             // make the outcome a collective decision anyway
             double bad[1] = {rc == 1001 ? 1.0 : 0.0};

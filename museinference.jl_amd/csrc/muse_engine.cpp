@@ -1411,6 +1411,10 @@ struct LoopShard {
     int include_data;
     unsigned long long* board;   // device pointer of the board: [(nsims + 1) * ntheta][2] granules, the data element's first
     unsigned int tag_base;       // the same on every rank (the board's tags grow from run to run)
+    // npeers > 0: a board per GPU in DEVICE memory, each mapped into every rank (hipIpc) -- `board` is this rank's own (what its
+    // stepper polls), peers[q] rank q's (this rank's own among them): the workers store their scores into all of them
+    unsigned long long* peers[8];
+    int npeers;
 };
 // Can this context run (its share of) the loop as ONE persistent launch?  On success *shape_out / *max_grid_out describe it.
 static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_out, int* max_grid_out) {
@@ -1444,12 +1448,16 @@ static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_o
         r.grid_lds = shape.lds;
         r.grid_max = mg;
     }
-    // ... and with one theta component, or one problem per worker: the loop kernels of the multi-theta instantiations carry their
-    // per-block state across the solver (35-114 spilled registers) and lose to the host loop when a worker has several problems --
-    // measured per iteration at 512 sims, host / device: N = 10^4: 53 / 50 us (1 component), 75 / 79 (2), 89 / 97 (4), 100 / 113 (8);
-    // N = 512: 25 / 20 (1), 38 / 44 (8) -- and win when it has one (100 sims: N = 3000 x 4 components 30.5 / 25.8, N = 512 x 8: 19.6 / 16.5)
+    // ... and with up to four theta components, or one problem per worker (round 5: the roles as two loops and one copy of the solve
+    // in the worker's loop took the loop kernels of one to four components out of scratch, or nearly; those of five to eight still
+    // carry 36-44 spilled registers and lose to the host loop when a worker has several problems).  Measured per iteration of a
+    // 30-iteration call at 512 sims, host loop / loop kernel (tools/loop_vs_host.py, one box):
+    //   N = 10^4: 52.2 / 47.9 us (1 component), 58.0 / 56.9 (2), 71.2 / 69.6 (4), 76.3 / 84.2 (8);  N = 4096: 45.9 / 39.8, 57.4 / 50.8,
+    //   60.9 / 53.9, 75.1 / 68.4;  N = 512: 23.6 / 16.2, 26.5 / 20.3, 27.7 / 23.4, 31.6 / 35.3
+    // and at 100 sims (one problem per worker) the loop kernel leads for every count (N = 10^4 x 8: 34.5 / 32.0).
+    // (round 4, before: 53 / 50, 75 / 79, 89 / 97, 100 / 113 at N = 10^4)
     static const bool any_nt = getenv("MUSE_DEBUG_LOOP_ANY_NTHETA") != nullptr;   // tuning aid / tests: the loop kernel whatever ntheta
-    if (r.grid_max < 2 || (nt > 1 && !any_nt && nlocal > r.grid_max - 1)) return false;
+    if (r.grid_max < 2 || (nt > 4 && !any_nt && nlocal > r.grid_max - 1)) return false;
     if (shape_out) *shape_out = shape;
     if (max_grid_out) *max_grid_out = r.grid_max;
     return true;
@@ -1510,7 +1518,11 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     // where the workers' scores go as granules: this GPU's own buffer, or this rank's rows of the node's board
     const int64_t row0 = sh ? (include_data ? 0 : 1 + sim_lo) : 0;
     a.gran = sh ? sh->board + (size_t)row0 * nt * 2 : r.gran;
-    a.gran_sys = sh ? 1 : 0;
+    a.gran_sys = sh ? (sh->npeers > 0 ? 2 : 1) : 0;
+    if (sh && sh->npeers > 0) {
+        a.ngran_peers = sh->npeers;
+        for (int q = 0; q < sh->npeers; ++q) a.gran_peers[q] = sh->peers[q] + (size_t)row0 * nt * 2;
+    }
     // the common fields, as launch_batch fills them
     a.N = c->N;
     a.ld = c->ld;
@@ -1635,8 +1647,8 @@ int muse_internal_loop_usable(muse_ctx* c, int nsims, int64_t nlocal) {
 }
 // rc: MUSE_OK; 1001: the kernel's bounded waits expired (workgroups not all resident) -- the caller decides with its peers; < 0: error
 int muse_internal_run_loop_shard(muse_ctx* c, uint64_t seed, const double* theta0, const muse_run_options* o, int64_t sim_lo, int64_t sim_hi,
-                                 int include_data, void* board_dev, unsigned int tag_base, int32_t* niter_out, double* theta_out,
-                                 double* hist_out, double* gsims_out, muse_info* info_out) {
+                                 int include_data, void* board_dev, void* const* peer_boards, int npeers, unsigned int tag_base,
+                                 int32_t* niter_out, double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out) {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!theta0 || !o || !niter_out || !theta_out || !hist_out || !gsims_out || !board_dev) return fail(MUSE_ERR_INVALID, "NULL argument");
@@ -1652,6 +1664,11 @@ int muse_internal_run_loop_shard(muse_ctx* c, uint64_t seed, const double* theta
     sh.sim_lo = sim_lo; sh.sim_hi = sim_hi; sh.include_data = include_data ? 1 : 0;
     sh.board = (unsigned long long*)board_dev;
     sh.tag_base = tag_base;
+    sh.npeers = 0;
+    if (peer_boards && npeers > 0 && npeers <= 8) {
+        sh.npeers = npeers;
+        for (int q = 0; q < npeers; ++q) sh.peers[q] = (unsigned long long*)peer_boards[q];
+    }
     rc = run_loop_launch(c, seed, theta0, o, &sh, shape, max_grid, niter_out, theta_out, hist_out, gsims_out, info_out);
     if (rc == MUSE_LOOP_NOT_RESIDENT && !getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;
     return rc;

@@ -944,7 +944,10 @@ struct Solver {
     // what that solve's last pass stored into the problem's slot (phantom slots: zeros, as an out-of-range load returns), so the
     // results are the same bits.  A path of its own, beside begin() instead of inside it: with z live through ALL of begin() --
     // the generator loop, the staging of a true-z start -- the register allocator spilled it (40 -> 111 spilled registers).
-    static constexpr bool kKeepZ = Place::kResident && Place::kXgLds && !Model::kStencil && MAXB == 1;   // (several components: the per-block state beside a kept z spilled)
+#ifndef MUSE_KEEPZ_MAXB
+#define MUSE_KEEPZ_MAXB 8   // (every tier: with ONE copy of the solve in the loop kernel the kept MAP costs no spilled register; 1 = one component only)
+#endif
+    static constexpr bool kKeepZ = Place::kResident && Place::kXgLds && !Model::kStencil && MAXB <= MUSE_KEEPZ_MAXB;
     // (workgroup-uniform) can problem p start from kept registers: a warm start whose x comes from cached normals or from the data
     __device__ __forceinline__ bool can_keep(int p) const {
         if constexpr (!kKeepZ) return false;
@@ -952,8 +955,9 @@ struct Solver {
         return dd.z0_mode == Z0_WARM && !dd.normals_only && dd.tsample < 0 &&
                ((dd.x_mode == X_SAMPLE && dd.nslot >= 0 && a.ncache_mode == 2) || dd.x_mode == X_DATA);
     }
-    __device__ __forceinline__ void run_kept(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p = -1) {
-        begin_kept(p, wg_scratch, lds_x, lds_g, pf);
+    // what run() does behind begin() (the loop kernel picks the begin itself: kept MAP or not)
+    __device__ __forceinline__ void after_begin(int p, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p) {
+        if (d.normals_only) return;
         pfp = &pf;
         if constexpr (Place::kResident && Place::kXgLds) {
             if (next_p >= 0 && a.ncache_mode == 2 && !(a.debug & 4)) prefetch_issue<T>(a, tid, next_p, lds_x, lds_g, pf, false);
@@ -2204,7 +2208,15 @@ struct Solver {
                     typedef __attribute__((address_space(1))) unsigned long long gu64;
                     gu64* gq = (gu64*)a.gran + (d.row * a.ntheta + tl) * 2;
                     const unsigned long long b = (unsigned long long)__double_as_longlong(sc), tg = (unsigned long long)a.gran_tag << 32;
-                    if (a.gran_sys) {   // the node's board in host memory: other GPUs' steppers read it
+                    if (a.gran_sys == 2) {   // a board per GPU, in device memory: the granules go into every rank's (kernarg: gran_peers)
+                        const BatchArgs* ka = reinterpret_cast<const BatchArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+                        const int64_t off = (int64_t)((gu64*)gq - (gu64*)a.gran);
+                        for (int q = 0; q < ka->ngran_peers; ++q) {
+                            gu64* pq = (gu64*)ka->gran_peers[q] + off;
+                            __hip_atomic_store(pq, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(pq + 1, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    } else if (a.gran_sys) {   // the node's board in host memory: other GPUs' steppers read it
                         __hip_atomic_store(gq, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(gq + 1, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     } else {

@@ -57,16 +57,18 @@ xd1 = np.cos(0.11 * np.arange(10000)) * 1.7
 p1 = M.HipMuseProblem(xd1, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
 p1.comm_init(world, rank, bytes.fromhex(sys.argv[7]))
 kw = dict(nsims=64, maxsteps=8, theta_rtol=0.0, atol=1e-2, alpha=0.7)
-for tag, host in (("dev", False), ("host", True)):
-    if host:
-        os.environ["MUSE_DEBUG_SHARDED_HOST_LOOP"] = "1"
-    else:
-        os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
+for tag, env in (("dev", {}), ("hostboard", {"MUSE_DEBUG_HOST_BOARD": "1"}), ("host", {"MUSE_DEBUG_SHARDED_HOST_LOOP": "1"})):
+    # dev: a board per GPU in device memory, every rank's mapped into every rank (hipIpc); hostboard: the one board in pinned host
+    # memory; host: the host-driven loop
+    for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
     n, theta, hist, gs, info = p1.run_muse_sharded(SEED, [1.0], **kw)
     res[f"s1_{tag}_n"], res[f"s1_{tag}_theta"], res[f"s1_{tag}_hist"], res[f"s1_{tag}_gs"] = n, theta, hist[:, :-1], gs
     res[f"s1_{tag}_it"], res[f"s1_{tag}_fc"] = info["iterations"], info["f_calls"]
     n, theta, hist, gs, info = p1.run_muse_sharded(SEED, theta, z0_warm=True, **dict(kw, maxsteps=3))
     res[f"s1_{tag}_warm_theta"], res[f"s1_{tag}_warm_gs"] = theta, gs
-os.environ.pop("MUSE_DEBUG_SHARDED_HOST_LOOP", None)
+for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
+    os.environ.pop(k, None)
 p1.close()
 np.savez(out, **res)

@@ -71,7 +71,8 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
     # The sharded loop at the headline's shape, as ONE persistent launch per rank -- the ranks' kernels resident side by side on this
     # one GPU, their scores meeting on the node's board in pinned host memory -- and as the host-driven loop: both the unsharded
     # loop's trajectory, bit for bit, on every rank; and the persistent launch is what ran (its timing line on stderr: the first
-    # sharded loop above -- N = 2000, two components, one element per worker -- and two of the three runs here).
+    # sharded loop above -- N = 2000, two components, one element per worker -- and four of the six runs here: the boards in device
+    # memory, mapped across the processes by hipIpc, and the one board in pinned host memory).
     xd1 = np.cos(0.11 * np.arange(10000)) * 1.7
     one = M.HipMuseProblem(xd1, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
     kw = dict(nsims=64, maxsteps=8, theta_rtol=0.0, atol=1e-2, alpha=0.7)
@@ -80,13 +81,13 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
     one.close()
     for r in range(world):
         lo, hi = M.block_partition(0, 64, world, r)
-        for tag in ("dev", "host"):
+        for tag in ("dev", "hostboard", "host"):
             assert int(res[r][f"s1_{tag}_n"]) == n1 and np.array_equal(res[r][f"s1_{tag}_theta"], t1), (r, tag)
             assert np.array_equal(res[r][f"s1_{tag}_hist"], h1[:, :-1]) and np.array_equal(res[r][f"s1_{tag}_gs"], g1), (r, tag)
             mine = np.concatenate([i1[:, :1], i1[:, 1 + lo:1 + hi]], axis=1) if r == 0 else i1[:, 1 + lo:1 + hi]
             assert np.array_equal(res[r][f"s1_{tag}_it"], mine["iterations"]) and np.array_equal(res[r][f"s1_{tag}_fc"], mine["f_calls"]), (r, tag)
             assert np.array_equal(res[r][f"s1_{tag}_warm_theta"], t2) and np.array_equal(res[r][f"s1_{tag}_warm_gs"], g2), (r, tag)
-        assert logs[r].count("[muse_run_device]") == 3, logs[r]
+        assert logs[r].count("[muse_run_device]") == 5, logs[r]
     big = [np.sin(np.arange(40000.0) * (q + 1)) for q in range(world)]
     total = big[0].copy()
     for q in range(1, world):

@@ -37,4 +37,8 @@ def test_built_libraries_keep_the_solver_state_out_of_scratch():
     rows = {r[0]: r for r in regs.library_report(main)}
     for key in ("11FunnelModelILi1EEENS_13PlaceResidentILi512ELi10ELb1ELb0EEELb0EE", "10NoiseModelENS_13PlaceResidentILi512ELi10ELb1ELb0EEELb0EE"):
         assert rows[key][2] == 0 and rows[key][4] == 0, rows[key]     # (vgpr_spill_count, scratch bytes)
-    assert len(rows) > 100
+    # round 5: the loop kernel muse() runs by default -- with the MAP kept in registers from one iteration to the next -- too
+    for key in ("loop:11FunnelModelILi1EEENS_13PlaceResidentILi512ELi10ELb1ELb0EEEENS_8LoopArgsE",
+                "loop:10NoiseModelENS_13PlaceResidentILi512ELi10ELb1ELb0EEEENS_8LoopArgsE"):
+        assert rows[key][2] == 0 and rows[key][4] == 0, rows[key]
+    assert len(rows) > 90     # (round 5 dropped the loop kernels of the streaming placements, which nothing launched)
