@@ -831,9 +831,24 @@ def launch_ranks(script, argv, nranks, extra_env=None, grace_s=20.0):
     import socket
     import subprocess
     import threading
-    with socket.socket() as s:  # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # a free rendezvous port on the loopback interface, BELOW the ephemeral range: a port handed out by bind(0) goes back to the pool when
+    # the probe socket closes, and one of the ranks' own outgoing connections (gloo opens many) can be given it before rank 0's store
+    # listens on it -- EADDRINUSE, seen once in a while with eight ranks
+    import random
+    port = None
+    for _ in range(64):
+        cand = random.randint(15000, 29999)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", cand))
+                port = cand
+                break
+            except OSError:
+                continue
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
     procs, lines0 = [], []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),

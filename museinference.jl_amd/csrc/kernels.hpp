@@ -279,34 +279,36 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
 #endif
     // (two loops, one per role -- round 5: in ONE loop with the roles as its branches, whatever a worker carries in registers from
     //  one iteration to the next -- the kept MAP -- was also live through the stepper's branch)
+    // the per-iteration fields of the worker's LDS copy of the arguments, by ONE thread: iteration 1's before the loop, iteration
+    // i + 1's while other lanes form the exponentials of its theta (one barrier and a serial stretch less between two iterations)
+    auto iteration_setup = [&](int it) {
+        LoopLds<Place> m(smem);
+        BatchArgs& a = *m.a;   // (mutable here: theta and the per-iteration fields are re-written between iterations)
+        const LoopArgs& L = *m.L;
+        a.z0_mode = (it > 1 || L.z0_warm) ? Z0_WARM : Z0_ZERO;
+        // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
+        // standard normals (or finds them: the host's mode), the later ones load them instead of running the generator
+        if (it > 1 && a.ncache) a.ncache_mode = 2;
+        a.scores = L.scores_out + (int64_t)(it - 1) * L.scores_stride;
+        a.info = L.info_out + (int64_t)(it - 1) * L.info_stride;
+        a.gran_tag = L.tag_base + (unsigned)it;
+        if constexpr (Place::kXgLds) {  // the dummy slot and the pad element (N odd) hold 0 while problems run
+            m.lds_x[a.ld] = 0.0;
+            m.lds_g[a.ld] = 0.0;
+            m.lds_x[a.ld + 1] = 0.0;
+            m.lds_g[a.ld + 1] = 0.0;
+            if (a.N < a.ld && pf.p < 0) {   // (a prefetched vector brings its pad element along; begin() masks it)
+                m.lds_x[a.N] = 0.0;
+                m.lds_g[a.N] = 0.0;
+            }
+        }
+    };
     if (!stepper) {
     for (int iter = 1;; ++iter) {
         int err = STEP_OK, converged = 0;
+        if (iter == 1 && tid == 0) iteration_setup(1);   // (the later iterations': beside the exponentials of the new theta, below)
         __syncthreads();
         {
-            if (tid == 0) {
-                LoopLds<Place> m(smem);
-                BatchArgs& a = *m.a;   // (mutable here: theta and the per-iteration fields are re-written between iterations)
-                const LoopArgs& L = *m.L;
-                a.z0_mode = (iter > 1 || L.z0_warm) ? Z0_WARM : Z0_ZERO;
-                // every iteration re-draws the same streams at a new theta (src/muse.jl:134,169): the first one stores the
-                // standard normals (or finds them: the host's mode), the later ones load them instead of running the generator
-                if (iter > 1 && a.ncache) a.ncache_mode = 2;
-                a.scores = L.scores_out + (int64_t)(iter - 1) * L.scores_stride;
-                a.info = L.info_out + (int64_t)(iter - 1) * L.info_stride;
-                a.gran_tag = L.tag_base + (unsigned)iter;
-                if constexpr (Place::kXgLds) {  // the dummy slot and the pad element (N odd) hold 0 while problems run
-                    m.lds_x[a.ld] = 0.0;
-                    m.lds_g[a.ld] = 0.0;
-                    m.lds_x[a.ld + 1] = 0.0;
-                    m.lds_g[a.ld + 1] = 0.0;
-                    if (a.N < a.ld && pf.p < 0) {   // (a prefetched vector brings its pad element along; begin() masks it)
-                        m.lds_x[a.N] = 0.0;
-                        m.lds_g[a.N] = 0.0;
-                    }
-                }
-            }
-            __syncthreads();
             loop_stamp(0);
             {
                 LoopLds<Place> m(smem);
@@ -397,8 +399,20 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 err = m.flags[2] ? (int)STEP_TIMEOUT : __builtin_amdgcn_readfirstlane((int)(ec & 0xffffffffull));
                 converged = __builtin_amdgcn_readfirstlane((int)(ec >> 32));
                 if (err != STEP_OK || converged || iter == m.L->maxsteps) break;
-                if (tid < kMaxTheta) make_map_theta_component(tid, nt, th, a.cur);   // (a lane per component: two exponentials each)
-                if (tid == 0) make_map_theta_const(nt, a.bnd, th, a.cur);
+                // a lane per exponential (step.hpp, make_map_theta_component's statements): exp(theta/2), exp(-theta) side by side, the
+                // constant term and the next iteration's fields on lanes of their own
+                if (tid < kMaxTheta) {
+                    const bool live = tid < nt;
+                    a.cur.t.theta[tid] = live ? th[tid] : 0.0;
+                    a.cur.t.sd[tid] = live ? muse_exp(0.5 * th[tid]) : 0.0;
+                } else if (tid < 2 * kMaxTheta) {
+                    const int k = tid - kMaxTheta;
+                    a.cur.t.iv[k] = k < nt ? muse_exp(-th[k]) : 0.0;
+                } else if (tid == 2 * kMaxTheta) {
+                    make_map_theta_const(nt, a.bnd, th, a.cur);
+                } else if (tid == 2 * kMaxTheta + 1) {
+                    iteration_setup(iter + 1);
+                }
                 // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
             }
         }

@@ -1746,8 +1746,13 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     // a sampling entry: exp(theta/2) of every block -- a SampleSd, or kBigTheta doubles in the big tier (solver.hpp, begin)
     const int ts_stride = tier_big(c, choose_place(c), 1) ? kBigTheta : kMaxTheta;
     static_assert(sizeof(SampleSd) == kMaxTheta * sizeof(double) && kBigTheta % kMaxTheta == 0, "sampling entries");
-    rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G) * (size_t)(ts_stride / kMaxTheta));
-    if (rc) return rc;
+    // a few entries shared by the simulations travel in the launch's own argument block (in the place of maps[]: the launch carries
+    // one map) -- no pinned staging, no upload on the stream between the two launches
+    const bool ts_in_kernarg = !per_unit && ts_stride == kMaxTheta && (size_t)nt * G * sizeof(SampleSd) <= sizeof(MapTheta) * kMaxMaps;
+    if (!ts_in_kernarg) {
+        rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G) * (size_t)(ts_stride / kMaxTheta));
+        if (rc) return rc;
+    }
     {
         BatchArgs a;
         base_args(c, a, theta0);
@@ -1775,12 +1780,15 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         if (rc) return rc;
     }
     // 2. the perturbed simulations, MAP and score at theta0
+    BatchArgs a2;
+    base_args(c, a2, theta0);
     {
         std::vector<double> th(nt);
+        double* ts_dst = ts_in_kernarg ? reinterpret_cast<double*>(a2.maps) : reinterpret_cast<double*>(c->tsample_pin);
         auto fill = [&](int64_t entry, int j, double off) {
             for (int k = 0; k < nt; ++k) th[k] = theta0[k];
             th[j] = theta0[j] + off;
-            double* sd = reinterpret_cast<double*>(c->tsample_pin) + entry * ts_stride;
+            double* sd = ts_dst + entry * ts_stride;
             for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? muse_exp(0.5 * th[k]) : 0.0;   // (make_map_theta_component's sd)
         };
         if (per_unit) {
@@ -1791,11 +1799,11 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
                 for (int g = 0; g < G; ++g) fill((int64_t)j * G + g, j, offsets[(int64_t)j * G + g]);
         }
     }
-    HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)(per_unit ? n : (int64_t)nt * G) * ts_stride * sizeof(double),
-                          hipMemcpyHostToDevice, c->stream));
+    if (!ts_in_kernarg)
+        HIPCHK(hipMemcpyAsync(c->tsample_dev, c->tsample_pin, (size_t)(per_unit ? n : (int64_t)nt * G) * ts_stride * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
     {
-        BatchArgs a;
-        base_args(c, a, theta0);
+        BatchArgs& a = a2;
         a.kind = BATCH_FD;
         a.seed = seed;
         a.atol = atol;
@@ -1806,7 +1814,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         a.p0 = (int)(G * (e_begin - (s_lo - sim_begin) * nt));  // the range may begin inside s_lo's Jacobian
         a.fid_slot = fid_mode == 0 ? 0 : -1;
         a.slot0 = 0;
-        a.tsample = c->tsample_dev;
+        a.tsample = ts_in_kernarg ? nullptr : c->tsample_dev;
         a.scores = c->scores_dev[1];
         a.info = c->info_dev[1];
         if (cached) {
@@ -1820,7 +1828,8 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     }
     rc = enqueue_results_copy(c, 1, n);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = muse_wait_event_or_stream(c);   // (polls the stream: the runtime's blocking wait wakes up late for a call of tens of microseconds)
+    if (rc) return rc;
     rc = check_error_flag(c);
     if (rc) return rc;
     if (cached) { c->nc_seed = seed; c->nc_sim0 = s_lo; c->nc_count = nsims; }   // both launches have completed

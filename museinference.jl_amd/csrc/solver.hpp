@@ -1076,6 +1076,14 @@ struct Solver {
         }
     }
 
+    // A finite-difference batch's sampling entries (exp(theta/2) per block of the theta a problem is DRAWN at): a device buffer, or
+    // -- a few entries shared by the simulations, round 5 -- the kernel-argument segment itself, in the place of maps[] (such a
+    // launch carries one map): no upload between the fiducial launch and this one
+    __device__ __forceinline__ const SampleSd* tsample_base() const {
+        if (a.tsample) return a.tsample;
+        return reinterpret_cast<const SampleSd*>(reinterpret_cast<const char*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) +
+                                                 offsetof(BatchArgs, maps));
+    }
     // -- phase 1: bind storage, produce x and the starting point
     template <bool KEEP_ZTRUE>
     __device__ __forceinline__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g) {
@@ -1096,7 +1104,7 @@ struct Solver {
         have_trial = false;
         stamp(p, 0);
         iv0 = a.cur.t.iv[0];
-        sd0 = d.tsample >= 0 ? a.tsample[d.tsample].sd[0] : a.cur.t.sd[0];
+        sd0 = d.tsample >= 0 ? tsample_base()[d.tsample].sd[0] : a.cur.t.sd[0];
         if constexpr (kBig) {
             // (generic pointers into the kernarg segment: BatchArgs is the kernel's only parameter)
             const BigTheta* bt = reinterpret_cast<const BigTheta*>(
@@ -1108,7 +1116,7 @@ struct Solver {
             // FD batches sample at a theta that differs from the MAP theta
             int tl = tid;
             asm volatile("" : "+v"(tl));  // (else tid * 8 is formed at the kernel's entry and held -- spilled -- across it)
-            if (tl < MAXB) sh_sd[tl] = d.tsample >= 0 ? a.tsample[d.tsample].sd[tl] : a.cur.t.sd[tl];
+            if (tl < MAXB) sh_sd[tl] = d.tsample >= 0 ? tsample_base()[d.tsample].sd[tl] : a.cur.t.sd[tl];
             wg_barrier<!Model::kStencil>();
         }
         // bind storage
