@@ -54,7 +54,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 78.6    # fp64 vector peak: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def algorithmic_bytes(info, N):

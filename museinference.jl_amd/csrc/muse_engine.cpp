@@ -1739,8 +1739,11 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     // every simulation is drawn G*ntheta times (same randoms, perturbed theta; src/muse.jl:426-432): its standard
     // normals are generated once -- by its own fiducial problem (fid_mode 1) or by a normals-only element of the
     // fiducial launch (fid_mode 0) -- and loaded by the perturbed problems
-    const bool cached = ensure_ncache(c, nsims);
-    const int64_t nprep = nfid + ((cached && fid_mode == 0) ? nsims : 0);
+    // (round 5: a cache that already holds these streams -- the muse! loop that ran before get_H!, an earlier call -- is used as it is)
+    const bool held = ncache_holds(c, seed, s_lo, nsims);
+    const bool cached = held || ensure_ncache(c, nsims);
+    const int64_t nc_sim0 = held ? c->nc_sim0 : s_lo, nc_cnt = held ? c->nc_count : nsims;
+    const int64_t nprep = nfid + ((cached && !held && fid_mode == 0) ? nsims : 0);
     rc = ensure_results(c, 1, n > nprep ? n : nprep);
     if (rc) return rc;
     // a sampling entry: exp(theta/2) of every block -- a SampleSd, or kBigTheta doubles in the big tier (solver.hpp, begin)
@@ -1764,10 +1767,10 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         a.norm_sim0 = s_lo;
         if (cached) {
             a.ncache = c->ncache;
-            a.ncache_sim0 = s_lo;
-            a.ncache_count = (int)nsims;
-            a.ncache_mode = 1;
-            c->nc_count = 0;   // (overwritten from here on; claimed below once the whole call has ended well)
+            a.ncache_sim0 = nc_sim0;
+            a.ncache_count = (int)nc_cnt;
+            a.ncache_mode = held ? 2 : 1;
+            if (!held) c->nc_count = 0;   // (overwritten from here on; claimed below once the whole call has ended well)
         }
         a.include_data = 0;
         a.z0_mode = MUSE_Z0_ZERO;
@@ -1819,8 +1822,8 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         a.info = c->info_dev[1];
         if (cached) {
             a.ncache = c->ncache;
-            a.ncache_sim0 = s_lo;
-            a.ncache_count = (int)nsims;
+            a.ncache_sim0 = nc_sim0;
+            a.ncache_count = (int)nc_cnt;
             a.ncache_mode = 2;
         }
         rc = launch_batch(c, a);
@@ -1832,7 +1835,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     if (rc) return rc;
     rc = check_error_flag(c);
     if (rc) return rc;
-    if (cached) { c->nc_seed = seed; c->nc_sim0 = s_lo; c->nc_count = nsims; }   // both launches have completed
+    if (cached && !held) { c->nc_seed = seed; c->nc_sim0 = s_lo; c->nc_count = nsims; }   // both launches have completed
     if (f_out) memcpy(f_out, c->scores_pin[1], (size_t)n * nt * sizeof(double));
     if (info_out) memcpy(info_out, c->info_pin[1], (size_t)n * sizeof(muse_info));
     return MUSE_OK;

@@ -49,11 +49,27 @@ int main(int argc, char** argv) {
     muse_shm::Gather g;
     g.timeout_s = 20.0;
     std::string err;
-    if (!g.open(name, nranks, rank, 4, B, err)) {
+    // MUSE_TEST_EXTRA=bytes: the segment carries an extra region behind the blocks (the score board of the sharded device loop,
+    // muse_comm.cpp): page-aligned, zero-filled, the same memory in every rank -- a word every rank writes before the exchanges is
+    // what every rank reads after them
+    const size_t extra = getenv("MUSE_TEST_EXTRA") ? (size_t)atol(getenv("MUSE_TEST_EXTRA")) : 0;
+    if (!g.open(name, nranks, rank, 4, B, err, extra)) {
         fprintf(stderr, "rank %d: open failed: %s\n", rank, err.c_str());
         return 3;
     }
-    return exchange(g, nranks, rank, rounds, B, abort_at);
+    volatile uint64_t* board = (volatile uint64_t*)g.extra();
+    if (extra) {
+        if (!board || ((uintptr_t)board & 4095) != 0 || g.extra_bytes() < extra || g.extra_bytes() % 4096 != 0) return 5;
+        if (board[(size_t)nranks * 8 + 1] != 0) return 6;   // (a fresh segment is zero-filled)
+        board[(size_t)rank * 8] = 0xABCD0000ull + (uint64_t)rank;
+    } else if (board) {
+        return 5;
+    }
+    const int rc = exchange(g, nranks, rank, rounds, B, abort_at);
+    if (rc == 0 && extra)
+        for (int q = 0; q < nranks; ++q)
+            if (board[(size_t)q * 8] != 0xABCD0000ull + (uint64_t)q) return 7;
+    return rc;
 }
 
 static int exchange(muse_shm::Gather& g, int nranks, int rank, int rounds, size_t B, int abort_at) {

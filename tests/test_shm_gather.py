@@ -17,12 +17,13 @@ def driver(tmp_path_factory):
     return exe
 
 
-def run_ranks(exe, nranks, rounds, block, abort_at=None):
+def run_ranks(exe, nranks, rounds, block, abort_at=None, extra=0):
     name = "/muse_test_" + uuid.uuid4().hex[:16]
     procs = []
+    env = dict(os.environ, MUSE_TEST_EXTRA=str(extra)) if extra else None
     for r in range(nranks):
         cmd = [exe, name, str(nranks), str(r), str(rounds), str(block)] + ([str(abort_at)] if abort_at is not None else [])
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     out = [p.communicate(timeout=120) for p in procs]
     assert not os.path.exists("/dev/shm" + name), "the creator unlinks the segment once everyone is attached"
     return [p.returncode for p in procs], out
@@ -43,3 +44,11 @@ def test_abort_releases_the_peers(driver):
     # the last rank gives up in round 37: the others leave their wait with "aborted by a peer" instead of a timeout
     codes, out = run_ranks(driver, 3, 1000, 64, abort_at=37)
     assert codes[-1] == 43 and codes[:-1] == [42, 42], (codes, out)
+
+
+@pytest.mark.parametrize("nranks,block,extra", [(3, 64, 256 * 1024), (8, 520, 5000)])
+def test_extra_region_behind_the_blocks(driver, nranks, block, extra):
+    """The region the sharded device loop's score board lives in (muse_comm.cpp registers it with the HIP runtime): on a page
+    boundary of its own, a whole number of pages, zero-filled, and the same memory in every rank."""
+    codes, out = run_ranks(driver, nranks, 200, block, extra=extra)
+    assert codes == [0] * nranks, out

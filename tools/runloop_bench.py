@@ -9,6 +9,8 @@ HOST_ONLY, DEV_ONLY, ONCE = "host" in sys.argv[1:], "dev" in sys.argv[1:], "once
 N, nsims, nth = (int(argv[0]), int(argv[1]), int(argv[2])) if len(argv) > 2 else (10000, 512, 1)
 xdata, _ = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N).sample_x_z(M.SimRng(0, M.DATA_SIM), [0.0] * nth)
 prob = M.HipMuseProblem(xdata, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+if os.environ.get("MUSE_LOOP_DEBUG"):   # muse_debug_flags: 4 no prefetch, 8 the old element order, 32 no speculation
+    M.load_library().muse_debug_flags(prob._ctx, int(os.environ["MUSE_LOOP_DEBUG"]))
 for dev in ((False,) if HOST_ONLY else (True,) if DEV_ONLY else (False, True, False, True)):
     best = 1e9
     for rep in range(1 if ONCE else 5):
