@@ -271,15 +271,25 @@ def test_bench_accounting_helpers():
     # funnel at theta != 0: E=3, K=1 -> 22 words; third sim E=5, K=2, one pair used -> 1 + 25 + (4 + 8) + 2 = 40
     assert bench.algorithmic_bytes(info, 10) == 8 * 10 * (22 + 22 + 40)
     # compulsory HBM bytes of the placement that ran: resident = zhat out (+ pairs and two-loop reads for K > 1);
-    # streaming elementwise K = 1, E = 3 = 7 words (x, s | s, x | s, x, z)
+    # streaming elementwise K = 1, E = 3 = 5 words (x, s | s, x, z: the second trial writes z + c s, the accepted step, into the MAP
+    # slot and no last update pass runs -- round 5; 7 before: x, s | s, x | s, x, z)
     assert bench.compulsory_bytes(info, 10, "resident") == 8 * 10 * (1 + 1 + (1 + 2 + 4))
-    assert bench.compulsory_bytes(info[:2], 10, "streaming") == 8 * 10 * (7 + 7)
+    assert bench.compulsory_bytes(info[:2], 10, "streaming") == 8 * 10 * (5 + 5)
+    e2 = np.zeros(1, dtype=_capi.INFO_DTYPE)
+    e2["f_calls"], e2["iterations"] = [2], [1]          # accepted at the first trial (fused into the sampler pass): the last pass runs
+    assert bench.compulsory_bytes(e2, 10, "streaming") == 8 * 10 * (2 + 3)
     assert bench.compulsory_bytes(info[2:], 10, "stencil") == 8 * 10 * (6 + 4 + 3 * 4 + 11 + 4 + 8)
     assert bench.compulsory_bytes(info[2:], 10, "stencil_lds") == 8 * 10 * (6 + 3 + 2 * 4 + 9 + 3 + 4)
     assert len(bench.csrc_fingerprint()) == 16
     assert 1 <= bench.usable_cores(4) <= 4
     assert bench.measured_traffic("no_such_workload") is None
-    assert set(bench.WORKLOADS) >= {"funnel_1e4", "funnel_512", "noise_1e6", "funnel4_1e4", "smooth_1e5"}
+    assert set(bench.WORKLOADS) >= {"funnel_1e4", "funnel_512", "noise_1e6", "funnel4_1e4", "smooth_1e5", "cfg4_fd_H", "cfg5_smooth_1e5"}
+    # the per-regime split of a loop's iteration times (round 5)
+    hist = np.zeros((5, 9)); hist[:, -1] = [60e-6, 50e-6, 52e-6, 40e-6, 38e-6]
+    inf = np.zeros((5, 4), dtype=_capi.INFO_DTYPE); inf["f_calls"] = [[3] * 4, [3] * 4, [3] * 4, [1] * 4, [1] * 4]
+    reg = bench.iteration_regimes(hist, inf)
+    assert reg["line_search"]["iterations"] == 2 and abs(reg["line_search"]["us_per_outer_iteration"] - 51.0) < 1e-9   # (the cold first one excluded)
+    assert reg["converged_at_start"]["iterations"] == 2 and abs(reg["converged_at_start"]["us_per_outer_iteration"] - 39.0) < 1e-9
 
 
 def test_native_path_selection(M, O, funnel512):
