@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -71,7 +72,7 @@ struct CommState {
     // iteration.  A collective decision at init (every rank must have opened every handle); the host board otherwise.
     unsigned long long* ipc_own = nullptr;
     void* ipc_peers[8] = {nullptr};   // [rank]: the peer's board as mapped here (own: ipc_own)
-    bool ipc_ok = false;
+    bool ipc_ok = false, ipc_tried = false;
     bool dev_loop_off = false;       // the device loop failed once on some rank (a shared GPU): host loop from then on, on every rank
     uint64_t seq[kAreas + 1] = {0};   // sequence number of the last exchange per area (the same on every rank)
     size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced PER MAP for the gather in flight
@@ -252,8 +253,23 @@ static int shm_allgather(CommState* st, const double* send, size_t count, double
     return MUSE_OK;
 }
 
-// A score board per GPU in device memory, every rank's mapped into every rank (CommState::ipc_*).  Collective over the segment.
+// The score boards of the sharded device loop, set up by the first muse_run_sharded call (collective over the segment): the one in
+// pinned host memory -- the segment's extra region, mapped into this GPU's address space where the runtime allows it -- and a board
+// per GPU in device memory, every rank's mapped into every rank (CommState::ipc_*).
 static void setup_ipc_boards(CommState* st) {
+    muse_shm::Gather* g = st->shm;
+    if (!getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(st->device) == hipSuccess && g->extra() &&
+        hipHostRegister(g->extra(), g->extra_bytes(), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, g->extra(), 0) == hipSuccess && dp) {
+            st->board_host = g->extra();
+            st->board_dev = (unsigned long long*)dp;
+            st->board_granules = g->extra_bytes() / sizeof(unsigned long long);
+        } else {
+            (void)hipHostUnregister(g->extra());
+        }
+    }
+    (void)hipGetLastError();
     st->ipc_ok = false;
     if (st->nranks > 8) return;
     bool ok = !getenv("MUSE_DEBUG_NO_IPC_BOARD") && !getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(st->device) == hipSuccess;
@@ -378,22 +394,9 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
             st->nranks = nranks;
             st->rank = rank;
             st->device = device;
-            // the score board: mapped into this GPU's address space where the runtime allows it (else: the host loop)
-            if (!getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(device) == hipSuccess && g->extra() &&
-                hipHostRegister(g->extra(), g->extra_bytes(), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
-                void* dp = nullptr;
-                if (hipHostGetDevicePointer(&dp, g->extra(), 0) == hipSuccess && dp) {
-                    st->board_host = g->extra();
-                    st->board_dev = (unsigned long long*)dp;
-                    st->board_granules = g->extra_bytes() / sizeof(unsigned long long);
-                } else {
-                    (void)hipHostUnregister(g->extra());
-                }
-            }
-            (void)hipGetLastError();
             *slot = st;
-            setup_ipc_boards(st);   // (collective; failure on any rank = no device boards on every rank)
-            return MUSE_OK;
+            return MUSE_OK;   // (the boards in device memory are set up by the first muse_run_sharded call: collective, and nothing a
+                              //  communicator that only gathers maps -- bench.py --gpus N -- has to go through)
         }
     }
     if (!load_rccl()) return muse_set_error(MUSE_ERR_RCCL, "librccl could not be loaded");
@@ -706,13 +709,21 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
     // memory that every GPU maps), every rank's stepper takes the same step from the same bits -- no host between two maps.  Every
     // rank must take the same loop: the decision is the minimum over the ranks of what each can do.
     if (st->shm) {
+        if (!st->ipc_tried) {   // (every rank makes its first call here together: collective; failure on any rank = the host board on all)
+            st->ipc_tried = true;
+            setup_ipc_boards(st);
+        }
         const bool ipc = st->ipc_ok && !getenv("MUSE_DEBUG_HOST_BOARD");   // (the same answer on every rank)
         const bool want = (ipc || st->board_dev) && !st->dev_loop_off && !getenv("MUSE_DEBUG_SHARDED_HOST_LOOP") &&
-                          (uint64_t)(S + 1) * (uint64_t)nt * 2 <= st->board_granules && st->board_tag < 0x70000000u &&
+                          (uint64_t)(S + 1) * (uint64_t)nt * 2 <= kBoardBytes / sizeof(unsigned long long) && st->board_tag < 0x70000000u &&
                           muse_internal_loop_usable(ctx, S, nlocal) != 0;
         double flag[1] = {want ? 1.0 : 0.0};
         rc = shm_allgather(st, flag, 1, flag, true);
         if (rc) return rc;
+        if (getenv("MUSE_DEBUG_RUN_TIMING"))   // tuning aid / tests: which loop, through which board
+            fprintf(stderr, "[muse_run_sharded] rank %d of %d: %s\n", rank, world,
+                    flag[0] != (double)world ? "host-driven loop" : ipc ? "persistent launch, boards in device memory (hipIpc)"
+                                                                        : "persistent launch, board in pinned host memory");
         if (flag[0] == (double)world) {
             const unsigned int tag_base = st->board_tag;
             st->board_tag += (unsigned)o->maxsteps + 1;

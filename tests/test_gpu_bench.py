@@ -100,3 +100,30 @@ def test_bench_single_gpu_runs_of_the_8_gpu_workloads(gpu):
     assert d["n_gpus"] == 1 and "4097 on this rank" in d["config"]["workload"] and 0 < d["roofline"]["frac"] <= 1
     d = run(["--workload", "cfg5_smooth_1e5", "--steps", "3", "--warmup", "1"], {})
     assert d["n_gpus"] == 1 and d["config"]["sims_per_step_total"] == 1024 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
+
+
+def test_bench_default_line_carries_the_other_workloads_and_projections(gpu):
+    """The driver's command as it is run (`python bench.py`: extras on; only the CPU baseline left out here): the other BASELINE
+    workloads are timed inside it, the two 8-GPU workloads are projected, and the dependent path's 8-GPU share -- the sharded loop as
+    ONE persistent launch through a one-rank communicator -- is in the line with both kinds of iteration told apart."""
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "10", "--min-seconds", "0.1", "--no-cpu-baseline"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    x = d["extra"]
+    for w in ("funnel4_1e4", "noise_1e6", "smooth_1e5"):
+        assert 0 < x["workloads"][w]["frac"] <= 1 and x["workloads"][w]["ms_per_step"] > 0, x["workloads"][w]
+    assert x["workloads"]["noise_1e6"]["bound"] == "hbm" and x["workloads"]["funnel4_1e4"]["bound"] == "valu"
+    sp = x["scale_projection"]
+    assert sp["cfg5_smooth_1e5"]["projected_speedup_at_8_gpus"] > 4 and sp["cfg4_fd_H"]["projected_speedup_at_8_gpus"] > 2
+    sh = x["muse_run_8gpu_share"]
+    assert sh["elements_per_rank"] == 65 and sh["projected_speedup_at_8_gpus"] > 2
+    # the persistent launch through the boards is faster than the host-driven loop, and the boards in device memory than the host's
+    dev, hostboard, hostloop = (sh[k]["us_per_outer_iteration_steady"] for k in
+                                ("sharded_loop_shm_1rank", "sharded_loop_host_board_shm_1rank", "sharded_host_loop_shm_1rank"))
+    assert dev < hostboard < hostloop, (dev, hostboard, hostloop)
+    assert set(sh["projected_by_regime"]) <= {"line_search", "converged_at_start"} and sh["projected_by_regime"]
+    assert "line_search" in x["muse_run"]["by_regime"]

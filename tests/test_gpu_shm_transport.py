@@ -88,6 +88,9 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
             assert np.array_equal(res[r][f"s1_{tag}_it"], mine["iterations"]) and np.array_equal(res[r][f"s1_{tag}_fc"], mine["f_calls"]), (r, tag)
             assert np.array_equal(res[r][f"s1_{tag}_warm_theta"], t2) and np.array_equal(res[r][f"s1_{tag}_warm_gs"], g2), (r, tag)
         assert logs[r].count("[muse_run_device]") == 5, logs[r]
+        # ... through the boards in device memory (the first sharded loop and two runs here), the host board (two), the host loop (two)
+        assert logs[r].count("boards in device memory (hipIpc)") == 3 and logs[r].count("board in pinned host memory") == 2, logs[r]
+        assert logs[r].count("host-driven loop") == 2, logs[r]
     big = [np.sin(np.arange(40000.0) * (q + 1)) for q in range(world)]
     total = big[0].copy()
     for q in range(1, world):

@@ -3,7 +3,9 @@
     scores, infos, theta), also with more elements than workers;
   * the cross-call normals cache: sequences of plain maps on a caching context against a non-caching one (bitwise);
   * several maps in one launch against separate launches (bitwise);
-  * muse_fd_values_columns against the oracle's per-simulation operators (rtol 1e-7).
+  * muse_fd_values_columns against the oracle's per-simulation operators (rtol 1e-7);
+  * round 5: muse_run_sharded over a one-rank communicator (persistent launch with the score board in device or in pinned host memory,
+    or the host-driven loop) against muse_run (bitwise).
 Usage: python tools/fuzz_loops.py [seconds] [seed]"""
 import os
 os.environ.setdefault("MUSE_DEBUG_LOOP_ANY_NTHETA", "1")   # (the loop kernel whatever ntheta: muse_run_device's default hands ntheta > 1 to the host loop)
@@ -18,14 +20,14 @@ O.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
-n = {"loop": 0, "multi": 0, "fd": 0, "lanes": 0, "cache": 0}
+n = {"loop": 0, "multi": 0, "fd": 0, "lanes": 0, "cache": 0, "sharded": 0}
 bad = 0
 while time.time() - t0 < budget:
     model = str(rng.choice(["funnel", "noise", "smooth"]))
     N = int(rng.choice([int(rng.integers(8, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)), int(rng.integers(10000, 30000))]))
     nth = 1 if model == "noise" else min(N, int(rng.choice([1, 2, 3, 4, 8])))
     seed = int(rng.integers(1, 2**40))
-    kind = str(rng.choice(["loop", "loop", "multi", "fd", "lanes", "cache"]))
+    kind = str(rng.choice(["loop", "loop", "multi", "fd", "lanes", "cache", "sharded"]))
     x = rng.standard_normal(N) * 1.3
     prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0) if rng.random() < 0.7 else None)
     ok, why = True, ""
@@ -60,6 +62,42 @@ while time.time() - t0 < budget:
                 if len(w):
                     why += f" | info differs at {w[:3].tolist()}: {a[4][tuple(w[0])]} vs {b[4][tuple(w[0])]}"
                 why += f" | th0 {th0.tolist()} prior {prob.prior}"
+        elif kind == "sharded":
+            # round 5: the sharded loop (muse_run_sharded over a ONE-rank shared-memory communicator) -- a persistent launch whose scores
+            # travel through a board in device memory (hipIpc mapping) or in pinned host memory, or the host-driven loop -- against
+            # the unsharded host loop: the same bits
+            nsims = int(rng.integers(2, 200)) if N < 5000 else int(rng.integers(2, 64))
+            if rng.random() < 0.25 and N <= 10000:
+                nsims = int(rng.integers(250, 700))
+            th0 = rng.uniform(-0.5, 1.5, size=nth)
+            kw = dict(nsims=nsims, maxsteps=int(rng.integers(1, 10)), theta_rtol=float(rng.choice([0.0, 1e-2, 1e-1])),
+                      atol=float(rng.choice([1e-2, 1e-4])), alpha=float(rng.uniform(0.3, 1.0)))
+            board = str(rng.choice(["ipc", "host", "hostloop"]))
+            for k in ("MUSE_DEBUG_HOST_BOARD", "MUSE_DEBUG_SHARDED_HOST_LOOP"):
+                os.environ.pop(k, None)
+            if board == "host":
+                os.environ["MUSE_DEBUG_HOST_BOARD"] = "1"
+            if board == "hostloop":
+                os.environ["MUSE_DEBUG_SHARDED_HOST_LOOP"] = "1"
+            try:
+                a = prob.run_muse(seed, th0, device_loop=False, **kw)
+            except M.MuseError as e:
+                a = str(e)
+            shp = M.HipMuseProblem(x, model=model, ntheta=nth, prior=prob.prior)
+            shp.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
+            try:
+                b = shp.run_muse_sharded(seed, th0, **kw)
+            except M.MuseError as e:
+                b = str(e)
+            shp.close()
+            for k in ("MUSE_DEBUG_HOST_BOARD", "MUSE_DEBUG_SHARDED_HOST_LOOP"):
+                os.environ.pop(k, None)
+            if isinstance(a, str) or isinstance(b, str):
+                ok = isinstance(a, str) and isinstance(b, str) and (("singular" in a) == ("singular" in b))
+            else:
+                ok = (a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2][:, :-1], b[2][:, :-1], equal_nan=True)
+                      and np.array_equal(a[3], b[3], equal_nan=True) and a[4].tobytes() == b[4].tobytes())
+            why = f"board {board} {kw} {a if isinstance(a, str) else a[0]} {b if isinstance(b, str) else b[0]}"
         elif kind == "cache":
             # the cross-call normals cache (round 4): a sequence of plain maps with repeated, nested and disjoint simulation ranges,
             # cold / true-z / warm starts, on a context that caches against one that does not -- the same bits
