@@ -84,7 +84,7 @@ while time.time() - t0 < budget:
             except M.MuseError as e:
                 a = str(e)
             shp = M.HipMuseProblem(x, model=model, ntheta=nth, prior=prob.prior)
-            shp.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
+            shp.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", max(4096, (nsims + 1) * nth)))   # (the host-driven loop gathers a block of nsims + 1 rows)
             try:
                 b = shp.run_muse_sharded(seed, th0, **kw)
             except M.MuseError as e:
