@@ -11,6 +11,7 @@ unadapted method of order P + 2).  As recalled -- FiniteDifferences cannot be ru
 
 The engine evaluates f in batches (HipMuseProblem.fd_values_columns); this module only holds the scalar algebra.
 """
+import functools
 import math
 from fractions import Fraction
 
@@ -19,6 +20,13 @@ import numpy as np
 
 def _coefs(grid, q):
     """Coefficients c with sum_g c_g g^i = q! delta_{iq}, i = 0..p-1, solved exactly (rationals) and rounded once."""
+    c = _coefs_exact(tuple(int(g) for g in grid), int(q))
+    c.flags.writeable = False      # one array per (grid, q) for the whole process: the rational solve costs ~0.3 ms, and a
+    return c                       # muse(get_covariance=True) at configs[1] is ~0.3 ms altogether without it
+
+
+@functools.lru_cache(maxsize=None)
+def _coefs_exact(grid, q):
     p = len(grid)
     A = [[Fraction(g) ** i for g in grid] + [Fraction(math.factorial(q)) if i == q else Fraction(0)] for i in range(p)]
     for col in range(p):

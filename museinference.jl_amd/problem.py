@@ -410,10 +410,11 @@ class HipMuseProblem(AbstractMuseProblem):
         """The muse! outer loop in the library's native code (muse_run / muse_run_device, include/muse_hip.h): returns
         (n, theta, hist [n, W], g_sims [n, nsims, nθ], info [n, nsims+1]).  device_loop=True: ONE launch runs every
         iteration -- map, exchange of the scores between the (all resident) workgroups, step, next map -- and nothing leaves
-        the GPU in between (the default: 44 against 48 us per iteration at N = 10^4 x 512 sims, and no host in the loop to be
+        the GPU in between (the default: 42 against 48 us per steady iteration at N = 10^4 x 512 sims, and no host in the loop to be
         slowed by whatever else the process does); False: one launch per iteration, the algebra on the host.  The same results
-        bit for bit either way; placements other than the resident ones (an element split, N > 10 000) and more than one theta component run the host loop whatever
-        is asked."""
+        bit for bit either way; placements other than the resident ones (an element split, N > 10 000) and five to eight theta
+        components with several elements per workgroup run the host loop whatever is asked; so does a context whose loop kernel
+        once failed to keep its workgroups resident (a shared GPU)."""
         native = self.native_prior()
         if native is None:
             raise _capi.MuseError(-1, "the native muse! loops take a flat or Gaussian prior and ntheta <= MUSE_MAX_THETA "
@@ -461,7 +462,9 @@ class HipMuseProblem(AbstractMuseProblem):
     def run_muse_sharded(self, rng, theta0, *, nsims, maxsteps, theta_rtol, atol, alpha, z0_warm=False):
         """This rank's part of the muse! loop over the ranks of the context's communicator (muse_run_sharded; comm_init
         first): (n, theta, hist, g_sims) as run_muse -- the same on every rank -- and THIS rank's solver infos
-        [n, count of its elements] (rank 0: the data element first)."""
+        [n, count of its elements] (rank 0: the data element first).  With the shared-memory transport and a resident placement
+        the loop is ONE persistent launch per rank (scores exchanged through boards in device memory that the ranks map into each
+        other by hipIpc, or through one board in pinned host memory); the host-driven loop otherwise -- the same bits."""
         native = self.native_prior()
         if native is None:
             raise _capi.MuseError(-1, "the native muse! loops take a flat or Gaussian prior and ntheta <= MUSE_MAX_THETA "

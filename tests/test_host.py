@@ -326,6 +326,11 @@ def test_fdm_coefficients_known_answers(M):
     assert m.bound_estimator.grid == [-2, -1, 0, 1, 2] and m.bound_estimator.q == 3 and m.bound_estimator.bound_estimator is None
     with pytest.raises(ValueError):
         central_fdm(2, 2)
+    # the exact-rational solve is done once per (grid, q) in a process and handed out read-only: it used to be most of the
+    # wall time of a muse(get_covariance=True) at BASELINE's configs[1] (tools/profile_muse_py.py)
+    assert central_fdm(3, 1).coefs is m.coefs and not m.coefs.flags.writeable
+    with pytest.raises(ValueError):
+        m.coefs[0] = 1.0
 
 
 def test_fdm_estimated_step_and_derivatives_match_the_restatement(M):
