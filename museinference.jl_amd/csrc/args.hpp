@@ -253,7 +253,10 @@ struct LoopArgs {
                                      // sweeps, a PCIe round trip each -- and takes the same step from the same bits)
     const unsigned long long* score_gran;  // what the stepper polls: [nprob_total * ntheta][2] tagged granules, data element first
     unsigned long long* theta_gran;  // this GPU's own: the stepper's theta_next [ntheta] and {err, converged}, two granules each
-    int nprob_total, pad_;           // elements of the WHOLE job (nsims + 1); BatchArgs::nproblems is this rank's share
+    int nprob_total;                 // elements of the WHOLE job (nsims + 1); BatchArgs::nproblems is this rank's share
+    int stepper_solves;              // 1: the last workgroup owns elements like the others and steps when its own are solved (more
+                                     // elements than workgroups: a workgroup that only steps would cost the others a round)
+    int deal_q, deal_r;              // the deal of the elements (the host's division): workgroup w owns deal_q + (w < deal_r) of them
     int64_t scores_stride;           // doubles between two iterations' score blocks at scores_out (0: one block, overwritten)
     double* scores_all_out;          // board mode: pinned [maxsteps][nprob_total][ntheta], written by the stepper
     double* hist_out;                // pinned [maxsteps][MUSE_RUN_HIST]

@@ -255,8 +255,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
     // travel while the slowest worker -- the one with an element more -- is still solving, and through the step) and wait
     // for theta.  (With the step on every workgroup -- the first version -- the step's arrays needed the LDS that now
     // receives the prefetched normals.)
-    const int nworkers = (int)gridDim.x - 1;
-    const bool stepper = (int)blockIdx.x == nworkers;
+    // (round 5, LoopArgs::stepper_solves: with more elements than workers the stepper owns elements too -- 513 elements on 255
+    //  workers are three rounds for three of them, on 256 solvers two rounds and the data element's shorter solve -- and sweeps
+    //  once its own are done, the entries of a chunk requested together as on a node's board)
+    const bool solving = ((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr())[(sizeof(BatchArgs) + offsetof(LoopArgs, stepper_solves)) / 4] != 0;
+    const int stepper_id = (int)gridDim.x - 1;
+    const int nworkers = solving ? (int)gridDim.x : (int)gridDim.x - 1;   // the workgroups that own elements
+    const bool stepper = (int)blockIdx.x == stepper_id;
     Prefetch<Place::EPT> pf;
     pf.p = -1;
     pf.have_n1 = pf.have_n2 = pf.have_x = pf.g_pending = false;
@@ -267,7 +272,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                      // of those with an element more), a worker in the middle and the stepper, behind the problems' rows
     auto loop_stamp = [&](int k) {
         LoopLds<Place> m(smem);
-        const int b = (int)blockIdx.x, row = b == 0 ? 0 : (b == nworkers / 2 ? 1 : (b == nworkers ? 2 : -1));
+        const int b = (int)blockIdx.x, row = b == stepper_id ? 2 : (b == 0 ? 0 : (b == stepper_id / 2 ? 1 : -1));
         if (tid == 0 && m.a->stamps && row >= 0) {
             unsigned long long t;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -322,11 +327,14 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 // MAP, the warm start it needs, is still in the z registers (Solver::run, keep_z: no load, no clear).  A
                 // worker with ONE element (the per-GPU share of a sharded job) never loads a warm start at all.  The solves are
                 // independent of one another, so the order changes no bit.  (MUSE_DEBUG bit 3: the old order, always reloading.)
-                const int cnt = (a.nproblems - (int)blockIdx.x + nworkers - 1) / nworkers;   // >= 1: the grid is <= nproblems + 1
+                // (debug bit 6, a tuning aid: a stepper that solves takes the data element, problem 0, for itself and the simulations are
+                //  dealt from problem 1 on -- see the stepper's loop)
+                const int first = (int)blockIdx.x + ((solving && a.include_data && (a.debug & 64)) ? 1 : 0);
+                const int cnt = m.L->deal_q + ((int)blockIdx.x < m.L->deal_r ? 1 : 0);   // >= 1: the host sizes the grid so
                 const bool alternate = Solver<Model, Place>::kKeepZ && !(a.debug & 8);
                 const bool up = !alternate || (iter & 1);
                 const int step = up ? nworkers : -nworkers;
-                int p = up ? (int)blockIdx.x : (int)blockIdx.x + (cnt - 1) * nworkers;
+                int p = up ? first : first + (cnt - 1) * nworkers;
                 // (ONE copy of the solve in the worker's loop -- round 5; the first problem used to be peeled off, a second copy of the
                 //  whole solver in the kernel)
                 for (int k = 0; k < cnt; ++k) {
@@ -352,7 +360,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 loop_stamp(2);
                 if constexpr (Place::kXgLds) {   // the next iteration's first problem: the one just solved (p), or the first again
                     if (iter < m.L->maxsteps && a.ncache_mode != 0 && !(a.debug & 4))
-                        prefetch_issue<T>(a, tid, alternate ? p : (int)blockIdx.x, m.lds_x, m.lds_g, pf, true);
+                        prefetch_issue<T>(a, tid, alternate ? p : first, m.lds_x, m.lds_g, pf, true);
                 }
                 loop_stamp(3);
             }
@@ -401,16 +409,18 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 if (err != STEP_OK || converged || iter == m.L->maxsteps) break;
                 // a lane per exponential (step.hpp, make_map_theta_component's statements): exp(theta/2), exp(-theta) side by side, the
                 // constant term and the next iteration's fields on lanes of their own
-                if (tid < kMaxTheta) {
-                    const bool live = tid < nt;
-                    a.cur.t.theta[tid] = live ? th[tid] : 0.0;
-                    a.cur.t.sd[tid] = live ? muse_exp(0.5 * th[tid]) : 0.0;
-                } else if (tid < 2 * kMaxTheta) {
-                    const int k = tid - kMaxTheta;
+                int tl = tid;
+                asm volatile("" : "+v"(tl));   // (else tid - kMaxTheta is formed at the kernel's entry and held -- spilled -- across the solves)
+                if (tl < kMaxTheta) {
+                    const bool live = tl < nt;
+                    a.cur.t.theta[tl] = live ? th[tl] : 0.0;
+                    a.cur.t.sd[tl] = live ? muse_exp(0.5 * th[tl]) : 0.0;
+                } else if (tl < 2 * kMaxTheta) {
+                    const int k = tl - kMaxTheta;
                     a.cur.t.iv[k] = k < nt ? muse_exp(-th[k]) : 0.0;
-                } else if (tid == 2 * kMaxTheta) {
+                } else if (tl == 2 * kMaxTheta) {
                     make_map_theta_const(nt, a.bnd, th, a.cur);
-                } else if (tid == 2 * kMaxTheta + 1) {
+                } else if (tl == 2 * kMaxTheta + 1) {
                     iteration_setup(iter + 1);
                 }
                 // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
@@ -420,7 +430,34 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
     } else {
     for (int iter = 1;; ++iter) {
         int err = STEP_OK, converged = 0;
+        if (solving && iter == 1 && tid == 0) iteration_setup(1);
         __syncthreads();
+        if (solving) {
+            // the stepper's own elements, as a worker's -- without the kept MAP and the fetch across the step (this workgroup's LDS
+            // is the step's between two iterations; it has the fewest elements of all and is not the one the others wait for)
+            loop_stamp(0);
+            LoopLds<Place> m(smem);
+            const BatchArgs& a = *m.a;
+            double* wg_scratch = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+            // (debug bit 6: the data element is the stepper's own and the workers hold simulations only -- at 512 of them on 256 compute
+            //  units two each.  Measured at configs[1], tools/stamps_run.py: iterations whose solves are converged at the start 32.8 us
+            //  against 39.2 with the data element dealt like the rest, but iterations whose solves take a line search -- every
+            //  iteration of a run as short as muse()'s own -- 56 against 53: data + 2 simulations are 47 us on whichever workgroup,
+            //  and a worker starts every second iteration with the data element's MAP still in its registers.  Not the default.)
+            const bool own_data = a.include_data && (a.debug & 64);
+            const int first = (int)blockIdx.x + (own_data ? 1 : 0);
+            for (int p = own_data ? 0 : first; p < a.nproblems;) {
+                const int nx = (own_data && p == 0) ? first : p + nworkers;
+                Solver<Model, Place> sv(a, tid, m.red, m.shs);
+                sv.pk[0] = pk0;
+                sv.pk[1] = pk1;
+                sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, nx < a.nproblems ? nx : -1);
+                wg_barrier<!Model::kStencil>();
+                p = nx;
+            }
+            loop_stamp(2);
+            __syncthreads();   // (x and g are dead from here on: the step's arrays alias them)
+        }
         {
             // ---- the stepper.  ONE wavefront does everything (the others wait at the barrier below): lane l takes the
             // simulations s = l, l + 64, ... -- it polls each score's two granules (one 16-byte load) until both carry this
@@ -436,8 +473,12 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
             double* small = gs + (int64_t)L.nprob_total * nt;   // (the whole job's elements: a sharded loop's rank solves a share of them)
             StepWork& w = *reinterpret_cast<StepWork*>(small + 24);
             if (tid == 0) {
+                int zero = 0;
+                asm volatile("" : "+v"(zero));   // (else a 64-bit zero is held across the stepper's own solves, in scratch)
                 a.gran_tag = L.tag_base + (unsigned)iter;
-                m.flags[0] = m.flags[1] = m.flags[2] = 0;
+                m.flags[0] = zero;
+                m.flags[1] = zero;
+                m.flags[2] = zero;
             }
             __syncthreads();
             if (tid < 64) {
@@ -448,27 +489,29 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 asm volatile("" : "+v"(lane));
                 // The node's board (muse_run_sharded's device loop): the scores of EVERY rank's elements, in pinned host memory.  A
                 // poll is a PCIe round trip (~2 us), so the in-order poll below -- eight dependent polls per lane at 512 simulations
-                // -- is replaced by batched sweeps: a lane's (up to) eight entries of a chunk of 512 are requested together and
+                // -- is replaced by batched sweeps: a lane's (up to) sixteen entries of a chunk of 1024 are requested together and
                 // re-requested until all of them carry this iteration's tag; complete entries go to gs[] in LDS, from which the
                 // sums below take them in the same order as ever.  After the last score has landed: one sweep.
-                const bool board = __builtin_amdgcn_readfirstlane(L.board) != 0;
+                const bool board = __builtin_amdgcn_readfirstlane(L.board) != 0 || solving;   // (a stepper with elements of its own: no
+                                                                                               //  poll was under way while it solved)
                 if (board) {
                     const int nent = L.nprob_total * nt;
-                    for (int e0 = 0; e0 < nent; e0 += 512) {
+                    constexpr int kSweep = 16;   // entries a lane has in flight: 513 entries (512 simulations and the data, one component) are ONE chunk
+                    for (int e0 = 0; e0 < nent; e0 += 64 * kSweep) {
                         unsigned pending = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pending |= (e0 + 64 * j + lane < nent) ? (1u << j) : 0u;
+                        for (int j = 0; j < kSweep; ++j) pending |= (e0 + 64 * j + lane < nent) ? (1u << j) : 0u;
                         unsigned spins = 0;
                         unsigned long long t_wait0 = 0;
                         for (;;) {
-                            double lo[8], hi[8];
+                            double lo[kSweep], hi[kSweep];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
+                            for (int j = 0; j < kSweep; ++j) {
                                 const int e = (pending >> j) & 1u ? e0 + 64 * j + lane : 0x08000000;   // (done or beyond the end: out of range, no access)
                                 load_f64x2<kCoherent>(grs, 2 * e, lo[j], hi[j]);
                             }
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
+                            for (int j = 0; j < kSweep; ++j) {
                                 const unsigned long long glo = (unsigned long long)__double_as_longlong(lo[j]), ghi = (unsigned long long)__double_as_longlong(hi[j]);
                                 if (((pending >> j) & 1u) && (unsigned)(glo >> 32) == tag && (unsigned)(ghi >> 32) == tag) {
                                     gs[e0 + 64 * j + lane] = __longlong_as_double((long long)((ghi << 32) | (glo & 0xffffffffull)));
@@ -656,9 +699,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     L.status[1] = e;
                     L.status[2] = cv;
                 }
-                if (e == STEP_OK) {   // (the stepper's own copy of theta: the next record's)
+                if (e == STEP_OK) {   // (the stepper's own copy of theta: the next record's -- and its next solves')
                     if (lane < kMaxTheta) make_map_theta_component(lane, nt, w.theta_next, a.cur);
                     if (lane == 0) make_map_theta_const(nt, a.bnd, w.theta_next, a.cur);
+                    if (solving) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the pad slots of x and g may lie inside the step's arrays)
+                        if (lane == 0) iteration_setup(iter + 1);
+                    }
                 }
             }
             __syncthreads();

@@ -851,6 +851,8 @@ int muse_set_timing(muse_ctx* c, int enabled) {
     c->timing = enabled != 0;
     return MUSE_OK;
 }
+// bits: 0 skip the solve, 1 x from the data vector, 2 the loop kernel does not prefetch, 3 its old element order, 4 test hook (odd workers
+// leave), 5 no speculating trials, 6 a solving stepper takes the data element for itself, 7 the stepper never solves
 int muse_debug_flags(muse_ctx* c, int flags) {  // not part of the public header: profiling aid
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     c->debug = flags;
@@ -1545,8 +1547,16 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
         const int g = atoi(e);
         if (g >= 1 && g < nworkers) nworkers = g;
     }
-    if (getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) nworkers = (int)nprob;   // test hook: more workgroups than can be resident at once
-    const int grid = nworkers + 1;
+    // More elements than workers: the stepper takes elements as well (round 5).  512 simulations + the data on 256 compute units: three
+    // of 255 workers had three elements (the others two, the stepper none); now one workgroup has three (the data element and two
+    // simulations) and the stepper two like everybody else.  With a worker per element the stepper stays what it was: it polls while
+    // the others solve.  tools/runloop_bench.py, wall per iteration of a 30-iteration call: 43.0-43.9 us against 48.1-49.1.
+    static const bool dedicated = getenv("MUSE_DEBUG_LOOP_DEDICATED_STEPPER") != nullptr;   // tuning aid / tests: the layout before
+                                                                                            // (muse_debug_flags bit 7 likewise)
+    bool solving = !dedicated && !(c->debug & 128) && (int64_t)nworkers < nprob;
+    if (getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) { nworkers = (int)nprob; solving = false; }   // test hook: more workgroups than can be resident at once
+    if (solving) ++nworkers;   // (the stepper's slot)
+    const int grid = solving ? nworkers : nworkers + 1;
     shape.grid = grid;
     a.scratch_stride = place_scratch_vectors(pl) * c->ld;
     rc = ensure_scratch(c, (size_t)grid * a.scratch_stride);
@@ -1563,6 +1573,12 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     l.theta_out = r.theta_out;
     l.status = r.status;
     l.nprob_total = (int)nprob_total;
+    l.stepper_solves = solving ? 1 : 0;
+    {   // workgroup w owns elements first + k * nworkers < nprob, first = w (+ 1 when the data element is the stepper's)
+        const int64_t dealt = nprob - ((solving && include_data && (c->debug & 64)) ? 1 : 0);   // (debug bit 6, a tuning aid: the data element is the stepper's)
+        l.deal_q = (int)(dealt / nworkers);
+        l.deal_r = (int)(dealt % nworkers);
+    }
     l.theta_gran = r.gran + (size_t)2 * nt * nprob_total;   // (behind the score granules of an unsharded loop)
     if (sh) {
         l.board = 1;

@@ -191,8 +191,13 @@ MUSE_HD void step_component(const StepParams& sp, int k, const double* theta, co
         w.gprior[k] = -(theta[k] - sp.prior_mean[k]) / sg2;
         w.hprior[k] = -1.0 / sg2;
     } else {
-        w.gprior[k] = 0.0;
-        w.hprior[k] = 0.0;
+        double zero = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(zero));   // (the loop kernel: else the 64-bit zero is formed before the stepper's loop and held -- in scratch --
+                                         //  across the stepper's own solves; the same bits either way)
+#endif
+        w.gprior[k] = zero;
+        w.hprior[k] = zero;
     }
     h[k] = theta[k];
     h[nt + k] = g_dat[k];                         // g_like_dat

@@ -134,13 +134,20 @@ def central_fdm(p, q, adapt=1, condition=10.0, factor=1.0, max_range=math.inf):
     return FiniteDifferenceMethod(_central_grid(int(p)), q, adapt=adapt, condition=condition, factor=factor, max_range=max_range)
 
 
+@functools.lru_cache(maxsize=64)
+def _from_spelling(spec):
+    """(a method holds no state that its calls change: one instance per spelling serves every get_H!)"""
+    import re
+    m = re.fullmatch(r"\s*central_fdm\(\s*(\d+)\s*,\s*(\d+)\s*\)\s*", spec)
+    return central_fdm(int(m.group(1)), int(m.group(2))) if m else None
+
+
 def as_fdm(spec):
     """A FiniteDifferenceMethod from an instance or from the spelling "central_fdm(p,q)"."""
     if isinstance(spec, FiniteDifferenceMethod):
         return spec
     if isinstance(spec, str):
-        import re
-        m = re.fullmatch(r"\s*central_fdm\(\s*(\d+)\s*,\s*(\d+)\s*\)\s*", spec)
-        if m:
-            return central_fdm(int(m.group(1)), int(m.group(2)))
+        m = _from_spelling(spec)
+        if m is not None:
+            return m
     raise ValueError(f"fdm must be a FiniteDifferenceMethod or 'central_fdm(p,q)', got {spec!r}")

@@ -174,6 +174,28 @@ def test_device_resident_muse_loop_equals_host_loop(gpu, M, O, model, N, nth, ns
     ref.close()
 
 
+@pytest.mark.parametrize("model,N,nth,nsims", [
+    ("funnel", 10000, 1, 512), ("funnel", 10000, 1, 255), ("funnel", 10000, 1, 256), ("funnel", 9999, 1, 700), ("noise", 10000, 1, 515),
+    ("funnel", 10000, 3, 530), ("funnel", 3000, 4, 1100), ("funnel", 512, 2, 1300)])
+def test_loop_kernel_layouts_change_no_bit(gpu, M, O, model, N, nth, nsims):
+    """Round 5: with more elements than workgroups the loop kernel's stepper solves elements too -- the last in the deal: it has the
+    fewest -- and sweeps the scores when its own are done.  Which workgroup solves an element changes no bit: the layouts
+    (muse_debug_flags bit 6: the data element is the stepper's own; bit 7: a stepper that only steps, the layout before) and the host
+    loop return the same history, scores and solver records."""
+    xdata, _ = O.sample_x_z(model, N, 3, M.DATA_SIM, np.zeros(nth))
+    prob = M.HipMuseProblem(xdata, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+    th0 = np.linspace(0.8, 0.2, nth)
+    kw = dict(nsims=nsims, maxsteps=5, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+    want = prob.run_muse(4, th0, device_loop=False, **kw)
+    for flags in (0, 64, 128, 0):
+        assert prob._lib.muse_debug_flags(prob._ctx, flags) == 0
+        got = prob.run_muse(4, th0, device_loop=True, **kw)
+        assert got[0] == want[0] == 5 and np.array_equal(got[1], want[1]) and np.array_equal(got[2][:, :-1], want[2][:, :-1])
+        assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4]), flags
+    assert prob._lib.muse_debug_flags(prob._ctx, 0) == 0
+    prob.close()
+
+
 def test_device_loop_reports_errors_like_the_host_loop(gpu, M):
     """A step that cannot be taken ends both loops with the same error: a NaN theta makes every score NaN, the score
     variance NaN and H^-1_like' singular (the device loop's step kernel raises its stop flag, the launches already

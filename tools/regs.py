@@ -49,10 +49,13 @@ HOT_LOOP = [
     ("NoiseModel, PlaceResident<512, 10, true>", 0),
     # (the multi-component counts move by a few registers with any change of the surrounding source -- 0-3, 22-25, 33-36, 36-40 over
     #  this round's builds: the limits leave that much room and no more)
-    ("FunnelModel<2>, PlaceResident<512, 10, true>", 6),
-    ("FunnelModel<4>, PlaceResident<512, 10, true>", 30),
-    ("FunnelModel<1>, PlaceResident<512, 4, false>", 44),
-    ("FunnelModel<4>, PlaceResident<512, 4, false>", 48),
+    # (with the stepper's own copy of the solve -- a stepper that owns elements, later in round 5 -- the one-component kernels stay at 0
+    #  and the others went up by 10-17: 4, 35, 55, 65; tools/loop_vs_host.py, the loop kernel against the host loop per iteration of a
+    #  30-iteration call, 512 sims: N = 10^4 x 4: 69.4 / 66.7 us wall, 60.1 / 59.7 steady; N = 4096 x 4: 52.6 / 61.3 wall)
+    ("FunnelModel<2>, PlaceResident<512, 10, true>", 8),
+    ("FunnelModel<4>, PlaceResident<512, 10, true>", 40),
+    ("FunnelModel<1>, PlaceResident<512, 4, false>", 60),
+    ("FunnelModel<4>, PlaceResident<512, 4, false>", 70),
 ]
 
 
