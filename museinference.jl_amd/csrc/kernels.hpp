@@ -264,7 +264,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
     const bool stepper = (int)blockIdx.x == stepper_id;
     Prefetch<Place::EPT> pf;
     pf.p = -1;
-    pf.have_n1 = pf.have_n2 = pf.have_x = pf.g_pending = false;
+    pf.have_n1 = pf.have_n2 = pf.have_x = pf.have_xg = pf.g_pending = false;
     typename Place::VZ zkeep;   // the MAP of the worker's last solve, carried in registers into the next iteration (see below)
     zkeep.clear();
     typedef __attribute__((address_space(1))) unsigned long long gu64;

@@ -852,7 +852,7 @@ int muse_set_timing(muse_ctx* c, int enabled) {
     return MUSE_OK;
 }
 // bits: 0 skip the solve, 1 x from the data vector, 2 the loop kernel does not prefetch, 3 its old element order, 4 test hook (odd workers
-// leave), 5 no speculating trials, 6 a solving stepper takes the data element for itself, 7 the stepper never solves
+// leave), 5 no speculating trials, 6 a solving stepper takes the data element for itself, 7 the stepper never solves, 8 the data vector does not travel through the g area
 int muse_debug_flags(muse_ctx* c, int flags) {  // not part of the public header: profiling aid
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     c->debug = flags;

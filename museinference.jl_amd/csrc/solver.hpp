@@ -22,6 +22,7 @@ struct Prefetch {
     bool have_n1;   // the g area holds the normals n1 of a simulation (X_SAMPLE with a cache slot)
     bool have_n2;   // the x area holds its n2
     bool have_x;    // the x area holds the data vector (X_DATA)
+    bool have_xg;   // the g area holds the data vector: sent there while another problem was being solved (begin() moves it over)
     bool g_pending; // n1 was sent to the g area while another problem is being solved: a solve that comes to need g
                     // (a second L-BFGS iteration) waits for the loads to land and drops the prefetch (Solver::drop_g_prefetch)
 };
@@ -47,11 +48,12 @@ __device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int 
     pf.have_n1 = sim;
     pf.have_n2 = sim && both;
     pf.have_x = d.x_mode == X_DATA && both;
-    pf.g_pending = sim && !both;
+    pf.have_xg = d.x_mode == X_DATA && !both && !(a.debug & 256);   // (debug bit 8, a tuning aid: the data vector is not sent ahead)
+    pf.g_pending = (sim || pf.have_xg) && !both;
     int tl = tid;
     asm volatile("" : "+v"(tl));
     const double* src_x = sim ? a.ncache + (int64_t)(2 * d.nslot + 1) * ld : a.x_data;   // n2, or the data
-    const double* src_g = a.ncache + (int64_t)(2 * d.nslot) * ld;                         // n1
+    const double* src_g = pf.have_xg ? a.x_data : a.ncache + (int64_t)(2 * d.nslot) * ld;   // n1 (or the data on its way through the g area)
     const int wave0 = __builtin_amdgcn_readfirstlane(tl) & ~63;   // the wave's first thread
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int 
         if (i0 < (int)ld) {   // (phantom pairs stay out of LDS: they would land beyond the vector)
             const int base = 2 * (wave0 + j * T);         // the wave's first element of this row: wave-uniform
             if (pf.have_n2 || pf.have_x) __builtin_amdgcn_global_load_lds((glds_src_t)(src_x + i0), (glds_dst_t)(lds_x + base), 16, 0, kNormalsAux);
-            if (pf.have_n1) __builtin_amdgcn_global_load_lds((glds_src_t)(src_g + i0), (glds_dst_t)(lds_g + base), 16, 0, kNormalsAux);
+            if (pf.have_n1 || pf.have_xg) __builtin_amdgcn_global_load_lds((glds_src_t)(src_g + i0), (glds_dst_t)(lds_g + base), 16, 0, kNormalsAux);
         }
     }
 }
@@ -1439,6 +1441,13 @@ struct Solver {
                 if (pf_hit && pf.have_x && d.x_mode == X_DATA && !z_zero) {   // the data vector is in the x area already, the warm start here
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA loads have landed
                     for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { z.set(jj, i, z0src.get(jj, i)); });
+                    done = true;
+                } else if (pf_hit && pf.have_xg && d.x_mode == X_DATA && !z_zero) {   // ... in the g area: it travelled during the previous solve
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
+                        x.set(jj, i, g.get(jj, i));
+                        z.set(jj, i, z0src.get(jj, i));
+                    });
                     done = true;
                 }
             }

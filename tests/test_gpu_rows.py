@@ -194,6 +194,16 @@ def test_loop_kernel_layouts_change_no_bit(gpu, M, O, model, N, nth, nsims):
         assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4]), flags
     assert prob._lib.muse_debug_flags(prob._ctx, 0) == 0
     prob.close()
+    # ... and a sharded loop's rank with more elements than workgroups (one rank in the communicator: its stepper reads the board)
+    if nsims in (512, 700):
+        shp = M.HipMuseProblem(xdata, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+        shp.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", (nsims + 1) * nth))
+        for flags in (0, 64, 128):
+            assert shp._lib.muse_debug_flags(shp._ctx, flags) == 0
+            got = shp.run_muse_sharded(4, th0, **kw)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2][:, :-1], want[2][:, :-1])
+            assert np.array_equal(got[3], want[3]), flags
+        shp.close()
 
 
 def test_device_loop_reports_errors_like_the_host_loop(gpu, M):

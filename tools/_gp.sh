@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r05u
-python -m pytest tests -m gpu -x -q > gpurun_out/r05u/pytest_gpu.log 2>&1
-python bench.py > gpurun_out/r05u/bench_default.json 2> gpurun_out/r05u/bench_default.err
-python tools/share_bench.py > gpurun_out/r05u/share_bench.log 2>&1
+mkdir -p gpurun_out/r05x
+python tools/loop_layouts.py > gpurun_out/r05x/layouts_1.log 2>&1
+python tools/loop_layouts.py 10000 512 2 > gpurun_out/r05x/layouts_2.log 2>&1
