@@ -29,7 +29,7 @@ o = out.astype(np.int64)
 if DEV:   # the loop kernel's own stamps of its last iteration (100 MHz clock -> us), relative to worker 0's iteration start
     lp = out_all[n:n + 3].astype(np.int64)
     t0 = lp[0, 0]
-    for nm, r in (("worker 0 (an element more)", lp[0]), ("a worker in the middle", lp[1]), ("the stepper", lp[2])):
+    for nm, r in (("workgroup 0 (an element more)", lp[0]), ("a worker in the middle", lp[1]), ("the stepper", lp[2])):
         print(f"  loop stamps, {nm:28s}: " + "  ".join(f"{k}:{(r[k] - t0) / 100.0:7.2f}" for k in range(6) if r[k] > 0),
               " [0 iteration start, 1 first problem done, 2 problems done, 3 prefetch issued, 4 theta received / sweep complete, 5 theta published]")
 st = o[:, :8]
@@ -61,8 +61,11 @@ for s0 in st[:, 0]:
     if k >= 0 and 0 < s0 - ends[k] < 20000: gaps.append(s0 - ends[k])
 if gaps: print("between two problems of a workgroup (end stamp -> next start stamp): median", np.median(gaps), "cycles over", len(gaps))
 if DEV:
-    nw = min(255, n)   # (workers of the loop kernel on a 256-CU part)
-    for wk in (0, 1, 100):
+    # (the workgroups that own elements on a 256-CU part: a worker per element and a stepper beside them, or -- more elements than
+    #  that -- all 256 with the stepper, the last one, among them; MUSE_LOOP_DEBUG=128: the stepper never solves)
+    dedicated = n <= 255 or (int(os.environ.get("MUSE_LOOP_DEBUG", "0")) & 128) or os.environ.get("MUSE_DEBUG_LOOP_DEDICATED_STEPPER")
+    nw = min(255, n) if dedicated else 256
+    for wk in (0, 1, 100) + (() if dedicated else (255,)):
         ps = [q for q in range(wk, n, nw)]
         print(f"  worker {wk}: problems {ps}: " + " | ".join(
             f"p{q}: begin {st[q,1]-st[q,0]} solve {st[q,6]-st[q,1]} total {st[q,7]-st[q,0]} (start +{st[q,0]-st[ps[0],0]})" for q in ps))
