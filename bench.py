@@ -649,7 +649,7 @@ def scale_projection(M, device, seed=0, ngpus=8):
         prob.close()
         out["cfg5_smooth_1e5"] = {"whole_job_ms": 1e3 * whole, "share_ms": 1e3 * part, "projected_speedup_at_8_gpus": whole / part,
                                   "sims_whole": nsims, "sims_share": share, "sims_per_s_whole": nsims / whole,
-                                  "bound": "HBM on both sides: 1024 and 128 sims are 64 and 8 rounds of the 16 clusters a GPU holds; the "
+                                  "bound": "HBM on both sides: 1024 and 128 sims are 32 and 4 rounds of the 32 clusters of 16 workgroups a GPU holds (two workgroups per compute unit); the "
                                            "exchange is one 8 KB hand-off per 2 ms map"}
     except Exception as e:  # noqa: BLE001
         out["cfg5_smooth_1e5"] = {"skipped": f"{type(e).__name__}: {e}"}
