@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects
                 ALGORITHMIC work (operation counts per element from the source x the measured issue cost of each kind) /
                 (SIMDs x launch time x the clock measured inside the kernel) for the register/LDS resident placements, whose
                 vectors never leave the chip, with the VALU-active-counter utilisation (rocprofv3, profiles/) beside it.
-                Launch time = min(mean duration between HIP events on the launch stream, pipelined step).  Both objects are
+                Launch time = the pipelined step of the timed region (N = 1; `frac_kernel_time` is the same figure against the
+                kernel's own mean duration between HIP events on the launch stream).  Both objects are
                 always present (`roofline.hbm`, `roofline.valu`); SURVEY 8.d3's accounting figure is kept as
                 `algorithmic_bytes_d3` and is not a roofline.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: "port") timed on this box's
@@ -54,7 +55,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 78.6    # fp64 vector peak: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def algorithmic_bytes(info, N):
@@ -136,9 +137,9 @@ def algorithmic_valu(info, N, clock_hz):
 
 def roofline_object(workload, model, N, info, pinfo, kernel_ms, launch_s, clock_hz_measured, lanes, ms_per_launch_pipelined, prow_ok=True):
     """The `roofline` object of a launch of `workload`: the solver kernel against the bound that binds the placement it ran in
-    (module docstring).  launch_s: the time a launch is charged with -- its own duration between HIP events, unless the pipelined
-    step is shorter (the event pair costs a launch ~3 us, and with two lanes a launch's own duration includes waiting for the
-    compute units the launch before it still holds, while launches complete once per step)."""
+    (module docstring).  launch_s: the time a launch is charged with -- the pipelined step of the timed region at N = 1 (launches
+    complete once per step; with two lanes a launch's own duration between HIP events includes waiting for the compute units the
+    launch before it still holds, and the event pair itself costs ~3 us), the kernel's mean duration otherwise."""
     mean_kernel_s = float(kernel_ms.mean()) * 1e-3
     placement = "resident" if pinfo["resident"] else (("stencil_lds" if pinfo["direction_in_lds"] else "stencil")
                                                       if model == "smooth" else "streaming")
@@ -183,6 +184,13 @@ def roofline_object(workload, model, N, info, pinfo, kernel_ms, launch_s, clock_
         "lanes": lanes, "ms_per_launch_pipelined": ms_per_launch_pipelined,
         "kernel_ms_min": float(kernel_ms.min()), "launches_timed": int(kernel_ms.size),
         "algorithmic_bytes_d3": algorithmic_bytes(info, N),
+        # ONE definition of `frac` across rounds: the launch is charged with the PIPELINED step of the timed region (launches complete
+        # once per step; what rounds 3-5 reported in effect).  The same figure against the kernel's own mean duration between HIP events
+        # (with two lanes that includes waiting for the compute units the launch before still holds) is beside it, never mixed in.
+        "frac_definition": "pipelined step of the timed region" if abs(launch_s - mean_kernel_s) > 1e-12 else "mean kernel duration between HIP events",
+        "frac_kernel_time": (valu if (placement == "resident" and valu is not None) else hbm)["frac"] * launch_s / mean_kernel_s,
+        "hbm_frac": hbm["frac"],
+        "valu_util_frac": (valu or {}).get("utilisation", {}).get("frac"),
         "hbm": hbm, "valu": valu,
         "profile": f"profiles/{PROFILE_TAG}_summary.csv" if prow is not None else None,
         "profile_note": why,
@@ -369,10 +377,10 @@ def quick_workload(M, name, device, seconds=0.3, seed=0):
             clock_hz = None
         assert np.all(info["status"] == 0), "a MAP solve did not converge"
         pinfo = prob.placement_info()
-        launch_s = min(float(kernel_ms.mean()) * 1e-3, dt)
+        launch_s = dt   # the pipelined step (the headline's definition)
         roof = roofline_object(name, model, N, info, pinfo, kernel_ms, launch_s, clock_hz, lanes, 1e3 * dt)
         return {"ms_per_step": 1e3 * dt, "sims_per_s": nsims / dt, "steps_timed": K, "nsims": nsims, "N": N, "ntheta": nth,
-                "bound": roof["bound"], "frac": roof["frac"], "traffic": roof["traffic"], "achieved": roof["achieved"],
+                "bound": roof["bound"], "frac": roof["frac"], "frac_kernel_time": roof["frac_kernel_time"], "traffic": roof["traffic"], "achieved": roof["achieved"],
                 "unit": roof["unit"], "kernel_ms_mean": roof["kernel_ms_mean"], "lanes": lanes, "placement": roof["placement"],
                 "compulsory_bytes_per_launch": roof["hbm"]["compulsory_bytes_per_launch"], "profile": roof["profile"],
                 "per_sim": roof["per_sim"]}
@@ -417,23 +425,22 @@ def share_rates(M, xdata, model, nth, nsims, seed, device, whole_job_steady_us, 
             out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])),
                          "by_regime": iteration_regimes(hist, info)}
         prob.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
-        for name, env in (("sharded_loop_shm_1rank", {}), ("sharded_loop_host_board_shm_1rank", {"MUSE_DEBUG_HOST_BOARD": "1"}),
-                          ("sharded_host_loop_shm_1rank", {"MUSE_DEBUG_SHARDED_HOST_LOOP": "1"})):
+        P = M.HipMuseProblem
+        for name, flags in (("sharded_loop_shm_1rank", 0), ("sharded_loop_host_board_shm_1rank", P.DEBUG_HOST_BOARD),
+                            ("sharded_host_loop_shm_1rank", P.DEBUG_SHARDED_HOST_LOOP)):
             # the sharded loop as the library runs it -- ONE persistent launch per rank, the ranks' scores meeting on a board per GPU in
             # device memory that every rank maps (hipIpc; round 5) --, the same with the ONE board in pinned host memory (what runs where
             # the ranks cannot map each other's device memory), and the host-driven loop of round 4 (gathered map, step on the host)
-            for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+            prob.debug_flags(flags)
             best = float("inf")
             for _ in range(3):
                 t0 = time.perf_counter()
                 n, _, hist, _, info = prob.run_muse_sharded(seed, [1.0] * nth, **kw)
                 best = min(best, (time.perf_counter() - t0) / max(1, n))
             out[name] = {"us_per_outer_iteration_30": 1e6 * best, "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])),
-                         "by_regime": iteration_regimes(hist, info)}
-        for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
-            os.environ.pop(k, None)
+                         "by_regime": iteration_regimes(hist, info), "loop_ran": prob.comm_board_status()["last_loop"]}
+        prob.debug_flags(0)
+        out["board_handshake"] = prob.comm_board_status()
         prob.close()
         if whole_job_steady_us:
             out["projected_speedup_at_8_gpus"] = whole_job_steady_us / out["sharded_loop_shm_1rank"]["us_per_outer_iteration_steady"]
@@ -659,6 +666,218 @@ def scale_projection(M, device, seed=0, ngpus=8):
     return out
 
 
+def sharded_extras(M, torch, dist, args, world, rank, local_rank, tdev, seed=0):
+    """What the driver's N > 1 command (`bench.py --gpus N`, default arguments) times BESIDE the headline's independent maps, so that
+    the first run on more than one GPU measures what was built for it -- every rank calls this (collective), about 3 s in all:
+      muse_run   the DEPENDENT path: muse_run_sharded over the N ranks at configs[1] (30 iterations of src/muse.jl:159-232, the pmap of
+                 :169 over the ranks, src/util.jl:74-83): us per iteration, WHICH loop ran (persistent launch through the boards in device
+                 memory / the board in pinned host memory / host-driven), the verdict of the boards' set-up hand-shake, and a bit-compare of
+                 every rank's theta trajectory and scores with rank 0's UNSHARDED muse_run of the same job;
+      cfg4_fd_H  configs[3]: get_H! by finite differences (src/muse.jl:426-442), the (sim, column) list in N blocks + one exchange;
+      cfg5_smooth_1e5  configs[4]: the 1024-sim s/J map of the stencil model (src/muse.jl:508-525) in N blocks + one exchange.
+    --small (development aid; the multi-rank tests on ONE GPU): the same code at sizes eight processes can share a GPU with."""
+    out = {}
+    P = M.HipMuseProblem
+
+    def uid_for(block_doubles):
+        u = [P.comm_unique_id("shm", block_doubles) if rank == 0 else None]
+        dist.broadcast_object_list(u, src=0)
+        return u[0]
+
+    def tmax(x):
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def sync(prob):
+        prob.synchronize()
+        dist.barrier()
+
+    # ---- the dependent path: the sharded muse! loop at configs[1]
+    try:
+        model, N, nth, theta, nsims = WORKLOADS["funnel_1e4"]
+        if args.small:
+            nsims = 16 * world
+        smp = P(None, model=model, ntheta=nth, N=N, device=local_rank)
+        xdata, _ = smp.sample_x_z(M.SimRng(seed, M.DATA_SIM), [0.0] * nth)     # the same bits on every rank
+        smp.close()
+        prob = P(xdata, model=model, ntheta=nth, device=local_rank, prior=M.GaussianPrior(0.0, 3.0))
+        prob.comm_init(world, rank, uid_for(max(4096, (nsims + 1) * nth)))
+        seen = prob.comm_ranks_seen()
+        t0 = time.perf_counter()
+        hs = prob.comm_board_status()          # collective: maps the boards, proves each kind by the hand-shake
+        t_setup = tmax(time.perf_counter() - t0)
+        kw = dict(nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7)
+        runs = {}
+        for name, flags in (("default", 0), ("host_board", P.DEBUG_HOST_BOARD), ("host_loop", P.DEBUG_SHARDED_HOST_LOOP)):
+            prob.debug_flags(flags)
+            prob.run_muse_sharded(seed, [1.0] * nth, **kw)     # warm: buffers, the loop kernel's code object
+            best, res = float("inf"), None
+            for _ in range(3):
+                sync(prob)
+                t0 = time.perf_counter()
+                res = prob.run_muse_sharded(seed, [1.0] * nth, **kw)
+                best = min(best, tmax(time.perf_counter() - t0))
+            n, th, hist, gs, info = res
+            runs[name] = {"us_per_outer_iteration_30": 1e6 * best / max(1, n), "us_per_outer_iteration_steady": 1e6 * float(np.median(hist[5:, -1])) if n > 6 else None,
+                          "iterations": int(n), "loop_ran": prob.comm_board_status()["last_loop"], "by_regime": iteration_regimes(hist, info)}
+            if name == "default":
+                mine = (n, th.copy(), hist[:, :-1].copy(), gs.copy())
+        prob.debug_flags(0)
+        # rank 0's unsharded loop of the same job (one launch per iteration, the step on the host: muse_run) -> every rank compares
+        ref = [None]
+        if rank == 0:
+            one = P(xdata, model=model, ntheta=nth, device=local_rank, prior=M.GaussianPrior(0.0, 3.0))
+            n1, t1, h1, g1, _ = one.run_muse(seed, [1.0] * nth, device_loop=False, **kw)
+            one.close()
+            ref[0] = (n1, t1, h1[:, :-1].copy(), g1)
+        dist.broadcast_object_list(ref, src=0)
+        n1, t1, h1, g1 = ref[0]
+        same = mine[0] == n1 and np.array_equal(mine[1], t1) and np.array_equal(mine[2], h1) and np.array_equal(mine[3], g1)
+        prob.close()
+        out["muse_run"] = {"nsims": nsims, "N": N, "ranks_seen": seen, "board": hs["board"], "handshake": hs, "board_setup_ms": 1e3 * t_setup,
+                           "runs": runs, "trajectory_bit_equal_to_unsharded_on_every_rank": all_ok(same), "theta": [float(t) for t in t1],
+                           "note": "muse_run_sharded over the ranks of this job, 30 iterations driven past convergence (theta_rtol 1e-12); wall of "
+                                   "the call / iterations, MAX over ranks, best of three; `default` is what the library runs by itself, the other two "
+                                   "are the fall-backs forced by a debug flag; the compare is against rank 0's unsharded muse_run: theta per "
+                                   "iteration, every record, every simulation's score, bit for bit"}
+    except Exception as e:  # noqa: BLE001 -- an extra: never at the cost of the line (every rank fails or none: the calls are collective)
+        out["muse_run"] = {"skipped": f"{type(e).__name__}: {e}"}
+    # ---- configs[3]: get_H! by finite differences, sharded over the (sim, column) list
+    try:
+        w = dict(FD_WORKLOAD)
+        if args.small:
+            w["nsims"] = 8 * world
+        nunits = w["nsims"] * w["ntheta"]
+        prob = P(None, model=w["model"], ntheta=w["ntheta"], N=w["N"], device=local_rank)
+        lo, hi = M.block_partition(0, nunits, world, rank)
+        prob.comm_init(world, rank, uid_for(4096))
+
+        def call():
+            cols, info = prob.fd_jacobian_columns(seed, 0, lo, hi, w["theta"], w["step"])
+            prob.allgather_scores(np.pad(cols.reshape(-1), (0, (-(-nunits // world)) * w["ntheta"] - cols.size)))
+            return info
+        call()
+        K = 8
+        sync(prob)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            info = call()
+        sync(prob)
+        dt = tmax(time.perf_counter() - t0) / K
+        ok = all_ok(bool(np.all(info["status"] == 0)))
+        prob.close()
+        out["cfg4_fd_H"] = {"ms_per_call": 1e3 * dt, "problems_per_call": 2 * nunits + 1, "maps_per_s": (2 * nunits + 1) / dt, "converged_on_every_rank": ok,
+                            "units_per_rank": hi - lo, "nsims": w["nsims"]}
+    except Exception as e:  # noqa: BLE001
+        out["cfg4_fd_H"] = {"skipped": f"{type(e).__name__}: {e}"}
+    # ---- configs[4]: the stencil model's s/J map, sharded over the sims
+    try:
+        model, N, nth, theta, nsims = WORKLOADS["cfg5_smooth_1e5"]
+        if args.small:
+            N, nsims = 20000, 4 * world
+        lo, hi = M.block_partition(0, nsims, world, rank)
+        rows = -(-nsims // world)
+        prob = P(None, model=model, ntheta=nth, N=N, device=local_rank)
+        prob.set_normals_cache(False)
+        prob.comm_init(world, rank, uid_for(rows * nth))
+        outs = [(np.empty((world, rows, nth)), np.zeros(hi - lo, dtype=M._capi.INFO_DTYPE)) for _ in range(4)]
+
+        def steps(K):
+            pend, last = [], None
+            for k in range(K):
+                prob.map_and_score_batch_gather_async(seed, lo, hi, theta, rows, atol=1e-2, z0_mode=M.Z0_ZERO, result_area=k % 4)
+                pend.append(k % 4)
+                if len(pend) > 3:
+                    a = pend.pop(0)
+                    last = prob.batch_wait_gathered(hi - lo, rows, a, out=outs[a])
+            while pend:
+                a = pend.pop(0)
+                last = prob.batch_wait_gathered(hi - lo, rows, a, out=outs[a])
+            return last
+        steps(1)
+        K = 4
+        sync(prob)
+        t0 = time.perf_counter()
+        g_all, info = steps(K)
+        sync(prob)
+        dt = tmax(time.perf_counter() - t0) / K
+        ok = all_ok(bool(np.all(info["status"] == 0)))
+        prob.close()
+        out["cfg5_smooth_1e5"] = {"ms_per_step": 1e3 * dt, "sims_per_s": nsims / dt, "nsims": nsims, "N": N, "sims_per_rank": hi - lo,
+                                  "converged_on_every_rank": ok}
+    except Exception as e:  # noqa: BLE001
+        out["cfg5_smooth_1e5"] = {"skipped": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def flat_sharded(cfg, sh):
+    """The sharded extras as FLAT scalars of `config` (the driver's record keeps flat scalars of config / roofline only)."""
+    mr = sh.get("muse_run", {})
+    if "runs" in mr:
+        d = mr["runs"]["default"]
+        cfg.update({"sharded_muse_iter_us": d["us_per_outer_iteration_30"], "sharded_muse_iter_steady_us": d["us_per_outer_iteration_steady"],
+                    "sharded_loop_ran": d["loop_ran"], "sharded_board": mr["board"], "sharded_bit_equal": bool(mr["trajectory_bit_equal_to_unsharded_on_every_rank"]),
+                    "sharded_ranks_seen": mr["ranks_seen"], "handshake_device": mr["handshake"]["device_handshake"],
+                    "handshake_host": mr["handshake"]["host_handshake"], "handshake_device_wait_us": mr["handshake"]["device_wait_us"],
+                    "handshake_host_wait_us": mr["handshake"]["host_wait_us"], "board_setup_ms": mr["board_setup_ms"],
+                    "sharded_muse_iter_host_board_us": mr["runs"]["host_board"]["us_per_outer_iteration_30"],
+                    "sharded_muse_iter_host_loop_us": mr["runs"]["host_loop"]["us_per_outer_iteration_30"]})
+    else:
+        cfg["sharded_muse_skipped"] = mr.get("skipped", "not run")
+    for name, key in (("cfg4_fd_H", "ms_per_call"), ("cfg5_smooth_1e5", "ms_per_step")):
+        r = sh.get(name, {})
+        if key in r:
+            cfg[f"{name}_sharded_ms"] = r[key]
+            cfg[f"{name}_sharded_ok"] = bool(r["converged_on_every_rank"])
+        else:
+            cfg[f"{name}_sharded_skipped"] = r.get("skipped", "not run")
+
+
+def flat_single(out):
+    """The single-GPU extras as FLAT scalars of `config` / `roofline` (the driver's record keeps flat scalars of those two objects and
+    drops `extra`): one number per workload -- the pipelined two-lane step (one lane for the stencil model) --, the muse! iteration,
+    the 8-GPU share and the projections."""
+    x, cfg = out.get("extra", {}), out["config"]
+    for name, tag in (("funnel4_1e4", "funnel4"), ("noise_1e6", "noise_1e6"), ("smooth_1e5", "smooth_1e5")):
+        wl = x.get("workloads", {}).get(name, {})
+        if "ms_per_step" in wl:
+            cfg[f"{tag}_ms"], cfg[f"{tag}_frac"], cfg[f"{tag}_bound"] = wl["ms_per_step"], wl["frac"], wl["bound"]
+            cfg[f"{tag}_frac_kernel_time"] = wl["frac_kernel_time"]
+    mr = x.get("muse_run", {})
+    if "us_per_outer_iteration_30" in mr:
+        cfg["muse_iter_us"] = mr["us_per_outer_iteration_30"]
+        cfg["muse_iter_steady_us"] = mr["us_per_outer_iteration_steady"]
+        cfg["muse_iter_host_loop_us"] = mr["us_per_outer_iteration_30_host_loop"]
+        for reg, v in mr.get("by_regime", {}).items():
+            cfg[f"muse_iter_{reg}_us"] = v["us_per_outer_iteration"]
+        cfg["muse_full_run_ms"] = 1e3 * mr["wall_s"]
+    sh = x.get("muse_run_8gpu_share", {})
+    if "sharded_loop_shm_1rank" in sh:
+        cfg["share_iter_us"] = sh["sharded_loop_shm_1rank"]["us_per_outer_iteration_steady"]
+        cfg["share_iter_30_us"] = sh["sharded_loop_shm_1rank"]["us_per_outer_iteration_30"]
+        cfg["proj_muse"] = sh.get("projected_speedup_at_8_gpus")
+        for reg, v in sh.get("projected_by_regime", {}).items():
+            cfg[f"proj_muse_{reg}"] = v["projected_speedup_at_8_gpus"]
+        hs = sh.get("board_handshake", {})
+        if hs:
+            cfg["handshake_device"], cfg["handshake_host"], cfg["sharded_board"] = hs["device_handshake"], hs["host_handshake"], hs["board"]
+    sp = x.get("scale_projection", {})
+    for name, tag in (("cfg4_fd_H", "cfg4"), ("cfg5_smooth_1e5", "cfg5")):
+        if "projected_speedup_at_8_gpus" in sp.get(name, {}):
+            cfg[f"proj_{tag}"] = sp[name]["projected_speedup_at_8_gpus"]
+            cfg[f"{tag}_whole_ms"], cfg[f"{tag}_share_ms"] = sp[name]["whole_job_ms"], sp[name]["share_ms"]
+    if "muse_map_warm_us_per_step" in x:
+        cfg["muse_map_warm_us"] = x["muse_map_warm_us_per_step"]
+    if "get_H_fd_configs3" in x:
+        cfg["get_H_fd_cfg4_ms"] = x["get_H_fd_configs3"]["ms_per_call"]
+
+
 def user_model_rates(M, device, N=10000, nsims=512):
     """User-supplied models (include/muse_model.h; the closures of SimpleMuseProblem, src/simple.jl:79-95, as a compiled header)
     at the headline shape, pipelined over the result areas and two lanes like the timed loop: the built-in funnel written as a
@@ -712,7 +931,9 @@ def main_fd(args, M, torch, dist, world, rank, local_rank, sharded, tdev):
     """--workload cfg4_fd_H: BASELINE.json configs[3], get_H! by finite differences (src/muse.jl:407-446), 512 sims x 4 theta.  A step
     is ONE call: the rank's block of the flattened (sim, column) list (muse_fd_jacobian_columns) and, with N > 1, the exchange of
     the column blocks through the engine's shared-memory communicator.  The unit of `value` is one MAP+score problem."""
-    w = FD_WORKLOAD
+    w = dict(FD_WORKLOAD)
+    if args.nsims > 0:
+        w["nsims"] = args.nsims   # development aid (the eight-rank test on one GPU)
     nth, N, seed = w["ntheta"], w["N"], 0
     nunits = w["nsims"] * nth
     prob = M.HipMuseProblem(None, model=w["model"], ntheta=nth, N=N, device=local_rank)
@@ -817,7 +1038,9 @@ def parse_args(argv=None):
     ap.add_argument("--nsims", type=int, default=0, help="development aid: sims per step instead of the workload's own "
                     "(e.g. 64 = one rank's share of the strongly scaled 8-GPU step, on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed muse!/get_H! rates")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed muse!/get_H! rates (N = 1) / the sharded muse! loop, configs[3] "
+                    "and configs[4] beside the headline (N > 1)")
+    ap.add_argument("--small", action="store_true", help="development aid: the N > 1 extras at sizes that eight processes can share ONE GPU with")
     return ap.parse_args(argv)
 
 
@@ -1173,7 +1396,7 @@ def main():
             "dt", "rounds", "host_us", "kernel_ms", "info", "split", "collective", "pinfo"))
 
         prow_ok = world == 1 and split == 1 and not sharded
-        launch_s = min(float(kernel_ms.mean()) * 1e-3, dt / best["launches"]) if world == 1 else float(kernel_ms.mean()) * 1e-3
+        launch_s = dt / best["launches"] if world == 1 else float(kernel_ms.mean()) * 1e-3
         primary = roofline_object(args.workload, model, N, info, pinfo, kernel_ms, launch_s, best["clock_hz"], lanes,
                                   1e3 * dt / best["launches"], prow_ok)
 
@@ -1264,9 +1487,16 @@ def main():
                 out["extra"]["user_model"] = user_model_rates(M, local_rank)
             except Exception as e:  # an extra: never at the cost of the line
                 out["extra"]["user_model"] = {"skipped": f"{type(e).__name__}: {e}"}
+        flat_single(out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, N, theta, seed)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if sharded and not args.no_extra and args.workload == "funnel_1e4":
+        # beside the headline's independent maps: the dependent path and the two workloads BASELINE.json puts on 8 GPUs, over THESE ranks
+        prob.close()
+        sh = sharded_extras(M, torch, dist, args, world, rank, local_rank, tdev)
+        out["sharded"] = sh
+        flat_sharded(out["config"], sh)
     if sharded:
         prob.close()
         dist.destroy_process_group()

@@ -176,6 +176,21 @@ int muse_profile_end(muse_ctx* ctx, float* ms_out, int cap, int* count);
  * shader-cycle counter and the constant 100 MHz counter at its entry and exit (no stamp executes otherwise). */
 int muse_profile_clock_hz(muse_ctx* ctx, double* hz_out);
 
+/* ---- diagnostics ------------------------------------------------------------------------------------------------------------
+ * Not needed by a caller of the reference's interface; declared because tests and the tuning tools use them and the library
+ * exports exactly what this header declares.
+ * muse_debug_flags: switches of a LIVE context (the environment switches of csrc/switches.hpp are read once, by muse_ctx_create).
+ * No bit changes a result (tests hold the alternatives bit-equal).  Kernel side: 1 x from the data vector; 2 the loop kernel does
+ * not fetch ahead; 3 its old element order; 4 test hook: odd workers leave before their first solve; 5 no speculating trials;
+ * 6 a solving stepper takes the data element itself; 7 the stepper never solves; 8 the data vector is not sent ahead.  Host side:
+ * 16 muse_run_sharded's scores meet on the board in pinned host memory; 17 muse_run_sharded runs the host-driven loop;
+ * 18 test hook: a loop launch with more workgroups than can be resident at once; 19 the native loops say on stderr which loop
+ * ran and what it cost.  (Bit 0, "skip the solve", is for timing the launch shell only: results are then meaningless.)
+ * muse_debug_stamps: a library built with -DMUSE_STAMPS records s_memtime stamps per problem (tools/stamps.py); out == NULL arms
+ * a buffer for nproblems problems, otherwise [nproblems][16] stamps are copied out.  The product build records none. */
+int muse_debug_flags(muse_ctx* ctx, int flags);
+int muse_debug_stamps(muse_ctx* ctx, int64_t nproblems, unsigned long long* out);
+
 /* ---- per-simulation operators (the AbstractMuseProblem interface, src/interface.jl:4-186) ----- */
 /* sample_x_z(prob, rng, theta) -> (;x, z)                       src/interface.jl:92-99, src/simple.jl:95 */
 int muse_sample_x_z(muse_ctx* ctx, uint64_t seed, int64_t sim, const double* theta, double* x_out,
@@ -374,6 +389,27 @@ int muse_batch_wait_gathered(muse_ctx* ctx, int result_area, double* g_all_out, 
  * host-driven loop, the same bits. */
 int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* opt, int32_t* niter_out,
                      double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
+/* The score boards of muse_run_sharded's persistent loop, decided at SET-UP (round 6): a COLLECTIVE call of a shared-memory
+ * communicator -- every rank makes it, or the first muse_run_sharded call makes it for them.  After the ranks have mapped each
+ * other's boards, a one-wavefront kernel per rank stores a tagged granule into every peer's board -- with the very store the loop
+ * kernel's workers use -- and polls its own board for every peer's tag -- with the stepper's load -- for at most a few
+ * milliseconds (MUSE_BOARD_HANDSHAKE_MS, default 50).  A rank that did not see every peer makes ALL ranks drop that board: a
+ * cross-GPU visibility failure costs milliseconds here instead of a bounded wait inside the first user call.  The boards in
+ * device memory are tried first, then the one in pinned host memory; with neither the loop is host-driven (the same bits).
+ *   status_out[0]  the board the persistent loop will use: MUSE_BOARD_NONE / _HOST / _DEVICE
+ *   status_out[1]  hand-shake of the device boards:  1 every rank saw every peer, 0 some rank did not, -1 not tried (no hipIpc
+ *                  mapping, more than 8 ranks, switched off)
+ *   status_out[2]  hand-shake of the host board, likewise
+ *   status_out[3]  peers THIS rank saw on the device boards, as a bit mask (bit q: rank q)
+ *   status_out[4]  ... on the host board
+ *   status_out[5]  what the last muse_run_sharded call of this context ran: MUSE_BOARD_NONE (host-driven loop, or no call yet),
+ *                  _HOST, _DEVICE
+ *   wait_us_out[0..1]  how long this rank's hand-shake kernel polled until its last peer's granule landed (device boards, host
+ *                  board; microseconds by the GPU's 100 MHz counter; the bound when it expired; 0 when not tried) */
+#define MUSE_BOARD_NONE 0
+#define MUSE_BOARD_HOST 1
+#define MUSE_BOARD_DEVICE 2
+int muse_comm_board_status(muse_ctx* ctx, int status_out[6], double wait_us_out[2]);
 /* The sharded form of muse_map_and_score_multi_async: this rank's block of `nmaps` maps in one launch, one exchange for
  * all of them.  The gathered block is [nranks][nmaps][rows_per_rank][ntheta]; info_out [nmaps][n]. */
 int muse_map_and_score_multi_gather_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end,

@@ -11,6 +11,7 @@ using MuseInference: AbstractMuseProblem, MuseResult, UnTransformedθ, Transform
 import MuseInference: sample_x_z, logLike_and_∇z_logLike, ∇θ_logLike, ẑ_at_θ, logPriorθ, standardizeθ,
                       muse!, get_J!, get_H!, finalize_result!
 using Random, Statistics, LinearAlgebra
+using Dates: Millisecond
 
 const libmuse_hip = get(ENV, "LIBMUSE_HIP", "libmuse_hip.so")
 # :user = the model of a library built from a user's header (include/muse_model.h: the closures of SimpleMuseProblem,
@@ -115,9 +116,11 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
         # native_prior = (kind, mean, sigma), kind 0 flat / 1 independent Gaussian): the whole loop runs in the library --
         # muse_run_device, ONE persistent launch for every iteration; it falls back to muse_run (one launch per iteration)
         # by itself where the loop kernel does not apply.  Same bits either way, and the same as the loop below.
-        kind, mean, sigma = native_prior
-        θ, hist, gs = muse_run_device(prob, seed, θ; nsims, maxsteps, θ_rtol, ∇z_logLike_atol, α, prior_kind=kind,
-                                      prior_mean=mean, prior_sigma=sigma)
+        # (names that shadow nothing: an `if` block opens no scope in Julia, so `mean = ...` here would make Statistics.mean a
+        #  function-wide local and break the loop below)
+        pkind, pmean, psigma = native_prior
+        θ, hist, gs = muse_run_device(prob, seed, θ; nsims, maxsteps, θ_rtol, ∇z_logLike_atol, α, prior_kind=pkind,
+                                      prior_mean=pmean, prior_sigma=psigma)
         nθ = prob.nθ
         for i in 1:size(hist, 2)          # MUSE_RUN_HIST record -> the reference's history record (src/muse.jl:211-221)
             h = hist[:, i]
@@ -131,6 +134,7 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
         end
         result.θ = θ
         result.gs = history[end].g_like_sims
+        result.time += Millisecond(round(Int, 1e3 * sum(hist[end, :])))   # src/muse.jl:232 (the record's t is in seconds)
         if get_covariance
             get_J!(result, prob; rng=seed, nsims, ∇z_logLike_atol)
             get_H!(result, prob; rng=seed, nsims=max(1, nsims ÷ 10), ∇z_logLike_atol)
@@ -146,7 +150,7 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
         t₀ = time()
         gs, infos = map_and_score_batch(prob, seed, 0:nsims-1, θ; include_data=true, atol=∇z_logLike_atol, z0_mode)
         g_like_dat, g_like_sims = gs[1], gs[2:end]
-        g_like′ = g_like_dat .- mean(g_like_sims)
+        g_like′ = g_like_dat .- Statistics.mean(g_like_sims)
         g_prior′ = MuseInference.AD.gradient(MuseInference.AD.ForwardDiffBackend(), θ -> logPriorθ(prob, θ), θ)[1]
         g_post′ = g_like′ .+ g_prior′
         H⁻¹_like′ = Diagonal(-1 ./ var(g_like_sims))
@@ -161,12 +165,22 @@ function muse!(result::MuseResult, prob::HipMuseProblem, θ₀=nothing; rng=noth
         θ = θ .- α .* (H⁻¹_post′ * g_post′)
         result.θ = θ
         result.gs = g_like_sims
+        result.time += Millisecond(round(Int, 1e3 * history[end].t))      # src/muse.jl:232
     end
     if get_covariance
         get_J!(result, prob; rng=seed, nsims, ∇z_logLike_atol)
         get_H!(result, prob; rng=seed, nsims=max(1, nsims ÷ 10), ∇z_logLike_atol)
     end
     result
+end
+
+# The score boards of muse_run_sharded's persistent loop (include/muse_hip.h: muse_comm_board_status) -- COLLECTIVE over a
+# shared-memory communicator the first time it is called: (board, device_handshake, host_handshake, device_seen, host_seen,
+# last_loop, wait_us) with board / last_loop 0 none, 1 pinned host memory, 2 device memory (hipIpc).
+function comm_board_status(prob::HipMuseProblem)
+    st = Vector{Cint}(undef, 6); w = Vector{Float64}(undef, 2)
+    check(ccall((:muse_comm_board_status, libmuse_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Float64}), prob.ctx, st, w))
+    (; board=st[1], device_handshake=st[2], host_handshake=st[3], device_seen=st[4], host_seen=st[5], last_loop=st[6], wait_us=w)
 end
 
 # Workgroups per map element (include/muse_hip.h: muse_set_element_split) -- for launches with fewer elements than

@@ -98,6 +98,9 @@ SIGNATURES = {
     "muse_allreduce_sum": (_i, [_vp, _vp, _i64]),
     "muse_map_and_score_batch_gather_async": (_i, [_vp, _u64, _i64, _i64, _i, _vp, _d, _i, _i64, _i]),
     "muse_batch_wait_gathered": (_i, [_vp, _i, _vp, _vp]),
+    "muse_comm_board_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
+    "muse_debug_flags": (_i, [_vp, _i]),
+    "muse_debug_stamps": (_i, [_vp, _i64, _vp]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@ OBJ_DIR = os.path.join(_HERE, "build")
 _API = os.path.join(_HERE, "..", "include", "muse_hip.h")
 _KERNEL_HEADERS = [os.path.join(CSRC, h) for h in ("rng.hpp", "args.hpp", "vec.hpp", "reduce.hpp", "models.hpp", "user_model.hpp", "solver.hpp",
                                                     "step.hpp", "kernels.hpp")]
+_SWITCHES = os.path.join(CSRC, "switches.hpp")
 # source -> (headers it depends on, extra flags)
 # -ffp-contract=off: the sampler's log/sincos sequences and the model gradients are defined in terms
 # of individually rounded IEEE operations (bit-equal to a host evaluation of the same sequence).
@@ -31,15 +32,22 @@ UNITS = {
     **{f"kernels_part{n}": ("kernels_part.hip", _KERNEL_HEADERS + [_API], _DEVICE_FLAGS + [f"-DMUSE_PART={n}"]) for n in range(KERNEL_PARTS)},
     # host code: plain C++ against the HIP runtime API (no device pass)
     # (-ffp-contract=off here too: step.hpp's algebra must round on the host exactly as in the step kernel)
-    "muse_engine": ("muse_engine.cpp", [os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), os.path.join(CSRC, "user_model.hpp"), _API],
+    "muse_engine": ("muse_engine.cpp", [os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), os.path.join(CSRC, "user_model.hpp"), _SWITCHES, _API],
                         ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
     # (step.hpp's algebra again: the sharded muse! loop takes the same step as muse_run)
-    "muse_comm": ("muse_comm.cpp", [_API, os.path.join(CSRC, "shm_gather.hpp"), os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp")],
+    "muse_comm": ("muse_comm.cpp", [_API, os.path.join(CSRC, "shm_gather.hpp"), os.path.join(CSRC, "args.hpp"), os.path.join(CSRC, "step.hpp"), _SWITCHES],
                       ["-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-O2", "-ffp-contract=off"]),
 }
 COMMON_FLAGS = ["-std=c++17", "-fPIC", "-Wno-unused-value"]
 SOURCES = sorted({os.path.join(CSRC, u[0]) for u in UNITS.values()})
-HEADERS = _KERNEL_HEADERS + [_API, os.path.join(CSRC, "shm_gather.hpp")]
+HEADERS = _KERNEL_HEADERS + [_API, os.path.join(CSRC, "shm_gather.hpp"), _SWITCHES]
+
+
+def declared_symbols():
+    """The entry points include/muse_hip.h declares (comments stripped): the library's export list."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", open(_API).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(muse_[a-z_A-Z0-9]+)\s*\(", text)))
 
 
 def _stale(target, deps):
@@ -110,7 +118,12 @@ def build_extension(force=False, verbose=False, defines=(), lib_path=None):
                 q.kill()
             raise subprocess.CalledProcessError(p.returncode, cmd)
     tmp = lib_path + ".tmp"
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-ldl", "-lrt", "-lpthread"]
+    # the library exports exactly what include/muse_hip.h declares: a linker version script written from the header (the accessors
+    # between muse_engine.cpp and muse_comm.cpp, the kernels' host stubs and the C++ runtime's weak symbols stay local)
+    vmap = os.path.join(obj_dir, "exports.map")
+    with open(vmap, "w") as f:
+        f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in declared_symbols()) + "  local: *;\n};\n")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-ldl", "-lrt", "-lpthread", f"-Wl,--version-script={vmap}"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=CSRC)

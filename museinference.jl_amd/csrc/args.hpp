@@ -143,6 +143,15 @@ struct BatchArgs {
                                    //  rank's GPU maps -- and gran_sys = 1: the stores are system-scope)
     unsigned int gran_tag;         // this iteration's tag
     int gran_sys;
+    // BATCH_FD with the fiducial MAP folded into the launch (round 6; muse_engine.cpp, fd_values_impl): problem 0 is the ONE fiducial
+    // MAP of src/muse.jl:417-423 (simulation fid_sim at theta0 from zero(z), stored to slot fid_slot), problems 1.. are the
+    // perturbed ones; each of those draws its x -- which does not need the fiducial -- and then waits for fid_flag to carry
+    // fid_tag before it loads its warm start (the fiducial's workgroup releases its stores and sets the flag: solver.hpp, run)
+    int fd_fold;
+    unsigned int fid_tag;
+    int64_t fid_sim;
+    unsigned int* fid_flag;
+    int64_t pad3_;
     union {  // read from the kernarg segment only (never copied to LDS)
         alignas(16) MapTheta maps[kMaxMaps];  // theta of every map, nmaps > 1
         BigTheta big;                         // ntheta > kMaxTheta
@@ -168,6 +177,8 @@ static_assert(sizeof(BatchArgs) <= 4096, "kernarg segment");
 struct ProblemDesc {
     int64_t sim;
     int64_t row;       // row of the element's score in the output block
+    int64_t irow;      // ... of its solver info (the problem's index, but for a finite-difference launch that carries its fiducial)
+    bool is_fid, wait_fid;   // BATCH_FD with fd_fold: the fiducial problem / a problem that starts from the fiducial MAP of this launch
     int nslot;         // slot of the simulation's normals in the cache, -1: none
     bool normals_only;
     int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
@@ -179,6 +190,8 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     ProblemDesc d;
     d.normals_only = false;
     d.row = p;
+    d.irow = p;
+    d.is_fid = d.wait_fid = false;
     if (a.kind == BATCH_STD && a.nmaps > 1) {  // several independent maps in one launch: slots and infos by p, scores by (map, element)
         const int m = p / a.n_per_map, e = p - m * a.n_per_map;
         const bool data = a.include_data && e == 0;
@@ -205,7 +218,21 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.tsample = -1;
         d.zslot = a.store_zhat ? a.slot0 + p : -1;
         d.z0slot = a.slot0 + p;
+    } else if (a.kind == BATCH_FD && a.fd_fold && p == 0) {   // the launch's own fiducial MAP: results behind the perturbed problems'
+        d.sim = a.fid_sim;
+        d.x_mode = X_SAMPLE;
+        d.z0_mode = Z0_ZERO;
+        d.tsample = -1;
+        d.zslot = a.fid_slot;
+        d.z0slot = a.fid_slot;
+        d.row = d.irow = a.nproblems - 1;
+        d.is_fid = true;
     } else if (a.kind == BATCH_FD) {
+        if (a.fd_fold) {
+            p -= 1;
+            d.row = d.irow = p;
+            d.wait_fid = true;
+        }
         const int per = a.fd_grid * a.ntheta, pp = p + a.p0;
         d.sim = a.sim_begin + pp / per;
         d.x_mode = X_SAMPLE;

@@ -27,6 +27,7 @@
 #include "../../include/muse_hip.h"
 #include "shm_gather.hpp"
 #include "step.hpp"
+#include "switches.hpp"
 
 // Minimal slice of the public RCCL/NCCL C API (rccl.h: ncclGetUniqueId, ncclCommInitRank,
 // ncclAllGather, ncclAllReduce, ncclCommDestroy).
@@ -73,6 +74,14 @@ struct CommState {
     unsigned long long* ipc_own = nullptr;
     void* ipc_peers[8] = {nullptr};   // [rank]: the peer's board as mapped here (own: ipc_own)
     bool ipc_ok = false, ipc_tried = false;
+    // the set-up hand-shake of the boards (setup_boards; muse_comm_board_status): 1 every rank saw every peer, 0 some rank did not,
+    // -1 not tried; the ranks THIS rank saw; how long its hand-shake kernel polled; what the last muse_run_sharded call ran
+    int hs_dev = -1, hs_host = -1;
+    unsigned long long hs_mask_dev = 0, hs_mask_host = 0;
+    double hs_wait_us[2] = {0.0, 0.0};
+    int last_loop = MUSE_BOARD_NONE;
+    unsigned int* hs_result = nullptr;   // pinned: the hand-shake kernel's {mask lo, mask hi, ticks}
+    const muse::Switches* sw = nullptr;  // the context's environment switches (switches.hpp: read once, by muse_ctx_create)
     bool dev_loop_off = false;       // the device loop failed once on some rank (a shared GPU): host loop from then on, on every rank
     uint64_t seq[kAreas + 1] = {0};   // sequence number of the last exchange per area (the same on every rank)
     size_t nlocal[kAreas] = {0};      // doubles this rank's solver produced PER MAP for the gather in flight
@@ -137,12 +146,17 @@ int muse_ctx_area_event(muse_ctx* ctx, int area, void** event, int* ntheta);
 int muse_internal_map_async(muse_ctx* ctx, uint64_t seed, int64_t sim_begin, int64_t sim_end, int include_data, int nmaps,
                             const double* thetas, double atol, int z0_mode, int area, int64_t map_stride, double* scores_dev);
 int muse_ctx_set_comm_reserve(muse_ctx* ctx, int cus);
+int muse_ctx_switches(muse_ctx* ctx, const muse::Switches** sw, int* debug);
 int muse_set_error(int code, const char* msg);
 int muse_wait_event(void* event);
 int muse_internal_loop_usable(muse_ctx* ctx, int nsims, int64_t nlocal);
 int muse_internal_run_loop_shard(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_options* o, int64_t sim_lo, int64_t sim_hi,
                                  int include_data, void* board_dev, void* const* peer_boards, int npeers, unsigned int tag_base,
                                  int32_t* niter_out, double* theta_out, double* hist_out, double* gsims_out, muse_info* info_out);
+}
+namespace muse {   // muse_kernels.hip
+hipError_t launch_board_handshake(unsigned long long* own, unsigned long long* const* store, int nstore, int nranks, int rank, unsigned int tag,
+                                  unsigned long long slot0, unsigned long long ticks, unsigned int* result, hipStream_t st);
 }
 
 static CommState* state_of(muse_ctx* ctx, void** stream_out = nullptr) {
@@ -218,6 +232,9 @@ struct ShmId {
 static_assert(sizeof(ShmId) == MUSE_UNIQUE_ID_BYTES, "the id travels in the same 128 bytes as RCCL's");
 constexpr size_t kShmDefaultBlock = 16384;
 constexpr size_t kBoardBytes = 256 * 1024;   // the score board: 32 768 granules -- (nsims + 1) * ntheta <= 16 384
+constexpr size_t kBoardHandshakeBytes = 4096;   // behind them: the set-up hand-shake's slots (a granule pair per rank, up to 64 ranks)
+constexpr size_t kBoardTotalBytes = kBoardBytes + kBoardHandshakeBytes;
+constexpr unsigned long long kBoardHandshakeSlot = kBoardBytes / sizeof(unsigned long long);
 
 #define SHMCHK(st, expr, what)                                                                            \
     do {                                                                                                  \
@@ -253,70 +270,133 @@ static int shm_allgather(CommState* st, const double* send, size_t count, double
     return MUSE_OK;
 }
 
-// The score boards of the sharded device loop, set up by the first muse_run_sharded call (collective over the segment): the one in
-// pinned host memory -- the segment's extra region, mapped into this GPU's address space where the runtime allows it -- and a board
-// per GPU in device memory, every rank's mapped into every rank (CommState::ipc_*).
-static void setup_ipc_boards(CommState* st) {
+// One hand-shake over a board kind (collective): this rank's one-wavefront kernel stores its tagged pair into `store[0..nstore)` and
+// polls `own` for every rank's pair (muse_kernels.hip: board_handshake_kernel), bounded by the switch handshake_ms (default 50 ms);
+// then the ranks tell each other whether they saw everybody.  Returns 1 (every rank saw every peer) or 0; mask/wait_us: this rank's.
+static int board_handshake(CommState* st, hipStream_t stream, unsigned long long* own, unsigned long long* const* store, int nstore,
+                           unsigned int tag, unsigned long long* mask_out, double* wait_us_out) {
+    const double bound_ms = st->sw && st->sw->handshake_ms > 0 ? st->sw->handshake_ms : 50.0;
+    const unsigned long long ticks = (unsigned long long)(bound_ms * 1e5);   // s_memrealtime: 100 MHz
+    bool ok = st->hs_result != nullptr;
+    if (ok) {
+        st->hs_result[0] = st->hs_result[1] = st->hs_result[2] = 0;
+        // (the ranks leave the collective before this within microseconds of each other; the launch itself is a few more)
+        ok = muse::launch_board_handshake(own, store, nstore, st->nranks, st->rank, tag, kBoardHandshakeSlot, ticks, st->hs_result, stream) == hipSuccess &&
+             hipStreamSynchronize(stream) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    const unsigned long long mask = ok ? ((unsigned long long)st->hs_result[1] << 32) | st->hs_result[0] : 0ull;
+    const unsigned long long full = st->nranks >= 64 ? ~0ull : ((1ull << st->nranks) - 1ull);
+    *mask_out = mask;
+    *wait_us_out = ok ? (double)st->hs_result[2] * 0.01 : 0.0;
+    double flag[1] = {(ok && mask == full) ? 1.0 : 0.0};
+    if (shm_allgather(st, flag, 1, flag, true) != MUSE_OK) return 0;
+    return flag[0] == (double)st->nranks ? 1 : 0;
+}
+
+// The score boards of the sharded device loop, set up ONCE per communicator -- by muse_comm_board_status or by the first
+// muse_run_sharded call, collective over the segment either way: the one in pinned host memory -- the segment's extra region, mapped
+// into this GPU's address space where the runtime allows it -- and a board per GPU in device memory, every rank's mapped into every
+// rank (CommState::ipc_*).  Each kind is then PROVED by a hand-shake (board_handshake) before the loop may use it: a store into
+// another GPU's board that its poll never sees costs milliseconds here, not a bounded wait inside the first user call.
+static void setup_boards(CommState* st, hipStream_t stream) {
     muse_shm::Gather* g = st->shm;
-    if (!getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(st->device) == hipSuccess && g->extra() &&
+    const muse::Switches none;
+    const muse::Switches& sw = st->sw ? *st->sw : none;
+    if (hipSetDevice(st->device) == hipSuccess && !st->hs_result) {
+        if (hipHostMalloc(&st->hs_result, 64, hipHostMallocDefault) != hipSuccess) st->hs_result = nullptr;
+    }
+    (void)hipGetLastError();
+    if (!sw.no_board && g->extra() && g->extra_bytes() >= kBoardTotalBytes && st->nranks <= 64 &&
         hipHostRegister(g->extra(), g->extra_bytes(), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, g->extra(), 0) == hipSuccess && dp) {
             st->board_host = g->extra();
             st->board_dev = (unsigned long long*)dp;
-            st->board_granules = g->extra_bytes() / sizeof(unsigned long long);
+            st->board_granules = kBoardBytes / sizeof(unsigned long long);
         } else {
             (void)hipHostUnregister(g->extra());
         }
     }
     (void)hipGetLastError();
     st->ipc_ok = false;
-    if (st->nranks > 8) return;
-    bool ok = !getenv("MUSE_DEBUG_NO_IPC_BOARD") && !getenv("MUSE_DEBUG_NO_BOARD") && hipSetDevice(st->device) == hipSuccess;
-    hipIpcMemHandle_t mine;
-    memset(&mine, 0, sizeof mine);
-    if (ok) {
-        void* p = nullptr;
-        // uncached where the runtime offers it: the board is written by other GPUs and polled by this one
-        if (hipExtMallocWithFlags(&p, kBoardBytes, hipDeviceMallocUncached) != hipSuccess) {
-            (void)hipGetLastError();
-            p = nullptr;
-            if (hipMalloc(&p, kBoardBytes) != hipSuccess) p = nullptr;
+    st->hs_dev = st->hs_host = -1;
+    if (st->nranks <= 8) {
+        bool ok = !sw.no_ipc_board && !sw.no_board && hipSetDevice(st->device) == hipSuccess;
+        hipIpcMemHandle_t mine;
+        memset(&mine, 0, sizeof mine);
+        if (ok) {
+            void* p = nullptr;
+            // The board is written by OTHER GPUs and polled by this one: uncached, or fine-grained, device memory.  Plain hipMalloc
+            // memory is coarse-grained and cached in this GPU's L2 -- a poll of it is not guaranteed ever to see a peer's store -- so
+            // without either kind there is no device board (every rank then uses the host board).
+            if (hipExtMallocWithFlags(&p, kBoardTotalBytes, hipDeviceMallocUncached) != hipSuccess) {
+                (void)hipGetLastError();
+                p = nullptr;
+                if (hipExtMallocWithFlags(&p, kBoardTotalBytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                    (void)hipGetLastError();
+                    p = nullptr;
+                }
+            }
+            ok = p != nullptr && hipMemset(p, 0, kBoardTotalBytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                 hipIpcGetMemHandle(&mine, p) == hipSuccess;
+            st->ipc_own = (unsigned long long*)p;
         }
-        ok = p != nullptr && hipMemset(p, 0, kBoardBytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-             hipIpcGetMemHandle(&mine, p) == hipSuccess;
-        st->ipc_own = (unsigned long long*)p;
-    }
-    (void)hipGetLastError();
-    // every rank's {ok, handle}: 1 + 8 doubles per rank (the 64 handle bytes travel as 8 doubles' bit patterns)
-    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle exchanged as 8 doubles");
-    double send[9], recv[9 * 8];
-    send[0] = ok ? 1.0 : 0.0;
-    memcpy(send + 1, &mine, 64);
-    if (shm_allgather(st, send, 9, recv, false) != MUSE_OK) ok = false;
-    bool all = ok;
-    for (int q = 0; q < st->nranks && all; ++q) all = recv[9 * q] == 1.0;
-    if (all) {
-        for (int q = 0; q < st->nranks; ++q) {
-            if (q == st->rank) { st->ipc_peers[q] = st->ipc_own; continue; }
-            hipIpcMemHandle_t h;
-            memcpy(&h, recv + 9 * q + 1, 64);
-            void* pp = nullptr;
-            if (hipIpcOpenMemHandle(&pp, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !pp) { all = false; (void)hipGetLastError(); break; }
-            st->ipc_peers[q] = pp;
-        }
-    }
-    double flag[1] = {all ? 1.0 : 0.0};   // did EVERY rank open EVERY handle
-    if (shm_allgather(st, flag, 1, flag, true) != MUSE_OK) flag[0] = 0.0;
-    st->ipc_ok = flag[0] == (double)st->nranks;
-    if (!st->ipc_ok) {
-        for (int q = 0; q < st->nranks; ++q)
-            if (q != st->rank && st->ipc_peers[q]) { (void)hipIpcCloseMemHandle(st->ipc_peers[q]); }
-        for (int q = 0; q < 8; ++q) st->ipc_peers[q] = nullptr;
-        if (st->ipc_own) (void)hipFree(st->ipc_own);
-        st->ipc_own = nullptr;
         (void)hipGetLastError();
+        // every rank's {ok, handle}: 1 + 8 doubles per rank (the 64 handle bytes travel as 8 doubles' bit patterns)
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle exchanged as 8 doubles");
+        double send[9], recv[9 * 8];
+        send[0] = ok ? 1.0 : 0.0;
+        memcpy(send + 1, &mine, 64);
+        if (shm_allgather(st, send, 9, recv, false) != MUSE_OK) ok = false;
+        bool all = ok;
+        for (int q = 0; q < st->nranks && all; ++q) all = recv[9 * q] == 1.0;
+        if (all) {
+            for (int q = 0; q < st->nranks; ++q) {
+                if (q == st->rank) { st->ipc_peers[q] = st->ipc_own; continue; }
+                hipIpcMemHandle_t h;
+                memcpy(&h, recv + 9 * q + 1, 64);
+                void* pp = nullptr;
+                if (hipIpcOpenMemHandle(&pp, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !pp) { all = false; (void)hipGetLastError(); break; }
+                st->ipc_peers[q] = pp;
+            }
+        }
+        double flag[1] = {all ? 1.0 : 0.0};   // did EVERY rank open EVERY handle
+        if (shm_allgather(st, flag, 1, flag, true) != MUSE_OK) flag[0] = 0.0;
+        st->ipc_ok = flag[0] == (double)st->nranks;
+        if (st->ipc_ok) {   // mapped everywhere: now prove that a store into a peer's board is SEEN by the peer's poll
+            unsigned long long* stores[8];
+            for (int q = 0; q < st->nranks; ++q) stores[q] = (unsigned long long*)st->ipc_peers[q];
+            st->hs_dev = board_handshake(st, stream, st->ipc_own, stores, st->nranks, 0x7ff00001u, &st->hs_mask_dev, &st->hs_wait_us[0]);
+            st->ipc_ok = st->hs_dev == 1;
+        }
+        if (!st->ipc_ok) {
+            for (int q = 0; q < st->nranks; ++q)
+                if (q != st->rank && st->ipc_peers[q]) { (void)hipIpcCloseMemHandle(st->ipc_peers[q]); }
+            for (int q = 0; q < 8; ++q) st->ipc_peers[q] = nullptr;
+            if (st->ipc_own) (void)hipFree(st->ipc_own);
+            st->ipc_own = nullptr;
+            (void)hipGetLastError();
+        }
     }
+    {   // the host board: every rank must have it mapped, and every rank's GPU must see every rank's stores through PCIe
+        double flag[1] = {st->board_dev ? 1.0 : 0.0};
+        if (shm_allgather(st, flag, 1, flag, true) != MUSE_OK) flag[0] = 0.0;
+        if (flag[0] == (double)st->nranks) {
+            unsigned long long* stores[1] = {st->board_dev};
+            st->hs_host = board_handshake(st, stream, st->board_dev, stores, 1, 0x7ff00002u, &st->hs_mask_host, &st->hs_wait_us[1]);
+        }
+        if (st->hs_host != 1 && st->board_host) {   // (a board some rank cannot use is no board: the loop is host-driven on every rank)
+            (void)hipHostUnregister(st->board_host);
+            (void)hipGetLastError();
+            st->board_host = nullptr;
+            st->board_dev = nullptr;
+        }
+    }
+    if (sw.run_timing)
+        fprintf(stderr, "[muse_comm] rank %d of %d: board hand-shake -- device boards %s (saw 0x%llx, %.1f us), host board %s (saw 0x%llx, %.1f us)\n",
+                st->rank, st->nranks, st->hs_dev == 1 ? "ok" : st->hs_dev == 0 ? "FAILED" : "not tried", st->hs_mask_dev, st->hs_wait_us[0],
+                st->hs_host == 1 ? "ok" : st->hs_host == 0 ? "FAILED" : "not tried", st->hs_mask_host, st->hs_wait_us[1]);
 }
 
 extern "C" {
@@ -369,6 +449,26 @@ int muse_comm_ranks_seen(muse_ctx* ctx, int* nranks_out) {
     return MUSE_OK;
 }
 
+int muse_comm_board_status(muse_ctx* ctx, int status_out[6], double wait_us_out[2]) {
+    void* stream = nullptr;
+    CommState* st = state_of(ctx, &stream);
+    if (!st) return muse_set_error(MUSE_ERR_INVALID, "muse_comm_init was not called");
+    if (!status_out || !wait_us_out) return muse_set_error(MUSE_ERR_INVALID, "NULL argument");
+    if (st->shm && !st->ipc_tried) {   // collective: every rank is here (or in its first muse_run_sharded call)
+        st->ipc_tried = true;
+        setup_boards(st, (hipStream_t)stream);
+    }
+    status_out[0] = st->ipc_ok ? MUSE_BOARD_DEVICE : st->board_dev ? MUSE_BOARD_HOST : MUSE_BOARD_NONE;
+    status_out[1] = st->hs_dev;
+    status_out[2] = st->hs_host;
+    status_out[3] = (int)(st->hs_mask_dev & 0x7fffffffull);
+    status_out[4] = (int)(st->hs_mask_host & 0x7fffffffull);
+    status_out[5] = st->last_loop;
+    wait_us_out[0] = st->hs_wait_us[0];
+    wait_us_out[1] = st->hs_wait_us[1];
+    return MUSE_OK;
+}
+
 int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     void** slot;
     int device;
@@ -383,9 +483,11 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
         if (sid.magic == muse_shm::kMagic) {
             sid.name[sizeof sid.name - 1] = 0;
             muse_shm::Gather* g = new muse_shm::Gather();
-            if (const char* t = getenv("MUSE_SHM_TIMEOUT_S")) g->timeout_s = atof(t) > 0 ? atof(t) : g->timeout_s;
+            const muse::Switches* sw = nullptr;
+            (void)muse_ctx_switches(ctx, &sw, nullptr);
+            if (sw && sw->shm_timeout_s > 0) g->timeout_s = sw->shm_timeout_s;
             std::string err;
-            if (!g->open(sid.name, nranks, rank, kAreas + 1, (size_t)sid.block_doubles, err, kBoardBytes)) {
+            if (!g->open(sid.name, nranks, rank, kAreas + 1, (size_t)sid.block_doubles, err, kBoardTotalBytes)) {
                 delete g;
                 return muse_set_error(MUSE_ERR_RCCL, ("shared-memory transport: " + err).c_str());
             }
@@ -394,9 +496,10 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
             st->nranks = nranks;
             st->rank = rank;
             st->device = device;
+            st->sw = sw;
             *slot = st;
-            return MUSE_OK;   // (the boards in device memory are set up by the first muse_run_sharded call: collective, and nothing a
-                              //  communicator that only gathers maps -- bench.py --gpus N -- has to go through)
+            return MUSE_OK;   // (the score boards are set up by muse_comm_board_status or the first muse_run_sharded call: collective, and
+                              //  nothing a communicator that only gathers maps has to go through)
         }
     }
     if (!load_rccl()) return muse_set_error(MUSE_ERR_RCCL, "librccl could not be loaded");
@@ -409,7 +512,8 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
     st->comm = comm;
     st->nranks = nranks;
     st->rank = rank;
-    if (getenv("MUSE_COMM_ONE_STREAM")) st->cstream = (hipStream_t)stream;  // tuning aid: collectives in line with the solver
+    (void)muse_ctx_switches(ctx, &st->sw, nullptr);
+    if (st->sw && st->sw->comm_one_stream) st->cstream = (hipStream_t)stream;  // tuning aid: collectives in line with the solver
     else {
         // Highest priority: the persistent solver kernel fills every CU (LDS- and VGPR-bound, nothing can
         // co-reside), so a collective can only be dispatched in the gap between two solver launches -- with
@@ -418,7 +522,7 @@ int muse_comm_init(muse_ctx* ctx, int nranks, int rank, const void* id) {
         HIPCHK2(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK2(hipStreamCreateWithPriority(&st->cstream, hipStreamNonBlocking, hi));
     }
-    st->direct_host = getenv("MUSE_COMM_DIRECT_HOST") != nullptr;
+    st->direct_host = st->sw && st->sw->comm_direct_host;
     st->own_stream = st->cstream != (hipStream_t)stream;
     for (int a = 0; a < kAreas; ++a) {
         HIPCHK2(hipEventCreateWithFlags(&st->kdone[a], hipEventDisableTiming));
@@ -439,11 +543,12 @@ int muse_comm_destroy(muse_ctx* ctx) {
     if (rc) return rc;
     if (CommState* st = (CommState*)*slot) {
         if (st->shm) {
-            if (st->board_host || st->ipc_own) {
+            if (st->board_host || st->ipc_own || st->hs_result) {
                 hipSetDevice(device);
                 (void)hipDeviceSynchronize();   // (nothing of this process may still be polling the board)
             }
             if (st->board_host) (void)hipHostUnregister(st->board_host);
+            if (st->hs_result) (void)hipHostFree(st->hs_result);
             if (st->ipc_ok) {
                 // (every rank closes its views before anyone frees: one more exchange; a peer that is gone already just times out)
                 for (int q = 0; q < st->nranks; ++q)
@@ -709,18 +814,27 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
     // memory that every GPU maps), every rank's stepper takes the same step from the same bits -- no host between two maps.  Every
     // rank must take the same loop: the decision is the minimum over the ranks of what each can do.
     if (st->shm) {
-        if (!st->ipc_tried) {   // (every rank makes its first call here together: collective; failure on any rank = the host board on all)
+        void* lane0 = nullptr;
+        (void)state_of(ctx, &lane0);
+        if (!st->ipc_tried) {   // (every rank makes its first call here together: collective; failure on any rank = the next board on all)
             st->ipc_tried = true;
-            setup_ipc_boards(st);
+            setup_boards(st, (hipStream_t)lane0);
         }
-        const bool ipc = st->ipc_ok && !getenv("MUSE_DEBUG_HOST_BOARD");   // (the same answer on every rank)
-        const bool want = (ipc || st->board_dev) && !st->dev_loop_off && !getenv("MUSE_DEBUG_SHARDED_HOST_LOOP") &&
+        int dbg = 0;
+        (void)muse_ctx_switches(ctx, nullptr, &dbg);
+        const bool sw_host_board = (st->sw && st->sw->host_board) || (dbg & muse::kDebugHostBoard);
+        const bool sw_host_loop = (st->sw && st->sw->sharded_host_loop) || (dbg & muse::kDebugShardedHostLoop);
+        const bool ipc = st->ipc_ok && !sw_host_board;   // (the same answer on every rank: every rank sets the same switches)
+        // (nlocal >= 1: with fewer simulations than ranks some rank owns no element -- its loop launch would be refused while its
+        //  peers' ran: the minimum over the ranks sends such a job to the host-driven loop)
+        const bool want = (ipc || st->board_dev) && !st->dev_loop_off && !sw_host_loop && nlocal >= 1 &&
                           (uint64_t)(S + 1) * (uint64_t)nt * 2 <= kBoardBytes / sizeof(unsigned long long) && st->board_tag < 0x70000000u &&
                           muse_internal_loop_usable(ctx, S, nlocal) != 0;
         double flag[1] = {want ? 1.0 : 0.0};
         rc = shm_allgather(st, flag, 1, flag, true);
         if (rc) return rc;
-        if (getenv("MUSE_DEBUG_RUN_TIMING"))   // tuning aid / tests: which loop, through which board
+        st->last_loop = flag[0] != (double)world ? MUSE_BOARD_NONE : ipc ? MUSE_BOARD_DEVICE : MUSE_BOARD_HOST;
+        if ((st->sw && st->sw->run_timing) || (dbg & muse::kDebugRunTiming))   // tuning aid / tests: which loop, through which board
             fprintf(stderr, "[muse_run_sharded] rank %d of %d: %s\n", rank, world,
                     flag[0] != (double)world ? "host-driven loop" : ipc ? "persistent launch, boards in device memory (hipIpc)"
                                                                         : "persistent launch, board in pinned host memory");
@@ -731,12 +845,18 @@ extern "C" int muse_run_sharded(muse_ctx* ctx, uint64_t seed, const double* thet
                                               ipc ? st->ipc_peers : nullptr, ipc ? world : 0, tag_base, niter_out, theta_out, hist_out,
                                               gsims_out, info_out);
             // a rank whose workgroups were not all resident (rc 1001) stalls every rank's stepper: all of them time out -- but
-            // make the outcome a collective decision anyway
-            double bad[1] = {rc == 1001 ? 1.0 : 0.0};
+            // make the outcome a collective decision anyway; and a rank that FAILED (rc < 0: before or after its launch) takes every
+            // rank out with an error -- its peers' steppers have waited for scores that never came
+            double bad[1] = {(rc == 1001 ? 1.0 : 0.0) + (rc < 0 ? 1000.0 : 0.0)};
             const int rc2 = shm_allgather(st, bad, 1, bad, true);
             if (rc < 0) return rc;
             if (rc2) return rc2;
+            if (bad[0] >= 1000.0) {
+                st->last_loop = MUSE_BOARD_NONE;
+                return muse_set_error(MUSE_ERR_RCCL, "muse_run_sharded: a peer rank's share of the persistent loop failed (its own call reports why)");
+            }
             if (bad[0] == 0.0) return MUSE_OK;
+            st->last_loop = MUSE_BOARD_NONE;
             st->dev_loop_off = true;
             if (o->z0_warm)   // (the aborted attempt has touched the resident MAPs the run was to start from)
                 return muse_set_error(MUSE_ERR_HIP, "muse_run_sharded: the workgroups of the loop kernel were not all resident at once on "

@@ -17,6 +17,7 @@
 #include "../../include/muse_hip.h"
 #include "args.hpp"
 #include "step.hpp"
+#include "switches.hpp"
 #include "user_model.hpp"
 
 // ================================================================================================
@@ -117,7 +118,8 @@ struct muse_ctx {
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
     int* error_flag = nullptr;           // pinned, device-mapped
-    int debug = 0;
+    int debug = 0;                       // muse_debug_flags
+    Switches sw;                         // the environment switches as muse_ctx_create found them (switches.hpp)
     int split = 0;                 // muse_set_element_split: 0 = by N alone, >= 2 = workgroups per element
     unsigned int ticket_base = 0;  // value of the device ticket counter when the next launch starts
     hipEvent_t launch_done = nullptr;  // set around launch_batch: the event this launch signals when it completes
@@ -148,6 +150,8 @@ static double theta_const(const muse_ctx* c, const double* theta) {
 }
 
 static bool place_is_cluster(int pl) { return pl >= P_C256; }
+// test hook (MUSE_DEBUG_LOOP_OVERSUBSCRIBE / muse_debug_flags bit 18): a loop launch with more workgroups than can be resident at once
+static bool oversubscribe(const muse_ctx* c) { return c->sw.loop_oversubscribe || (c->debug & kDebugLoopOversubscribe) != 0; }
 
 // Cluster size: a function of N alone (results must not depend on how many problems share a launch), unless the
 // caller asked for a split (muse_set_element_split: results then depend on (N, split), still not on the launch).
@@ -159,12 +163,11 @@ static size_t stencil_lds_s_bytes(const muse_ctx* c, int csize) {
     return (size_t)cap * 256 * 16;
 }
 static bool stencil_lds_s(const muse_ctx* c, int csize) {
-    static const bool off = getenv("MUSE_DEBUG_NO_LDS_S") != nullptr;  // tuning aid
-    return !off && c->model == MUSE_MODEL_SMOOTH && csize >= 2 && stencil_lds_s_bytes(c, csize) <= 72 * 1024;
+    return !c->sw.no_lds_s && c->model == MUSE_MODEL_SMOOTH && csize >= 2 && stencil_lds_s_bytes(c, csize) <= 72 * 1024;
 }
 static int cluster_size(const muse_ctx* c) {
     if (c->split >= 2) return c->split;
-    if (const char* e = getenv("MUSE_DEBUG_CLUSTER_SIZE")) return atoi(e);  // tuning aid
+    if (c->sw.cluster_size > 0) return c->sw.cluster_size;  // tuning aid
     // stencil model: clusters of 16 where that lets the search direction live in LDS (N <= ~147 000)
     if (c->model == MUSE_MODEL_SMOOTH && c->N >= kClusterMinN && c->N < 4194304 && stencil_lds_s(c, 16)) return 16;
     return c->N >= 4194304 ? 16 : (c->N >= kClusterMinN ? 8 : 1);  // 8: smooth_1e5 2.80 ms (4: 3.22), noise_1e6 1.56 (4: 1.61)
@@ -194,12 +197,10 @@ static int choose_place(const muse_ctx* c) {
 // the small tier's compare chain and selected accumulations in every trip).  The stencil model gains nothing (2.32 / 2.38 ms).
 static bool tier_big(const muse_ctx* c, int pl, int nmaps) {
     if (c->ntheta > kMaxTheta) return true;
-    static const bool off = getenv("MUSE_DEBUG_NO_BIG_TIER") != nullptr;  // tuning aid (A/B)
-    return !off && c->ntheta > 1 && c->model != MUSE_MODEL_SMOOTH && nmaps <= 1 && (pl == P_S256 || pl == P_S512 || pl == P_C256);
+    return !c->sw.no_big_tier && c->ntheta > 1 && c->model != MUSE_MODEL_SMOOTH && nmaps <= 1 && (pl == P_S256 || pl == P_S512 || pl == P_C256);
 }
 static bool ncache_applies(const muse_ctx* c) {
-    static const bool off = getenv("MUSE_DEBUG_NO_NCACHE") != nullptr;  // tuning aid
-    return !off && choose_place(c) == P_R512x10;
+    return !c->sw.no_ncache && choose_place(c) == P_R512x10;
 }
 static int place_threads(int pl) { return (pl == P_S256 || pl == P_R256x1 || pl == P_C256) ? 256 : 512; }
 // workgroups per CU the grid is sized from (cluster placements: every member must be resident at once, and the
@@ -309,7 +310,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         a.n_per_map = a.nproblems;
         a.map_stride = a.nproblems;
     }
-    a.debug = c->debug;
+    a.debug = c->debug & 0xffff;   // (bits 16-19 are host-side: switches.hpp)
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     a.clock_out = c->prof_on ? c->clock_pin : nullptr;  // roofline leg only
     const bool implicit = a.kind == BATCH_IMPLICIT;
@@ -325,7 +326,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         // ... and so do the launches of OTHER PROCESSES on this GPU, which the engine cannot see: MUSE_SHARED_GPU_RANKS=n says that n
         // processes share the device (the development set-up of bench.py's gloo mode and of the multi-process tests: eight ranks
         // on one GPU -- without it their cluster launches starve each other of compute units until the bounded waits expire)
-        static const int sharers = [] { const char* e = getenv("MUSE_SHARED_GPU_RANKS"); return e ? atoi(e) : 1; }();
+        const int sharers = c->sw.shared_gpu_ranks;
         if (sharers > 1) grid = grid / sharers > 0 ? grid / sharers : 1;
     }
     a.nclusters = 0;
@@ -357,8 +358,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         // XCD-local clusters (muse_kernels.hip) for the elementwise models, whose members meet in scalar exchanges only:
         // 22.2 -> 21.3 us at 64 sims split 4, noise_1e6 1.555 -> 1.52 ms.  The stencil model, whose members also stream
         // each other's boundary elements, measured slower with all of a cluster's traffic in one XCD (2.35 -> 2.47 ms).
-        static const bool no_xcd = getenv("MUSE_DEBUG_NO_XCD_LOCAL") != nullptr;
-        a.xcd_local = (!no_xcd && ncl % 8 == 0 && c->model != MUSE_MODEL_SMOOTH) ? 1 : 0;
+        a.xcd_local = (!c->sw.no_xcd_local && ncl % 8 == 0 && c->model != MUSE_MODEL_SMOOTH) ? 1 : 0;
     } else {
         if (grid > a.nproblems) grid = a.nproblems;
         if (grid < 1) grid = 1;
@@ -540,6 +540,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     muse_ctx* c = new muse_ctx();
+    c->sw = Switches::from_environment();   // the ONE place the environment is read (switches.hpp)
     c->model = model;
     c->N = N;
     c->ld = (N + 1) & ~(int64_t)1;
@@ -585,6 +586,12 @@ int muse_ctx_comm_slot(muse_ctx* c, void*** comm, int* device, void** stream) {
     *comm = &c->comm;
     *device = c->device;
     *stream = (void*)c->stream;
+    return MUSE_OK;
+}
+int muse_ctx_switches(muse_ctx* c, const Switches** sw, int* debug) {
+    if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
+    if (sw) *sw = &c->sw;
+    if (debug) *debug = c->debug;
     return MUSE_OK;
 }
 int muse_ctx_set_comm_reserve(muse_ctx* c, int cus) {
@@ -851,9 +858,11 @@ int muse_set_timing(muse_ctx* c, int enabled) {
     c->timing = enabled != 0;
     return MUSE_OK;
 }
-// bits: 0 skip the solve, 1 x from the data vector, 2 the loop kernel does not prefetch, 3 its old element order, 4 test hook (odd workers
-// leave), 5 no speculating trials, 6 a solving stepper takes the data element for itself, 7 the stepper never solves, 8 the data vector does not travel through the g area
-int muse_debug_flags(muse_ctx* c, int flags) {  // not part of the public header: profiling aid
+// Diagnostics (include/muse_hip.h).  Bits 0-8 travel to the kernels: 0 skip the solve, 1 x from the data vector, 2 the loop kernel
+// does not prefetch, 3 its old element order, 4 test hook (odd workers leave), 5 no speculating trials, 6 a solving stepper takes the
+// data element for itself, 7 the stepper never solves, 8 the data vector does not travel through the g area; bits 16-19 are
+// host-side (switches.hpp): 16 host board, 17 host-driven sharded loop, 18 oversubscribed loop launch (test hook), 19 run timing.
+int muse_debug_flags(muse_ctx* c, int flags) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     c->debug = flags;
     return MUSE_OK;
@@ -1110,10 +1119,7 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         // for its normals are stored beside the solve, from the third time on they are loaded instead of generated (the
         // same doubles: bit-identical results).  Lane 0 only: stream order is what puts the storing launch before the
         // loading ones.  A map that never repeats (the pipelined cold steps of bench.py) stores nothing.
-        static const int64_t budget = [] {
-            const char* e = getenv("MUSE_NCACHE_MAX_MB");
-            return (e ? atoll(e) : 8192ll) << 20;
-        }();
+        const int64_t budget = (int64_t)c->sw.ncache_max_bytes;
         if (ncache_holds(c, seed, sim_begin, nsim)) {
             a.ncache = c->ncache;
             a.ncache_sim0 = c->nc_sim0;
@@ -1130,8 +1136,7 @@ static int map_async_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     }
     // the area's completion event is signalled by this launch itself; with timing events around the launch (profiling)
     // the plain record after it keeps the order start, kernel, stop, done
-    static const bool no_ext = getenv("MUSE_DEBUG_NO_EXT_LAUNCH") != nullptr;
-    c->launch_done = (c->timing || c->prof_on || no_ext) ? nullptr : c->area_done[area];
+    c->launch_done = (c->timing || c->prof_on || c->sw.no_ext_launch) ? nullptr : c->area_done[area];
     c->launch_done_used = false;
     // A storing launch overwrites the cache: whatever it held is gone the moment the launch is issued, and the new range is
     // claimed only once the launch HAS been issued -- a launch that fails leaves no tag behind under which a later map would
@@ -1429,7 +1434,7 @@ static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_o
     shape.done_event = nullptr;
     const bool xg_lds = pl == P_R512x10;
     shape.lds = place_lds(c, pl) + loop_extra_lds(xg_lds, nprob_total, nt);
-    static const bool host_only = getenv("MUSE_DEBUG_NO_LOOP_KERNEL") != nullptr;  // tuning aid
+    const bool host_only = c->sw.no_loop_kernel;  // tuning aid
     const size_t lds_limit = 160 * 1024;
     // the loop kernel pays where an iteration is short: the resident placements (N <= 10^4).  In the streaming ones an iteration is
     // hundreds of microseconds of HBM traffic, the host's share of it nothing, and the loop kernel's static deal of the elements
@@ -1458,7 +1463,7 @@ static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_o
     //   60.9 / 53.9, 75.1 / 68.4;  N = 512: 23.6 / 16.2, 26.5 / 20.3, 27.7 / 23.4, 31.6 / 35.3
     // and at 100 sims (one problem per worker) the loop kernel leads for every count (N = 10^4 x 8: 34.5 / 32.0).
     // (round 4, before: 53 / 50, 75 / 79, 89 / 97, 100 / 113 at N = 10^4)
-    static const bool any_nt = getenv("MUSE_DEBUG_LOOP_ANY_NTHETA") != nullptr;   // tuning aid / tests: the loop kernel whatever ntheta
+    const bool any_nt = c->sw.loop_any_ntheta;   // tuning aid / tests: the loop kernel whatever ntheta
     if (r.grid_max < 2 || (nt > 4 && !any_nt && nlocal > r.grid_max - 1)) return false;
     if (shape_out) *shape_out = shape;
     if (max_grid_out) *max_grid_out = r.grid_max;
@@ -1537,24 +1542,21 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     a.zhat = c->zhat;
     a.work_counter = c->counter;
     a.ticket_base = (int)c->ticket_base;   // (no tickets are drawn: elements are dealt statically)
-    a.debug = c->debug;
+    a.debug = c->debug & 0xffff;   // (bits 16-19 are host-side: switches.hpp)
     a.stamps = (c->stamps && a.nproblems + 3 <= c->stamps_cap) ? c->stamps : nullptr;   // (+3: the loop kernel's own rows)
     a.csize = 1;
     a.error_flag = c->error_flag;
     // workers (each owns elements w, w + nworkers, ...) and one stepper, all resident at once
     int nworkers = max_grid - 1 < (int)nprob ? max_grid - 1 : (int)nprob;
-    if (const char* e = getenv("MUSE_DEBUG_LOOP_GRID")) {   // tuning aid (never more than what is resident at once)
-        const int g = atoi(e);
-        if (g >= 1 && g < nworkers) nworkers = g;
-    }
+    if (c->sw.loop_grid >= 1 && c->sw.loop_grid < nworkers) nworkers = c->sw.loop_grid;   // tuning aid (never more than what is resident at once)
     // More elements than workers: the stepper takes elements as well (round 5).  512 simulations + the data on 256 compute units: three
     // of 255 workers had three elements (the others two, the stepper none); now one workgroup has three (the data element and two
     // simulations) and the stepper two like everybody else.  With a worker per element the stepper stays what it was: it polls while
     // the others solve.  tools/runloop_bench.py, wall per iteration of a 30-iteration call: 43.0-43.9 us against 48.1-49.1.
-    static const bool dedicated = getenv("MUSE_DEBUG_LOOP_DEDICATED_STEPPER") != nullptr;   // tuning aid / tests: the layout before
+    const bool dedicated = c->sw.loop_dedicated_stepper;   // tuning aid / tests: the layout before
                                                                                             // (muse_debug_flags bit 7 likewise)
     bool solving = !dedicated && !(c->debug & 128) && (int64_t)nworkers < nprob;
-    if (getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) { nworkers = (int)nprob; solving = false; }   // test hook: more workgroups than can be resident at once
+    if (oversubscribe(c)) { nworkers = (int)nprob; solving = false; }   // test hook: more workgroups than can be resident at once
     if (solving) ++nworkers;   // (the stepper's slot)
     const int grid = solving ? nworkers : nworkers + 1;
     shape.grid = grid;
@@ -1602,7 +1604,7 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     }
     r.status[0] = r.status[1] = r.status[2] = 0;
     for (int k = 0; k < nt; ++k) r.theta_out[k] = theta0[k];
-    static const bool trace = getenv("MUSE_DEBUG_RUN_TIMING") != nullptr;   // tuning aid: where a call's own time goes
+    const bool trace = c->sw.run_timing || (c->debug & kDebugRunTiming);   // tuning aid: where a call's own time goes
     auto now_us = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
     const double t_a = trace ? now_us() : 0.0;
     {
@@ -1634,7 +1636,7 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     return MUSE_OK;
 }
 static int not_resident_error(muse_ctx* c) {
-    if (!getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;   // (the test hook provokes the failure on purpose)
+    if (!oversubscribe(c)) c->loop_unfit = true;   // (the test hook provokes the failure on purpose)
     return fail(MUSE_ERR_HIP, "muse_run_device: the workgroups of the loop kernel were not all resident at once (another process on "
                               "this GPU?); muse_run gives the same results with one launch per iteration, and later calls of "
                               "muse_run_device on this context take that loop by themselves");
@@ -1686,7 +1688,7 @@ int muse_internal_run_loop_shard(muse_ctx* c, uint64_t seed, const double* theta
         for (int q = 0; q < npeers; ++q) sh.peers[q] = (unsigned long long*)peer_boards[q];
     }
     rc = run_loop_launch(c, seed, theta0, o, &sh, shape, max_grid, niter_out, theta_out, hist_out, gsims_out, info_out);
-    if (rc == MUSE_LOOP_NOT_RESIDENT && !getenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")) c->loop_unfit = true;
+    if (rc == MUSE_LOOP_NOT_RESIDENT && !oversubscribe(c)) c->loop_unfit = true;
     return rc;
 }
 

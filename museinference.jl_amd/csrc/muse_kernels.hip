@@ -29,6 +29,7 @@
 #include <math.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -260,6 +261,74 @@ size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta) {
     return (size_t)kLoopPersistDoubles * sizeof(double) + (xg_lds ? 0 : step);
 }
 size_t loop_step_bytes(int64_t nprob, int ntheta) { return ((size_t)nprob * ntheta + 24) * sizeof(double) + sizeof(StepWork); }
+
+// ---- the score boards' set-up hand-shake (muse_comm.cpp: setup_boards; include/muse_hip.h: muse_comm_board_status) ---------------
+// ONE wavefront per rank.  Lane q < nstore stores this rank's tagged granule pair into board q -- the system-scope relaxed 8-byte
+// stores of Solver::finish (solver.hpp: gran_sys; the boards in device memory: one per rank, nstore = nranks; the board in pinned
+// host memory: the one, nstore = 1) -- and lane q < nranks then polls ITS OWN GPU's view of the board for rank q's pair with the
+// stepper's 16-byte coherent buffer load (kernels.hpp), until the pair carries the tag and this hand-shake's payload or `ticks` of
+// the 100 MHz counter have passed.  result (pinned host memory): [0..1] bit mask of the ranks seen, [2] ticks until the last one
+// landed (the bound when it expired).  The slots are a region of their own behind the score granules.
+struct HandshakeArgs {
+    unsigned long long* own;
+    unsigned long long* store[8];
+    int nstore, nranks, rank;
+    unsigned int tag;
+    unsigned long long slot0;      // granule index of rank 0's pair (rank r: slot0 + 2 r)
+    unsigned long long ticks;
+    unsigned int* result;
+};
+__global__ void __launch_bounds__(64) board_handshake_kernel(HandshakeArgs h) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    const int lane = (int)threadIdx.x;
+    const unsigned long long tg = (unsigned long long)h.tag << 32;
+    if (lane < h.nstore) {
+        gu64* pq = (gu64*)h.store[lane] + h.slot0 + 2 * (unsigned long long)h.rank;
+        __hip_atomic_store(pq, tg | (unsigned long long)(unsigned)(h.rank + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pq + 1, tg | (unsigned long long)(unsigned)(0x5a5a0000 + h.rank), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const rsrc_t grs = make_rsrc(h.own, (int64_t)(h.slot0 + 128) * 8);
+    bool seen = lane >= h.nranks;
+    unsigned long long t0, now;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    now = t0;
+    for (;;) {
+        if (!seen) {
+            double lo, hi;
+            load_f64x2<kCoherent>(grs, (int)h.slot0 + 2 * lane, lo, hi);
+            const unsigned long long glo = (unsigned long long)__double_as_longlong(lo), ghi = (unsigned long long)__double_as_longlong(hi);
+            seen = glo == (tg | (unsigned long long)(unsigned)(lane + 1)) && ghi == (tg | (unsigned long long)(unsigned)(0x5a5a0000 + lane));
+        }
+        const bool all = __builtin_amdgcn_ballot_w64(!seen) == 0ull;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        if (all || now - t0 > h.ticks) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(seen && lane < h.nranks);
+    if (lane == 0) {
+        __hip_atomic_store((gu32*)h.result, (unsigned)(mask & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((gu32*)h.result + 1, (unsigned)(mask >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((gu32*)h.result + 2, (unsigned)(now - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+hipError_t launch_board_handshake(unsigned long long* own, unsigned long long* const* store, int nstore, int nranks, int rank, unsigned int tag,
+                                  unsigned long long slot0, unsigned long long ticks, unsigned int* result, hipStream_t st) {
+    if (nstore < 1 || nstore > 8 || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return hipErrorInvalidValue;
+    HandshakeArgs h;
+    memset(&h, 0, sizeof h);
+    h.own = own;
+    for (int q = 0; q < nstore; ++q) h.store[q] = store[q];
+    h.nstore = nstore;
+    h.nranks = nranks;
+    h.rank = rank;
+    h.tag = tag;
+    h.slot0 = slot0;
+    h.ticks = ticks;
+    h.result = result;
+    hipLaunchKernelGGL(board_handshake_kernel, dim3(1), dim3(64), 0, st, h);
+    return hipGetLastError();
+}
 
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t st) {
     const int grid = (int)((a.N + 255) / 256 < 4096 ? (a.N + 255) / 256 : 4096);

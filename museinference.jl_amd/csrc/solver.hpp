@@ -1451,6 +1451,12 @@ struct Solver {
                     done = true;
                 }
             }
+            if constexpr (Place::kResident && Place::kXgLds) {
+                // a data vector that was fetched ahead into the x / g area but is not taken from there (a start from zero: only the
+                // debug orders of the deal reach this today): its LDS-DMA loads must have landed before the plain path writes x and
+                // the solve its gradients over them
+                if (!done && pf_hit && (pf.have_x || pf.have_xg || pf.g_pending)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (!done)
             for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                 x.set(jj, i, xs.get(jj, i));
@@ -2182,7 +2188,7 @@ struct Solver {
                 inf.hist_words = hist_words;
                 inf.f_min = f;
                 inf.gnorm = gmax;
-                a.info[p] = inf;
+                a.info[d.irow] = inf;
             }
         } else {
             double acc[MAXB], mx[1] = {0.0};
@@ -2250,7 +2256,7 @@ struct Solver {
                 inf.hist_words = hist_words;
                 inf.f_min = f;
                 inf.gnorm = gmax;
-                a.info[p] = inf;
+                a.info[d.irow] = inf;
             }
         }
         stamp(p, 7);

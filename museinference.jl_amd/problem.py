@@ -601,6 +601,26 @@ class HipMuseProblem(AbstractMuseProblem):
         self._check(self._lib.muse_comm_ranks_seen(self._ctx, C.byref(n)))
         return n.value
 
+    BOARDS = {0: "none", 1: "host", 2: "device"}
+    # host-side bits of debug_flags (csrc/switches.hpp)
+    DEBUG_HOST_BOARD, DEBUG_SHARDED_HOST_LOOP, DEBUG_LOOP_OVERSUBSCRIBE, DEBUG_RUN_TIMING = 1 << 16, 1 << 17, 1 << 18, 1 << 19
+
+    def debug_flags(self, flags):
+        """Diagnostic switches of this live context (include/muse_hip.h, "diagnostics": no bit changes a result)."""
+        self._check(self._lib.muse_debug_flags(self._ctx, int(flags)))
+
+    def comm_board_status(self):
+        """The score boards of the sharded muse! loop (muse_comm_board_status): COLLECTIVE over a shared-memory communicator the first
+        time it (or run_muse_sharded) is called -- the boards are mapped and each kind is proved by a millisecond hand-shake between
+        the ranks' GPUs.  Returns {"board": "device" | "host" | "none" (what the persistent loop will use), "device_handshake" /
+        "host_handshake": 1 ok, 0 failed, -1 not tried, "device_seen" / "host_seen": bit mask of the ranks this rank saw,
+        "device_wait_us" / "host_wait_us", "last_loop": what the last run_muse_sharded call ran}."""
+        st = (C.c_int * 6)()
+        w = (C.c_double * 2)()
+        self._check(self._lib.muse_comm_board_status(self._ctx, st, w))
+        return {"board": self.BOARDS[st[0]], "device_handshake": st[1], "host_handshake": st[2], "device_seen": st[3], "host_seen": st[4],
+                "last_loop": self.BOARDS[st[5]], "device_wait_us": w[0], "host_wait_us": w[1]}
+
     def comm_transport(self):
         t = C.c_int(-1)
         self._check(self._lib.muse_comm_transport(self._ctx, C.byref(t)))

@@ -52,23 +52,26 @@ res["run_n"], res["run_theta"], res["run_hist"], res["run_gs"], res["run_it"] = 
 pm.close()
 # ... and at the headline's shape (N = 10^4, one component: the LDS-resident placement, the MAP kept in registers from one iteration
 # to the next), by both loops: the persistent launch per rank whose scores meet on the node's board (round 5: what the library
-# runs), and the host-driven loop (MUSE_DEBUG_SHARDED_HOST_LOOP).  A second run continues from the resident MAPs (z0_warm).
+# runs), and the host-driven loop (debug flag bit 17).  A second run continues from the resident MAPs (z0_warm).
 xd1 = np.cos(0.11 * np.arange(10000)) * 1.7
 p1 = M.HipMuseProblem(xd1, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
 p1.comm_init(world, rank, bytes.fromhex(sys.argv[7]))
 kw = dict(nsims=64, maxsteps=8, theta_rtol=0.0, atol=1e-2, alpha=0.7)
-for tag, env in (("dev", {}), ("hostboard", {"MUSE_DEBUG_HOST_BOARD": "1"}), ("host", {"MUSE_DEBUG_SHARDED_HOST_LOOP": "1"})):
+res["board_status"] = np.array([-9] * 6)
+for tag, flags in (("dev", 0), ("hostboard", M.HipMuseProblem.DEBUG_HOST_BOARD), ("host", M.HipMuseProblem.DEBUG_SHARDED_HOST_LOOP)):
     # dev: a board per GPU in device memory, every rank's mapped into every rank (hipIpc); hostboard: the one board in pinned host
-    # memory; host: the host-driven loop
-    for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    # memory; host: the host-driven loop -- chosen on the live context (debug_flags: the environment is read once, at context creation)
+    p1.debug_flags(flags | M.HipMuseProblem.DEBUG_RUN_TIMING)
     n, theta, hist, gs, info = p1.run_muse_sharded(SEED, [1.0], **kw)
     res[f"s1_{tag}_n"], res[f"s1_{tag}_theta"], res[f"s1_{tag}_hist"], res[f"s1_{tag}_gs"] = n, theta, hist[:, :-1], gs
     res[f"s1_{tag}_it"], res[f"s1_{tag}_fc"] = info["iterations"], info["f_calls"]
+    res[f"s1_{tag}_last_loop"] = np.array(p1.comm_board_status()["last_loop"])
     n, theta, hist, gs, info = p1.run_muse_sharded(SEED, theta, z0_warm=True, **dict(kw, maxsteps=3))
     res[f"s1_{tag}_warm_theta"], res[f"s1_{tag}_warm_gs"] = theta, gs
-for k in ("MUSE_DEBUG_SHARDED_HOST_LOOP", "MUSE_DEBUG_HOST_BOARD"):
-    os.environ.pop(k, None)
+p1.debug_flags(0)
+bs = p1.comm_board_status()   # the set-up hand-shake's verdict for both kinds of board (made by the first sharded run above)
+res["board_status"] = np.array([{"none": 0, "host": 1, "device": 2}[bs["board"]], bs["device_handshake"], bs["host_handshake"], bs["device_seen"],
+                                bs["host_seen"], 0])
+res["board_wait_us"] = np.array([bs["device_wait_us"], bs["host_wait_us"]])
 p1.close()
 np.savez(out, **res)

@@ -26,6 +26,31 @@ def test_header_symbols_are_exported(M):
     assert sorted(M._capi.SIGNATURES) == names
 
 
+def test_library_exports_exactly_the_header(M):
+    """`nm -D` of the product library = the entry points include/muse_hip.h declares, nothing else: the accessors between the
+    library's own translation units, the kernels' host stubs and the C++ runtime's weak symbols are local (a linker version
+    script written from the header, build.py)."""
+    import subprocess
+    path = M.build_extension()
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip() and " A " not in line})
+    assert exported == declared_symbols(), (sorted(set(exported) - set(declared_symbols())), sorted(set(declared_symbols()) - set(exported)))
+
+
+def test_no_getenv_outside_context_creation():
+    """The environment switches are read once per context (csrc/switches.hpp, from muse_ctx_create): no other getenv in the library."""
+    csrc = os.path.join(ROOT, "museinference.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        if f == "switches.hpp":
+            assert "getenv" in text
+        else:
+            assert "getenv" not in text, f
+    eng = open(os.path.join(csrc, "muse_engine.cpp")).read()
+    assert eng.count("Switches::from_environment()") == 1
+
+
 def test_no_cpu_fallback(M):
     import torch
     if torch.cuda.is_available():

@@ -230,12 +230,12 @@ def test_loop_kernel_that_cannot_stay_resident_falls_back_to_the_host_loop(gpu, 
     prob = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
     kw = dict(nsims=300, maxsteps=3, theta_rtol=0.0, atol=1e-2, alpha=0.7)
     want = prob.run_muse(5, [0.8], device_loop=False, **kw)
-    monkeypatch.setenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE", "1")
+    prob.debug_flags(M.HipMuseProblem.DEBUG_LOOP_OVERSUBSCRIBE)   # (the environment switch of the same name is read at context creation)
     with pytest.raises(M.MuseError, match="not all resident"):
         prob.run_muse(5, [0.8], device_loop=True, **kw)
     with pytest.warns(RuntimeWarning, match="host loop"):
         got = prob.run_muse(5, [0.8], **kw)
-    monkeypatch.delenv("MUSE_DEBUG_LOOP_OVERSUBSCRIBE")
+    prob.debug_flags(0)
     assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2][:, :-1], want[2][:, :-1])
     assert np.array_equal(got[3], want[3])
     again = prob.run_muse(5, [0.8], device_loop=True, **kw)     # the loop kernel itself, afterwards
@@ -353,7 +353,7 @@ def test_element_split_vs_oracle_and_invariances(gpu, M, O, model, N, nth, theta
     go, zo, io = O.map_and_score_batch(model, N, 42, 0, 24, theta, atol=1e-2, x_data=xdata, z0_mode=0)
     # elements on the oracle's L-BFGS path: scores rtol 1e-10, MAPs 1e-9; an element that left it (the split changes the
     # summation tree; long stencil solves only) is still BOUNDED: both sides converged, |dz| <= 2 atol / lambda_min
-    same = assert_same_path_or_close(info, io, zh, zo, g, go, model, theta, 1e-2, f"split {split}")
+    same = assert_same_path_or_close(info, io, zh, zo, g, go, 1e-2, theta, model, f"split {split}")
     assert same.mean() >= 0.9
     g2, info2 = prob.map_and_score_batch(42, 0, 24, theta, include_data=True, atol=1e-2)
     assert np.array_equal(g, g2) and np.array_equal(info, info2) and np.array_equal(zh, prob.get_zhat(0, 25))

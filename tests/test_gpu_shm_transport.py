@@ -87,6 +87,16 @@ def test_gathered_map_and_collectives_over_shared_memory(world, tmp_path):
             mine = np.concatenate([i1[:, :1], i1[:, 1 + lo:1 + hi]], axis=1) if r == 0 else i1[:, 1 + lo:1 + hi]
             assert np.array_equal(res[r][f"s1_{tag}_it"], mine["iterations"]) and np.array_equal(res[r][f"s1_{tag}_fc"], mine["f_calls"]), (r, tag)
             assert np.array_equal(res[r][f"s1_{tag}_warm_theta"], t2) and np.array_equal(res[r][f"s1_{tag}_warm_gs"], g2), (r, tag)
+        # which loop each run took, from the library's own record (muse_comm_board_status) ...
+        assert [str(res[r][f"s1_{tag}_last_loop"]) for tag in ("dev", "hostboard", "host")] == ["device", "host", "none"], r
+        # ... and the verdict of the boards' set-up hand-shake (round 6): both kinds of board were PROVED before the first loop used
+        # them -- every rank's one-wavefront kernel stored its tagged pair into every rank's board and saw every peer's pair in its own
+        # within the millisecond bound; the persistent loop uses the boards in device memory
+        bs = res[r]["board_status"]
+        assert bs[0] == 2 and bs[1] == 1 and bs[2] == 1, (r, bs)
+        assert bs[3] == (1 << world) - 1 and bs[4] == (1 << world) - 1, (r, bs)
+        assert np.all(res[r]["board_wait_us"] < 50e3), res[r]["board_wait_us"]
+        assert logs[r].count("board hand-shake -- device boards ok") == 2, logs[r]   # (the two contexts that ran sharded loops)
         assert logs[r].count("[muse_run_device]") == 5, logs[r]
         # ... through the boards in device memory (the first sharded loop and two runs here), the host board (two), the host loop (two)
         assert logs[r].count("boards in device memory (hipIpc)") == 3 and logs[r].count("board in pinned host memory") == 2, logs[r]

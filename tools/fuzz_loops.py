@@ -73,25 +73,18 @@ while time.time() - t0 < budget:
             kw = dict(nsims=nsims, maxsteps=int(rng.integers(1, 10)), theta_rtol=float(rng.choice([0.0, 1e-2, 1e-1])),
                       atol=float(rng.choice([1e-2, 1e-4])), alpha=float(rng.uniform(0.3, 1.0)))
             board = str(rng.choice(["ipc", "host", "hostloop"]))
-            for k in ("MUSE_DEBUG_HOST_BOARD", "MUSE_DEBUG_SHARDED_HOST_LOOP"):
-                os.environ.pop(k, None)
-            if board == "host":
-                os.environ["MUSE_DEBUG_HOST_BOARD"] = "1"
-            if board == "hostloop":
-                os.environ["MUSE_DEBUG_SHARDED_HOST_LOOP"] = "1"
             try:
                 a = prob.run_muse(seed, th0, device_loop=False, **kw)
             except M.MuseError as e:
                 a = str(e)
             shp = M.HipMuseProblem(x, model=model, ntheta=nth, prior=prob.prior)
             shp.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", max(4096, (nsims + 1) * nth)))   # (the host-driven loop gathers a block of nsims + 1 rows)
+            shp.debug_flags({"ipc": 0, "host": M.HipMuseProblem.DEBUG_HOST_BOARD, "hostloop": M.HipMuseProblem.DEBUG_SHARDED_HOST_LOOP}[board])
             try:
                 b = shp.run_muse_sharded(seed, th0, **kw)
             except M.MuseError as e:
                 b = str(e)
             shp.close()
-            for k in ("MUSE_DEBUG_HOST_BOARD", "MUSE_DEBUG_SHARDED_HOST_LOOP"):
-                os.environ.pop(k, None)
             if isinstance(a, str) or isinstance(b, str):
                 ok = isinstance(a, str) and isinstance(b, str) and (("singular" in a) == ("singular" in b))
             else:
