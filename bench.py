@@ -712,7 +712,7 @@ def sharded_extras(M, torch, dist, args, world, rank, local_rank, tdev, seed=0):
         t0 = time.perf_counter()
         hs = prob.comm_board_status()          # collective: maps the boards, proves each kind by the hand-shake
         t_setup = tmax(time.perf_counter() - t0)
-        kw = dict(nsims=nsims, maxsteps=30, theta_rtol=1e-12, atol=1e-2, alpha=0.7)
+        kw = dict(nsims=nsims, maxsteps=10 if args.small else 30, theta_rtol=1e-12, atol=1e-2, alpha=0.7)
         runs = {}
         for name, flags in (("default", 0), ("host_board", P.DEBUG_HOST_BOARD), ("host_loop", P.DEBUG_SHARDED_HOST_LOOP)):
             prob.debug_flags(flags)
@@ -1279,7 +1279,8 @@ def main():
         resident_n = model != "smooth" and N <= M.load_library().muse_max_resident_n()   # one workgroup per element and CU
         if sharded and args.split < 0 and resident_n:
             # as many maps as make the launch the shape of the 1-GPU step: two problems per compute unit
-            G = max(1, min(M._capi.MAX_MAPS, (2 * cus) // max(1, nlocal))) if os.environ.get("MUSE_BENCH_MAPS") is None \
+            # (from `rows`, the largest block: the same count on every rank -- with 512 sims on 3 ranks the blocks are 171, 171, 170)
+            G = max(1, min(M._capi.MAX_MAPS, (2 * cus) // max(1, rows))) if os.environ.get("MUSE_BENCH_MAPS") is None \
                 else max(1, min(M._capi.MAX_MAPS, int(os.environ["MUSE_BENCH_MAPS"])))
         state["nmaps"] = G
         split = args.split
@@ -1494,7 +1495,20 @@ def main():
     if sharded and not args.no_extra and args.workload == "funnel_1e4":
         # beside the headline's independent maps: the dependent path and the two workloads BASELINE.json puts on 8 GPUs, over THESE ranks
         prob.close()
+        # (a collective of the extras that never completes -- a peer that died, a board wait -- must not cost the line: the same
+        #  watchdog as for a hung transport; it prints the headline without the extras and leaves with status 3)
+        def fire_extras():
+            print(f"[bench rank {rank}] the sharded extras did not finish within {deadline:.0f} s: reporting without them", file=sys.stderr)
+            if rank == 0:
+                out["config"]["sharded_muse_skipped"] = f"did not finish within {deadline:.0f} s (watchdog)"
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(3)
+        timer = threading.Timer(deadline, fire_extras)
+        timer.daemon = True
+        timer.start()
         sh = sharded_extras(M, torch, dist, args, world, rank, local_rank, tdev)
+        timer.cancel()
         out["sharded"] = sh
         flat_sharded(out["config"], sh)
     if sharded:

@@ -177,8 +177,6 @@ static_assert(sizeof(BatchArgs) <= 4096, "kernarg segment");
 struct ProblemDesc {
     int64_t sim;
     int64_t row;       // row of the element's score in the output block
-    int64_t irow;      // ... of its solver info (the problem's index, but for a finite-difference launch that carries its fiducial)
-    bool is_fid, wait_fid;   // BATCH_FD with fd_fold: the fiducial problem / a problem that starts from the fiducial MAP of this launch
     int nslot;         // slot of the simulation's normals in the cache, -1: none
     bool normals_only;
     int x_mode, z0_mode, tsample;  // tsample < 0: sample at tmap
@@ -190,8 +188,6 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
     ProblemDesc d;
     d.normals_only = false;
     d.row = p;
-    d.irow = p;
-    d.is_fid = d.wait_fid = false;
     if (a.kind == BATCH_STD && a.nmaps > 1) {  // several independent maps in one launch: slots and infos by p, scores by (map, element)
         const int m = p / a.n_per_map, e = p - m * a.n_per_map;
         const bool data = a.include_data && e == 0;
@@ -225,13 +221,11 @@ __device__ __forceinline__ ProblemDesc describe(const BatchArgs& a, int p) {
         d.tsample = -1;
         d.zslot = a.fid_slot;
         d.z0slot = a.fid_slot;
-        d.row = d.irow = a.nproblems - 1;
-        d.is_fid = true;
+        d.row = a.nproblems - 1;   // (solver.hpp, info_row: the info likewise)
     } else if (a.kind == BATCH_FD) {
         if (a.fd_fold) {
             p -= 1;
-            d.row = d.irow = p;
-            d.wait_fid = true;
+            d.row = p;
         }
         const int per = a.fd_grid * a.ntheta, pp = p + a.p0;
         d.sim = a.sim_begin + pp / per;

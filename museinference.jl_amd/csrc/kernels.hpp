@@ -55,6 +55,7 @@ map_score_kernel(const BatchArgs /*read via the kernarg segment*/) {
         kernarg_ptr kp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         uint32_t* dst = reinterpret_cast<uint32_t*>(args_lds);
         for (int w = tid; w < (int)(kArgsHeadBytes / 4); w += T) dst[w] = kp[w];  // (not the trailing maps[]: see load_problem_theta)
+        if (tid == 0) ticket[2] = 0;   // (solver.hpp, wait_fiducial: the tag of the fiducial MAP this workgroup has seen published)
     }
     __syncthreads();
     const BatchArgs& a = *reinterpret_cast<const BatchArgs*>(args_lds);
@@ -350,7 +351,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                             kept = true;
                         }
                     }
-                    if (!kept) sv.template begin<false>(p, wg_scratch, m.lds_x, m.lds_g, pf);
+                    if (!kept) sv.template begin<false, false>(p, wg_scratch, m.lds_x, m.lds_g, pf);
                     sv.after_begin(p, m.lds_x, m.lds_g, pf, nx);
                     if constexpr (Solver<Model, Place>::kKeepZ) zkeep = sv.z;   // (the last one's stays: the next iteration's first)
                     wg_barrier<!Model::kStencil>();   // (raw: the next problem's n1 is on its way into the g area)
@@ -451,7 +452,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 Solver<Model, Place> sv(a, tid, m.red, m.shs);
                 sv.pk[0] = pk0;
                 sv.pk[1] = pk1;
-                sv.run(p, wg_scratch, m.lds_x, m.lds_g, pf, nx < a.nproblems ? nx : -1);
+                sv.template run<false>(p, wg_scratch, m.lds_x, m.lds_g, pf, nx < a.nproblems ? nx : -1);
                 wg_barrier<!Model::kStencil>();
                 p = nx;
             }

@@ -118,6 +118,8 @@ struct muse_ctx {
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
     int* error_flag = nullptr;           // pinned, device-mapped
+    unsigned int* fid_flag = nullptr;    // device word: the tag of the last fiducial MAP published inside a finite-difference launch
+    unsigned int fid_tag = 0;            // (fd_values_impl; grows with every such launch)
     int debug = 0;                       // muse_debug_flags
     Switches sw;                         // the environment switches as muse_ctx_create found them (switches.hpp)
     int split = 0;                 // muse_set_element_split: 0 = by N alone, >= 2 = workgroups per element
@@ -310,7 +312,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         a.n_per_map = a.nproblems;
         a.map_stride = a.nproblems;
     }
-    a.debug = c->debug & 0xffff;   // (bits 16-19 are host-side: switches.hpp)
+    a.debug = c->debug & 0xffff;   // (bits 16-20 are host-side: switches.hpp)
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     a.clock_out = c->prof_on ? c->clock_pin : nullptr;  // roofline leg only
     const bool implicit = a.kind == BATCH_IMPLICIT;
@@ -556,6 +558,8 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     HIPCHK(hipMalloc(&c->x_data, (size_t)c->ld * sizeof(double)));
     HIPCHK(hipMalloc(&c->counter, 16));
     HIPCHK(hipMemset(c->counter, 0, 16));
+    HIPCHK(hipMalloc(&c->fid_flag, 64));
+    HIPCHK(hipMemset(c->fid_flag, 0, 64));
     HIPCHK(hipHostMalloc(&c->error_flag, 64, hipHostMallocDefault));
     c->error_flag[0] = c->error_flag[1] = 0;
     HIPCHK(hipHostMalloc(&c->clock_pin, 64, hipHostMallocDefault));
@@ -643,7 +647,7 @@ int muse_ctx_destroy(muse_ctx* c) {
         for (int k = 0; k < MUSE_MODEL_MAX_CONST; ++k) { muse_host_consts[k] = nullptr; muse_host_const_len[k] = 0; }
     }
 #endif
-    hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->tmp);
+    hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->fid_flag); hipFree(c->tmp);
     hipFree(c->small_dev); if (c->tsample_dev) hipFree(c->tsample_dev); if (c->tsample_pin) hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
     for (int r = 0; r < kResultAreas; ++r) {
@@ -861,7 +865,8 @@ int muse_set_timing(muse_ctx* c, int enabled) {
 // Diagnostics (include/muse_hip.h).  Bits 0-8 travel to the kernels: 0 skip the solve, 1 x from the data vector, 2 the loop kernel
 // does not prefetch, 3 its old element order, 4 test hook (odd workers leave), 5 no speculating trials, 6 a solving stepper takes the
 // data element for itself, 7 the stepper never solves, 8 the data vector does not travel through the g area; bits 16-19 are
-// host-side (switches.hpp): 16 host board, 17 host-driven sharded loop, 18 oversubscribed loop launch (test hook), 19 run timing.
+// host-side (switches.hpp): 16 host board, 17 host-driven sharded loop, 18 oversubscribed loop launch (test hook), 19 run timing,
+// 20 the finite-difference map carries its fiducial MAP.
 int muse_debug_flags(muse_ctx* c, int flags) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     c->debug = flags;
@@ -1542,7 +1547,7 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     a.zhat = c->zhat;
     a.work_counter = c->counter;
     a.ticket_base = (int)c->ticket_base;   // (no tickets are drawn: elements are dealt statically)
-    a.debug = c->debug & 0xffff;   // (bits 16-19 are host-side: switches.hpp)
+    a.debug = c->debug & 0xffff;   // (bits 16-20 are host-side: switches.hpp)
     a.stamps = (c->stamps && a.nproblems + 3 <= c->stamps_cap) ? c->stamps : nullptr;   // (+3: the loop kernel's own rows)
     a.csize = 1;
     a.error_flag = c->error_flag;
@@ -1762,7 +1767,16 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
     const bool cached = held || ensure_ncache(c, nsims);
     const int64_t nc_sim0 = held ? c->nc_sim0 : s_lo, nc_cnt = held ? c->nc_count : nsims;
     const int64_t nprep = nfid + ((cached && !held && fid_mode == 0) ? nsims : 0);
-    rc = ensure_results(c, 1, n > nprep ? n : nprep);
+    // Round 6, built, measured and left OFF (MUSE_FD_FOLD / debug flag bit 20 switch it on; tests hold it bit-equal): with the
+    // simulations' normals in the cache already the ONE fiducial MAP can be problem 0 of the perturbed problems' launch, whose other
+    // problems stage their x while it is solved and wait for its tag before they load their warm start (args.hpp: fd_fold).  It
+    // removes a launch, but not the fiducial's ~22 us from the critical path -- every perturbed solve STARTS from that MAP -- and
+    // pays for it with an L2 write-back and a 513th problem that makes a third, one-problem round: a 513-problem call (one rank's
+    // share of configs[3] on 8 GPUs) 89.7 us against 81.8 us for the two launches, the whole 4097-problem job 279 us either way
+    // (gpurun_out/r06d/fd_ab2.log -> profiles/r06_fd_fold_ab.log).
+    const bool fold = held && fid_mode == 0 && choose_place(c) == P_R512x10 && (c->sw.fd_fold || (c->debug & kDebugFdFold)) &&
+                      n + 1 <= 0x7fffffff;
+    rc = ensure_results(c, 1, (n > nprep ? n : nprep) + 1);
     if (rc) return rc;
     // a sampling entry: exp(theta/2) of every block -- a SampleSd, or kBigTheta doubles in the big tier (solver.hpp, begin)
     const int ts_stride = tier_big(c, choose_place(c), 1) ? kBigTheta : kMaxTheta;
@@ -1774,7 +1788,7 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         rc = ensure_tsample(c, (size_t)(per_unit ? n : (int64_t)nt * G) * (size_t)(ts_stride / kMaxTheta));
         if (rc) return rc;
     }
-    {
+    if (!fold) {
         BatchArgs a;
         base_args(c, a, theta0);
         a.kind = BATCH_STD;
@@ -1828,7 +1842,18 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         a.kind = BATCH_FD;
         a.seed = seed;
         a.atol = atol;
-        a.nproblems = (int)n;
+        a.nproblems = (int)n + (fold ? 1 : 0);
+        if (fold) {
+            a.fd_fold = 1;
+            a.fid_sim = fid_sim;
+            a.fid_flag = c->fid_flag;
+            a.fid_tag = ++c->fid_tag;
+            if (c->fid_tag >= 0x7ffffff0u) {   // (the tag never wraps onto a value the flag may still hold)
+                HIPCHK(hipMemsetAsync(c->fid_flag, 0, 64, c->stream));
+                c->fid_tag = 0;
+                a.fid_tag = ++c->fid_tag;
+            }
+        }
         a.sim_begin = s_lo;
         a.fd_grid = G;
         a.fd_per_problem = per_unit ? 1 : 0;

@@ -930,8 +930,11 @@ struct Solver {
         run(p, wg_scratch, lds_x, lds_g, none);
     }
     // (next_p: the workgroup's next problem of the same iteration, -1: none -- its n1 travels into the g area during this solve)
+    // (FD: the launch may be a finite-difference map that carries its fiducial -- never the loop kernel's, which says so: its code
+    //  then holds neither the wait nor the publication)
+    template <bool FD = true>
     __device__ __forceinline__ void run(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p = -1) {
-        begin<false>(p, wg_scratch, lds_x, lds_g, pf);
+        begin<false, FD>(p, wg_scratch, lds_x, lds_g, pf);
         if (d.normals_only) return;  // the element only filled its slot of the normals cache
         pfp = &pf;
         if constexpr (Place::kResident && Place::kXgLds) {
@@ -939,6 +942,57 @@ struct Solver {
         }
         solve(p);
         finish(p);
+        if constexpr (FD) {
+            if (is_fid(p)) publish_fiducial();
+        }
+    }
+    // ---- a finite-difference launch that carries its own fiducial MAP (BatchArgs::fd_fold; src/muse.jl:417-432 in ONE launch) ----
+    // The fiducial's workgroup: every wave's stores of the MAP have been acknowledged by the L2 (vmcnt(0)), the workgroup meets, and
+    // one thread's agent-scope RELEASE store of the launch's tag writes the L2's dirty lines back before the flag can be seen -- the
+    // compute units of the other XCDs read the MAP through L2s of their own.  ONE such event per launch: a fence is the right tool
+    // here (the per-pass exchanges of the cluster placements use tagged granules instead, which cost no write-back).
+    // (derived from the launch's arguments where they are needed, not kept in the problem's descriptor: that lives in registers
+    //  through the solve)
+    __device__ __forceinline__ bool is_fid(int p) const { return a.kind == BATCH_FD && a.fd_fold && p == 0; }
+    __device__ __forceinline__ bool wait_fid(int p) const { return a.kind == BATCH_FD && a.fd_fold && p != 0; }
+    __device__ __forceinline__ int info_row(int p) const {   // a problem's solver info: its index, but for a launch that carries its fiducial
+        return (a.kind == BATCH_FD && a.fd_fold) ? (p == 0 ? a.nproblems - 1 : p - 1) : p;
+    }
+    __device__ __forceinline__ void publish_fiducial() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.fid_flag, a.fid_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // A perturbed problem: its x is staged; before the warm start is loaded the flag must carry this launch's tag.  Once per
+    // WORKGROUP (the outcome is remembered in LDS beside the ticket): the lines of the fiducial's slot cannot be in this compute
+    // unit's L1 or this XCD's L2 from earlier in the launch -- nobody reads the slot before the flag is seen, and the launch began with
+    // the caches invalidated -- but the acquire fence behind the poll is what the memory model asks for, and once per workgroup it is
+    // free.  Bounded by time (2 s) like every other wait of the engine: an expired wait raises the launch's error word.
+    __device__ __forceinline__ void wait_fiducial() {
+        int* seen = reinterpret_cast<int*>(sh_rho + 40) + 2;   // ticket[2] of the kernel's LDS carve (kernels.hpp)
+        if ((unsigned)__builtin_amdgcn_readfirstlane(seen[0]) == a.fid_tag) return;
+        // ONE wavefront polls (every workgroup of the launch but one waits here for ~20 us: eight polling wavefronts each were a stream
+        // of requests for one address that the fiducial's own traffic had to queue behind); the others wait at the barrier
+        if ((__builtin_amdgcn_readfirstlane(tid) >> 6) == 0) {
+            unsigned long long t0 = 0;
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.fid_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fid_tag) {
+                __builtin_amdgcn_s_sleep(32);
+                if ((++spins & 0x3fu) == 0) {
+                    unsigned long long now;
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > 200000000ull) {
+                        typedef __attribute__((address_space(1))) int gi32;
+                        __hip_atomic_store((gi32*)a.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0) seen[0] = (int)a.fid_tag;
     }
     // The loop kernel's first problem of an outer iteration > 1 (LDS-resident layout): the problem this workgroup solved LAST in
     // the previous iteration (it visits its elements in alternating order), so its warm start -- the MAP that solve ended with --
@@ -1095,7 +1149,7 @@ struct Solver {
         pfp = nullptr;
         begin<KEEP_ZTRUE>(p, wg_scratch, lds_x, lds_g, none);
     }
-    template <bool KEEP_ZTRUE>
+    template <bool KEEP_ZTRUE, bool FD = true>
     __device__ __forceinline__ void begin(int p, double* wg_scratch, double* lds_x, double* lds_g, Prefetch<EPT>& pf) {
         d = describe(a, p);
         // the loop kernel fetched this problem's theta-free inputs ahead (LDS-resident layout only; workgroup-uniform)
@@ -1179,7 +1233,10 @@ struct Solver {
                     asm volatile("" : "+v"(tl));  // per-slot offsets recomputed here, not held across the kernel
                     const bool n1_here = pf_hit && pf.have_n1, n2_here = pf_hit && pf.have_n2;   // in the g / x area already
                     if (n1_here) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA loads have landed
-                    if (z_warm) {   // the warm start's loads first, then what is not here yet: all in flight at once
+                    // (a finite-difference launch that carries its own fiducial MAP: x first -- it does not need the fiducial --, the
+                    //  warm start once the fiducial's workgroup has published it: wait_fiducial below)
+                    const bool fold_wait = FD && wait_fid(p);   // workgroup-uniform
+                    if (z_warm && !fold_wait) {   // the warm start's loads first, then what is not here yet: all in flight at once
 #pragma unroll
                         for (int j = 0; j < EPT; ++j) load_f64x2(z0src.rsrc, 2 * (tl + j * T), zw[j][0], zw[j][1]);
                         z_loaded = true;
@@ -1220,6 +1277,12 @@ struct Solver {
                             g.set(2 * j, i0, zt0);
                             g.set(2 * j + 1, i0 + 1, valid1 ? zt1 : 0.0);
                         }
+                    }
+                    if (z_warm && fold_wait) {
+                        wait_fiducial();
+#pragma unroll
+                        for (int j = 0; j < EPT; ++j) load_f64x2(z0src.rsrc, 2 * (tl + j * T), zw[j][0], zw[j][1]);
+                        z_loaded = true;
                     }
                 } else {
                     // sampling sd of the element in (run-time) slot jj: the slot's packed block index selects the value in LDS.
@@ -1451,12 +1514,6 @@ struct Solver {
                     done = true;
                 }
             }
-            if constexpr (Place::kResident && Place::kXgLds) {
-                // a data vector that was fetched ahead into the x / g area but is not taken from there (a start from zero: only the
-                // debug orders of the deal reach this today): its LDS-DMA loads must have landed before the plain path writes x and
-                // the solve its gradients over them
-                if (!done && pf_hit && (pf.have_x || pf.have_xg || pf.g_pending)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             if (!done)
             for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) {
                 x.set(jj, i, xs.get(jj, i));
@@ -1464,7 +1521,11 @@ struct Solver {
                 else if (!z_in_place) z.set(jj, i, z0src.get(jj, i));
             }, x, when(z_zero || !z_in_place, z));
         }
-        if (pf_hit) {   // consumed
+        if (pf_hit) {   // consumed -- or not taken from the x / g area (a data element that starts from zero: only the debug orders of
+            // the deal reach that today): then its LDS-DMA loads must have landed before the solve writes gradients over them
+            if constexpr (Place::kResident && Place::kXgLds) {
+                if (pf.g_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             pf.p = -1;
             pf.g_pending = false;
         }
@@ -2188,7 +2249,7 @@ struct Solver {
                 inf.hist_words = hist_words;
                 inf.f_min = f;
                 inf.gnorm = gmax;
-                a.info[d.irow] = inf;
+                a.info[info_row(p)] = inf;
             }
         } else {
             double acc[MAXB], mx[1] = {0.0};
@@ -2256,7 +2317,7 @@ struct Solver {
                 inf.hist_words = hist_words;
                 inf.f_min = f;
                 inf.gnorm = gmax;
-                a.info[d.irow] = inf;
+                a.info[info_row(p)] = inf;
             }
         }
         stamp(p, 7);

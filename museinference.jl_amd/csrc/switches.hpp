@@ -2,8 +2,8 @@
 //
 // The environment is read ONCE per context, by muse_ctx_create (Switches::from_environment); no call path after that calls
 // getenv.  The communicator of a context (muse_comm.cpp) uses its context's copy.  What a test or a tuning run wants to change
-// on a LIVE context goes through muse_debug_flags (include/muse_hip.h, "Diagnostics"): bits 16-19 there are the run-time forms of
-// host_board, sharded_host_loop, loop_oversubscribe and run_timing.
+// on a LIVE context goes through muse_debug_flags (include/muse_hip.h, "Diagnostics"): bits 16-20 there are the run-time forms of
+// host_board, sharded_host_loop, loop_oversubscribe, run_timing and fd_fold.
 //
 // None of these changes a result bit (they choose between code paths that tests hold bit-equal) except cluster_size, which
 // -- like muse_set_element_split -- changes the summation tree of a cluster placement.
@@ -18,6 +18,8 @@ struct Switches {
     bool no_xcd_local = false;          // MUSE_DEBUG_NO_XCD_LOCAL: clusters of the elementwise models span the XCDs
     bool no_big_tier = false;           // MUSE_DEBUG_NO_BIG_TIER: 2-8 components in a streaming placement run the small tiers' kernels
     bool no_ext_launch = false;         // MUSE_DEBUG_NO_EXT_LAUNCH: a result area's completion event is recorded behind the launch
+    bool fd_fold = false;               // MUSE_FD_FOLD: get_H!'s finite-difference map as ONE launch that carries its fiducial MAP (bit 20; built
+                                        // and measured in round 6: 8 us SLOWER per 513-problem call than the two launches -- off by default)
     int cluster_size = 0;               // MUSE_DEBUG_CLUSTER_SIZE=k: workgroups per element of the streaming clusters (0: by N and model)
     int shared_gpu_ranks = 1;           // MUSE_SHARED_GPU_RANKS=n: n processes share this GPU; cluster launches take 1/n of the compute units
     // ---- normals cache
@@ -48,6 +50,7 @@ struct Switches {
         s.no_xcd_local = on("MUSE_DEBUG_NO_XCD_LOCAL");
         s.no_big_tier = on("MUSE_DEBUG_NO_BIG_TIER");
         s.no_ext_launch = on("MUSE_DEBUG_NO_EXT_LAUNCH");
+        s.fd_fold = on("MUSE_FD_FOLD");
         s.cluster_size = num("MUSE_DEBUG_CLUSTER_SIZE", 0);
         s.shared_gpu_ranks = num("MUSE_SHARED_GPU_RANKS", 1);
         s.no_ncache = on("MUSE_DEBUG_NO_NCACHE");
@@ -76,6 +79,7 @@ enum : int {
     kDebugShardedHostLoop = 1 << 17,    // muse_run_sharded runs the host-driven loop
     kDebugLoopOversubscribe = 1 << 18, // test hook: a loop launch with more workgroups than can be resident at once
     kDebugRunTiming = 1 << 19,         // the native loops report on stderr which loop ran
+    kDebugFdFold = 1 << 20,            // get_H!'s finite-difference map as one launch that carries its fiducial MAP
 };
 
 }  // namespace muse

@@ -93,6 +93,39 @@ def test_config4_fd_jacobian_64_sims(gpu, M, O):
     prob.close()
 
 
+@pytest.mark.parametrize("N,nth", [(10000, 4), (10000, 1), (7001, 3), (4097, 8)])
+def test_fd_launch_that_carries_its_fiducial_changes_no_bit(gpu, M, O, N, nth):
+    """get_H!'s finite-difference map (src/muse.jl:417-442) once the simulations' normals are cached, as ONE launch whose problem 0 is the
+    fiducial MAP and whose other problems draw their x and then wait for its tag (round 6: built, 8 us slower per call than the two
+    launches, left off; debug flag bit 20 switches it on) -- against the two launches, against the first call of a fresh context
+    (nothing cached), in whole Jacobians and in column ranges that begin and end inside a simulation's Jacobian; and against the oracle."""
+    th = np.linspace(0.4, 1.3, nth)
+    step = np.full(nth, 0.05)
+    S = 70
+    prob = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
+    first, i1 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)         # fills the cache: fiducial launch + perturbed launch
+    two, i3 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)           # cache held, two launches (the default)
+    prob.debug_flags(1 << 20)
+    folded, i2 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)        # cache held: the one launch
+    assert np.array_equal(first, folded) and np.array_equal(two, folded)
+    assert i1.tobytes() == i2.tobytes() == i3.tobytes() and np.all(i2["status"] == 0)
+    lo, hi = 2 * nth + (1 if nth > 1 else 0), 41 * nth - (1 if nth > 1 else 0)   # units of the list (sim 3, column 0), (sim 3, column 1), ...
+    cols, ic = prob.fd_jacobian_columns(21, 3, lo, hi, th, step, atol=1e-2)
+    whole = folded.transpose(0, 2, 1).reshape(-1, nth)                            # unit e = (sim, column j): d g_i / d theta_j over i
+    assert np.array_equal(cols, whole[lo:hi])
+    # a different theta on the same context: the flag's tag moves on, nothing of the previous call's fiducial is taken
+    th2 = th + 0.3
+    a, _ = prob.fd_jacobian_batch(21, 3, 3 + S, th2, step, atol=1e-2)
+    prob.debug_flags(0)
+    b, _ = prob.fd_jacobian_batch(21, 3, 3 + S, th2, step, atol=1e-2)
+    assert np.array_equal(a, b) and not np.array_equal(a, folded)
+    _, zfid, _ = O.map_and_score_batch("funnel", N, 21, M.MASTER_SIM, M.MASTER_SIM + 1, th, atol=1e-2, z0_mode=0)
+    for s in (0, S - 1):
+        Ho = O.fd_jacobian("funnel", N, 21, 3 + s, th, step, zfid[0], atol=1e-2)
+        np.testing.assert_allclose(folded[s], Ho, rtol=1e-8, atol=1e-8 * np.abs(Ho).max())
+    prob.close()
+
+
 # ---- row f2: muse! keyword variants on the HIP path ---------------------------------------------------
 def test_outer_loop_variants_on_hip(gpu, M):
     """Broyden / diagonal-Broyden (with memory limit, with a user H^-1_like'), callable alpha + regularize, and
