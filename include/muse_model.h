@@ -74,6 +74,40 @@
  * (the funnel: ozz = 1 + iv, ozx = -1, bz = 2 z, bx = 0, dx/dsd = n1).  Without MUSE_MODEL_SECOND the implicit entries refuse
  * the model and get_H! runs by finite differences (muse_fd_*: model-agnostic).  muse_model_eval of muse_hip.h evaluates the
  * header's functions on the host for one element -- what check_model_consistency differentiates numerically.
+ *
+ * TWO PARAMETERS PER BLOCK (round 6: location-type parameters).  In the family above a block has ONE parameter, the log-variance
+ * of one Gaussian factor, and the engine knows how it enters: through exp(theta/2) in the draw, exp(-theta) in the objective,
+ * 1/2 (iv sum B - n) in the score.  A header that says
+ *     #define MUSE_MODEL_PAIR 1                        (before including this file)
+ * states all of that itself, for blocks with TWO parameters acting on the same elements -- a mean AND a log-variance, a slope and a
+ * scale, ...: ntheta = 2 K (at most MUSE_MAX_THETA = 8), the N elements in K contiguous equal blocks, block k's parameters
+ * a_k = theta[k] and b_k = theta[K + k], and with c_k[0..3] FOUR coefficients the header forms from them,
+ *
+ *     -logLike(x, z, theta) = 1/2 sum_i o(c_k(i); x_i, z_i) + 1/2 sum_k n_k C(a_k, b_k)
+ *     (x_i, z_i) ~ P(x, z | theta):  a function of c_k(i)[0], c_k(i)[1] and two independent standard normals
+ *
+ *     MUSE_MODEL_FN double muse_model_coefs(double a, double b, double* c);
+ *         fills c[0..3] and returns C(a, b).  Evaluated on the host, once per theta; exponentials through muse_model_exp(x), the
+ *         engine's fixed-sequence exp (the CPU checker evaluates the same sequence), every other operation an IEEE + - * / sqrt, fma
+ *     MUSE_MODEL_FN void   muse_model_sample(const double* c, double n1, double n2, double* z, double* x, long i);
+ *         the joint draw; may read c[0] and c[1] ONLY (a finite-difference get_H! re-draws at perturbed parameters and
+ *         carries just those two per block)
+ *     MUSE_MODEL_FN double muse_model_grad(const double* c, double x, double z, double* acc, long i);
+ *         returns d(1/2 o)/dz_i and ADDS o(c; x, z) to *acc
+ *     MUSE_MODEL_FN void   muse_model_score_terms(const double* c, double x, double z, double* t0, double* t1, long i);
+ *         the element's terms of the block's TWO sums S0 = sum t0, S1 = sum t1
+ *     MUSE_MODEL_FN void   muse_model_score(const double* c, double S0, double S1, double n, double* ga, double* gb);
+ *         *ga = d logLike / d a_k, *gb = d logLike / d b_k from the block's coefficients, sums and element count
+ *         (the d/d theta of the constant term included)
+ * The pad element of an odd-length vector and the phantom slots behind it are given ZERO coefficients (a location parameter has a
+ * gradient at x = z = 0): with c = {0, 0, 0, 0} and x = z = 0, muse_model_grad must return 0 leaving *acc as it was and
+ * muse_model_score_terms must give 0, 0 -- the engine checks that when a context is created.
+ * models/normal_mean_var.h is the shipped member: z_i ~ N(mu_k, e^tau_k), x_i ~ N(z_i, 1); c = {mu, e^(tau/2), e^-tau, 0}, C = tau,
+ * o = (x - z)^2 + e^-tau (z - mu)^2, t0 = z - mu, t1 = (z - mu)^2, ga = e^-tau S0, gb = 1/2 (e^-tau S1 - n).
+ * Everything of the C ABI applies -- batched maps in every placement (register/LDS resident, streaming, workgroup clusters, an
+ * element split), multi-map launches, lanes, muse_run, both exchanges between ranks, the finite-difference get_H! -- except: the
+ * device-resident loop (muse_run_device runs muse_run's loop: the step between two iterations forms the one-parameter family's
+ * exponentials on the device), the implicit-differentiation get_H! and more than MUSE_MAX_THETA parameters.
  */
 #ifndef MUSE_MODEL_H
 #define MUSE_MODEL_H

@@ -252,7 +252,7 @@ set_normals_cache(prob::HipMuseProblem, enabled::Bool) =
 # dx/dsd): what a consistency check differentiates numerically where the reference has AD (src/simple.jl:84-85)
 model_has_second() = ccall((:muse_model_has_second, libmuse_hip), Cint, ()) != 0
 function model_eval(prob::HipMuseProblem, iv, sd, x, z, n1, n2, i::Integer)
-    out = Vector{Float64}(undef, 10)
+    out = Vector{Float64}(undef, 12)
     check(ccall((:muse_model_eval, libmuse_hip), Cint, (Ptr{Cvoid}, Float64, Float64, Float64, Float64, Float64, Float64, Int64, Ptr{Float64}),
                 prob.ctx, iv, sd, x, z, n1, n2, i, out))
     out

@@ -857,9 +857,15 @@ hipError_t loop_place(const LaunchShape& s, const LoopCall& c) {
     X template hipError_t loop_place<M>(const LaunchShape&, const LoopCall&);
 #define MUSE_INSTANTIATE_USER_BIG(X, M) X template hipError_t launch_place_big<M>(const LaunchShape&, const BatchArgs&, hipStream_t);
 #endif
+#ifdef MUSE_MODEL_PAIR   // two parameters per block: tiers of 2, 4 and 8 components (1, 2, up to 4 blocks), the map kernel only
+#define MUSE_PART_0(X) X template hipError_t launch_place<UserModel<2>>(const LaunchShape&, const BatchArgs&, hipStream_t);
+#define MUSE_PART_1(X) X template hipError_t launch_place<UserModel<4>>(const LaunchShape&, const BatchArgs&, hipStream_t);
+#define MUSE_PART_2(X) X template hipError_t launch_place<UserModel<kMaxTheta>>(const LaunchShape&, const BatchArgs&, hipStream_t);
+#else
 #define MUSE_PART_0(X) MUSE_INSTANTIATE_USER(X, UserModel<1>)
 #define MUSE_PART_1(X) MUSE_INSTANTIATE_USER(X, UserModel<kMaxTheta>)
 #define MUSE_PART_2(X) MUSE_INSTANTIATE_USER_BIG(X, UserModel<kBigTheta>)
+#endif
 #define MUSE_PART_3(X)
 #define MUSE_PART_4(X)
 #define MUSE_PART_5(X)

@@ -24,6 +24,8 @@ __device__ __forceinline__ int block_of(const BatchArgs& a, int i) {
 template <int MAXB_>
 struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
     static constexpr int MAXB = MAXB_;
+    static constexpr bool kPair = false;   // one parameter per block: the coefficients are plain doubles
+    using SCoef = double; using GCoef = double;
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_FUNNEL;
     __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x, int) {
@@ -39,6 +41,8 @@ struct FunnelModel {  // z_i ~ N(0, e^theta_k), x_i ~ N(z_i, 1)
 };
 struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
     static constexpr int MAXB = 1;
+    static constexpr bool kPair = false;   // one parameter per block: the coefficients are plain doubles
+    using SCoef = double; using GCoef = double;
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_NOISE;
     __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x, int) {
@@ -58,17 +62,27 @@ struct NoiseModel {  // z_i ~ N(0,1), x_i ~ N(z_i, e^theta)
 template <int MAXB_>
 struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4); streaming policy only
     static constexpr int MAXB = MAXB_;
+    static constexpr bool kPair = false;   // one parameter per block: the coefficients are plain doubles
+    using SCoef = double; using GCoef = double;
     static constexpr bool kStencil = true;
     static constexpr int kId = MUSE_MODEL_SMOOTH;
     __device__ static __forceinline__ double score_term(double, double z, int) { return z * z; }
 };
 
+// Coefficients of an element's block for the models with TWO parameters per block (include/muse_model.h, MUSE_MODEL_PAIR): what the
+// draw takes (c[0], c[1]) and what the objective takes (all four).  Plain aggregates: they live in registers.
+struct PairS { double c[2]; };
+struct PairG { double c[4]; };
+
 #ifdef MUSE_USER_MODEL_HEADER
+#ifndef MUSE_MODEL_PAIR
 template <int MAXB_>
 struct UserModel {  // include/muse_model.h: the three functions of the user's header behind the elementwise model concept
     static constexpr int MAXB = MAXB_;
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_USER;
+    static constexpr bool kPair = false;
+    using SCoef = double; using GCoef = double;
     __device__ static __forceinline__ void sample(double sd, double n1, double n2, double& z, double& x, int i) {
         muse_model_sample(sd, n1, n2, &z, &x, (long)i);
     }
@@ -86,6 +100,31 @@ struct UserModel {  // include/muse_model.h: the three functions of the user's h
     }
 #endif
 };
+#else
+// A header of the two-parameter family (include/muse_model.h, "TWO PARAMETERS PER BLOCK"): K = ntheta / 2 blocks, block k's parameters
+// theta[k] and theta[K + k], four coefficients per block, two block sums per block, the score assembled by the header.
+template <int MAXB_>
+struct UserModel {
+    static_assert(MAXB_ % 2 == 0, "two parameters per block");
+    static constexpr int MAXB = MAXB_;
+    static constexpr bool kStencil = false;
+    static constexpr int kId = MUSE_MODEL_USER;
+    static constexpr bool kPair = true;
+    using SCoef = PairS; using GCoef = PairG;
+    __device__ static __forceinline__ void sample(const PairS& c, double n1, double n2, double& z, double& x, int i) {
+        muse_model_sample(c.c, n1, n2, &z, &x, (long)i);
+    }
+    __device__ static __forceinline__ double grad(const PairG& c, double x, double z, double& facc, int i) {
+        return muse_model_grad(c.c, x, z, &facc, (long)i);
+    }
+    __device__ static __forceinline__ void score_terms(const PairG& c, double x, double z, double& t0, double& t1, int i) {
+        muse_model_score_terms(c.c, x, z, &t0, &t1, (long)i);
+    }
+    __device__ static __forceinline__ void score(const PairG& c, double s0, double s1, double n, double& ga, double& gb) {
+        muse_model_score(c.c, s0, s1, n, &ga, &gb);
+    }
+};
+#endif
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -139,15 +139,49 @@ struct muse_ctx {
     size_t comm_buf_doubles = 0;
 };
 
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+// A library of the two-parameter family (include/muse_model.h, MUSE_MODEL_PAIR): K = ntheta / 2 blocks; block k's parameters are
+// theta[k] and theta[K + k], its coefficients and constant come from the HEADER (muse_model_coefs, evaluated here on the host) and
+// sit in the tables' slots {sd[k], sd[K + k], iv[k], iv[K + k]} (solver.hpp, gcoef / scoef).
+constexpr bool kPairModel = true;
+static void pair_map_theta(int nt, const int64_t* bnd, const double* theta, MapTheta& m) {
+    const int K = nt / 2;
+    memset(&m, 0, sizeof m);
+    double cst = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double cf[4] = {0.0, 0.0, 0.0, 0.0};
+        const double C = muse_model_coefs(theta[k], theta[K + k], cf);
+        m.t.theta[k] = theta[k];
+        m.t.theta[K + k] = theta[K + k];
+        m.t.sd[k] = cf[0];
+        m.t.sd[K + k] = cf[1];
+        m.t.iv[k] = cf[2];
+        m.t.iv[K + k] = cf[3];
+        cst += (double)(bnd[k + 1] - bnd[k]) * C;
+    }
+    m.f_const = cst;
+}
+#else
+constexpr bool kPairModel = false;
+#endif
+static int nblocks_of(int ntheta) { return kPairModel ? ntheta / 2 : ntheta; }
 // exp(theta/2), exp(-theta) and the constant term: step.hpp's fixed sequences (the device-resident loop forms the same bits)
 static void make_thetaset(const muse_ctx* c, const double* theta, ThetaSet& t) {
     MapTheta m;
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+    pair_map_theta(c->ntheta, c->bnd, theta, m);
+#else
     make_map_theta(c->ntheta, c->bnd, theta, m);
+#endif
     t = m.t;
 }
 static double theta_const(const muse_ctx* c, const double* theta) {
     MapTheta m;
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+    pair_map_theta(c->ntheta, c->bnd, theta, m);
+#else
     make_map_theta(c->ntheta, c->bnd, theta, m);
+#endif
     return m.f_const;
 }
 
@@ -199,6 +233,7 @@ static int choose_place(const muse_ctx* c) {
 // the small tier's compare chain and selected accumulations in every trip).  The stencil model gains nothing (2.32 / 2.38 ms).
 static bool tier_big(const muse_ctx* c, int pl, int nmaps) {
     if (c->ntheta > kMaxTheta) return true;
+    if (kPairModel) return false;   // (one tier: models.hpp, UserModel of the two-parameter family)
     return !c->sw.no_big_tier && c->ntheta > 1 && c->model != MUSE_MODEL_SMOOTH && nmaps <= 1 && (pl == P_S256 || pl == P_S512 || pl == P_C256);
 }
 static bool ncache_applies(const muse_ctx* c) {
@@ -302,7 +337,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
     a.ntheta = c->ntheta;
     for (int k = 0; k <= kMaxTheta; ++k) {
         a.bnd[k] = c->bnd[k];
-        a.bnd32[k] = k < c->ntheta ? (int)c->bnd[k] : 0x7fffffff;
+        a.bnd32[k] = k < nblocks_of(c->ntheta) ? (int)c->bnd[k] : 0x7fffffff;
     }
     a.x_data = c->x_data;
     if (!a.zhat) a.zhat = c->zhat;
@@ -520,6 +555,20 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
 #ifdef MUSE_MODEL_N  // a model with per-element tables is built for one N (include/muse_model.h)
     if (N != (int64_t)(MUSE_MODEL_N)) return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME " was built for another N (MUSE_MODEL_N)");
 #endif
+#ifdef MUSE_MODEL_PAIR
+    if (ntheta % 2 != 0 || ntheta > kMaxTheta)
+        return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME " has two parameters per block (MUSE_MODEL_PAIR): ntheta must be even and <= MUSE_MAX_THETA");
+    if (ntheta / 2 > N) return fail(MUSE_ERR_INVALID, "more blocks than elements");
+    {   // the pad element's contract of the two-parameter family: zero coefficients, x = z = 0 -> no contribution anywhere
+        const double zero4[4] = {0.0, 0.0, 0.0, 0.0};
+        double acc = 1.25, t0 = 1.0, t1 = 1.0;
+        const double g0 = muse_model_grad(zero4, 0.0, 0.0, &acc, (long)N);
+        muse_model_score_terms(zero4, 0.0, 0.0, &t0, &t1, (long)N);
+        if (!(g0 == 0.0 && acc == 1.25 && t0 == 0.0 && t1 == 0.0))
+            return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": with all four coefficients 0 and x = z = 0, muse_model_grad must return 0 and "
+                                          "leave acc unchanged and muse_model_score_terms must give 0, 0 (include/muse_model.h)");
+    }
+#else
     {   // the zero-element requirements of include/muse_model.h (the pad element of an odd-length vector must not contribute)
         double acc = 1.25;
         const double g0 = muse_model_grad(0.7, 0.0, 0.0, &acc, (long)N);
@@ -533,6 +582,7 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
             return fail(MUSE_ERR_INVALID, "model " MUSE_MODEL_NAME ": muse_model_second(iv, 0, 0, ..., N) must be finite (include/muse_model.h)");
 #endif
     }
+#endif
 #endif
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -549,9 +599,12 @@ int muse_ctx_create(int model, int64_t N, int ntheta, int device, muse_ctx** out
     c->ntheta = ntheta;
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
-    for (int k = 0; k <= kBigTheta; ++k) {
-        const int kk = k < ntheta ? k : ntheta;
-        c->bnd[k] = ((int64_t)kk * N + ntheta - 1) / ntheta;
+    {
+        const int nb = nblocks_of(ntheta);   // (two parameters per block: ntheta / 2 blocks)
+        for (int k = 0; k <= kBigTheta; ++k) {
+            const int kk = k < nb ? k : nb;
+            c->bnd[k] = ((int64_t)kk * N + nb - 1) / nb;
+        }
     }
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -788,7 +841,7 @@ int muse_set_constants(muse_ctx* c, int k, const double* values, int64_t count, 
 #endif
 }
 int muse_model_has_second(void) {
-#if defined(MUSE_USER_MODEL_HEADER) && !defined(MUSE_MODEL_SECOND)
+#if defined(MUSE_USER_MODEL_HEADER) && (!defined(MUSE_MODEL_SECOND) || defined(MUSE_MODEL_PAIR))
     return 0;
 #else
     return 1;
@@ -803,6 +856,21 @@ int muse_model_eval(muse_ctx* c, double iv, double sd, double x, double z, doubl
     (void)c;                 // a model without run-time constants needs no context (and no GPU) for this
 #endif
     if (!out || i < 0) return fail(MUSE_ERR_INVALID, "bad argument");
+#ifdef MUSE_MODEL_PAIR
+    // the two-parameter family: iv and sd are the block's two PARAMETERS here (a, b); out = {grad, objective term, t0, c0..c3 at
+    // [3..6], z, x, the block's constant C, t1, 0}
+    {
+        double cf[4] = {0.0, 0.0, 0.0, 0.0}, acc = 0.0;
+        out[9] = muse_model_coefs(iv, sd, cf);
+        out[0] = muse_model_grad(cf, x, z, &acc, (long)i);
+        out[1] = acc;
+        muse_model_score_terms(cf, x, z, &out[2], &out[10], (long)i);
+        for (int k = 0; k < 4; ++k) out[3 + k] = cf[k];
+        muse_model_sample(cf, n1, n2, &out[7], &out[8], (long)i);
+        out[11] = 0.0;
+        return MUSE_OK;
+    }
+#else
     double acc = 0.0;
     out[0] = muse_model_grad(iv, x, z, &acc, (long)i);
     out[1] = acc;
@@ -814,7 +882,9 @@ int muse_model_eval(muse_ctx* c, double iv, double sd, double x, double z, doubl
 #else
     out[3] = out[4] = out[5] = out[6] = out[9] = NAN;
 #endif
+    out[10] = out[11] = NAN;
     return MUSE_OK;
+#endif
 #else
     (void)c; (void)iv; (void)sd; (void)x; (void)z; (void)n1; (void)n2; (void)i; (void)out;
     return fail(MUSE_ERR_INVALID, "muse_model_eval evaluates a user-supplied model's header; this library holds the built-in models");
@@ -920,11 +990,11 @@ static void base_args(muse_ctx* c, BatchArgs& a, const double* theta) {
     a.ntheta = c->ntheta;
     for (int k = 0; k <= kMaxTheta; ++k) {
         a.bnd[k] = c->bnd[k];
-        a.bnd32[k] = k < c->ntheta ? (int)c->bnd[k] : 0x7fffffff;
+        a.bnd32[k] = k < nblocks_of(c->ntheta) ? (int)c->bnd[k] : 0x7fffffff;
     }
     make_thetaset(c, theta, a.cur.t);
     a.cur.f_const = theta_const(c, theta);
-    if (c->ntheta > 1 && c->model != MUSE_MODEL_NOISE)  // the big tier (tier_big): every block's coefficients, where its kernels read
+    if (c->ntheta > 1 && c->model != MUSE_MODEL_NOISE && !kPairModel)  // the big tier (tier_big): every block's coefficients, where its kernels read
         for (int k = 0; k < c->ntheta; ++k) {           // them from the kernarg segment (a launch of several maps overwrites them: maps[])
             a.big.sd[k] = muse_exp(0.5 * theta[k]);
             a.big.iv[k] = muse_exp(-theta[k]);
@@ -1541,7 +1611,7 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     a.ntheta = nt;
     for (int k = 0; k <= kMaxTheta; ++k) {
         a.bnd[k] = c->bnd[k];
-        a.bnd32[k] = k < nt ? (int)c->bnd[k] : 0x7fffffff;
+        a.bnd32[k] = k < nblocks_of(nt) ? (int)c->bnd[k] : 0x7fffffff;
     }
     a.x_data = c->x_data;
     a.zhat = c->zhat;
@@ -1824,7 +1894,13 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             for (int k = 0; k < nt; ++k) th[k] = theta0[k];
             th[j] = theta0[j] + off;
             double* sd = ts_dst + entry * ts_stride;
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+            MapTheta mt;   // the sampling coefficients of every block at the perturbed theta: the header's (slots as in pair_map_theta)
+            pair_map_theta(nt, c->bnd, th.data(), mt);
+            for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? mt.t.sd[k] : 0.0;
+#else
             for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? muse_exp(0.5 * th[k]) : 0.0;   // (make_map_theta_component's sd)
+#endif
         };
         if (per_unit) {
             for (int64_t e = 0; e < ne; ++e)

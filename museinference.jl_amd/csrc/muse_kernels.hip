@@ -81,7 +81,14 @@ __global__ void __launch_bounds__(256) sample_user_kernel(BatchArgs a, uint64_t 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = any_block(a, i);
         const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
+#ifdef MUSE_MODEL_PAIR
+        PairS c;
+        c.c[0] = a.cur.t.sd[k];
+        c.c[1] = a.cur.t.sd[(a.ntheta >> 1) + k];
+        UserModel<kMaxTheta>::sample(c, np.n1, np.n2, z[i], x[i], (int)i);
+#else
         UserModel<1>::sample(any_sd(a, k), np.n1, np.n2, z[i], x[i], (int)i);
+#endif
     }
 }
 #endif
@@ -114,6 +121,22 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
     // vectors are padded to the even length ld with a zero pad element (phantom zero, see for_elems)
     for_elems<T, 0, 1>(a.ld, tid, T, [&](int, int i) {
         const int k = MAXB > 1 ? any_block(a, i) : 0;
+        if constexpr (Model::kPair) {   // two parameters per block (include/muse_model.h): four coefficients, two block sums
+            const int K = a.ntheta >> 1;
+            const bool valid = i < Ni;   // (the pad element: zero coefficients, no contribution -- solver.hpp, gcoef)
+            PairG c;
+            c.c[0] = valid ? a.cur.t.sd[k] : 0.0;
+            c.c[1] = valid ? a.cur.t.sd[K + k] : 0.0;
+            c.c[2] = valid ? a.cur.t.iv[k] : 0.0;
+            c.c[3] = valid ? a.cur.t.iv[K + k] : 0.0;
+            const double gp = Model::grad(c, xin[i], zin[i], sum[0], i);
+            if (gout) gout[i] = -gp;
+            double t0, t1;
+            Model::score_terms(c, xin[i], zin[i], t0, t1, i);
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t0 : ((k + K == b) ? t1 : 0.0);
+            return;
+        } else {
         const double ivk = any_iv(a, k);
         double gi;
         if constexpr (Model::kStencil) {
@@ -134,17 +157,30 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
         const double t = Model::score_term(xin[i], zin[i], i);
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
+        }
     });
     block_allreduce<T, 2, 0>(sum, mx, red, parity, tid);
     block_allreduce<T, MAXB, 0>(acc, mx, red, parity, tid);
-    auto count = [&](int k) {  // elements of block k: bnd[k] = ceil(k N / ntheta)
-        const int64_t nt = a.ntheta;
+    auto count = [&](int k) {  // elements of block k: bnd[k] = ceil(k N / nblocks)
+        const int64_t nt = Model::kPair ? a.ntheta >> 1 : a.ntheta;
         return (double)(((int64_t)(k + 1) * N + nt - 1) / nt - ((int64_t)k * N + nt - 1) / nt);
     };
     if (tid == 0) {
         out[0] = -(0.5 * (sum[0] + a.cur.f_const));
+        if constexpr (Model::kPair) {
+            const int K = a.ntheta >> 1;
+            for (int k = 0; k < K; ++k) {
+                PairG c;
+                c.c[0] = a.cur.t.sd[k];
+                c.c[1] = a.cur.t.sd[K + k];
+                c.c[2] = a.cur.t.iv[k];
+                c.c[3] = a.cur.t.iv[K + k];
+                Model::score(c, acc[k], acc[K + k], count(k), out[1 + k], out[1 + K + k]);
+            }
+        } else {
         for (int b = 0; b < MAXB; ++b)
             if (b < a.ntheta) out[1 + b] = 0.5 * (any_iv(a, b) * acc[b] - count(b));
+        }
     }
     if constexpr (kBig) {
         for (int c = 8; c < a.ntheta; c += 8) {
@@ -180,6 +216,10 @@ MUSE_PART_0(extern) MUSE_PART_1(extern) MUSE_PART_2(extern) MUSE_PART_3(extern) 
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t st) {
 #ifdef MUSE_INSPECT  // development aid (tools/regs.py --check): instantiate ONE kernel, for a quick look at its assembly
     return launch_one<MUSE_INSPECT>(s, a, st);
+#elif defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)   // ... of the two-parameter family: 2 ... kMaxTheta components, no big tier,
+    if (s.model != MUSE_MODEL_USER || s.big || s.implicit) return hipErrorInvalidValue;   // no implicit differentiation
+    return s.ntheta == 2 ? launch_place<UserModel<2>>(s, a, st) : s.ntheta <= 4 ? launch_place<UserModel<4>>(s, a, st)
+                                                                                : launch_place<UserModel<kMaxTheta>>(s, a, st);
 #elif defined(MUSE_USER_MODEL_HEADER)  // a library built from a user's model header holds that model only (user_model.hpp)
     if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
     if (s.big && !s.implicit) return launch_place_big<UserModel<kBigTheta>>(s, a, st);
@@ -229,6 +269,8 @@ static hipError_t loop_dispatch(const LaunchShape& s, const LoopCall& c) {
     return loop_one<MUSE_INSPECT_LOOP>(s, c);
 #elif defined(MUSE_INSPECT)
     return hipErrorNotSupported;
+#elif defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+    return hipErrorNotSupported;   // (the step's coefficient update on the device is the one-parameter family's: muse_run runs these)
 #elif defined(MUSE_USER_MODEL_HEADER)
     if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
     return s.ntheta == 1 ? loop_place<UserModel<1>>(s, c) : loop_place<UserModel<kMaxTheta>>(s, c);
@@ -350,8 +392,13 @@ hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x,
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t st) {
 #ifdef MUSE_USER_MODEL_HEADER
     if (model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+#ifdef MUSE_MODEL_PAIR
+    if (a.ntheta > kMaxTheta) return hipErrorInvalidValue;
+#else
     if (a.ntheta > kMaxTheta) hipLaunchKernelGGL(loglike_kernel<UserModel<kBigTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
-    else hipLaunchKernelGGL(loglike_kernel<UserModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
+    else
+#endif
+    hipLaunchKernelGGL(loglike_kernel<UserModel<kMaxTheta>>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);
     return hipGetLastError();
 #endif
     if (model == MUSE_MODEL_NOISE) hipLaunchKernelGGL(loglike_kernel<NoiseModel>, dim3(1), dim3(1024), 0, st, a, x, z, g, out);

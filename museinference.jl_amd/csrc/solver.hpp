@@ -67,8 +67,16 @@ __device__ __forceinline__ void prefetch_issue(const BatchArgs& a, int tid, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// (the two-parameter family with ONE block: its four coefficients and the draw's two live in registers like iv0 / sd0 -- members of
+//  an empty base for every other model, so that the Solver of the built-in models is laid out as it always was)
+template <bool PAIR>
+struct PairState {};
+template <>
+struct PairState<true> {
+    double pc[4], psd[2];
+};
 template <class Model, class Place>
-struct Solver {
+struct Solver : PairState<Model::kPair> {
     static constexpr int T = Place::T, EPT = Place::EPT, U = Place::U, MAXB = Model::MAXB;
     // The big tier (kMaxTheta < ntheta <= kBigTheta, streaming placements only): the per-block coefficients come from the
     // kernel-argument segment (BatchArgs::big) or a finite-difference batch's sampling entry instead of the LDS argument block,
@@ -285,6 +293,70 @@ struct Solver {
         else if constexpr (kBig) return big_sd[blk(0, i)];
         else return sh_sd[block_of<MAXB>(a, i)];
     }
+    // The coefficients of the element in slot jj / at index i AS THE MODEL'S FUNCTIONS TAKE THEM: the block's exp(-theta) / exp(theta/2)
+    // for the one-parameter models (ivk / sdk above), and for the two-parameter family (models.hpp, kPair; include/muse_model.h,
+    // MUSE_MODEL_PAIR: block k's parameters are theta[k] and theta[K + k], K = ntheta / 2) the block's four coefficients -- the tables'
+    // slots {sd[k], sd[K + k], iv[k], iv[K + k]} of the MAP's theta for the objective, the first two of the theta the problem is
+    // DRAWN at (sh_sd) for the draw.
+    __device__ __forceinline__ auto gcoef(int jj, int i) const {
+        if constexpr (Model::kPair && MAXB == 2) {
+            const bool valid = i < (int)a.N;
+            PairG c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c.c[q] = valid ? this->pc[q] : 0.0;
+            return c;
+        } else if constexpr (Model::kPair) {
+            // (the zero pad element of an odd-length vector and the phantom slots behind it get ZERO coefficients: a model with a
+            //  location parameter has a gradient at x = z = 0, and the header's contract -- no contribution from c = 0, x = z = 0 --
+            //  keeps those slots out of every sum)
+            const int k = blk(jj, i), K = a.ntheta >> 1;
+            const bool valid = i < (int)a.N;
+            PairG c;
+            c.c[0] = valid ? a.cur.t.sd[k] : 0.0;
+            c.c[1] = valid ? a.cur.t.sd[K + k] : 0.0;
+            c.c[2] = valid ? a.cur.t.iv[k] : 0.0;
+            c.c[3] = valid ? a.cur.t.iv[K + k] : 0.0;
+            return c;
+        } else {
+            return ivk(jj, i);
+        }
+    }
+    __device__ __forceinline__ auto scoef_of_block(int k) const {   // (pair models only)
+        PairS c;
+        if constexpr (MAXB == 2) {
+            c.c[0] = this->psd[0];
+            c.c[1] = this->psd[1];
+        } else {
+            c.c[0] = sh_sd[k];
+            c.c[1] = sh_sd[(a.ntheta >> 1) + k];
+        }
+        return c;
+    }
+    __device__ __forceinline__ auto scoef(int jj, int i) const {
+        if constexpr (Model::kPair) return scoef_of_block(blk(jj, i));
+        else return sdk(jj, i);
+    }
+    // The element's share of the block sums the score is assembled from: acc[b] += B(x, z) for the element's block b, or -- two
+    // sums per block -- acc[k] += t0, acc[K + k] += t1 (the score's components in the order of theta).
+    template <int NB>
+    __device__ __forceinline__ void score_add(double* acc, double xi, double zi, int jj, int i, int first = 0) const {
+        if constexpr (Model::kPair) {
+            double t0, t1;
+            Model::score_terms(gcoef(jj, i), xi, zi, t0, t1, i);
+            const int k = blk(jj, i) - first, K = a.ntheta >> 1;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] += (k == b) ? t0 : ((k + K == b) ? t1 : 0.0);
+        } else {
+            const double t = Model::score_term(xi, zi, i);
+            if constexpr (NB == 1) {
+                acc[0] += t;
+            } else {
+                const int k = blk(jj, i) - first;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] += (k == b) ? t : 0.0;
+            }
+        }
+    }
     __device__ __forceinline__ void pack_blocks() {
         pk[0] = pk[1] = 0u;
         if constexpr (MAXB > 1 && Place::kResident) {
@@ -455,9 +527,9 @@ struct Solver {
             const int i = i0 + v;
             const bool valid = i < N;
             double zt, xt;
-            Model::sample(sdk(v, i), np[v].n1, np[v].n2, zt, xt, i);
+            Model::sample(scoef(v, i), np[v].n1, np[v].n2, zt, xt, i);
             xt = valid ? xt : 0.0;
-            const double ivi = ivk(v, i);
+            const auto ivi = gcoef(v, i);
             const double gi = Model::grad(ivi, xt, 0.0, gen.sum[0], i);
             const double sd = -gi;
             gen.sum[1] = fma(gi, sd, gen.sum[1]);
@@ -596,7 +668,7 @@ struct Solver {
                     zi = fma(c, si, zi);
                 }
                 const double xi = x.get(jj, i);
-                const double gi = Model::grad(ivk(jj, i), xi, zi, sum[0], i);
+                const double gi = Model::grad(gcoef(jj, i), xi, zi, sum[0], i);
                 if constexpr (STORE_G) g.set(jj, i, gi);
                 if constexpr (USE_S) sum[1] = fma(gi, si, sum[1]);
                 if constexpr (INIT_S) {
@@ -608,14 +680,7 @@ struct Solver {
                 if constexpr (SPEC) {   // the sums of solve()'s last pass, should this be the accepted step (same statements, same order)
                     mx[1] = absmax(mx[1], zi - zo);
                     if constexpr (!Place::kResident) z.set(jj, i, zi);   // (streaming, from the virtual zero: the MAP slot itself)
-                    const double t = Model::score_term(xi, zi, i);
-                    if constexpr (KB == 1) {
-                        sum[2] += t;
-                    } else {
-                        const int k = blk(jj, i);
-#pragma unroll
-                        for (int b = 0; b < KB; ++b) sum[2 + b] += (k == b) ? t : 0.0;
-                    }
+                    score_add<KB>(sum + 2, xi, zi, jj, i);
                 }
             }, when(STORE_G, g), when(INIT_S, s), when(SPEC && !Place::kResident && spec_on, z));
         } else {
@@ -662,7 +727,8 @@ struct Solver {
     __device__ __forceinline__ void eval_init_with_trial(double c0, double& f, double& dphi, double& gmax) {
         double sum[4] = {0.0, 0.0, 0.0, 0.0}, mx[2] = {0.0, 0.0};
         for_elems<T, EPT, U>(a.ld, tfirst, ps(), [&](int jj, int i) {
-            const double zi = z.get(jj, i), xi = x.get(jj, i), ivi = ivk(jj, i);
+            const double zi = z.get(jj, i), xi = x.get(jj, i);
+            const auto ivi = gcoef(jj, i);
             const double gi = Model::grad(ivi, xi, zi, sum[0], i);
             const double sd = -gi;
             s.set(jj, i, sd);
@@ -1032,6 +1098,12 @@ struct Solver {
             stamp(p, 0);
             iv0 = a.cur.t.iv[0];
             sd0 = a.cur.t.sd[0];
+            if constexpr (Model::kPair && MAXB == 2) {
+                this->pc[0] = this->psd[0] = a.cur.t.sd[0];
+                this->pc[1] = this->psd[1] = a.cur.t.sd[1];
+                this->pc[2] = a.cur.t.iv[0];
+                this->pc[3] = a.cur.t.iv[1];
+            }
             if constexpr (MAXB > 1) {
                 int tl = tid;
                 asm volatile("" : "+v"(tl));
@@ -1058,8 +1130,8 @@ struct Solver {
                         const double a0 = g.get(2 * j, i0), a1 = g.get(2 * j + 1, i0 + 1);
                         const double b0 = x.get(2 * j, i0), b1 = x.get(2 * j + 1, i0 + 1);
                         double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk(2 * j, i0), a0, b0, zt0, xt0, i0);
-                        Model::sample(sdk(2 * j + 1, i0 + 1), a1, b1, zt1, xt1, i0 + 1);
+                        Model::sample(scoef(2 * j, i0), a0, b0, zt0, xt0, i0);
+                        Model::sample(scoef(2 * j + 1, i0 + 1), a1, b1, zt1, xt1, i0 + 1);
                         const bool valid1 = i0 + 1 < (int)N;
                         x.set(2 * j, i0, xt0);
                         x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
@@ -1093,8 +1165,8 @@ struct Solver {
                     for (int j = 0; j < EPT; ++j) {
                         const int i0 = 2 * (tl + j * T);
                         double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
-                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
+                        Model::sample(scoef(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
+                        Model::sample(scoef(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
                         const bool valid1 = i0 + 1 < (int)N;
                         x.set(2 * j, i0, xt0);
                         x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
@@ -1161,6 +1233,14 @@ struct Solver {
         stamp(p, 0);
         iv0 = a.cur.t.iv[0];
         sd0 = d.tsample >= 0 ? tsample_base()[d.tsample].sd[0] : a.cur.t.sd[0];
+        if constexpr (Model::kPair && MAXB == 2) {   // one block: its coefficients are workgroup-uniform
+            this->pc[0] = a.cur.t.sd[0];
+            this->pc[1] = a.cur.t.sd[1];
+            this->pc[2] = a.cur.t.iv[0];
+            this->pc[3] = a.cur.t.iv[1];
+            this->psd[0] = sd0;
+            this->psd[1] = d.tsample >= 0 ? tsample_base()[d.tsample].sd[1] : a.cur.t.sd[1];
+        }
         if constexpr (kBig) {
             // (generic pointers into the kernarg segment: BatchArgs is the kernel's only parameter)
             const BigTheta* bt = reinterpret_cast<const BigTheta*>(
@@ -1268,9 +1348,16 @@ struct Solver {
                     for (int j = 0; j < EPT; ++j) {
                         const int i0 = 2 * (tl + j * T);
                         double zt0, xt0, zt1, xt1;
-                        Model::sample(sdk(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
-                        Model::sample(sdk(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
+                        Model::sample(scoef(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
+                        Model::sample(scoef(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
                         const bool valid1 = i0 + 1 < (int)N;
+                        if constexpr (Model::kPair) {
+                            // (a thread's slots beyond the vector -- their normals load as zeros -- draw (0, 0) in the one-parameter family
+                            //  by themselves; a location parameter would put its value there)
+                            const bool valid0 = i0 < (int)N;
+                            xt0 = valid0 ? xt0 : 0.0;
+                            zt0 = valid0 ? zt0 : 0.0;
+                        }
                         x.set(2 * j, i0, xt0);
                         x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
                         if (stage_ztrue) {
@@ -1293,7 +1380,8 @@ struct Solver {
                         else {
                             const unsigned w = jj >= 10 ? pk[1] : pk[0];
                             const int sh = 3 * (jj >= 10 ? jj - 10 : jj);
-                            return sh_sd[(w >> sh) & 7u];
+                            if constexpr (Model::kPair) return scoef_of_block((int)((w >> sh) & 7u));
+                            else return sh_sd[(w >> sh) & 7u];
                         }
                     };
                     // One trip draws kSamplerPairs pairs (2 * kSamplerPairs independent Philox/Box-Muller chains in one basic
@@ -1428,14 +1516,14 @@ struct Solver {
                             const bool valid = i < N;
                             const NormalPair np = npv[jj % (2 * kGenU)];
                             double zt, xt;
-                            Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt, i);
+                            Model::sample(scoef(jj, i), np.n1, np.n2, zt, xt, i);
                             zt = valid ? zt : 0.0;
                             xt = valid ? xt : 0.0;
                             if constexpr (KEEP_ZTRUE) ztrue.set(jj, i, keep_value(valid, zt, sdk(jj, i), np, i));
                             x.set(jj, i, xt);
                             const double z0v = ztrue_start ? zt : 0.0;
                             if (Place::kResident || ztrue_start) z.set(jj, i, z0v);  // registers: always defined
-                            const double ivi = ivk(jj, i);
+                            const auto ivi = gcoef(jj, i);
                             const double gi = Model::grad(ivi, xt, z0v, sum[0], i);
                             const double sd = -gi;
                             s.set(jj, i, sd);
@@ -1468,7 +1556,7 @@ struct Solver {
                         xt = np.n2;                           // noise now, + A z after the barrier
                         g.set(jj, i, valid ? zt : 0.0);       // true z staged in the (still unused) gradient buffer
                     } else {
-                        Model::sample(sdk(jj, i), np.n1, np.n2, zt, xt, i);
+                        Model::sample(scoef(jj, i), np.n1, np.n2, zt, xt, i);
                     }
                     zt = valid ? zt : 0.0;
                     xt = valid ? xt : 0.0;
@@ -1802,7 +1890,7 @@ struct Solver {
                         for_elems_zz([&](auto zz, int jj, int i) {
                             double unused = 0.0;
                             const double zi = decltype(zz)::value ? 0.0 : z.get(jj, i);
-                            g.set(jj, i, Model::grad(ivk(jj, i), x.get(jj, i), zi, unused, i));
+                            g.set(jj, i, Model::grad(gcoef(jj, i), x.get(jj, i), zi, unused, i));
                         }, g);
                         g_stored = true;
                     }
@@ -1877,14 +1965,7 @@ struct Solver {
                     if constexpr (Place::kResident) {
                         if (store) zout.set(jj, i, zn);
                     }
-                    const double t = Model::score_term(x.get(jj, i), zn, i);
-                    if constexpr (KB == 1) {
-                        acc[0] += t;
-                    } else {
-                        const int k = blk(jj, i);
-#pragma unroll
-                        for (int b = 0; b < KB; ++b) acc[b] += (k == b) ? t : 0.0;
-                    }
+                    score_add<KB>(acc, x.get(jj, i), zn, jj, i);
                 }, z);
                 if (iterations == 1) stamp(p, 14);
                 if constexpr (KB + 1 <= 8) {
@@ -1912,7 +1993,8 @@ struct Solver {
                     z.set(jj, i, zn);
                     mx[0] = absmax(mx[0], zn - zo);
                     double unused = 0.0;
-                    const double xi = x.get(jj, i), ivi = ivk(jj, i);
+                    const double xi = x.get(jj, i);
+                    const auto ivi = gcoef(jj, i);
                     const double gn = Model::grad(ivi, xi, zn, unused, i);
                     double go;
                     if constexpr (decltype(have_g)::value) go = g.get(jj, i);
@@ -2267,14 +2349,7 @@ struct Solver {
                     if constexpr (Place::kResident) {
                         if (store) zout.set(jj, i, zi);
                     }
-                    const double t = Model::score_term(x.get(jj, i), zi, i);
-                    if constexpr (MAXB == 1) {
-                        acc[0] += t;
-                    } else {
-                        const int k = blk(jj, i);
-#pragma unroll
-                        for (int b = 0; b < MAXB; ++b) acc[b] += (k == b) ? t : 0.0;
-                    }
+                    score_add<MAXB>(acc, x.get(jj, i), zi, jj, i);
                 });
                 reduce<MAXB, 0>(acc, mx);
             }
@@ -2284,9 +2359,32 @@ struct Solver {
                 double mine = acc[0];
 #pragma unroll
                 for (int b = 1; b < MAXB; ++b) mine = (tl == b) ? acc[b] : mine;
+                double sc;
+                if constexpr (Model::kPair) {
+                    // lane tl writes component tl of the score: parameter tl / K of block k = tl mod K, from the block's two sums
+                    // (acc[k], acc[K + k]), its coefficients and its element count -- assembled by the header (muse_model_score)
+                    const int K = a.ntheta >> 1, k = tl < K ? tl : tl - K;
+                    double s0 = acc[0], s1 = acc[0];
+#pragma unroll
+                    for (int b = 1; b < MAXB; ++b) {
+                        s0 = (k == b) ? acc[b] : s0;
+                        s1 = (k + K == b) ? acc[b] : s1;
+                    }
+                    const double cnt = (double)((k == K - 1 ? (int)a.N : a.bnd32[k + 1]) - a.bnd32[k]);
+                    PairG c;
+                    c.c[0] = a.cur.t.sd[k];
+                    c.c[1] = a.cur.t.sd[K + k];
+                    c.c[2] = a.cur.t.iv[k];
+                    c.c[3] = a.cur.t.iv[K + k];
+                    double ga, gb;
+                    Model::score(c, s0, s1, cnt, ga, gb);
+                    sc = tl < K ? ga : gb;
+                    (void)mine;
+                } else {
                 const double cnt = (double)(a.bnd32[tl < a.ntheta - 1 ? tl + 1 : 0] - a.bnd32[tl]);
                 const double cnt_last = (double)((int)a.N - a.bnd32[tl]);  // bnd32[ntheta] is a sentinel, not N
-                const double sc = 0.5 * (a.cur.t.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
+                sc = 0.5 * (a.cur.t.iv[tl] * mine - (tl == a.ntheta - 1 ? cnt_last : cnt));
+                }
                 a.scores[d.row * a.ntheta + tl] = sc;
                 if (a.gran) {  // device-resident muse! loop: the component also leaves as two tagged granules (args.hpp)
                     typedef __attribute__((address_space(1))) unsigned long long gu64;

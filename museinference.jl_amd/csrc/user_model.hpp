@@ -14,6 +14,10 @@
 // where a launch's run-time constants sit in its kernel-argument block (args.hpp, BatchArgs::consts; muse_model.h, muse_const)
 #include "args.hpp"
 #define MUSE_KERNARG_CONSTS (muse::kArgsConstsOffset)
+// what a header of the two-parameter family forms its coefficients with (include/muse_model.h, MUSE_MODEL_PAIR): the engine's exp --
+// one fixed sequence of IEEE operations, the same on host and device (step.hpp) and in the CPU checker
+#include "step.hpp"
+#define muse_model_exp(x) muse::muse_exp(x)
 #include MUSE_USER_MODEL_HEADER
 #ifndef MUSE_MODEL_NAME
 #error "the model header must #define MUSE_MODEL_NAME (include/muse_model.h)"

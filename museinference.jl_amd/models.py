@@ -101,6 +101,15 @@ class ElementwiseModel:
         return "\n".join(out) + "\n"
 
     @property
+    def pair(self):
+        """True for a header of the two-parameter family (include/muse_model.h: `#define MUSE_MODEL_PAIR`): ntheta = 2 K, block k's
+        parameters are theta[k] and theta[K + k]."""
+        if not hasattr(self, "_pair"):
+            text = re.sub(r"/\*.*?\*/", "", open(self.header).read(), flags=re.S)
+            self._pair = re.search(r"^\s*#\s*define\s+MUSE_MODEL_PAIR\b", text, flags=re.M) is not None
+        return self._pair
+
+    @property
     def library_name(self):
         return getattr(self, "_libname", self.name)
 

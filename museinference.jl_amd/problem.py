@@ -213,9 +213,12 @@ class HipMuseProblem(AbstractMuseProblem):
         """The functions of a user-supplied model's header at one element, evaluated on the host (muse_model_eval): a dict with
         grad (d(-logLike)/dz_i), term (A + iv B), B, ozz, ozx, bz, bx (muse_model_second) and z, x, dx_dsd of the draw at
         (sd, n1, n2).  What check_model_consistency differentiates numerically."""
-        out = np.empty(10)
+        out = np.empty(12)
         self._check(self._lib.muse_model_eval(self._ctx, float(iv), float(sd), float(x), float(z), float(n1), float(n2), int(i),
                                               _capi.ptr(out)))
+        if getattr(self.user_model, "pair", False):
+            # a header of the two-parameter family (include/muse_model.h, MUSE_MODEL_PAIR): `iv` and `sd` were the block's parameters a, b
+            return dict(zip(("grad", "term", "t0", "c0", "c1", "c2", "c3", "z", "x", "C", "t1"), out.tolist()))
         return dict(zip(("grad", "term", "B", "ozz", "ozx", "bz", "bx", "z", "x", "dx_dsd"), out.tolist()))
 
     def close(self):

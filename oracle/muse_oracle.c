@@ -95,6 +95,8 @@ static double* ws_alloc(size_t n) {
 #define MO_MODEL_USER 3
 #ifdef MO_USER_MODEL_HEADER
 #define MUSE_MODEL_FN static inline
+static double mo_exp(double x);              /* (defined below: the engine's fixed-sequence exp, restated) */
+#define muse_model_exp(x) mo_exp(x)          /* what a header of the two-parameter family forms its coefficients with */
 #include MO_USER_MODEL_HEADER
 const char* mo_user_model_name(void) { return MUSE_MODEL_NAME; }
 #ifdef MUSE_MODEL_NCONST /* run-time constants (include/muse_model.h: muse_const): this checker's copies */
@@ -342,6 +344,21 @@ static double mo_theta_const(int64_t N, int ntheta, const double* theta) {
     return cst;
 }
 
+#if defined(MO_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+/* A header of the two-parameter family (include/muse_model.h, MUSE_MODEL_PAIR): K = ntheta / 2 blocks, block k's parameters
+ * theta[k] and theta[K + k]; its four coefficients c[k][0..3] and the constant sum_k n_k C(a_k, b_k) come from the header. */
+static double mo_pair_coefs(int64_t N, int ntheta, const double* theta, double c[][4]) {
+    const int K = ntheta / 2;
+    double cst = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int64_t lo = ((int64_t)k * N + K - 1) / K, hi = ((int64_t)(k + 1) * N + K - 1) / K;
+        c[k][0] = c[k][1] = c[k][2] = c[k][3] = 0.0;
+        cst += (double)(hi - lo) * muse_model_coefs(theta[k], theta[K + k], c[k]);
+    }
+    return cst;
+}
+#endif
+
 /* sample_x_z(prob, rng, theta) -> (x, z)   [src/interface.jl:92-99, src/simple.jl:61-65] */
 void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim, const double* theta,
                    double* x, double* z) {
@@ -350,11 +367,21 @@ void mo_sample_x_z(int model, int64_t N, int ntheta, uint64_t seed, uint64_t sim
 #ifdef MO_USER_MODEL_HEADER
     if (model == MO_MODEL_USER) {
         MO_USER_CHECK_N(N);
+#ifdef MUSE_MODEL_PAIR
+        double c[32][4];
+        mo_pair_coefs(N, ntheta, theta, c);
+        for (int64_t i = 0; i < N; ++i) {
+            double n1, n2;
+            mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
+            muse_model_sample(c[mo_block(i, N, ntheta / 2)], n1, n2, &z[i], &x[i], (long)i);
+        }
+#else
         for (int64_t i = 0; i < N; ++i) {
             double n1, n2;
             mo_normal_pair(seed, sim, (uint64_t)i, &n1, &n2);
             muse_model_sample(sd[mo_block(i, N, ntheta)], n1, n2, &z[i], &x[i], (long)i);
         }
+#endif
         return;
     }
 #endif
@@ -414,11 +441,21 @@ double mo_negloglike_grad(int model, int64_t N, int ntheta, const double* x, con
 #ifdef MO_USER_MODEL_HEADER
     if (model == MO_MODEL_USER) {
         MO_USER_CHECK_N(N);
+#ifdef MUSE_MODEL_PAIR
+        double c[32][4];
+        const double cst2 = mo_pair_coefs(N, ntheta, theta, c);
+        for (int64_t i = 0; i < N; ++i) {
+            const double gi = muse_model_grad(c[mo_block(i, N, ntheta / 2)], x[i], z[i], &acc, (long)i);
+            if (G) G[i] = gi;
+        }
+        return 0.5 * (acc + cst2);
+#else
         for (int64_t i = 0; i < N; ++i) {
             const double gi = muse_model_grad(iv[mo_block(i, N, ntheta)], x[i], z[i], &acc, (long)i);
             if (G) G[i] = gi;
         }
         return 0.5 * (acc + mo_theta_const(N, ntheta, theta));
+#endif
     }
 #endif
     if (model == MO_MODEL_NOISE) {
@@ -479,11 +516,30 @@ void mo_grad_theta(int model, int64_t N, int ntheta, const double* x, const doub
 #ifdef MO_USER_MODEL_HEADER
     if (model == MO_MODEL_USER) {
         MO_USER_CHECK_N(N);
+#ifdef MUSE_MODEL_PAIR
+        {   /* two block sums per block, the score's two components of a block assembled by the header */
+            const int K = ntheta / 2;
+            double c[32][4], s0[32], s1[32];
+            mo_pair_coefs(N, ntheta, theta, c);
+            for (int k = 0; k < K; ++k) s0[k] = s1[k] = 0.0;
+            for (int64_t i = 0; i < N; ++i) {
+                int k = mo_block(i, N, K);
+                double t0, t1;
+                muse_model_score_terms(c[k], x[i], z[i], &t0, &t1, (long)i);
+                s0[k] += t0;
+                s1[k] += t1;
+                cnt[k] += 1;
+            }
+            for (int k = 0; k < K; ++k) muse_model_score(c[k], s0[k], s1[k], (double)cnt[k], &out[k], &out[K + k]);
+            return;
+        }
+#else
         for (int64_t i = 0; i < N; ++i) {
             int k = mo_block(i, N, ntheta);
             acc[k] += muse_model_score_term(x[i], z[i], (long)i);
             cnt[k] += 1;
         }
+#endif
     } else
 #endif
     for (int64_t i = 0; i < N; ++i) {
