@@ -116,7 +116,7 @@ def compulsory_bytes(info, N, placement):
 #   evaluation passes (funnel/noise gradient: 5 fp64; + g.s fma, |g| max):
 #     sampler-fused initial evaluation AND first trial 14;  every further line-search trial 8;
 #     last update pass (z += alpha s, step norm, score term) 5;  a kept update pass (K > 1) 14
-# Issue cost per wave-instruction on one SIMD, measured by tools/clockprobe.hip with all CUs busy: fp64 4.4
+# Issue cost per wave-instruction on one SIMD, measured by tools/clockprobe.hip with all CUs busy (HISTORY.md §6): fp64 4.4
 # cycles (nominal 4: 16 lanes/clk), v_mad_u64_u32 4.75, 32-bit integer / select 2.7.
 ALG_OPS = {"sampler_fp64": 5 + 29 + 11 + 29 + 2 + 2, "sampler_mul64": 20, "sampler_int32": 40 + 4 + 8 + 8,
            "init_fp64": 14, "trial_fp64": 8, "last_fp64": 5, "kept_fp64": 14}
@@ -162,7 +162,7 @@ def roofline_object(workload, model, N, info, pinfo, kernel_ms, launch_s, clock_
                        "of each kind (tools/clockprobe.hip) / (1024 SIMDs x launch time x measured clock); independent of how "
                        "many instructions the compiled kernel spends on them.  The peak is the PROBE's rate -- ~10 % softer than "
                        "the spec rates (fp64 4 cycles, 32-bit 2) and optimistic for this mix: the generator as a kernel of its own "
-                       "at eight waves per SIMD (built, measured and removed in round 4: DESIGN.md section 6) ran no faster than "
+                       "at eight waves per SIMD (built, measured and removed in round 4: HISTORY.md section 6) ran no faster than "
                        "inside this kernel, i.e. the sampler -- two thirds of the launch -- already runs at the VALU's throughput"}
         valu = {"bound": "valu", "achieved": alg["frac_of_issue_peak"] * VALU_PEAK_TFLOPS, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": alg["frac_of_issue_peak"], "traffic": traffic, "algorithmic": alg,

@@ -136,10 +136,10 @@ int muse_placement_info(muse_ctx* ctx, int* threads, int* workgroups_per_element
 int muse_set_constants(muse_ctx* ctx, int k, const double* values, int64_t count, int mem);
 /* The functions of a user-supplied model's header evaluated on the HOST for one element (include/muse_model.h) -- what the
  * reference gets from AD for free has to be checkable for hand-written derivatives (src/simple.jl:84-85): Python's
- * check_model_consistency differentiates these values numerically.  out[12] = { muse_model_grad's return value, the objective
+ * check_model_consistency differentiates these values numerically.  out[10] = { muse_model_grad's return value, the objective
  * term it adds to its accumulator (A + iv B), muse_model_score_term (B), ozz, ozx, bz, bx of muse_model_second, and z, x,
  * dx/dsd of muse_model_sample / muse_model_dx_dsd at (sd, n1, n2) }; entries 3-6 and 9 are NaN when the header does not define
- * MUSE_MODEL_SECOND; entries 10-11 are NaN.  A header of the two-parameter family (MUSE_MODEL_PAIR, round 6): `iv` and `sd` are the
+ * MUSE_MODEL_SECOND.  A header of the two-parameter family (MUSE_MODEL_PAIR, round 6) writes TWELVE doubles: `iv` and `sd` are the
  * block's two PARAMETERS a, b, and out[12] = { muse_model_grad, the objective term, t0 of muse_model_score_terms, the four
  * coefficients of muse_model_coefs(a, b), z, x of muse_model_sample, the block's constant C(a, b), t1, 0 }.  The model's run-time
  * constants are the context's; a model without them needs no context (ctx may be NULL, and no GPU is touched).  Built-in models:

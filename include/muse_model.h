@@ -105,9 +105,9 @@
  * models/normal_mean_var.h is the shipped member: z_i ~ N(mu_k, e^tau_k), x_i ~ N(z_i, 1); c = {mu, e^(tau/2), e^-tau, 0}, C = tau,
  * o = (x - z)^2 + e^-tau (z - mu)^2, t0 = z - mu, t1 = (z - mu)^2, ga = e^-tau S0, gb = 1/2 (e^-tau S1 - n).
  * Everything of the C ABI applies -- batched maps in every placement (register/LDS resident, streaming, workgroup clusters, an
- * element split), multi-map launches, lanes, muse_run, both exchanges between ranks, the finite-difference get_H! -- except: the
- * device-resident loop (muse_run_device runs muse_run's loop: the step between two iterations forms the one-parameter family's
- * exponentials on the device), the implicit-differentiation get_H! and more than MUSE_MAX_THETA parameters.
+ * element split), multi-map launches, lanes, the native muse! loops (muse_run, muse_run_device: the step between two iterations
+ * calls muse_model_coefs on the device -- the same statements as on the host, the same bits --, muse_run_sharded), both exchanges
+ * between ranks, the finite-difference get_H! -- except the implicit-differentiation get_H! and more than MUSE_MAX_THETA parameters.
  */
 #ifndef MUSE_MODEL_H
 #define MUSE_MODEL_H
@@ -115,6 +115,13 @@
 #define MUSE_MODEL_FN static inline
 #endif
 #define MUSE_MODEL_MAX_CONST 4
+#ifndef muse_model_exp
+/* The exponential a header of the two-parameter family forms its coefficients with.  The engine and its CPU checker define it
+ * before they include the header -- one fixed sequence of IEEE operations, the same bits on host, device and checker; a plain
+ * compile of the header by itself (a syntax check, an editor) gets libm's. */
+#include <math.h>
+#define muse_model_exp(x) exp(x)
+#endif
 #ifdef MUSE_MODEL_NCONST
 #if MUSE_MODEL_NCONST < 1 || MUSE_MODEL_NCONST > MUSE_MODEL_MAX_CONST
 #error "MUSE_MODEL_NCONST must be in [1, MUSE_MODEL_MAX_CONST]"

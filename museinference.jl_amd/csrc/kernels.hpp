@@ -217,6 +217,39 @@ struct LoopLds {
     }
 };
 
+// The per-block tables of a new theta for the two-parameter family (include/muse_model.h, MUSE_MODEL_PAIR): lane k < K evaluates the
+// HEADER's muse_model_coefs for block k -- the statements the host runs in pair_map_theta (muse_engine.cpp), so the same bits -- and
+// lane 0 the constant term in block order.
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+__device__ __forceinline__ void pair_theta_update(int lane, int nt, const int64_t* bnd, const double* th, MapTheta& m) {
+    const int K = nt >> 1;
+    if (lane < K) {
+        double cf[4] = {0.0, 0.0, 0.0, 0.0};
+        (void)muse_model_coefs(th[lane], th[K + lane], cf);
+        m.t.theta[lane] = th[lane];
+        m.t.theta[K + lane] = th[K + lane];
+        m.t.sd[lane] = cf[0];
+        m.t.sd[K + lane] = cf[1];
+        m.t.iv[lane] = cf[2];
+        m.t.iv[K + lane] = cf[3];
+    } else if (lane >= 2 * K && lane < kMaxTheta) {   // (the slots beyond: as pair_map_theta's memset leaves them)
+        m.t.theta[lane] = 0.0;
+        m.t.sd[lane] = 0.0;
+        m.t.iv[lane] = 0.0;
+    }
+    if (lane == kMaxTheta) {
+        double cst = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double cf[4] = {0.0, 0.0, 0.0, 0.0};
+            const double C = muse_model_coefs(th[k], th[K + k], cf);
+            cst += (double)(bnd[k + 1] - bnd[k]) * C;
+        }
+        m.f_const = cst;
+        m.pad_ = 0.0;
+    }
+}
+#endif
+
 template <class Model, class Place>
 __global__ void __launch_bounds__(Place::T) __attribute__((amdgpu_waves_per_eu(Place::kWavesPerEu)))
 muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArgs /*likewise*/) {
@@ -412,6 +445,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 // constant term and the next iteration's fields on lanes of their own
                 int tl = tid;
                 asm volatile("" : "+v"(tl));   // (else tid - kMaxTheta is formed at the kernel's entry and held -- spilled -- across the solves)
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+                if (tl <= kMaxTheta) {
+                    pair_theta_update(tl, nt, a.bnd, th, a.cur);
+                } else if (tl == 2 * kMaxTheta + 1) {
+                    iteration_setup(iter + 1);
+                }
+#else
                 if (tl < kMaxTheta) {
                     const bool live = tl < nt;
                     a.cur.t.theta[tl] = live ? th[tl] : 0.0;
@@ -424,6 +464,7 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 } else if (tl == 2 * kMaxTheta + 1) {
                     iteration_setup(iter + 1);
                 }
+#endif
                 // (the barrier at the top of the next iteration orders these writes before the first problem reads them)
             }
         }
@@ -701,8 +742,12 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                     L.status[2] = cv;
                 }
                 if (e == STEP_OK) {   // (the stepper's own copy of theta: the next record's -- and its next solves')
+#if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
+                    if (lane <= kMaxTheta) pair_theta_update(lane, nt, a.bnd, w.theta_next, a.cur);
+#else
                     if (lane < kMaxTheta) make_map_theta_component(lane, nt, w.theta_next, a.cur);
                     if (lane == 0) make_map_theta_const(nt, a.bnd, w.theta_next, a.cur);
+#endif
                     if (solving) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the pad slots of x and g may lie inside the step's arrays)
                         if (lane == 0) iteration_setup(iter + 1);
@@ -857,10 +902,13 @@ hipError_t loop_place(const LaunchShape& s, const LoopCall& c) {
     X template hipError_t loop_place<M>(const LaunchShape&, const LoopCall&);
 #define MUSE_INSTANTIATE_USER_BIG(X, M) X template hipError_t launch_place_big<M>(const LaunchShape&, const BatchArgs&, hipStream_t);
 #endif
-#ifdef MUSE_MODEL_PAIR   // two parameters per block: tiers of 2, 4 and 8 components (1, 2, up to 4 blocks), the map kernel only
-#define MUSE_PART_0(X) X template hipError_t launch_place<UserModel<2>>(const LaunchShape&, const BatchArgs&, hipStream_t);
-#define MUSE_PART_1(X) X template hipError_t launch_place<UserModel<4>>(const LaunchShape&, const BatchArgs&, hipStream_t);
-#define MUSE_PART_2(X) X template hipError_t launch_place<UserModel<kMaxTheta>>(const LaunchShape&, const BatchArgs&, hipStream_t);
+#ifdef MUSE_MODEL_PAIR   // two parameters per block: tiers of 2, 4 and 8 components (1, 2, up to 4 blocks); no implicit differentiation, no big tier
+#define MUSE_INSTANTIATE_PAIR(X, M)                                                                 \
+    X template hipError_t launch_place<M>(const LaunchShape&, const BatchArgs&, hipStream_t);       \
+    X template hipError_t loop_place<M>(const LaunchShape&, const LoopCall&);
+#define MUSE_PART_0(X) MUSE_INSTANTIATE_PAIR(X, UserModel<2>)
+#define MUSE_PART_1(X) MUSE_INSTANTIATE_PAIR(X, UserModel<4>)
+#define MUSE_PART_2(X) MUSE_INSTANTIATE_PAIR(X, UserModel<kMaxTheta>)
 #else
 #define MUSE_PART_0(X) MUSE_INSTANTIATE_USER(X, UserModel<1>)
 #define MUSE_PART_1(X) MUSE_INSTANTIATE_USER(X, UserModel<kMaxTheta>)

@@ -882,8 +882,7 @@ int muse_model_eval(muse_ctx* c, double iv, double sd, double x, double z, doubl
 #else
     out[3] = out[4] = out[5] = out[6] = out[9] = NAN;
 #endif
-    out[10] = out[11] = NAN;
-    return MUSE_OK;
+    return MUSE_OK;   // (out[0..9] only: callers of the one-parameter family pass ten doubles, as before round 6)
 #endif
 #else
     (void)c; (void)iv; (void)sd; (void)x; (void)z; (void)n1; (void)n2; (void)i; (void)out;

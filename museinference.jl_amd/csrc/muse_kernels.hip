@@ -270,7 +270,8 @@ static hipError_t loop_dispatch(const LaunchShape& s, const LoopCall& c) {
 #elif defined(MUSE_INSPECT)
     return hipErrorNotSupported;
 #elif defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
-    return hipErrorNotSupported;   // (the step's coefficient update on the device is the one-parameter family's: muse_run runs these)
+    if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
+    return s.ntheta == 2 ? loop_place<UserModel<2>>(s, c) : s.ntheta <= 4 ? loop_place<UserModel<4>>(s, c) : loop_place<UserModel<kMaxTheta>>(s, c);
 #elif defined(MUSE_USER_MODEL_HEADER)
     if (s.model != MUSE_MODEL_USER) return hipErrorInvalidValue;
     return s.ntheta == 1 ? loop_place<UserModel<1>>(s, c) : loop_place<UserModel<kMaxTheta>>(s, c);

@@ -1133,6 +1133,7 @@ struct Solver : PairState<Model::kPair> {
                         Model::sample(scoef(2 * j, i0), a0, b0, zt0, xt0, i0);
                         Model::sample(scoef(2 * j + 1, i0 + 1), a1, b1, zt1, xt1, i0 + 1);
                         const bool valid1 = i0 + 1 < (int)N;
+                        if constexpr (Model::kPair) xt0 = i0 < (int)N ? xt0 : 0.0;   // (a location parameter in a slot beyond the vector: begin())
                         x.set(2 * j, i0, xt0);
                         x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
                     }
@@ -1168,6 +1169,7 @@ struct Solver : PairState<Model::kPair> {
                         Model::sample(scoef(2 * j, i0), c1[j][0], c2[j][0], zt0, xt0, i0);
                         Model::sample(scoef(2 * j + 1, i0 + 1), c1[j][1], c2[j][1], zt1, xt1, i0 + 1);
                         const bool valid1 = i0 + 1 < (int)N;
+                        if constexpr (Model::kPair) xt0 = i0 < (int)N ? xt0 : 0.0;
                         x.set(2 * j, i0, xt0);
                         x.set(2 * j + 1, i0 + 1, valid1 ? xt1 : 0.0);
                     }

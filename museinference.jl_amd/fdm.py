@@ -2,7 +2,7 @@
 vendored in the reference) that `fdm = central_fdm(3,1)` / `fdm(f, x[, step])` at src/muse.jl:300 and src/util.jl:13 reach,
 restated from the package's published algorithm (Fornberg-type coefficients from the Vandermonde system, and the step
 that minimises the bound  C1 h^-Q + C2 h^(P-Q)  on round-off + truncation error, with |f^(P)| estimated by a second,
-unadapted method of order P + 2).  As recalled -- FiniteDifferences cannot be run here -- and marked so in DESIGN.md.
+unadapted method of order P + 2).  As recalled -- FiniteDifferences cannot be run here -- and marked so in DESIGN.md §5 / HISTORY.md §4.
 
     m = central_fdm(p, q)                   p grid points, q-th derivative, adapt = 1, condition = 10, factor = 1
     m.grid, m.coefs                         e.g. central_fdm(3, 1): (-1, 0, 1), (-1/2, 0, 1/2)

@@ -8,7 +8,7 @@ checker build -- runs the kernel's solver on such an objective in all three stor
 restatement that reproduces the Optim.jl documentation's Rosenbrock counters (tests/test_oracle.py) -- solves the same
 problems: 8-30 L-BFGS iterations with 2.7-2.9 evaluations each.  Equal iteration and evaluation counts, MAPs to 1e-9,
 minima to 1e-12 where the paths agree; where a count differs (tree-ordered against sequential sums over 10^4-10^5 terms,
-DESIGN.md §4) both must have converged to the same MAP within the solve's tolerance (the objective is strictly convex:
+DESIGN.md §5) both must have converged to the same MAP within the solve's tolerance (the objective is strictly convex:
 lambda_min >= 1)."""
 import os
 

@@ -3,7 +3,7 @@
 Tolerances (fp64, stated per north_star): the sampler is bit-exact; scores/logLike rtol 1e-10;
 MAPs agree to 1e-9 absolute when both sides follow the same L-BFGS path.
 
-Iteration-count parity is empirical, not a theorem (DESIGN.md §4): the kernel reduces in a fixed tree, the oracle
+Iteration-count parity is empirical, not a theorem (DESIGN.md §5): the kernel reduces in a fixed tree, the oracle
 sequentially, and over a long solve the O(sqrt(N) eps) difference of a dot product can move an evaluation count by one
 or two.  Every case committed here follows the same path today and `assert_same_path_or_close` says so loudly if a
 future change moves one: equal counts => the tight tolerances; different counts => both solves must still have
@@ -284,7 +284,7 @@ def test_fuzz_offpath_cases(gpu, M, O):
     """The 64 cases on which round 2's randomized runs (tools/fuzz_parity.py, 301 433 cases) found the HIP path and the
     oracle apart -- different iteration / evaluation counts, or scores apart by more than 1e-9 with equal counts: all the
     stencil model at N <= 140 with 25-53 L-BFGS iterations, where tree-ordered and sequential sums differ by O(sqrt(N) eps)
-    per dot product and a long, ill-conditioned solve amplifies that.  Iteration-count parity is empirical (DESIGN.md §4);
+    per dot product and a long, ill-conditioned solve amplifies that.  Iteration-count parity is empirical (DESIGN.md §5);
     what must hold regardless: both sides converge (same status), stop within a few iterations of each other, and their
     MAPs agree to the solve's own tolerance, |dz|_inf <= 2 atol / lambda_min (lambda_min = e^-max(theta): the stencil's
     A^T A is singular at the Nyquist mode), the scores to the bound that implies."""

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ---- BASELINE.json configs at their own sizes ------------------------------------------------------
 def test_config5_smooth_1e5_8theta_vs_oracle(gpu, M, O):
     """configs[4]: hierarchical linear-Gaussian (stencil) model, N = 10^5, 8 theta blocks -- cluster placement.
-    Two sims against the oracle.  Iteration-count parity is empirical, not a theorem (DESIGN.md §4: tree vs
+    Two sims against the oracle.  Iteration-count parity is empirical, not a theorem (DESIGN.md §5: tree vs
     sequential sums can move an evaluation count on long solves); where the counts agree the scores must agree to
     rtol 1e-10, and in any case to the accuracy the MAP tolerance implies."""
     N, nth, atol = 100000, 8, 1e-2

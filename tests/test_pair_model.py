@@ -117,6 +117,15 @@ def test_muse_on_the_checker_against_the_exact_posterior(M, O):
     assert np.all(np.abs(mode - truth) / sigma < 4.0)
 
 
+def test_check_model_consistency_of_the_pair_header_on_the_checker(M, O):
+    """What AD guarantees in the reference (src/simple.jl:84-85) checked for the hand-written header: grad_z and BOTH kinds of score
+    component (location, scale) against central differences of logLike, through the checker-backed problem."""
+    from oracle_problem import OracleMuseProblem
+    with O.user_model(HEADER, NAME):
+        res = M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=4, N=2001), [0.4, -0.3, 0.9, 0.2], rng=5)
+    assert res["grad_z"] <= 2e-5 + res["noise_floor"] and res["grad_theta"] <= 2e-5 + res["noise_floor"] and res["noise_floor"] < 1e-4
+
+
 def test_header_kind_is_read_from_the_source(M):
     assert M.ElementwiseModel.packaged(NAME).pair is True
     assert M.ElementwiseModel.packaged("cubic").pair is False
@@ -200,23 +209,36 @@ def test_pair_model_hip_against_the_checker(gpu, M, O, N, nth, theta, placement,
 
 
 @pytest.mark.gpu
-def test_pair_model_refusals_and_routing(gpu, M):
+def test_pair_model_refusals_and_routing(gpu, M, capfd):
     """An odd ntheta and more than MUSE_MAX_THETA parameters are refused at context creation; the implicit-differentiation get_H! is
-    refused with a message that names the way out; the device-resident loop is not built for the family -- run_muse(device_loop=True)
-    runs muse_run's loop and gives the host loop's bits."""
+    refused; the device-resident loop (one persistent launch for all iterations: the step's coefficient update on the device calls the
+    HEADER's muse_model_coefs) gives the host loop's bits -- and is what ran."""
     model = M.ElementwiseModel.packaged(NAME)
     for nth in (1, 3, 10):
         with pytest.raises(M.MuseError, match="two parameters per block|MUSE_MAX_THETA"):
             M.HipMuseProblem(None, model=model, ntheta=nth, N=1000)
-    x = np.sin(0.3 * np.arange(5000)) + 0.4
-    prob = M.HipMuseProblem(x, model=model, ntheta=2, prior=M.GaussianPrior(0.0, PRIOR_SIGMA))
-    assert not prob.has_second_derivatives
-    with pytest.raises(M.MuseError):
-        prob.implicit_H_batch(1, 0, 2, [0.1, 0.2])
-    kw = dict(nsims=40, maxsteps=4, theta_rtol=0.0, atol=1e-4, alpha=0.7)
-    a = prob.run_muse(3, [0.0, 0.0], device_loop=True, **kw)
-    b = prob.run_muse(3, [0.0, 0.0], device_loop=False, **kw)
-    assert a[0] == b[0] == 4 and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    for N, nth, th0 in ((5000, 2, [0.0, 0.0]), (10000, 4, [0.2, -0.1, 0.3, 0.0]), (3000, 8, [0.0] * 8), (400, 2, [0.1, 0.5])):
+        x = np.sin(0.3 * np.arange(N)) + 0.4 + 0.8 * np.cos(1.7 * np.arange(N))
+        prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, PRIOR_SIGMA))
+        assert not prob.has_second_derivatives
+        with pytest.raises(M.MuseError):
+            prob.implicit_H_batch(1, 0, 2, th0)
+        kw = dict(nsims=40, maxsteps=5, theta_rtol=0.0, atol=1e-6, alpha=0.7)
+        b = prob.run_muse(3, th0, device_loop=False, **kw)
+        capfd.readouterr()
+        prob.debug_flags(M.HipMuseProblem.DEBUG_RUN_TIMING)
+        a = prob.run_muse(3, th0, device_loop=True, **kw)
+        prob.debug_flags(0)
+        assert "[muse_run_device] launch call" in capfd.readouterr().err, (N, nth)      # the loop kernel, not muse_run's fall-back
+        assert a[0] == b[0] == 5 and np.array_equal(a[1], b[1]) and np.array_equal(a[2][:, :-1], b[2][:, :-1]) and np.array_equal(a[3], b[3]), (N, nth)
+        assert a[4].tobytes() == b[4].tobytes()
+        c = prob.run_muse(3, a[1], device_loop=True, z0_warm=True, **dict(kw, maxsteps=3))        # continues from the resident MAPs
+        d = prob.run_muse(3, a[1], device_loop=False, **dict(kw, maxsteps=5))                      # (leaves other MAPs behind)
+        prob.run_muse(3, th0, device_loop=False, **kw)
+        e2 = prob.run_muse(3, a[1], device_loop=False, z0_warm=True, **dict(kw, maxsteps=3))
+        assert np.array_equal(c[1], e2[1]) and np.array_equal(c[3], e2[3]), (N, nth)
+        if N != 400:
+            prob.close()
     e = prob.model_eval(0.4, 0.6, 1.0, 0.7, 0.2, -0.3)      # (a, b) = (mu, tau): coefficients, draw, terms of the header on the host
     np.testing.assert_allclose([e["c0"], e["c1"], e["c2"], e["C"]], [0.4, np.exp(0.3), np.exp(-0.6), 0.6], rtol=1e-15)
     np.testing.assert_allclose([e["z"], e["x"], e["t0"], e["t1"]], [0.4 + np.exp(0.3) * 0.2, 0.4 + np.exp(0.3) * 0.2 - 0.3, 0.3, 0.09], rtol=1e-14)

@@ -339,8 +339,9 @@ def test_second_derivative_check_on_the_host(M):
     assert lib.muse_model_has_second() == 1 and M.load_library().muse_model_has_second() == 1
 
     def ev(iv, sd, x, z, n1, n2, i=0):
-        out = np.empty(10)
+        out = np.full(12, -7.0)
         assert lib.muse_model_eval(None, iv, sd, x, z, n1, n2, int(i), M._capi.ptr(out)) == 0
+        assert out[10] == -7.0 and out[11] == -7.0     # a header of the one-parameter family writes ten doubles, as it always did
         return dict(zip(("grad", "term", "B", "ozz", "ozx", "bz", "bx", "z", "x", "dx_dsd"), out.tolist()))
     e = ev(0.7, 1.2, 0.9, 0.4, -0.3, 0.8)
     hp, r = 1 + 0.3 * 0.16, 0.9 - h(0.4)
