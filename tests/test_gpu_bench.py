@@ -93,6 +93,31 @@ def test_bench_gpus4_sharded_extras_run_the_persistent_loop(gpu):
     assert c["cfg4_fd_H_sharded_ok"] is True and c["cfg5_smooth_1e5_sharded_ok"] is True
 
 
+def test_bench_under_torch_distributed_run(gpu):
+    """The driver's N > 1 command verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (bench.py then does NOT start ranks itself: it reads RANK / LOCAL_RANK / WORLD_SIZE) -- with
+    two gloo ranks on this one GPU: rank 0 prints ONE JSON line, with the N > 1 extras as flat scalars of `config`."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, MUSE_BENCH_BACKEND="gloo", MUSE_SHARED_GPU_RANKS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--min-seconds", "0", "--small"]
+    p = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["transport"] == "shm" and d["transports"]["shm"]["ranks_seen"] == 2
+    assert "cpu_baseline" not in d            # (rank 0 at N = 1 only)
+    c = d["config"]
+    assert c["sharded_bit_equal"] is True and c["sharded_ranks_seen"] == 2 and c["sharded_loop_ran"] == "device", c
+    assert c["handshake_device"] == 1 and c["handshake_host"] == 1 and c["cfg4_fd_H_sharded_ok"] is True and c["cfg5_smooth_1e5_sharded_ok"] is True
+
+
 def test_bench_forced_dist_reports_both_transports(gpu):
     d = run(["--nsims", "64"], {"MUSE_BENCH_FORCE_DIST": "1"})
     assert d["n_gpus"] == 1 and set(d["transports"]) == {"shm", "rccl"}

@@ -7,7 +7,11 @@ N / ntheta / theta / seed / atol / start mode / placement / element split / maps
   off path    a decision of the line search fell the other way (tree-ordered against sequential sums over many iterations): the
               counts differ -- or, rarely, coincide while the iterates do not -> both converged, MAPs agree to 2 atol
   MISMATCH    anything else (printed).
-Usage (GPU box): python tools/fuzz_user_model.py [seconds] [seed]"""
+Usage (GPU box): python tools/fuzz_user_model.py [seconds] [seed] [pair]
+`pair`: the two-parameter family's shipped member (models/normal_mean_var.h: ntheta = 2 K in {2, 4, 6, 8}, location parameters in
+[-1.5, 1.5], no implicit-differentiation H; its objective is quadratic, so every case is expected on the same path) -- with the native
+loops on every third case: muse_run_device (the loop kernel, whose step calls the header's muse_model_coefs on the device) against
+muse_run, bit for bit."""
 import os
 import sys
 import time
@@ -20,16 +24,24 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-model = M.ElementwiseModel.packaged("cubic")
+PAIR = len(sys.argv) > 3 and sys.argv[3] == "pair"
+NAME = "normal_mean_var" if PAIR else "cubic"
+model = M.ElementwiseModel.packaged(NAME)
+os.environ.setdefault("MUSE_DEBUG_LOOP_ANY_NTHETA", "1")
 t0 = time.time()
+nloop = nloop_bad = 0
 ncase = nsame = ntight = noff = noff_equal = nbad = nimp = nimp_bad = 0
 maxit = 0
-with O.user_model(model.header, "cubic"):
+with O.user_model(model.header, NAME):
     while time.time() - t0 < budget:
         N = int(rng.choice([int(rng.integers(5, 600)), int(rng.integers(600, 4200)), int(rng.integers(4000, 10100)),
                             int(rng.integers(10000, 30000)), int(rng.integers(65000, 80000))]))
         nth = min(int(rng.choice([1, 2, 3, 4, 8, 8, int(rng.integers(9, 65))])), N)   # (9..64: the big tier)
         theta = rng.uniform(-2.0, 0.8, size=nth)
+        if PAIR:
+            nth = int(rng.choice([2, 2, 4, 6, 8]))
+            N = max(N, nth)
+            theta = np.concatenate([rng.uniform(-1.5, 1.5, size=nth // 2), rng.uniform(-2.0, 1.5, size=nth // 2)])
         atol = float(rng.choice([1e-2, 1e-4, 1e-6]))
         z0 = int(rng.choice([0, 1]))
         n = 4 if N < 20000 else 2
@@ -45,7 +57,7 @@ with O.user_model(model.header, "cubic"):
             split = 0
         nmaps = 1 if nth > 8 else int(rng.choice([1, 1, 2, 3]))
         if nmaps > 1:
-            thetas = np.vstack([theta] + [rng.uniform(-2.0, 0.8, size=nth) for _ in range(nmaps - 1)])
+            thetas = np.vstack([theta] + [theta + rng.uniform(-0.3, 0.3, size=nth) for _ in range(nmaps - 1)])
             tot = prob.map_and_score_multi_async(seed, s0, s0 + n, thetas, atol=atol, z0_mode=z0, result_area=2)
             g, info = prob.batch_wait(tot, 2)
             g, info = g[:n], info[:n]
@@ -54,10 +66,28 @@ with O.user_model(model.header, "cubic"):
         zh = prob.get_zhat(0, n)
         # every fourth case: the implicit-differentiation H of one simulation (the header's second derivatives) against the checker's
         imp = None
-        if rng.random() < 0.25 and N >= 20:
+        if not PAIR and rng.random() < 0.25 and N >= 20:
             Hi, its = prob.implicit_H_batch(seed, s0, s0 + 1, theta, atol=1e-1, cg_maxiter=100)
             imp = (Hi[0], its[0])
         prob.close()
+        if PAIR and ncase % 3 == 0 and N <= 10000 and not split and placement < 0:
+            # the native loops on the same shape: ONE persistent launch for all iterations against one launch per iteration
+            xd = np.cos(0.37 * np.arange(N)) * 1.3 + 0.2
+            lp = M.HipMuseProblem(xd, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+            kw = dict(nsims=int(rng.integers(2, 90)), maxsteps=int(rng.integers(1, 7)), theta_rtol=0.0, atol=atol, alpha=float(rng.uniform(0.4, 1.0)))
+            th0 = theta * 0.5
+            try:
+                a = lp.run_muse(seed, th0, device_loop=False, **kw)
+                b = lp.run_muse(seed, th0, device_loop=True, **kw)
+                ok = a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2][:, :-1], b[2][:, :-1], equal_nan=True) \
+                    and np.array_equal(a[3], b[3], equal_nan=True) and a[4].tobytes() == b[4].tobytes()
+            except M.MuseError as e:
+                ok = "singular" in str(e)
+            lp.close()
+            nloop += 1
+            if not ok:
+                nloop_bad += 1
+                print("LOOP MISMATCH", "N", N, "nth", nth, theta.tolist(), kw, seed, flush=True)
         if imp is not None:
             Ho, io_cg = O.implicit_H("user", N, seed, s0, theta, atol=1e-1, cg_maxiter=100)
             nimp += 1
@@ -84,4 +114,5 @@ with O.user_model(model.header, "cubic"):
                   info["iterations"], io["iterations"], info["f_calls"], io["f_calls"], info["status"], io["status"], dz,
                   float(np.abs(g - go).max()), flush=True)
 print(f"{ncase} cases: {nsame} same path ({ntight} of them with MAPs to 1e-9), {noff} off path (converged, MAPs within 2 atol; {noff_equal} of them with equal counts), {nbad} MISMATCHES; longest solve {maxit} iterations; "
-      f"implicit-differentiation H: {nimp} cases, {nimp_bad} beyond 1e-6 or two CG iterations; {time.time() - t0:.0f} s")
+      f"implicit-differentiation H: {nimp} cases, {nimp_bad} beyond 1e-6 or two CG iterations; "
+      f"native loops (device against host): {nloop} cases, {nloop_bad} mismatches; {time.time() - t0:.0f} s")
