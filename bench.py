@@ -28,6 +28,17 @@ Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects
                 `algorithmic_bytes_d3` and is not a roofline.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: "port") timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1 only)
+and, because the driver's record keeps only FLAT scalars of `config` / `roofline` / `cpu_baseline`:
+  config.*      N = 1: the other BASELINE workloads (`funnel4_ms`, `noise_1e6_ms`, `smooth_1e5_ms` and their `_frac`: the pipelined
+                step, two lanes -- one for the stencil model), the muse! iteration (`muse_iter_us`, `muse_iter_steady_us`,
+                `muse_iter_line_search_us`), the 8-GPU share and the projections (`share_iter_us`, `proj_muse`, `proj_cfg4`, `proj_cfg5`),
+                the score boards' hand-shake (`handshake_device`, `handshake_host`) -- flat_single();
+                N > 1 (round 6): what was built for several GPUs, measured over THESE ranks beside the independent maps --
+                `sharded_muse_iter_us` (muse_run_sharded, 30 iterations), `sharded_loop_ran` ("device" | "host" | "none"),
+                `sharded_bit_equal` (every rank's trajectory against rank 0's unsharded muse_run), `handshake_*`,
+                `cfg4_fd_H_sharded_ms`, `cfg5_smooth_1e5_sharded_ms` -- sharded_extras(), flat_sharded(); the full objects are under
+                `extra` (N = 1) and `sharded` (N > 1)
+  roofline.*    `frac` (ONE definition: work / (peak x the pipelined step)), `frac_kernel_time`, `hbm_frac`, `valu_util_frac`
 """
 import argparse
 import json
