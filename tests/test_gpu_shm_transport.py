@@ -122,3 +122,43 @@ def test_block_capacity_is_checked():
     g, _ = prob.map_and_score_batch(1, 0, 4, np.zeros(2))
     assert np.array_equal(g_all[0], g)
     prob.close()
+
+
+@pytest.mark.parametrize("env,board,dev_hs,host_hs", [({}, "device", 1, 1), ({"MUSE_DEBUG_NO_IPC_BOARD": "1"}, "host", -1, 1),
+                                                      ({"MUSE_DEBUG_NO_BOARD": "1"}, "none", -1, -1)])
+def test_board_status_follows_the_switches_and_every_board_gives_the_same_bits(env, board, dev_hs, host_hs):
+    """muse_comm_board_status on a one-rank shared-memory communicator under the set-up switches (read at context creation, so in a
+    process of its own): the board the persistent loop will use, the hand-shake's verdict per kind of board (-1: not tried), which
+    loop the run then took -- and the trajectory is the unsharded loop's bit for bit whichever it was.  An RCCL communicator has no
+    boards at all."""
+    code = r'''
+import sys, json
+import numpy as np
+import museinference_jl_amd as M
+x = np.cos(0.11 * np.arange(10000)) * 1.7
+kw = dict(nsims=40, maxsteps=6, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+one = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+a = one.run_muse(5, [1.0], device_loop=False, **kw)
+one.close()
+p = M.HipMuseProblem(x, model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+p.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("shm", 4096))
+before = p.comm_board_status()
+b = p.run_muse_sharded(5, [1.0], **kw)
+after = p.comm_board_status()
+p.close()
+same = a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2][:, :-1], b[2][:, :-1]) and np.array_equal(a[3], b[3])
+r = M.HipMuseProblem(None, model="funnel", ntheta=1, N=1000)
+r.comm_init(1, 0, M.HipMuseProblem.comm_unique_id("rccl"))
+rc = r.comm_board_status()
+r.close()
+print(json.dumps({"before": before, "after": after, "same": bool(same), "rccl": rc}))
+'''
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["same"] is True
+    assert d["before"]["board"] == board and d["before"]["device_handshake"] == dev_hs and d["before"]["host_handshake"] == host_hs, d
+    assert d["before"]["last_loop"] == "none" and d["after"]["last_loop"] == board, d
+    assert d["rccl"]["board"] == "none" and d["rccl"]["device_handshake"] == -1 and d["rccl"]["host_handshake"] == -1
