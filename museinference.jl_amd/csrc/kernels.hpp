@@ -228,15 +228,16 @@ __device__ __forceinline__ void pair_theta_update(int lane, int nt, const int64_
         (void)muse_model_coefs(th[lane], th[K + lane], cf);
         m.t.theta[lane] = th[lane];
         m.t.theta[K + lane] = th[K + lane];
-        m.t.sd[lane] = cf[0];
-        m.t.sd[K + lane] = cf[1];
-        m.t.iv[lane] = cf[2];
-        m.t.iv[K + lane] = cf[3];
-    } else if (lane >= 2 * K && lane < kMaxTheta) {   // (the slots beyond: as pair_map_theta's memset leaves them)
-        m.t.theta[lane] = 0.0;
-        m.t.sd[lane] = 0.0;
-        m.t.iv[lane] = 0.0;
+        double* rec = &m.t.sd[0] + 4 * lane;   // (models.hpp, pair_table: sd and iv as ONE [block][4] table)
+        rec[0] = cf[0];
+        rec[1] = cf[1];
+        rec[2] = cf[2];
+        rec[3] = cf[3];
+    } else if (lane < kMaxTheta / 2) {   // (the records beyond, and their parameters: as pair_map_theta's memset leaves them)
+        double* rec = &m.t.sd[0] + 4 * lane;
+        rec[0] = rec[1] = rec[2] = rec[3] = 0.0;
     }
+    if (lane >= 2 * K && lane < kMaxTheta) m.t.theta[lane] = 0.0;
     if (lane == kMaxTheta) {
         double cst = 0.0;
         for (int k = 0; k < K; ++k) {

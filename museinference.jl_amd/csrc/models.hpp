@@ -70,9 +70,17 @@ struct SmoothModel {  // z as funnel, x = A z + n, A = periodic (1/4, 1/2, 1/4);
 };
 
 // Coefficients of an element's block for the models with TWO parameters per block (include/muse_model.h, MUSE_MODEL_PAIR): what the
-// draw takes (c[0], c[1]) and what the objective takes (all four).  Plain aggregates: they live in registers.
+// draw takes (c[0], c[1]) and what the objective takes (all four).  The tables hold a block's coefficients side by side:
+// ThetaSet::sd and ::iv read as ONE array of [block][4] (pair_table), a sampling entry (SampleSd) as [block][2].
+// One block (the tier of two components): plain values -- they are workgroup-uniform and live in scalar registers; the pad element
+// gets zeros.  Several blocks: a POINTER to the block's record in LDS and the element's validity -- four doubles per element in
+// vector registers (two elements of a pair in flight) were 500 spilled registers in the LDS-resident kernel; the model's functions
+// read what they use where they use it, and the pad element's contribution is dropped behind the call.
 struct PairS { double c[2]; };
-struct PairG { double c[4]; };
+struct PairGv { double c[4]; };
+struct PairGp { const double* p; bool valid; };
+__host__ __device__ __forceinline__ const double* pair_table(const ThetaSet& t) { return &t.sd[0]; }
+static_assert(offsetof(ThetaSet, iv) == offsetof(ThetaSet, sd) + kMaxTheta * sizeof(double), "sd and iv as one [block][4] table");
 
 #ifdef MUSE_USER_MODEL_HEADER
 #ifndef MUSE_MODEL_PAIR
@@ -110,18 +118,30 @@ struct UserModel {
     static constexpr bool kStencil = false;
     static constexpr int kId = MUSE_MODEL_USER;
     static constexpr bool kPair = true;
-    using SCoef = PairS; using GCoef = PairG;
+    using SCoef = PairS;
+    using GCoef = typename std::conditional<MAXB_ == 2, PairGv, PairGp>::type;
     __device__ static __forceinline__ void sample(const PairS& c, double n1, double n2, double& z, double& x, int i) {
         muse_model_sample(c.c, n1, n2, &z, &x, (long)i);
     }
-    __device__ static __forceinline__ double grad(const PairG& c, double x, double z, double& facc, int i) {
+    __device__ static __forceinline__ double grad(const PairGv& c, double x, double z, double& facc, int i) {
         return muse_model_grad(c.c, x, z, &facc, (long)i);
     }
-    __device__ static __forceinline__ void score_terms(const PairG& c, double x, double z, double& t0, double& t1, int i) {
+    __device__ static __forceinline__ void score_terms(const PairGv& c, double x, double z, double& t0, double& t1, int i) {
         muse_model_score_terms(c.c, x, z, &t0, &t1, (long)i);
     }
-    __device__ static __forceinline__ void score(const PairG& c, double s0, double s1, double n, double& ga, double& gb) {
-        muse_model_score(c.c, s0, s1, n, &ga, &gb);
+    __device__ static __forceinline__ double grad(const PairGp& c, double x, double z, double& facc, int i) {
+        double a2 = facc;
+        const double g = muse_model_grad(c.p, x, z, &a2, (long)i);
+        facc = c.valid ? a2 : facc;     // (the pad element and the phantom slots: no contribution, whatever the model's location)
+        return c.valid ? g : 0.0;
+    }
+    __device__ static __forceinline__ void score_terms(const PairGp& c, double x, double z, double& t0, double& t1, int i) {
+        muse_model_score_terms(c.p, x, z, &t0, &t1, (long)i);
+        t0 = c.valid ? t0 : 0.0;
+        t1 = c.valid ? t1 : 0.0;
+    }
+    __device__ static __forceinline__ void score(const double* c, double s0, double s1, double n, double& ga, double& gb) {
+        muse_model_score(c, s0, s1, n, &ga, &gb);
     }
 };
 #endif

@@ -142,7 +142,7 @@ struct muse_ctx {
 #if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
 // A library of the two-parameter family (include/muse_model.h, MUSE_MODEL_PAIR): K = ntheta / 2 blocks; block k's parameters are
 // theta[k] and theta[K + k], its coefficients and constant come from the HEADER (muse_model_coefs, evaluated here on the host) and
-// sit in the tables' slots {sd[k], sd[K + k], iv[k], iv[K + k]} (solver.hpp, gcoef / scoef).
+// sit side by side in the tables: ThetaSet::sd and ::iv read as one [block][4] array, a sampling entry as [block][2] (csrc/models.hpp).
 constexpr bool kPairModel = true;
 static void pair_map_theta(int nt, const int64_t* bnd, const double* theta, MapTheta& m) {
     const int K = nt / 2;
@@ -153,10 +153,8 @@ static void pair_map_theta(int nt, const int64_t* bnd, const double* theta, MapT
         const double C = muse_model_coefs(theta[k], theta[K + k], cf);
         m.t.theta[k] = theta[k];
         m.t.theta[K + k] = theta[K + k];
-        m.t.sd[k] = cf[0];
-        m.t.sd[K + k] = cf[1];
-        m.t.iv[k] = cf[2];
-        m.t.iv[K + k] = cf[3];
+        double* rec = &m.t.sd[0] + 4 * k;   // (csrc/models.hpp, pair_table: ThetaSet::sd and ::iv as ONE [block][4] table)
+        for (int j = 0; j < 4; ++j) rec[j] = cf[j];
         cst += (double)(bnd[k + 1] - bnd[k]) * C;
     }
     m.f_const = cst;
@@ -1894,9 +1892,9 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
             th[j] = theta0[j] + off;
             double* sd = ts_dst + entry * ts_stride;
 #if defined(MUSE_USER_MODEL_HEADER) && defined(MUSE_MODEL_PAIR)
-            MapTheta mt;   // the sampling coefficients of every block at the perturbed theta: the header's (slots as in pair_map_theta)
+            MapTheta mt;   // the draw's two coefficients of every block at the perturbed theta: the header's, [block][2]
             pair_map_theta(nt, c->bnd, th.data(), mt);
-            for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? mt.t.sd[k] : 0.0;
+            for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? (&mt.t.sd[0])[4 * (k >> 1) + (k & 1)] : 0.0;
 #else
             for (int k = 0; k < ts_stride; ++k) sd[k] = k < nt ? muse_exp(0.5 * th[k]) : 0.0;   // (make_map_theta_component's sd)
 #endif

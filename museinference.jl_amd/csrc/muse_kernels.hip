@@ -82,9 +82,9 @@ __global__ void __launch_bounds__(256) sample_user_kernel(BatchArgs a, uint64_t 
         const int k = any_block(a, i);
         const NormalPair np = normal_pair(a.seed, sim, (uint64_t)i);
 #ifdef MUSE_MODEL_PAIR
-        PairS c;
-        c.c[0] = a.cur.t.sd[k];
-        c.c[1] = a.cur.t.sd[(a.ntheta >> 1) + k];
+        PairS c;   // (models.hpp, pair_table: a block's coefficients side by side)
+        c.c[0] = pair_table(a.cur.t)[4 * k];
+        c.c[1] = pair_table(a.cur.t)[4 * k + 1];
         UserModel<kMaxTheta>::sample(c, np.n1, np.n2, z[i], x[i], (int)i);
 #else
         UserModel<1>::sample(any_sd(a, k), np.n1, np.n2, z[i], x[i], (int)i);
@@ -123,12 +123,9 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
         const int k = MAXB > 1 ? any_block(a, i) : 0;
         if constexpr (Model::kPair) {   // two parameters per block (include/muse_model.h): four coefficients, two block sums
             const int K = a.ntheta >> 1;
-            const bool valid = i < Ni;   // (the pad element: zero coefficients, no contribution -- solver.hpp, gcoef)
-            PairG c;
-            c.c[0] = valid ? a.cur.t.sd[k] : 0.0;
-            c.c[1] = valid ? a.cur.t.sd[K + k] : 0.0;
-            c.c[2] = valid ? a.cur.t.iv[k] : 0.0;
-            c.c[3] = valid ? a.cur.t.iv[K + k] : 0.0;
+            PairGp c;   // (the block's record and the element's validity: models.hpp -- the pad element contributes nothing)
+            c.p = pair_table(a.cur.t) + 4 * k;
+            c.valid = i < Ni;
             const double gp = Model::grad(c, xin[i], zin[i], sum[0], i);
             if (gout) gout[i] = -gp;
             double t0, t1;
@@ -169,14 +166,7 @@ __global__ void __launch_bounds__(1024) loglike_kernel(BatchArgs a, const double
         out[0] = -(0.5 * (sum[0] + a.cur.f_const));
         if constexpr (Model::kPair) {
             const int K = a.ntheta >> 1;
-            for (int k = 0; k < K; ++k) {
-                PairG c;
-                c.c[0] = a.cur.t.sd[k];
-                c.c[1] = a.cur.t.sd[K + k];
-                c.c[2] = a.cur.t.iv[k];
-                c.c[3] = a.cur.t.iv[K + k];
-                Model::score(c, acc[k], acc[K + k], count(k), out[1 + k], out[1 + K + k]);
-            }
+            for (int k = 0; k < K; ++k) Model::score(pair_table(a.cur.t) + 4 * k, acc[k], acc[K + k], count(k), out[1 + k], out[1 + K + k]);
         } else {
         for (int b = 0; b < MAXB; ++b)
             if (b < a.ntheta) out[1 + b] = 0.5 * (any_iv(a, b) * acc[b] - count(b));

@@ -297,25 +297,22 @@ struct Solver : PairState<Model::kPair> {
     // for the one-parameter models (ivk / sdk above), and for the two-parameter family (models.hpp, kPair; include/muse_model.h,
     // MUSE_MODEL_PAIR: block k's parameters are theta[k] and theta[K + k], K = ntheta / 2) the block's four coefficients -- the tables'
     // slots {sd[k], sd[K + k], iv[k], iv[K + k]} of the MAP's theta for the objective, the first two of the theta the problem is
-    // DRAWN at (sh_sd) for the draw.
+    // DRAWN at (sh_sd) for the draw.  Layout: the tables hold a block's coefficients side by side (models.hpp, pair_table: [block][4];
+    // a sampling entry and sh_sd: [block][2]).
     __device__ __forceinline__ auto gcoef(int jj, int i) const {
         if constexpr (Model::kPair && MAXB == 2) {
+            // (the zero pad element of an odd-length vector and the phantom slots behind it get ZERO coefficients: a model with a
+            //  location parameter has a gradient at x = z = 0, and the header's contract -- no contribution from c = 0, x = z = 0 --
+            //  keeps those slots out of every sum)
             const bool valid = i < (int)a.N;
-            PairG c;
+            PairGv c;
 #pragma unroll
             for (int q = 0; q < 4; ++q) c.c[q] = valid ? this->pc[q] : 0.0;
             return c;
         } else if constexpr (Model::kPair) {
-            // (the zero pad element of an odd-length vector and the phantom slots behind it get ZERO coefficients: a model with a
-            //  location parameter has a gradient at x = z = 0, and the header's contract -- no contribution from c = 0, x = z = 0 --
-            //  keeps those slots out of every sum)
-            const int k = blk(jj, i), K = a.ntheta >> 1;
-            const bool valid = i < (int)a.N;
-            PairG c;
-            c.c[0] = valid ? a.cur.t.sd[k] : 0.0;
-            c.c[1] = valid ? a.cur.t.sd[K + k] : 0.0;
-            c.c[2] = valid ? a.cur.t.iv[k] : 0.0;
-            c.c[3] = valid ? a.cur.t.iv[K + k] : 0.0;
+            PairGp c;   // (models.hpp: the block's record in the LDS copy of the arguments, read by the model's functions themselves)
+            c.p = pair_table(a.cur.t) + 4 * blk(jj, i);
+            c.valid = i < (int)a.N;
             return c;
         } else {
             return ivk(jj, i);
@@ -327,8 +324,8 @@ struct Solver : PairState<Model::kPair> {
             c.c[0] = this->psd[0];
             c.c[1] = this->psd[1];
         } else {
-            c.c[0] = sh_sd[k];
-            c.c[1] = sh_sd[(a.ntheta >> 1) + k];
+            c.c[0] = sh_sd[2 * k];
+            c.c[1] = sh_sd[2 * k + 1];
         }
         return c;
     }
@@ -1099,15 +1096,19 @@ struct Solver : PairState<Model::kPair> {
             iv0 = a.cur.t.iv[0];
             sd0 = a.cur.t.sd[0];
             if constexpr (Model::kPair && MAXB == 2) {
-                this->pc[0] = this->psd[0] = a.cur.t.sd[0];
+                this->pc[0] = this->psd[0] = a.cur.t.sd[0];   // (one block: pair_table's record 0 = sd[0..3])
                 this->pc[1] = this->psd[1] = a.cur.t.sd[1];
-                this->pc[2] = a.cur.t.iv[0];
-                this->pc[3] = a.cur.t.iv[1];
+                this->pc[2] = a.cur.t.sd[2];
+                this->pc[3] = a.cur.t.sd[3];
             }
             if constexpr (MAXB > 1) {
                 int tl = tid;
                 asm volatile("" : "+v"(tl));
+                if constexpr (Model::kPair) {   // the draw's two coefficients per block, [block][2], out of the [block][4] table
+                    if (tl < MAXB) sh_sd[tl] = pair_table(a.cur.t)[4 * (tl >> 1) + (tl & 1)];
+                } else {
                 if (tl < MAXB) sh_sd[tl] = a.cur.t.sd[tl];
+                }
                 wg_barrier<true>();
             }
             hist = wg_scratch;
@@ -1236,10 +1237,10 @@ struct Solver : PairState<Model::kPair> {
         iv0 = a.cur.t.iv[0];
         sd0 = d.tsample >= 0 ? tsample_base()[d.tsample].sd[0] : a.cur.t.sd[0];
         if constexpr (Model::kPair && MAXB == 2) {   // one block: its coefficients are workgroup-uniform
-            this->pc[0] = a.cur.t.sd[0];
+            this->pc[0] = a.cur.t.sd[0];   // (pair_table's record 0 = sd[0..3])
             this->pc[1] = a.cur.t.sd[1];
-            this->pc[2] = a.cur.t.iv[0];
-            this->pc[3] = a.cur.t.iv[1];
+            this->pc[2] = a.cur.t.sd[2];
+            this->pc[3] = a.cur.t.sd[3];
             this->psd[0] = sd0;
             this->psd[1] = d.tsample >= 0 ? tsample_base()[d.tsample].sd[1] : a.cur.t.sd[1];
         }
@@ -1254,7 +1255,11 @@ struct Solver : PairState<Model::kPair> {
             // FD batches sample at a theta that differs from the MAP theta
             int tl = tid;
             asm volatile("" : "+v"(tl));  // (else tid * 8 is formed at the kernel's entry and held -- spilled -- across it)
+            if constexpr (Model::kPair) {   // (a sampling entry is [block][2] already; the MAP's table is [block][4])
+                if (tl < MAXB) sh_sd[tl] = d.tsample >= 0 ? tsample_base()[d.tsample].sd[tl] : pair_table(a.cur.t)[4 * (tl >> 1) + (tl & 1)];
+            } else {
             if (tl < MAXB) sh_sd[tl] = d.tsample >= 0 ? tsample_base()[d.tsample].sd[tl] : a.cur.t.sd[tl];
+            }
             wg_barrier<!Model::kStencil>();
         }
         // bind storage
@@ -2373,13 +2378,8 @@ struct Solver : PairState<Model::kPair> {
                         s1 = (k + K == b) ? acc[b] : s1;
                     }
                     const double cnt = (double)((k == K - 1 ? (int)a.N : a.bnd32[k + 1]) - a.bnd32[k]);
-                    PairG c;
-                    c.c[0] = a.cur.t.sd[k];
-                    c.c[1] = a.cur.t.sd[K + k];
-                    c.c[2] = a.cur.t.iv[k];
-                    c.c[3] = a.cur.t.iv[K + k];
                     double ga, gb;
-                    Model::score(c, s0, s1, cnt, ga, gb);
+                    Model::score(pair_table(a.cur.t) + 4 * k, s0, s1, cnt, ga, gb);
                     sc = tl < K ? ga : gb;
                     (void)mine;
                 } else {
