@@ -223,8 +223,9 @@ def csrc_fingerprint():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "museinference.jl_amd", "csrc")
+    host_only = ("switches.hpp", "shm_gather.hpp")   # (headers of muse_engine.cpp / muse_comm.cpp alone: no kernel includes them)
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):  # device code only: muse_kernels.hip and the headers it includes
+        if f.endswith((".hip", ".hpp")) and f not in host_only:  # device code only: muse_kernels.hip and the headers it includes
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

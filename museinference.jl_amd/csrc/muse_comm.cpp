@@ -366,7 +366,9 @@ static void setup_boards(CommState* st, hipStream_t stream) {
         st->ipc_ok = flag[0] == (double)st->nranks;
         if (st->ipc_ok) {   // mapped everywhere: now prove that a store into a peer's board is SEEN by the peer's poll
             unsigned long long* stores[8];
-            for (int q = 0; q < st->nranks; ++q) stores[q] = (unsigned long long*)st->ipc_peers[q];
+            // (test hook: the granules land 64 slots early -- inside the board, beside what the peer polls)
+            const long miss = (sw.handshake_fail & 1) ? -64 : 0;
+            for (int q = 0; q < st->nranks; ++q) stores[q] = (unsigned long long*)st->ipc_peers[q] + miss;
             st->hs_dev = board_handshake(st, stream, st->ipc_own, stores, st->nranks, 0x7ff00001u, &st->hs_mask_dev, &st->hs_wait_us[0]);
             st->ipc_ok = st->hs_dev == 1;
         }
@@ -383,7 +385,7 @@ static void setup_boards(CommState* st, hipStream_t stream) {
         double flag[1] = {st->board_dev ? 1.0 : 0.0};
         if (shm_allgather(st, flag, 1, flag, true) != MUSE_OK) flag[0] = 0.0;
         if (flag[0] == (double)st->nranks) {
-            unsigned long long* stores[1] = {st->board_dev};
+            unsigned long long* stores[1] = {st->board_dev + ((sw.handshake_fail & 2) ? -64 : 0)};
             st->hs_host = board_handshake(st, stream, st->board_dev, stores, 1, 0x7ff00002u, &st->hs_mask_host, &st->hs_wait_us[1]);
         }
         if (st->hs_host != 1 && st->board_host) {   // (a board some rank cannot use is no board: the loop is host-driven on every rank)

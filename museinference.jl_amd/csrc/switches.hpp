@@ -41,6 +41,9 @@ struct Switches {
     bool comm_direct_host = false;      // MUSE_COMM_DIRECT_HOST: RCCL receives straight into pinned host memory
     double shm_timeout_s = 0.0;         // MUSE_SHM_TIMEOUT_S: bound of every wait of the shared-memory transport (0: its default, 60 s)
     double handshake_ms = 0.0;          // MUSE_BOARD_HANDSHAKE_MS: bound of the boards' set-up hand-shake (0: its default, 50 ms)
+    int handshake_fail = 0;             // MUSE_DEBUG_HANDSHAKE_FAIL=1|2|3: test hook -- the hand-shake of the device boards (1), of the host board
+                                        // (2) or of both (3) stores its granules beside the slots it polls: the verdict is "not seen", as it
+                                        // would be if stores into a peer's board never became visible to the peer
 
     static Switches from_environment() {
         Switches s;
@@ -69,6 +72,7 @@ struct Switches {
         s.comm_direct_host = on("MUSE_COMM_DIRECT_HOST");
         if (const char* e = getenv("MUSE_SHM_TIMEOUT_S")) s.shm_timeout_s = atof(e) > 0 ? atof(e) : 0.0;
         if (const char* e = getenv("MUSE_BOARD_HANDSHAKE_MS")) s.handshake_ms = atof(e) > 0 ? atof(e) : 0.0;
+        s.handshake_fail = num("MUSE_DEBUG_HANDSHAKE_FAIL", 0);
         return s;
     }
 };
