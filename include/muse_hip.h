@@ -188,7 +188,8 @@ int muse_profile_clock_hz(muse_ctx* ctx, double* hz_out);
  * 6 a solving stepper takes the data element itself; 7 the stepper never solves; 8 the data vector is not sent ahead.  Host side:
  * 16 muse_run_sharded's scores meet on the board in pinned host memory; 17 muse_run_sharded runs the host-driven loop;
  * 18 test hook: a loop launch with more workgroups than can be resident at once; 19 the native loops say on stderr which loop
- * ran and what it cost; 20 get_H!'s finite-difference map as ONE launch that carries its fiducial MAP (measured slower: off).  (Bit 0, "skip the solve", is for timing the launch shell only: results are then meaningless.)
+ * ran and what it cost; 20 get_H!'s finite-difference map as ONE launch that carries its fiducial MAP (measured slower: off);
+ * 21 get_H!'s fiducial MAP draws its own normals (default: a kernel of its own draws them with the whole GPU).  (Bit 0, "skip the solve", is for timing the launch shell only: results are then meaningless.)
  * muse_debug_stamps: a library built with -DMUSE_STAMPS records s_memtime stamps per problem (tools/stamps.py); out == NULL arms
  * a buffer for nproblems problems, otherwise [nproblems][16] stamps are copied out.  The product build records none. */
 int muse_debug_flags(muse_ctx* ctx, int flags);

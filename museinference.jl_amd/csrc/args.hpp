@@ -300,6 +300,9 @@ struct LaunchShape {
 };
 hipError_t launch_solver(const LaunchShape& s, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_sample(int model, const BatchArgs& a, uint64_t sim, double* x, double* z, double* noise, hipStream_t stream);
+// the standard normals of ONE stream into a slot of the normals cache's layout ([2][ld]: n1, n2), drawn by the whole GPU instead of
+// by the one workgroup that solves the stream's problem (muse_engine.cpp, fd_values_impl: the fiducial MAP of get_H!)
+hipError_t launch_normals(uint64_t seed, uint64_t sim, int64_t ld, double* slot, hipStream_t stream);
 hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const double* z, double* g, double* out, hipStream_t stream);
 // the device-resident loop: false where the placement has no loop kernel (cluster placements); max_grid = the number of
 // workgroups that are certainly resident at once (they meet at the end of every iteration)

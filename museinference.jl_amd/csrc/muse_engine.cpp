@@ -118,6 +118,7 @@ struct muse_ctx {
     unsigned int* cl_state = nullptr;    // [cl_cap] granule-exchange epochs
     int cl_cap = 0;
     int* error_flag = nullptr;           // pinned, device-mapped
+    double* fid_norm = nullptr;          // [2][ld]: the standard normals of get_H!'s fiducial stream, drawn by a kernel of its own (fd_values_impl)
     unsigned int* fid_flag = nullptr;    // device word: the tag of the last fiducial MAP published inside a finite-difference launch
     unsigned int fid_tag = 0;            // (fd_values_impl; grows with every such launch)
     int debug = 0;                       // muse_debug_flags
@@ -345,7 +346,7 @@ static int launch_batch(muse_ctx* c, BatchArgs& a) {
         a.n_per_map = a.nproblems;
         a.map_stride = a.nproblems;
     }
-    a.debug = c->debug & 0xffff;   // (bits 16-20 are host-side: switches.hpp)
+    a.debug = c->debug & 0xffff;   // (bits 16-21 are host-side: switches.hpp)
     a.stamps = (c->stamps && a.nproblems <= c->stamps_cap) ? c->stamps : nullptr;
     a.clock_out = c->prof_on ? c->clock_pin : nullptr;  // roofline leg only
     const bool implicit = a.kind == BATCH_IMPLICIT;
@@ -698,7 +699,7 @@ int muse_ctx_destroy(muse_ctx* c) {
         for (int k = 0; k < MUSE_MODEL_MAX_CONST; ++k) { muse_host_consts[k] = nullptr; muse_host_const_len[k] = 0; }
     }
 #endif
-    hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->fid_flag); hipFree(c->tmp);
+    hipFree(c->x_data); hipFree(c->zhat); hipFree(c->scratch); hipFree(c->counter); hipFree(c->fid_flag); hipFree(c->fid_norm); hipFree(c->tmp);
     hipFree(c->small_dev); if (c->tsample_dev) hipFree(c->tsample_dev); if (c->tsample_pin) hipHostFree(c->tsample_pin);
     if (c->comm_buf) hipFree(c->comm_buf);
     for (int r = 0; r < kResultAreas; ++r) {
@@ -933,7 +934,7 @@ int muse_set_timing(muse_ctx* c, int enabled) {
 // does not prefetch, 3 its old element order, 4 test hook (odd workers leave), 5 no speculating trials, 6 a solving stepper takes the
 // data element for itself, 7 the stepper never solves, 8 the data vector does not travel through the g area; bits 16-19 are
 // host-side (switches.hpp): 16 host board, 17 host-driven sharded loop, 18 oversubscribed loop launch (test hook), 19 run timing,
-// 20 the finite-difference map carries its fiducial MAP.
+// 20 the finite-difference map carries its fiducial MAP, 21 get_H!'s fiducial MAP draws its own normals.
 int muse_debug_flags(muse_ctx* c, int flags) {
     if (!c) return fail(MUSE_ERR_INVALID, "ctx is NULL");
     c->debug = flags;
@@ -1614,7 +1615,7 @@ static int run_loop_launch(muse_ctx* c, uint64_t seed, const double* theta0, con
     a.zhat = c->zhat;
     a.work_counter = c->counter;
     a.ticket_base = (int)c->ticket_base;   // (no tickets are drawn: elements are dealt statically)
-    a.debug = c->debug & 0xffff;   // (bits 16-20 are host-side: switches.hpp)
+    a.debug = c->debug & 0xffff;   // (bits 16-21 are host-side: switches.hpp)
     a.stamps = (c->stamps && a.nproblems + 3 <= c->stamps_cap) ? c->stamps : nullptr;   // (+3: the loop kernel's own rows)
     a.csize = 1;
     a.error_flag = c->error_flag;
@@ -1845,6 +1846,19 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
                       n + 1 <= 0x7fffffff;
     rc = ensure_results(c, 1, (n > nprep ? n : nprep) + 1);
     if (rc) return rc;
+    // Round 6: the ONE fiducial MAP is the serial part of the call -- every perturbed solve starts from it -- and two thirds of a
+    // cold problem is its generator, run by ONE workgroup.  With the perturbed problems' normals in the cache already (so that the
+    // fiducial's launch carries nothing else) a kernel of its own draws the fiducial stream's normals with the whole GPU (40
+    // workgroups, ~3 us) into a slot of the cache's layout, and the fiducial problem LOADS them: the same function of (seed,
+    // stream, element), the same bits.  LDS-resident placement (where the solver can load normals at all).
+    const bool fidn = held && !fold && fid_mode == 0 && choose_place(c) == P_R512x10 && !c->sw.no_fid_normals && !(c->debug & kDebugNoFidNormals);
+    if (fidn) {
+        if (!c->fid_norm && hipMalloc(&c->fid_norm, (size_t)2 * c->ld * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->fid_norm = nullptr;
+        }
+        if (c->fid_norm) HIPCHK(launch_normals(seed, (uint64_t)fid_sim, c->ld, c->fid_norm, c->stream));
+    }
     // a sampling entry: exp(theta/2) of every block -- a SampleSd, or kBigTheta doubles in the big tier (solver.hpp, begin)
     const int ts_stride = tier_big(c, choose_place(c), 1) ? kBigTheta : kMaxTheta;
     static_assert(sizeof(SampleSd) == kMaxTheta * sizeof(double) && kBigTheta % kMaxTheta == 0, "sampling entries");
@@ -1864,7 +1878,12 @@ static int fd_values_impl(muse_ctx* c, uint64_t seed, int64_t sim_begin, int64_t
         a.nproblems = (int)nprep;
         a.nstd = (int)nfid;
         a.norm_sim0 = s_lo;
-        if (cached) {
+        if (fidn && c->fid_norm) {   // the launch is the fiducial problem alone: its normals are in fid_norm (slot 0 of a one-stream cache)
+            a.ncache = c->fid_norm;
+            a.ncache_sim0 = fid_sim;
+            a.ncache_count = 1;
+            a.ncache_mode = 2;
+        } else if (cached) {
             a.ncache = c->ncache;
             a.ncache_sim0 = nc_sim0;
             a.ncache_count = (int)nc_cnt;

@@ -92,6 +92,15 @@ __global__ void __launch_bounds__(256) sample_user_kernel(BatchArgs a, uint64_t 
     }
 }
 #endif
+// The standard normals of one stream, one element per thread (rng.hpp: the same function of (seed, sim, element) the solver's
+// generator evaluates, so a problem that LOADS these draws the same bits it would have generated).
+__global__ void __launch_bounds__(256) normals_kernel(uint64_t seed, uint64_t sim, int64_t ld, double* __restrict__ n1, double* __restrict__ n2) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ld; i += (int64_t)gridDim.x * blockDim.x) {
+        const NormalPair np = normal_pair(seed, sim, (uint64_t)i);
+        n1[i] = np.n1;
+        n2[i] = np.n2;
+    }
+}
 __global__ void __launch_bounds__(256) smooth_finish_kernel(int64_t N, const double* __restrict__ z,
                                                             const double* __restrict__ noise, double* __restrict__ x) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -360,6 +369,12 @@ hipError_t launch_board_handshake(unsigned long long* own, unsigned long long* c
     h.ticks = ticks;
     h.result = result;
     hipLaunchKernelGGL(board_handshake_kernel, dim3(1), dim3(64), 0, st, h);
+    return hipGetLastError();
+}
+
+hipError_t launch_normals(uint64_t seed, uint64_t sim, int64_t ld, double* slot, hipStream_t st) {
+    const int grid = (int)((ld + 255) / 256 < 4096 ? (ld + 255) / 256 : 4096);
+    hipLaunchKernelGGL(normals_kernel, dim3(grid), dim3(256), 0, st, seed, sim, ld, slot, slot + ld);
     return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@ struct Switches {
     bool no_ext_launch = false;         // MUSE_DEBUG_NO_EXT_LAUNCH: a result area's completion event is recorded behind the launch
     bool fd_fold = false;               // MUSE_FD_FOLD: get_H!'s finite-difference map as ONE launch that carries its fiducial MAP (bit 20; built
                                         // and measured in round 6: 8 us SLOWER per 513-problem call than the two launches -- off by default)
+    bool no_fid_normals = false;        // MUSE_DEBUG_NO_FID_NORMALS: get_H!'s fiducial MAP draws its own normals (bit 21; round 6: a kernel of
+                                        // its own draws them with the whole GPU -- the fiducial is the one serial problem of the call)
     int cluster_size = 0;               // MUSE_DEBUG_CLUSTER_SIZE=k: workgroups per element of the streaming clusters (0: by N and model)
     int shared_gpu_ranks = 1;           // MUSE_SHARED_GPU_RANKS=n: n processes share this GPU; cluster launches take 1/n of the compute units
     // ---- normals cache
@@ -54,6 +56,7 @@ struct Switches {
         s.no_big_tier = on("MUSE_DEBUG_NO_BIG_TIER");
         s.no_ext_launch = on("MUSE_DEBUG_NO_EXT_LAUNCH");
         s.fd_fold = on("MUSE_FD_FOLD");
+        s.no_fid_normals = on("MUSE_DEBUG_NO_FID_NORMALS");
         s.cluster_size = num("MUSE_DEBUG_CLUSTER_SIZE", 0);
         s.shared_gpu_ranks = num("MUSE_SHARED_GPU_RANKS", 1);
         s.no_ncache = on("MUSE_DEBUG_NO_NCACHE");
@@ -84,6 +87,7 @@ enum : int {
     kDebugLoopOversubscribe = 1 << 18, // test hook: a loop launch with more workgroups than can be resident at once
     kDebugRunTiming = 1 << 19,         // the native loops report on stderr which loop ran
     kDebugFdFold = 1 << 20,            // get_H!'s finite-difference map as one launch that carries its fiducial MAP
+    kDebugNoFidNormals = 1 << 21,      // get_H!'s fiducial MAP draws its own normals
 };
 
 }  // namespace muse

@@ -104,7 +104,12 @@ def test_fd_launch_that_carries_its_fiducial_changes_no_bit(gpu, M, O, N, nth):
     S = 70
     prob = M.HipMuseProblem(None, model="funnel", ntheta=nth, N=N)
     first, i1 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)         # fills the cache: fiducial launch + perturbed launch
-    two, i3 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)           # cache held, two launches (the default)
+    two, i3 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)           # cache held, two launches (the default): the fiducial's
+                                                                                  # normals drawn by a kernel of their own (round 6) ...
+    prob.debug_flags(1 << 21)
+    own, i4 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)           # ... against the fiducial problem drawing them itself
+    prob.debug_flags(0)
+    assert np.array_equal(own, two) and i4.tobytes() == i3.tobytes()
     prob.debug_flags(1 << 20)
     folded, i2 = prob.fd_jacobian_batch(21, 3, 3 + S, th, step, atol=1e-2)        # cache held: the one launch
     assert np.array_equal(first, folded) and np.array_equal(two, folded)
