@@ -80,6 +80,19 @@ class ElementwiseModel:
         m.runtime_constants = list(runtime_constants) if runtime_constants else []
         return m
 
+    @classmethod
+    def from_expressions(cls, name, A, B, z, x, directory=None, constants=None, runtime_constants=None):
+        """A model of the one-parameter family from its TERMS -- A(x, z), B(x, z) of -logLike = 1/2 sum [A + e^-theta B] + 1/2 sum n theta,
+        and the draw z(sd, n1, n2), x(z, sd, n1, n2) -- as expressions (strings in x, z, sd, n1, n2 and the names of the per-element
+        constants, or sympy expressions): every derivative the engine needs, the second derivatives of the implicit-differentiation
+        get_H! included, is formed symbolically (museinference_jl_amd.symbolic) -- the counterpart of the AD the reference applies to
+        a SimpleMuseProblem's closures (src/simple.jl:84-85).  `ElementwiseModel.from_expressions("cubic_gen",
+        A="(x - (z + z**3/10))**2", B="z**2", z="sd*n1", x="z + z**3/10 + n2")` is models/cubic.h."""
+        from .symbolic import header_from_expressions
+        names = list(constants or {}) + list(runtime_constants or [])
+        return cls.from_source(name, header_from_expressions(name, A, B, z, x, constant_names=names), directory=directory,
+                               constants=constants, runtime_constants=runtime_constants)
+
     @staticmethod
     def _tables(constants):
         import numpy as np

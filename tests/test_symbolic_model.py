@@ -1,0 +1,201 @@
+"""Model headers generated from the model's terms (museinference_jl_amd.symbolic; ElementwiseModel.from_expressions): where the
+reference differentiates a SimpleMuseProblem's closures by AD (src/simple.jl:84-85), the derivatives a header has to state -- the
+gradient, the score term, the second derivatives of the implicit-differentiation get_H! (src/muse.jl:335-405) -- are formed by
+sympy from A(x, z), B(x, z) and the draw.
+
+CPU: the generated text against the hand-written models/cubic.h through the CPU checker's build of both (draw, value, gradient,
+score, MAP, implicit H), the contract refusals, per-element constants.  GPU: the generated model's engine library against the
+checker's build of the same text, and get_H! by both branches.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_same_path_or_close
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CUBIC = os.path.join(ROOT, "museinference.jl_amd", "models", "cubic.h")
+
+CUBIC_TERMS = dict(A="(x - (z + z**3/10))**2", B="z**2", z="sd*n1", x="z + z**3/10 + n2")
+# a known spectrum P_i and a saturating (rational) response: x = z / sqrt(1 + z^2) + n2, z ~ N(0, e^theta P_i)
+SAT_TERMS = dict(A="(x - z/sqrt(1 + z**2))**2", B="z**2/P", z="sd*sqrt(P)*n1", x="z/sqrt(1 + z**2) + n2")
+
+
+def generated_cubic(M, directory=None):
+    return M.ElementwiseModel.from_expressions("cubic_gen", directory=directory, **CUBIC_TERMS)
+
+
+def spectrum(N):
+    return 4.0 / (1.0 + np.arange(N) % 50) ** 1.2 + 0.1
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_generated_header_is_plain_c_and_states_what_it_came_from(M, tmp_path):
+    m = generated_cubic(M, str(tmp_path))
+    text = open(m.header).read()
+    assert "GENERATED" in text and "#define MUSE_MODEL_SECOND 1" in text and '#define MUSE_MODEL_NAME "cubic_gen"' in text
+    for fn in ("muse_model_sample", "muse_model_grad", "muse_model_score_term", "muse_model_second", "muse_model_dx_dsd"):
+        assert text.count(f" {fn}(") == 1
+    assert "pow(" not in text and "exp(" not in text
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"),
+                           "-include", "math.h", "-x", "c", m.header])
+    assert generated_cubic(M, str(tmp_path)).header == m.header          # the same terms: the same text, the same library
+    assert not m.pair and m.runtime_constants == []
+
+
+def test_generated_cubic_equals_the_hand_written_header_on_the_oracle(M, O, tmp_path):
+    """The same model twice -- terms differentiated by sympy, and models/cubic.h written by hand -- in the CPU checker: equal
+    draws, values, gradients, scores, MAPs and implicit-differentiation H to rounding (the two evaluate different but
+    equivalent IEEE sequences)."""
+    m = generated_cubic(M, str(tmp_path))
+    N, theta = 1201, [0.4, -0.3, 0.9]
+    got = {}
+    for tag, (hdr, name) in {"gen": (m.header, m.library_name), "hand": (CUBIC, "cubic")}.items():
+        with O.user_model(hdr, name):
+            x, z = O.sample_x_z("user", N, 17, 3, theta)
+            zz = 0.6 * z + 0.05
+            f, g = O.logLike_and_grad_z("user", x, zz, theta)
+            s = O.grad_theta("user", x, zz, theta)
+            zh, info = O.zhat_at_theta("user", x, np.zeros(N), theta, 1e-8)
+            H, _ = O.implicit_H("user", N, 5, 0, theta, atol=1e-12)
+            got[tag] = dict(x=x, z=z, f=f, g=g, s=s, zh=zh, H=H, status=info["status"])
+    a, b = got["gen"], got["hand"]
+    # (2 = the value stopped changing, Optim's f_converged with f_tol = 0: at |g| ~ 3e-7 a step lowers f ~ 880 by less than an
+    #  ulp; which of the two stops a header meets first depends on its rounding)
+    assert a["status"] in (0, 2) and b["status"] in (0, 2)
+    assert np.array_equal(a["z"], b["z"])
+    np.testing.assert_allclose(a["x"], b["x"], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(a["f"], b["f"], rtol=1e-13)
+    np.testing.assert_allclose(a["g"], b["g"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(a["s"], b["s"], rtol=1e-12)
+    np.testing.assert_allclose(a["zh"], b["zh"], atol=2e-6)
+    np.testing.assert_allclose(a["H"], b["H"], rtol=1e-8, atol=1e-8 * np.abs(b["H"]).max())
+
+
+def test_generated_model_passes_the_consistency_checks(M, O):
+    """check_model_consistency (first derivatives against differences of the value) through an oracle-backed problem, and the
+    generated second derivatives against differences of the generated first ones on the host (muse_model_eval of the model's own
+    engine library -- the one __graft_entry__.build() pre-builds -- needs no GPU for a model without run-time constants)."""
+    from oracle_problem import OracleMuseProblem
+    from museinference_jl_amd import models as MM
+    m = generated_cubic(M)
+    with O.user_model(m.header, m.library_name):
+        res = M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=3, N=2001), [0.4, -0.3, 0.9], rng=5)
+    assert res["grad_z"] <= 2e-5 + res["noise_floor"] and res["grad_theta"] <= 2e-5 + res["noise_floor"]
+    lib = M._capi.load_library(m.library())
+    assert lib.muse_model_has_second() == 1
+
+    def ev(iv, sd, x, z, n1, n2, i=0):
+        out = np.empty(12)
+        assert lib.muse_model_eval(None, iv, sd, x, z, n1, n2, int(i), M._capi.ptr(out)) == 0
+        return dict(zip(("grad", "term", "B", "ozz", "ozx", "bz", "bx", "z", "x", "dx_dsd"), out.tolist()))
+    rs = np.random.RandomState(2)
+    assert MM._check_second(ev, np.array([0.4, -0.3]), rs.randn(600), 0.7 * rs.randn(600), 8, 2e-5) <= 2e-5
+    e = ev(0.7, 1.2, 0.9, 0.4, -0.3, 0.8)                      # ... and against models/cubic.h's closed forms at one point
+    hp, r = 1 + 0.3 * 0.16, 0.9 - (0.4 + 0.1 * 0.4 ** 3)
+    np.testing.assert_allclose([e["grad"], e["B"], e["ozz"], e["ozx"], e["bz"], e["bx"]],
+                               [0.7 * 0.4 - r * hp, 0.16, 0.7 + hp * hp - r * 0.24, -hp, 0.8, 0.0], rtol=1e-13, atol=1e-300)
+
+
+def test_terms_with_per_element_constants_and_a_square_root(M, O, tmp_path):
+    N, theta = 801, [0.3, -0.5]
+    P = spectrum(N)
+    m = M.ElementwiseModel.from_expressions("saturating_gen", directory=str(tmp_path), constants={"P": P}, **SAT_TERMS)
+    text = open(m.header).read()
+    assert "P(i)" in text and "sqrt(" in text and f"#define MUSE_MODEL_N {N}" in text
+    from oracle_problem import OracleMuseProblem
+    with O.user_model(m.header, m.library_name):
+        x, z = O.sample_x_z("user", N, 4, 1, theta)
+        n1, n2 = O.normals(4, 1, N)
+        k = (np.arange(N) * 2) // N
+        np.testing.assert_allclose(z, np.exp(0.5 * np.asarray(theta))[k] * np.sqrt(P) * n1, rtol=1e-14)
+        np.testing.assert_allclose(x, z / np.sqrt(1 + z * z) + n2, rtol=1e-14, atol=1e-15)
+        zz = 0.7 * z - 0.02
+        f, g = O.logLike_and_grad_z("user", x, zz, theta)
+        hz = zz / np.sqrt(1 + zz * zz)
+        want = -0.5 * np.sum((x - hz) ** 2 + np.exp(-np.asarray(theta))[k] * zz * zz / P) - 0.5 * np.sum(np.asarray(theta)[k])
+        np.testing.assert_allclose(f, want, rtol=1e-13)
+        np.testing.assert_allclose(g, (x - hz) * (1 + zz * zz) ** -1.5 - np.exp(-np.asarray(theta))[k] * zz / P, rtol=1e-11, atol=1e-13)
+        res = M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=2, N=N), theta, rng=3)
+        assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"]
+        H, _ = O.implicit_H("user", N, 5, 0, theta, atol=1e-12)
+        _, zfid, _ = O.map_and_score_batch("user", N, 5, 0, 1, theta, atol=1e-12, z0_mode=0)
+        Hfd = O.fd_jacobian("user", N, 5, 0, theta, [1e-3] * 2, zfid[0], atol=1e-12)
+        np.testing.assert_allclose(H, Hfd, rtol=2e-5, atol=2e-5 * np.abs(Hfd).max())
+
+
+def test_terms_outside_the_family_are_refused(M, tmp_path):
+    """What the header contract forbids is refused when the text is generated, with the reason: a contribution of the pad element
+    (x = z = 0), a transcendental function (host, device and checker must evaluate one IEEE sequence), symbols A and B may not
+    depend on, a name that is not an identifier."""
+    f = lambda **kw: M.ElementwiseModel.from_expressions(kw.pop("name", "bad"), directory=str(tmp_path), **{**CUBIC_TERMS, **kw})
+    with pytest.raises(ValueError, match="vanish at x = z = 0"):
+        f(A="(x - z - 1)**2")
+    with pytest.raises(ValueError, match="vanish at x = z = 0"):
+        f(B="z**2 + 1")
+    with pytest.raises(ValueError, match="not allowed in a model header"):
+        f(A="(x - sin(z))**2", x="sin(z) + n2")
+    with pytest.raises(ValueError, match="half-integer exponents"):
+        f(B="z**2 * (1 + z**2)**(1/3)")
+    with pytest.raises(ValueError, match="functions of x and z"):
+        f(A="(x - z*sd)**2")
+    with pytest.raises(ValueError, match="function of sd, n1, n2"):
+        f(z="sd*n1 + x")
+    with pytest.raises(ValueError, match="model name"):
+        f(name="../evil")
+    assert os.listdir(str(tmp_path)) == []           # nothing was written for a refused model
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nth,theta", [(3000, 2, [0.4, -0.2]), (10000, 1, [0.3]), (9999, 3, [0.5, 0.0, -0.4]), (70001, 2, [0.3, 0.1])])
+def test_generated_model_hip_against_oracle(gpu, M, O, N, nth, theta):
+    """The generated header's engine library against the CPU checker's build of the same text: draws bit-equal, the batched map
+    on the same solver path (or within the documented tolerance), and the implicit-differentiation H from the generated second
+    derivatives."""
+    m = generated_cubic(M)
+    prob = M.HipMuseProblem(None, model=m, ntheta=nth, N=N)
+    assert prob.has_second_derivatives
+    with O.user_model(m.header, m.library_name):
+        x, z = prob.sample_x_z(M.SimRng(11, 2), theta)
+        xo, zo = O.sample_x_z("user", N, 11, 2, theta)
+        assert np.array_equal(x, xo) and np.array_equal(z, zo)
+        g, info = prob.map_and_score_batch(11, 0, 4, theta, atol=1e-4, z0_mode=0)
+        zh = prob.get_zhat(0, 4)
+        go, zho, io = O.map_and_score_batch("user", N, 11, 0, 4, theta, atol=1e-4, z0_mode=0)
+        long = int(io["iterations"].max()) > 20
+        same = assert_same_path_or_close(info, io, zh, zho, g, go, 1e-4, theta, "funnel", z_atol=1e-7 if long else 1e-9, g_rtol=1e-6 if long else 1e-10)
+        assert same.all() if not long else same.mean() >= 0.5
+        Hs, its = prob.implicit_H_batch(5, 0, 2, theta, atol=1e-1, cg_maxiter=100)
+        for s in range(2):
+            Ho, ito = O.implicit_H("user", N, 5, s, theta, atol=1e-1, cg_maxiter=100)
+            assert np.all(np.abs(its[s] - ito) <= 1)
+            np.testing.assert_allclose(Hs[s], Ho, rtol=1e-7, atol=1e-7 * np.abs(Ho).max())
+    res = M.check_model_consistency(prob, theta, rng=4)          # first AND second derivatives (the header has MUSE_MODEL_SECOND)
+    assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"] and res["second"] <= 2e-5
+    prob.close()
+
+
+@pytest.mark.gpu
+def test_generated_model_whole_run_equals_the_hand_written_model(gpu, M, O):
+    """muse() with covariance on the generated model and on models/cubic.h, same data and streams: the same estimate to the
+    solver's tolerance (equivalent arithmetic, different rounding), J and H by both get_H! branches included."""
+    with O.user_model(CUBIC, "cubic"):
+        x, _ = O.sample_x_z("user", 4000, 9, M.DATA_SIM, [0.2, -0.3])
+    out = []
+    for model in (generated_cubic(M), M.ElementwiseModel.packaged("cubic")):
+        prob = M.HipMuseProblem(x, model=model, ntheta=2, prior=M.GaussianPrior(0.0, 3.0))
+        res = M.muse(prob, [0.0, 0.0], rng=2, nsims=40, maxsteps=8, get_covariance=True)
+        Hfd = res.H.copy()
+        res.Hs, res.H = [], None
+        M.get_H_(res, prob, nsims=8, implicit_diff=True)
+        out.append((res.theta.copy(), res.J.copy(), Hfd, res.H.copy()))
+        prob.close()
+    (ta, Ja, Ha, Ia), (tb, Jb, Hb, Ib) = out
+    np.testing.assert_allclose(ta, tb, atol=1e-5)
+    np.testing.assert_allclose(Ja, Jb, rtol=1e-4, atol=1e-4 * np.abs(Jb).max())
+    np.testing.assert_allclose(Ha, Hb, rtol=1e-3, atol=1e-3 * np.abs(Hb).max())
+    np.testing.assert_allclose(Ia, Ib, rtol=1e-4, atol=1e-4 * np.abs(Ib).max())
