@@ -93,6 +93,16 @@ class ElementwiseModel:
         return cls.from_source(name, header_from_expressions(name, A, B, z, x, constant_names=names), directory=directory,
                                constants=constants, runtime_constants=runtime_constants)
 
+    @classmethod
+    def from_pair_expressions(cls, name, coefs, C, o, z, x, directory=None):
+        """A model of the TWO-parameter family (include/muse_model.h, MUSE_MODEL_PAIR: block k's parameters a = theta[k],
+        b = theta[K + k]) from its terms: the coefficients c0 .. c3 as expressions in a, b (exp allowed there), the block's constant
+        C(a, b), the element's objective term o(c; x, z) and the draw z(c0, c1, n1, n2), x(z, c0, c1, n1, n2) -- gradient and score by
+        symbolic differentiation (museinference_jl_amd.symbolic.pair_header_from_expressions).  models/normal_mean_var.h is
+        `from_pair_expressions("nmv", coefs=["a", "exp(b/2)", "exp(-b)"], C="b", o="(x - z)**2 + c2*(z - c0)**2", z="c0 + c1*n1", x="z + n2")`."""
+        from .symbolic import pair_header_from_expressions
+        return cls.from_source(name, pair_header_from_expressions(name, coefs, C, o, z, x), directory=directory)
+
     @staticmethod
     def _tables(constants):
         import numpy as np

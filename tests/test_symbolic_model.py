@@ -199,3 +199,121 @@ def test_generated_model_whole_run_equals_the_hand_written_model(gpu, M, O):
     np.testing.assert_allclose(Ja, Jb, rtol=1e-4, atol=1e-4 * np.abs(Jb).max())
     np.testing.assert_allclose(Ha, Hb, rtol=1e-3, atol=1e-3 * np.abs(Hb).max())
     np.testing.assert_allclose(Ia, Ib, rtol=1e-4, atol=1e-4 * np.abs(Ib).max())
+
+
+# ================================================================================================ the two-parameter family
+NMV_TERMS = dict(coefs=["a", "exp(b/2)", "exp(-b)"], C="b", o="(x - z)**2 + c2*(z - c0)**2", z="c0 + c1*n1", x="z + n2")
+
+
+def generated_nmv(M, directory=None):
+    return M.ElementwiseModel.from_pair_expressions("nmv_gen", directory=directory, **NMV_TERMS)
+
+
+def test_generated_pair_header_on_the_checker_against_closed_forms(M, O, tmp_path):
+    """z_i ~ N(mu_k, e^tau_k), x_i ~ N(z_i, 1) from its terms (models/normal_mean_var.h is the hand-written one): the checker's build
+    of the generated text against the model's closed forms -- draw, value, gradient, BOTH kinds of score component, the MAP --, the
+    hand-written header's draw bit for bit, and the consistency check AD would have made unnecessary."""
+    from oracle_problem import OracleMuseProblem
+    from test_pair_model import HEADER, NAME, blocks, closed_forms
+    m = generated_nmv(M, str(tmp_path))
+    text = open(m.header).read()
+    assert m.pair and "#define MUSE_MODEL_PAIR 1" in text and text.count("muse_model_exp(") == 2 and " exp(" not in text.split("*/")[1]
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"),
+                           "-include", "math.h", "-x", "c", m.header])
+    N, theta = 1001, np.array([0.7, -0.3, 0.4, 1.1])
+    K = 2
+    k = blocks(N, K)
+    with O.user_model(HEADER, NAME):
+        xh, zh_ = O.sample_x_z("user", N, 5, 3, theta)
+    with O.user_model(m.header, m.library_name):
+        x, z = O.sample_x_z("user", N, 5, 3, theta)
+        np.testing.assert_allclose(z, zh_, rtol=1e-14, atol=1e-15)        # (c0 + c1 n1 against fma(c1, n1, c0))
+        np.testing.assert_allclose(x, xh, rtol=1e-14, atol=1e-15)
+        zz = 0.7 * z + 0.1
+        f, g = O.logLike_and_grad_z("user", x, zz, theta)
+        fo, go, so = closed_forms(x, zz, theta)
+        np.testing.assert_allclose(f, fo, rtol=1e-13)
+        np.testing.assert_allclose(g, go, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(O.grad_theta("user", x, zz, theta), so, rtol=1e-12, atol=1e-12)
+        zhat, info = O.zhat_at_theta("user", x, np.zeros(N), theta, atol=1e-9)
+        iv = np.exp(-theta[K + k])
+        np.testing.assert_allclose(zhat, (x + iv * theta[k]) / (1 + iv), rtol=0, atol=1e-9)
+        res = M.check_model_consistency(OracleMuseProblem(None, model="user", ntheta=4, N=2001), [0.4, -0.3, 0.9, 0.2], rng=5)
+    assert res["grad_z"] <= 2e-5 + res["noise_floor"] and res["grad_theta"] <= 2e-5 + res["noise_floor"]
+
+
+def test_pair_terms_outside_the_family_are_refused(M, tmp_path):
+    f = lambda **kw: M.ElementwiseModel.from_pair_expressions("bad", directory=str(tmp_path), **{**NMV_TERMS, **kw})
+    with pytest.raises(ValueError, match="vanish at x = z = 0 with zero coefficients"):
+        f(o="(x - z)**2 + (z - c0)**2/c1**2")                     # a coefficient in a denominator: the pad element gives 0/0
+    with pytest.raises(ValueError, match="vanish at x = z = 0 with zero coefficients|not a function of the coefficients alone"):
+        f(coefs=["a", "exp(b/2)", "a*exp(-b)"], o="(x - z)**2 + c2*z")   # d c2 / d a = e^-b, which no coefficient holds
+    with pytest.raises(ValueError, match="may read c0 and c1 only"):
+        f(z="c0 + n1/sqrt(c2)")
+    with pytest.raises(ValueError, match="between one and four"):
+        f(coefs=["a", "b", "a*b", "a + b", "a - b"])
+    with pytest.raises(ValueError, match="not allowed in a model header"):
+        f(o="(x - z)**2 + c2*(z - c0)**2 + z*sin(z)")
+    assert os.listdir(str(tmp_path)) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nth,theta,split", [(300, 4, [0.4, -0.3, 0.9, 0.1], 0), (10000, 2, [1.0, 1.0], 0), (9001, 6, [0.0, 0.7, -0.4, 0.3, 0.0, -0.3], 8),
+                                               (70001, 4, [0.3, -0.2, 0.1, 0.9], 0)])
+def test_generated_pair_model_hip_against_the_checker(gpu, M, O, N, nth, theta, split):
+    """The generated two-parameter header's engine library against the checker's build of the same text (resident, LDS-resident,
+    register clusters, streaming clusters): the draw bit for bit, maps on the same solver path with scores rtol 1e-10, the MAP in
+    closed form, the finite-difference get_H!."""
+    from test_pair_model import blocks
+    theta = np.asarray(theta)
+    m = generated_nmv(M)
+    K = nth // 2
+    k = blocks(N, K)
+    with O.user_model(m.header, m.library_name):
+        xdata, _ = O.sample_x_z("user", N, 77, M.DATA_SIM, np.concatenate([np.full(K, 0.3), np.zeros(K)]))
+        prob = M.HipMuseProblem(xdata, model=m, ntheta=nth)
+        if split:
+            prob.set_element_split(split)
+        x, z = prob.sample_x_z(M.SimRng(1234, 2**40 + 7), theta)
+        xo, zo = O.sample_x_z("user", N, 1234, 2**40 + 7, theta)
+        assert np.array_equal(z, zo) and np.array_equal(x, xo)
+        nsims = 5 if N > 20000 else 13
+        g, info = prob.map_and_score_batch(42, 3, 3 + nsims, theta, include_data=True, atol=1e-6, z0_mode=0)
+        go, zo, io = O.map_and_score_batch("user", N, 42, 3, 3 + nsims, theta, atol=1e-6, x_data=xdata, z0_mode=0)
+        zh = prob.get_zhat(0, nsims + 1)
+        same = assert_same_path_or_close(info, io, zh, zo, g, go, 1e-6, theta, "funnel", g_rtol=1e-10)
+        assert same.all() and np.all(info["status"] == 0)
+        iv = np.exp(-theta[K + k])
+        np.testing.assert_allclose(zh[0], (xdata + iv * theta[k]) / (1 + iv), rtol=0, atol=2e-6)
+        step = np.full(nth, 0.05)
+        Hs, _ = prob.fd_jacobian_batch(11, 2, 4, theta, step, atol=1e-6)
+        _, zfid, _ = O.map_and_score_batch("user", N, 11, M.MASTER_SIM, M.MASTER_SIM + 1, theta, atol=1e-6, z0_mode=0)
+        for s in range(2):
+            Ho = O.fd_jacobian("user", N, 11, 2 + s, theta, step, zfid[0], atol=1e-6)
+            np.testing.assert_allclose(Hs[s], Ho, rtol=1e-7, atol=1e-7 * np.abs(Ho).max())
+    res = M.check_model_consistency(prob, theta, rng=4)
+    assert max(res["grad_z"], res["grad_theta"]) <= 2e-5 + res["noise_floor"]
+    prob.close()
+
+
+@pytest.mark.gpu
+def test_muse_on_the_generated_pair_model_against_the_exact_posterior(gpu, M):
+    """muse() with covariance on the generated model, device-resident loop and host loop the same bits, against the exact marginal
+    posterior of x_i ~ N(mu_k, 1 + e^tau_k) (tests/test_pair_model.py's acceptance test for the hand-written header)."""
+    from test_pair_model import PRIOR_SIGMA, exact_posterior
+    m = generated_nmv(M)
+    N, K, truth, nsims = 10000, 2, [0.8, -0.6, 0.5, 1.0], 256
+    tmp = M.HipMuseProblem(None, model=m, ntheta=2 * K, N=N)
+    x, _ = tmp.sample_x_z(M.SimRng(99, M.DATA_SIM), truth)
+    tmp.close()
+    mode, sigma = exact_posterior(x, K)
+    prob = M.HipMuseProblem(x, model=m, ntheta=2 * K, prior=M.GaussianPrior(0.0, PRIOR_SIGMA))
+    kw = dict(nsims=40, maxsteps=5, theta_rtol=0.0, atol=1e-6, alpha=0.7)
+    a, b = prob.run_muse(3, [0.0] * 4, device_loop=True, **kw), prob.run_muse(3, [0.0] * 4, device_loop=False, **kw)
+    assert a[0] == b[0] == 5 and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    res = M.muse(prob, [0.0] * (2 * K), rng=20240, nsims=nsims, maxsteps=60, theta_rtol=1e-5, grad_z_logLike_atol=1e-6, alpha=1.0, get_covariance=True)
+    dev = np.abs(np.asarray(res.theta) - mode) / (sigma / np.sqrt(nsims))
+    assert np.all(dev < 4.0), (res.theta, mode, dev)
+    got = np.sqrt(np.diag(np.atleast_2d(res.Sigma)))
+    assert np.all(np.abs(got / sigma - 1.0) < 5.0 * 0.5 * np.sqrt(2.0 / (nsims - 1)) + 0.03), (got, sigma)
+    prob.close()
