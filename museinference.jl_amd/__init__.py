@@ -8,6 +8,7 @@ and drivers.  See DESIGN.md and INTEGRATION.md at the repository root.
 from . import _capi
 from ._capi import MuseError, STATUS_NAMES, Z0_TRUE, Z0_WARM, Z0_ZERO, load_library
 from .build import build_extension
+from .covariance import LinearShrinkage, SimpleCovariance
 from .fdm import FiniteDifferenceMethod, central_fdm
 from .models import ElementwiseModel, check_model_consistency
 from .distributed import ShardedMuseProblem, block_partition, ranks_share_node
@@ -19,7 +20,7 @@ from .problem import (DATA_SIM, MASTER_SIM, AbstractMuseProblem, HipMuseProblem,
 __all__ = [
     "AbstractMuseProblem", "HipMuseProblem", "ShardedMuseProblem", "MuseResult", "Normal", "SimRng",
     "muse", "muse_", "get_J_", "get_H_", "finalize_result_", "split_rng", "block_partition", "ranks_share_node", "central_fdm", "FiniteDifferenceMethod",
-    "ElementwiseModel", "check_model_consistency", "GaussianPrior", "FlatPrior", "CallablePrior", "build_extension", "load_library", "MuseError",
+    "ElementwiseModel", "check_model_consistency", "SimpleCovariance", "LinearShrinkage", "GaussianPrior", "FlatPrior", "CallablePrior", "build_extension", "load_library", "MuseError",
     "save_result", "load_result", "check_optim_soln", "check_self_consistency", "PositiveThetaProblem", "Transformedθ", "UnTransformedθ",
     "Z0_ZERO", "Z0_TRUE", "Z0_WARM", "MASTER_SIM", "DATA_SIM", "STATUS_NAMES",
 ]

@@ -300,7 +300,10 @@ def get_J_(result, prob, theta0=None, *, z0=None, grad_z_logLike_atol=1e-2, rng=
            progress=False, skip_errors=False, covariance_method="simple_corrected"):
     """get_J!(result, prob, θ₀; ...)   (src/muse.jl:484-532).  J = var(gs) / corrected sample covariance
     (SimpleCovariance(corrected=true), src/muse.jl:495,529); only nsims - length(result.gs) new sims are
-    run, continuing the same streams (src/muse.jl:499-506)."""
+    run, continuing the same streams (src/muse.jl:499-506).  covariance_method: the estimator applied to the scores
+    (src/muse.jl:480: any CovarianceEstimator) -- covariance.SimpleCovariance / LinearShrinkage, a callable scores -> J, or a name."""
+    from .covariance import as_covariance_method
+    estimator = as_covariance_method(covariance_method)       # (refused before any simulation runs)
     _note_ignored(pool=pool, progress=progress)
     rng = int(_something(rng, result.rng, _default_rng()))
     theta0 = prob.standardize_theta(_something(theta0, result.theta))
@@ -318,7 +321,7 @@ def get_J_(result, prob, theta0=None, *, z0=None, grad_z_logLike_atol=1e-2, rng=
                                      grad_z_logLike_atol, _capi.Z0_WARM if z0 is not None else _capi.Z0_TRUE)
         result.gs = list(result.gs) + list(g)
     G = np.array(result.gs)
-    result.J = np.atleast_2d(np.cov(G, rowvar=False, ddof=1))
+    result.J = np.atleast_2d(np.asarray(estimator(G), dtype=np.float64))
     return finalize_result_(result, prob)
 
 
