@@ -307,7 +307,7 @@ hipError_t launch_loglike(int model, const BatchArgs& a, const double* x, const 
 // the device-resident loop: false where the placement has no loop kernel (cluster placements); max_grid = the number of
 // workgroups that are certainly resident at once (they meet at the end of every iteration)
 bool loop_supported(const LaunchShape& s);
-hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid);
+hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid, int* scratch_bytes);
 hipError_t launch_loop(const LaunchShape& s, const BatchArgs& a, const LoopArgs& l, hipStream_t stream);
 size_t loop_extra_lds(bool xg_lds, int64_t nprob, int ntheta);  // LDS of the loop kernel beside the map kernel's
 size_t loop_step_bytes(int64_t nprob, int ntheta);              // the step's own arrays (they alias x and g in the LDS-resident layout)

@@ -840,6 +840,7 @@ struct LoopCall {
     hipStream_t st;
     int num_cus;
     int* max_grid;
+    int* scratch_bytes;   // LOOP_GRID: the kernel's private segment per lane (what its spilled registers take)
 };
 template <class Model, class Place>
 static hipError_t loop_one(const LaunchShape& s, const LoopCall& c) {
@@ -858,6 +859,12 @@ static hipError_t loop_one(const LaunchShape& s, const LoopCall& c) {
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, Place::T, s.lds);
         if (e != hipSuccess) return e;
         *c.max_grid = per_cu * c.num_cus;
+        if (c.scratch_bytes) {
+            hipFuncAttributes at;
+            const hipError_t e2 = hipFuncGetAttributes(&at, (const void*)kern);
+            if (e2 != hipSuccess) return e2;
+            *c.scratch_bytes = (int)at.localSizeBytes;
+        }
         return hipSuccess;
     }
     hipLaunchKernelGGL(kern, dim3(s.grid), dim3(Place::T), s.lds, c.st, *c.a, *c.l);

@@ -1411,6 +1411,7 @@ struct RunBuffers {
     int* status = nullptr;
     int64_t cap_hist = 0, cap_scores = 0, cap_infos = 0;
     int grid_place = -1, grid_max = 0;    // the occupancy query's answer for (placement, LDS bytes): asked once
+    int grid_scratch = 0;                 // ... and the loop kernel's private segment per lane (bytes of spilled registers)
     size_t grid_lds = 0;
 };
 // S: simulations of the whole job; nlocal: elements this context solves (S + 1 unless the loop is sharded over ranks)
@@ -1519,15 +1520,24 @@ static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_o
     if (!c->run) c->run = new RunBuffers();
     RunBuffers& r = *c->run;
     if (r.grid_place != pl || r.grid_lds != shape.lds) {
-        int mg = 0;
-        if (loop_max_grid(shape, c->num_cus, &mg) != hipSuccess) {
+        int mg = 0, scratch = 0;
+        if (loop_max_grid(shape, c->num_cus, &mg, &scratch) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
         r.grid_place = pl;
         r.grid_lds = shape.lds;
         r.grid_max = mg;
+        r.grid_scratch = scratch;
     }
+    // A loop kernel most of whose state the compiler spilled (a user's header can do that: the two-parameter model whose score terms
+    // multiply every element by a further coefficient -- 630 spilled registers, 420 bytes per lane, against 126 / 120 for the same
+    // model with the factor applied to the block's sum) is slower than the host loop, and in that regime the compiler's own spill
+    // code was seen to lose uniform values held across the solve (the solver's evaluation counters came back wrong while every
+    // number of the run was right: tools/fuzz_user_model.py pairgen, round 6).  Beyond the product's own bound on a kernel's
+    // scratch (tools/regs.py, LIBRARY_SCRATCH_LIMIT) the host loop runs.
+    constexpr int kLoopScratchLimit = 256;
+    if (r.grid_scratch > kLoopScratchLimit && !c->sw.loop_any_scratch) return false;
     // ... and with up to four theta components, or one problem per worker (round 5: the roles as two loops and one copy of the solve
     // in the worker's loop took the loop kernels of one to four components out of scratch, or nearly; those of five to eight still
     // carry 36-44 spilled registers and lose to the host loop when a worker has several problems).  Measured per iteration of a

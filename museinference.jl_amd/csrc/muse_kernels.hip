@@ -289,12 +289,12 @@ bool loop_supported(const LaunchShape& s) {
     LoopCall c{LOOP_QUERY, nullptr, nullptr, nullptr, 0, nullptr};
     return loop_dispatch(s, c) == hipSuccess;
 }
-hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid) {
-    LoopCall c{LOOP_GRID, nullptr, nullptr, nullptr, num_cus, max_grid};
+hipError_t loop_max_grid(const LaunchShape& s, int num_cus, int* max_grid, int* scratch_bytes) {
+    LoopCall c{LOOP_GRID, nullptr, nullptr, nullptr, num_cus, max_grid, scratch_bytes};
     return loop_dispatch(s, c);
 }
 hipError_t launch_loop(const LaunchShape& s, const BatchArgs& a, const LoopArgs& l, hipStream_t st) {
-    LoopCall c{LOOP_LAUNCH, &a, &l, st, 0, nullptr};
+    LoopCall c{LOOP_LAUNCH, &a, &l, st, 0, nullptr, nullptr};
     return loop_dispatch(s, c);
 }
 // LDS of the loop kernel beside the map kernel's: the persistent block, and -- where x and g are not in LDS -- the step's arrays

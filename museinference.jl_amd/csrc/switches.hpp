@@ -30,6 +30,7 @@ struct Switches {
     // ---- the native muse! loops
     bool no_loop_kernel = false;        // MUSE_DEBUG_NO_LOOP_KERNEL: muse_run_device runs the host loop
     bool loop_any_ntheta = false;       // MUSE_DEBUG_LOOP_ANY_NTHETA: the loop kernel whatever ntheta (tests, fuzz_loops.py)
+    bool loop_any_scratch = false;      // MUSE_DEBUG_LOOP_ANY_SCRATCH: the loop kernel however much of its state the compiler spilled
     bool loop_dedicated_stepper = false;   // MUSE_DEBUG_LOOP_DEDICATED_STEPPER: the stepper never owns elements (debug flag bit 7 likewise)
     bool loop_oversubscribe = false;    // MUSE_DEBUG_LOOP_OVERSUBSCRIBE: test hook, more workgroups than are resident at once (bit 18)
     int loop_grid = 0;                  // MUSE_DEBUG_LOOP_GRID=n: the loop kernel with n workers (0: as many as are resident)
@@ -63,6 +64,7 @@ struct Switches {
         if (const char* e = getenv("MUSE_NCACHE_MAX_MB")) s.ncache_max_bytes = atoll(e) << 20;
         s.no_loop_kernel = on("MUSE_DEBUG_NO_LOOP_KERNEL");
         s.loop_any_ntheta = on("MUSE_DEBUG_LOOP_ANY_NTHETA");
+        s.loop_any_scratch = on("MUSE_DEBUG_LOOP_ANY_SCRATCH");
         s.loop_dedicated_stepper = on("MUSE_DEBUG_LOOP_DEDICATED_STEPPER");
         s.loop_oversubscribe = on("MUSE_DEBUG_LOOP_OVERSUBSCRIBE");
         s.loop_grid = num("MUSE_DEBUG_LOOP_GRID", 0);

@@ -26,6 +26,7 @@ def models():
     out.append(M.ElementwiseModel.from_source("spectrum", T.SPECTRUM_SOURCE, runtime_constants=["P"]))   # (one library for every N and P)
     out.append(M.ElementwiseModel.from_source("noise_second", T.NOISE_SECOND_SOURCE))
     import test_symbolic_model as TS
+    out.append(M.ElementwiseModel("pair_heavy_score", TS.HEAVY))   # (a correct header whose loop kernels exceed the scratch bound)
     out.append(TS.generated_nmv(M))                       # (... of the two-parameter family)
     out.append(TS.generated_cubic(M))                     # (a header generated from the model's terms: museinference_jl_amd.symbolic)
     terms = open(os.path.join(ROOT, "examples", "model_from_terms.py")).read().split("TERMS = dict(")[1].split(")\n")[0]

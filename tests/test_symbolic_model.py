@@ -317,3 +317,41 @@ def test_muse_on_the_generated_pair_model_against_the_exact_posterior(gpu, M):
     got = np.sqrt(np.diag(np.atleast_2d(res.Sigma)))
     assert np.all(np.abs(got / sigma - 1.0) < 5.0 * 0.5 * np.sqrt(2.0 / (nsims - 1)) + 0.03), (got, sigma)
     prob.close()
+
+
+HEAVY = os.path.join(HERE, "models", "pair_heavy_score.h")
+
+
+@pytest.mark.gpu
+def test_a_loop_kernel_beyond_the_scratch_bound_is_not_launched(gpu, M, capfd):
+    """A correct header can cost a loop kernel most of its registers (tests/models/pair_heavy_score.h: 420 bytes of scratch per lane
+    for three or four blocks in the LDS-resident placement).  Beyond the product's bound (256 bytes) muse_run_device runs the host
+    loop -- the same bits, solver records included -- while the same header's kernels within the bound still run as one launch."""
+    model = M.ElementwiseModel("pair_heavy_score", HEAVY)
+    for N, nth, th0, device in ((10000, 8, [0.2, -0.1, 0.3, 0.0, 0.5, -0.5, 0.0, 1.0], False), (10000, 2, [0.1, 0.4], True),
+                                (3000, 8, [0.0] * 8, True)):
+        x = np.sin(0.3 * np.arange(N)) + 0.4 + 0.8 * np.cos(1.7 * np.arange(N))
+        prob = M.HipMuseProblem(x, model=model, ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+        kw = dict(nsims=40, maxsteps=4, theta_rtol=0.0, atol=1e-6, alpha=0.7)
+        b = prob.run_muse(3, th0, device_loop=False, **kw)
+        capfd.readouterr()
+        prob.debug_flags(M.HipMuseProblem.DEBUG_RUN_TIMING)
+        a = prob.run_muse(3, th0, device_loop=True, **kw)
+        prob.debug_flags(0)
+        assert ("[muse_run_device] launch call" in capfd.readouterr().err) == device, (N, nth)
+        assert a[0] == b[0] == 4 and np.array_equal(a[1], b[1]) and np.array_equal(a[2][:, :-1], b[2][:, :-1]) and np.array_equal(a[3], b[3])
+        assert a[4].tobytes() == b[4].tobytes(), (N, nth)          # iterations, evaluation counts, history words, status, f, |g|
+        prob.close()
+    # the generated header of the same model keeps the factor on the sums (symbolic.py, split): its loop kernels are within the bound
+    gen = generated_nmv(M)
+    x = np.sin(0.3 * np.arange(10000)) + 0.4
+    prob = M.HipMuseProblem(x, model=gen, ntheta=8, prior=M.GaussianPrior(0.0, 3.0))
+    kw = dict(nsims=40, maxsteps=4, theta_rtol=0.0, atol=1e-6, alpha=0.7)
+    b = prob.run_muse(3, [0.1] * 8, device_loop=False, **kw)
+    capfd.readouterr()
+    prob.debug_flags(M.HipMuseProblem.DEBUG_RUN_TIMING)
+    a = prob.run_muse(3, [0.1] * 8, device_loop=True, **kw)
+    prob.debug_flags(0)
+    assert "[muse_run_device] launch call" in capfd.readouterr().err
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and a[4].tobytes() == b[4].tobytes()
+    prob.close()

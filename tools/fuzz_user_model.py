@@ -7,7 +7,9 @@ N / ntheta / theta / seed / atol / start mode / placement / element split / maps
   off path    a decision of the line search fell the other way (tree-ordered against sequential sums over many iterations): the
               counts differ -- or, rarely, coincide while the iterates do not -> both converged, MAPs agree to 2 atol
   MISMATCH    anything else (printed).
-Usage (GPU box): python tools/fuzz_user_model.py [seconds] [seed] [pair]
+Usage (GPU box): python tools/fuzz_user_model.py [seconds] [seed] [cubic|pair|gen|pairgen]
+`gen` / `pairgen`: the cubic model / the two-parameter model as headers GENERATED from their terms (ElementwiseModel.from_expressions /
+from_pair_expressions) instead of the hand-written ones.
 `pair`: the two-parameter family's shipped member (models/normal_mean_var.h: ntheta = 2 K in {2, 4, 6, 8}, location parameters in
 [-1.5, 1.5], no implicit-differentiation H; its objective is quadratic, so every case is expected on the same path) -- with the native
 loops on every third case: muse_run_device (the loop kernel, whose step calls the header's muse_model_coefs on the device) against
@@ -24,9 +26,16 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-PAIR = len(sys.argv) > 3 and sys.argv[3] == "pair"
-NAME = "normal_mean_var" if PAIR else "cubic"
-model = M.ElementwiseModel.packaged(NAME)
+MODE = sys.argv[3] if len(sys.argv) > 3 else "cubic"
+PAIR = MODE in ("pair", "pairgen")
+if MODE in ("gen", "pairgen"):   # the same two models GENERATED from their terms (museinference_jl_amd.symbolic; tests/test_symbolic_model.py)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import test_symbolic_model as TS
+    model = TS.generated_nmv(M) if PAIR else TS.generated_cubic(M)
+    NAME = model.library_name
+else:
+    NAME = "normal_mean_var" if PAIR else "cubic"
+    model = M.ElementwiseModel.packaged(NAME)
 os.environ.setdefault("MUSE_DEBUG_LOOP_ANY_NTHETA", "1")
 t0 = time.time()
 nloop = nloop_bad = 0
