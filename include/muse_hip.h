@@ -185,7 +185,8 @@ int muse_profile_clock_hz(muse_ctx* ctx, double* hz_out);
  * muse_debug_flags: switches of a LIVE context (the environment switches of csrc/switches.hpp are read once, by muse_ctx_create).
  * No bit changes a result (tests hold the alternatives bit-equal).  Kernel side: 1 x from the data vector; 2 the loop kernel does
  * not fetch ahead; 3 its old element order; 4 test hook: odd workers leave before their first solve; 5 no speculating trials;
- * 6 a solving stepper takes the data element itself; 7 the stepper never solves; 8 the data vector is not sent ahead.  Host side:
+ * 6 a solving stepper takes the data element itself; 7 the stepper never solves; 8 the data vector is not sent ahead; 9 the loop kernel
+ * stores every MAP in every iteration (default: the one a worker carries into the next iteration in registers when the loop ends).  Host side:
  * 16 muse_run_sharded's scores meet on the board in pinned host memory; 17 muse_run_sharded runs the host-driven loop;
  * 18 test hook: a loop launch with more workgroups than can be resident at once; 19 the native loops say on stderr which loop
  * ran and what it cost; 20 get_H!'s finite-difference map as ONE launch that carries its fiducial MAP (measured slower: off);

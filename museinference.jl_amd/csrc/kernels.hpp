@@ -386,6 +386,13 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                         }
                     }
                     if (!kept) sv.template begin<false, false>(p, wg_scratch, m.lds_x, m.lds_g, pf);
+                    // Round 6: an iteration is bound by memory (four words per element and problem).  The LAST problem's
+                    // MAP stays in registers for the next iteration's first solve, and nothing else reads its slot while the loop
+                    // runs: it is not stored now (a word less for one problem in two -- for the only problem of a worker with one
+                    // element: a rank's share, the reference's default 100 simulations) but when the loop ends, below.
+                    if constexpr (Solver<Model, Place>::kKeepZ) {
+                        if (k == cnt - 1 && alternate && iter < m.L->maxsteps && !(a.debug & 512) && sv.keeps_next(p)) sv.d.zslot = -1;
+                    }
                     sv.after_begin(p, m.lds_x, m.lds_g, pf, nx);
                     if constexpr (Solver<Model, Place>::kKeepZ) zkeep = sv.z;   // (the last one's stays: the next iteration's first)
                     wg_barrier<!Model::kStencil>();   // (raw: the next problem's n1 is on its way into the g area)
@@ -441,7 +448,24 @@ muse_loop_kernel(const BatchArgs /*read via the kernarg segment*/, const LoopArg
                 const unsigned long long ec = (unsigned long long)__double_as_longlong(th[nt]);
                 err = m.flags[2] ? (int)STEP_TIMEOUT : __builtin_amdgcn_readfirstlane((int)(ec & 0xffffffffull));
                 converged = __builtin_amdgcn_readfirstlane((int)(ec >> 32));
-                if (err != STEP_OK || converged || iter == m.L->maxsteps) break;
+                if (err != STEP_OK || converged || iter == m.L->maxsteps) {
+                    if constexpr (Solver<Model, Place>::kKeepZ) {
+                        // the loop ends before its last iteration: the MAP held back above (the same conditions, formed again rather
+                        // than carried across the solves) goes to its slot
+                        const bool alternate = !(a.debug & 8);
+                        if (iter < m.L->maxsteps && alternate && !(a.debug & 512)) {
+                            const int first = (int)blockIdx.x + ((solving && a.include_data && (a.debug & 64)) ? 1 : 0);
+                            const int cnt = m.L->deal_q + ((int)blockIdx.x < m.L->deal_r ? 1 : 0);
+                            const int last = (iter & 1) ? first + (cnt - 1) * nworkers : first;
+                            Solver<Model, Place> sv(a, tid, m.red, m.shs);
+                            if (sv.keeps_next(last)) {
+                                sv.z = zkeep;
+                                sv.store_kept(last);
+                            }
+                        }
+                    }
+                    break;
+                }
                 // a lane per exponential (step.hpp, make_map_theta_component's statements): exp(theta/2), exp(-theta) side by side, the
                 // constant term and the next iteration's fields on lanes of their own
                 int tl = tid;

@@ -1074,6 +1074,25 @@ struct Solver : PairState<Model::kPair> {
         return dd.z0_mode == Z0_WARM && !dd.normals_only && dd.tsample < 0 &&
                ((dd.x_mode == X_SAMPLE && dd.nslot >= 0 && a.ncache_mode == 2) || dd.x_mode == X_DATA);
     }
+    // (workgroup-uniform) will problem p, solved LAST in this iteration of the device-resident loop, start the next iteration from the
+    // registers it ends in (can_keep as the next iteration will see it: a warm start, the normals from the cache)?  Then its MAP need not
+    // go to memory now: nothing reads the slot before the loop ends, and the worker stores it then (store_kept).
+    __device__ __forceinline__ bool keeps_next(int p) const {
+        if constexpr (!kKeepZ) return false;
+        const ProblemDesc dd = describe(a, p);
+        return !dd.normals_only && dd.tsample < 0 && dd.zslot >= 0 &&
+               ((dd.x_mode == X_SAMPLE && dd.nslot >= 0 && a.ncache != nullptr && a.ncache_mode != 0) || dd.x_mode == X_DATA);
+    }
+    __device__ __forceinline__ void store_kept(int p) {   // z (registers) -> problem p's slot
+        if constexpr (kKeepZ) {
+            const ProblemDesc dd = describe(a, p);
+            if (dd.zslot < 0) return;
+            const int64_t ld = a.ld;
+            VH zout;
+            zout.bind(a.zhat + dd.zslot * ld, ld);
+            for_elems<T, EPT, U>(ld, tfirst, ps(), [&](int jj, int i) { zout.set(jj, i, z.get(jj, i)); });
+        }
+    }
     // what run() does behind begin() (the loop kernel picks the begin itself: kept MAP or not)
     __device__ __forceinline__ void after_begin(int p, double* lds_x, double* lds_g, Prefetch<EPT>& pf, int next_p) {
         if (d.normals_only) return;

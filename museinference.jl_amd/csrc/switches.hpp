@@ -82,7 +82,7 @@ struct Switches {
     }
 };
 
-// Host-side bits of muse_debug_flags (bits 0-8 travel to the kernels in BatchArgs::debug).
+// Host-side bits of muse_debug_flags (bits 0-9 travel to the kernels in BatchArgs::debug).
 enum : int {
     kDebugHostBoard = 1 << 16,          // the sharded loop's scores meet on the board in pinned host memory
     kDebugShardedHostLoop = 1 << 17,    // muse_run_sharded runs the host-driven loop

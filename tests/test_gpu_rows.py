@@ -183,11 +183,14 @@ def test_device_resident_muse_loop_equals_host_loop(gpu, M, O, model, N, nth, ns
     for dev in (False, True, True):
         n, theta, hist, gs, info = prob.run_muse(11, th0, nsims=nsims, maxsteps=maxsteps, theta_rtol=rtol, atol=1e-2, alpha=0.7,
                                                  device_loop=dev)
-        outs.append((n, theta, hist, gs, info))
-    n0, theta0, hist0, gs0, info0 = outs[0]
+        outs.append((n, theta, hist, gs, info, prob.get_zhat(0, nsims + 1)))
+    n0, theta0, hist0, gs0, info0, zh0 = outs[0]
     assert 2 <= n0 <= maxsteps
-    for n, theta, hist, gs, info in outs[1:]:
+    for n, theta, hist, gs, info, zh in outs[1:]:
         assert n == n0
+        # the MAPs the loop leaves in memory -- a worker's last one is carried in registers from iteration to iteration and
+        # stored when the loop ENDS (round 6), on convergence as at maxsteps
+        assert np.array_equal(zh, zh0)
         assert np.array_equal(theta, theta0)
         assert np.array_equal(hist[:, :-1], hist0[:, :-1])       # (last column: the iteration's wall time)
         assert np.all(hist[:, -1] > 0) and np.all(hist[:, -1] < 1.0)
@@ -225,9 +228,11 @@ def test_loop_kernel_layouts_change_no_bit(gpu, M, O, model, N, nth, nsims):
     th0 = np.linspace(0.8, 0.2, nth)
     kw = dict(nsims=nsims, maxsteps=5, theta_rtol=0.0, atol=1e-2, alpha=0.7)
     want = prob.run_muse(4, th0, device_loop=False, **kw)
-    for flags in (0, 64, 128, 0):
+    zh = prob.get_zhat(0, nsims + 1)
+    for flags in (0, 64, 128, 512, 0):     # (512: every MAP stored in every iteration, as before round 6)
         assert prob._lib.muse_debug_flags(prob._ctx, flags) == 0
         got = prob.run_muse(4, th0, device_loop=True, **kw)
+        assert np.array_equal(prob.get_zhat(0, nsims + 1), zh), flags
         assert got[0] == want[0] == 5 and np.array_equal(got[1], want[1]) and np.array_equal(got[2][:, :-1], want[2][:, :-1])
         assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4]), flags
     assert prob._lib.muse_debug_flags(prob._ctx, 0) == 0
