@@ -14,13 +14,14 @@ from .models import ElementwiseModel, check_model_consistency
 from .distributed import ShardedMuseProblem, block_partition, ranks_share_node
 from .muse import (MuseResult, Normal, finalize_result_, get_H_, get_J_, load_result, muse, muse_, save_result)
 from .priors import CallablePrior, FlatPrior, GaussianPrior
+from .simple import TorchMuseProblem
 from .problem import (DATA_SIM, MASTER_SIM, AbstractMuseProblem, HipMuseProblem, PositiveThetaProblem, SimRng,
                       Transformedθ, UnTransformedθ, check_optim_soln, check_self_consistency, split_rng)
 
 __all__ = [
     "AbstractMuseProblem", "HipMuseProblem", "ShardedMuseProblem", "MuseResult", "Normal", "SimRng",
     "muse", "muse_", "get_J_", "get_H_", "finalize_result_", "split_rng", "block_partition", "ranks_share_node", "central_fdm", "FiniteDifferenceMethod",
-    "ElementwiseModel", "check_model_consistency", "SimpleCovariance", "LinearShrinkage", "GaussianPrior", "FlatPrior", "CallablePrior", "build_extension", "load_library", "MuseError",
+    "ElementwiseModel", "check_model_consistency", "SimpleCovariance", "LinearShrinkage", "TorchMuseProblem", "GaussianPrior", "FlatPrior", "CallablePrior", "build_extension", "load_library", "MuseError",
     "save_result", "load_result", "check_optim_soln", "check_self_consistency", "PositiveThetaProblem", "Transformedθ", "UnTransformedθ",
     "Z0_ZERO", "Z0_TRUE", "Z0_WARM", "MASTER_SIM", "DATA_SIM", "STATUS_NAMES",
 ]

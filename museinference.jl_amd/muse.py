@@ -102,6 +102,14 @@ def _has_batch(prob):
 
 # ----------------------------------------------------------------------------------------------
 # the map bodies, element by element (LocalWorkerPool path) for problems without batched seams
+def _zeros_like(v):
+    return v.new_zeros(v.shape) if hasattr(v, "new_zeros") else np.zeros_like(v)   # (a torch tensor stays on its device)
+
+
+def _as_vector(v):
+    return v if hasattr(v, "new_zeros") else np.asarray(v, dtype=np.float64)
+
+
 def _map_serial(prob, rng, theta, theta_t, sims, include_data, zprev, atol, z0_mode):
     gs, gts, zs, infos = [], [], [], []
     elems = ([None] if include_data else []) + [SimRng(rng, s) for s in sims]
@@ -115,7 +123,8 @@ def _map_serial(prob, rng, theta, theta_t, sims, include_data, zprev, atol, z0_m
         elif z0_mode == _capi.Z0_TRUE and ztrue is not None:
             z0 = ztrue
         else:
-            z0 = np.zeros_like(x)
+            # zero(sample_x_z(prob, copy(rng), θ).z) (src/muse.jl:146): the latent space need not have the data's shape
+            z0 = _zeros_like(ztrue if ztrue is not None else prob.sample_x_z(SimRng(rng, 0), theta)[1])
         zhat, info = prob.zhat_at_theta(x, z0, theta, atol)
         gs.append(np.atleast_1d(prob.grad_theta_logLike(x, zhat, theta, UnTransformedθ)))
         gts.append(np.atleast_1d(prob.grad_theta_logLike(x, zhat, theta_t, Transformedθ)))
@@ -164,7 +173,7 @@ def muse_(result, prob, theta0=None, *, rng=None, z0=None, maxsteps=50, theta_rt
     batched = _has_batch(prob)
     if z0 is not None and batched:  # starting guess for every element's MAP (src/muse.jl:151)
         prob.set_zhat(0, np.tile(np.asarray(z0, dtype=np.float64), (nsims + 1, 1)))
-    zs = None if z0 is None else [np.asarray(z0, dtype=np.float64)] * (nsims + 1)
+    zs = None if z0 is None else [_as_vector(z0)] * (nsims + 1)
     Hinv_like = None if Hinv_like0 is None else np.atleast_2d(np.asarray(Hinv_like0, dtype=np.float64))
     first = True  # ẑs = fill(z₀ | zero(z), nsims+1) on every call, resumed or not (src/muse.jl:151)
 
@@ -316,7 +325,7 @@ def get_J_(result, prob, theta0=None, *, z0=None, grad_z_logLike_atol=1e-2, rng=
                 g, _ = prob.scores_in_both_spaces(g, theta0, prob.transform_theta(theta0))
             g, _ = _apply_skip_errors(g, info, skip_errors, "get_J!")
         else:
-            zst = None if z0 is None else [np.asarray(z0, dtype=np.float64)] * (nsims - existing)
+            zst = None if z0 is None else [_as_vector(z0)] * (nsims - existing)
             g, _, _, _ = _map_serial(prob, rng, theta0, theta0, range(existing, nsims), False, zst,
                                      grad_z_logLike_atol, _capi.Z0_WARM if z0 is not None else _capi.Z0_TRUE)
         result.gs = list(result.gs) + list(g)
