@@ -82,7 +82,25 @@ class AbstractMuseProblem:
         raise NotImplementedError
 
     def zhat_at_theta(self, x, z0, theta, grad_z_logLike_atol=1e-2):
-        raise NotImplementedError
+        """The interface's DEFAULT (src/interface.jl:140-166): minimise -logLike over z from z0 with L-BFGS + HagerZhang (optim.py),
+        g_tol = the tolerance, through the problem's own logLike_and_grad_z_logLike -- numpy vectors (solved on the host) or torch
+        tensors (solved where they live).  HipMuseProblem overrides it with the HIP solver; a subclass that states its logLike and
+        gradient gets this one, as a subclass of AbstractMuseProblem does in the reference."""
+        import torch
+        from . import _capi, optim
+        as_np = not torch.is_tensor(z0)
+        shape = np.shape(z0) if as_np else z0.shape
+        z0t = torch.as_tensor(np.asarray(z0, dtype=np.float64)).reshape(-1) if as_np else z0.reshape(-1)
+
+        def fg(z):
+            f, g = self.logLike_and_grad_z_logLike(x, z.numpy().reshape(shape) if as_np else z.reshape(shape), theta)
+            g = torch.as_tensor(np.asarray(g, dtype=np.float64)) if as_np else g
+            return -float(f), -g.reshape(-1)
+        z, info = optim.lbfgs(fg, z0t, grad_z_logLike_atol)
+        rec = np.zeros((), dtype=_capi.INFO_DTYPE)
+        for k in ("iterations", "f_calls", "status", "f_min", "gnorm"):
+            rec[k] = info[k]
+        return (z.numpy().reshape(shape) if as_np else z.reshape(shape)), rec
 
     def zhat_guess_from_truth(self, x, z, theta):
         """zero(z) (src/interface.jl:184-186)."""

@@ -214,3 +214,43 @@ def test_closure_problems_with_their_tensors_on_the_gpu(gpu, M):
     sigma = float(np.sqrt(ref.Sigma[0, 0]))
     assert abs(float(res.theta[0]) - float(ref.theta[0])) < 4.0 * sigma * np.sqrt(1 / 60 + 1 / 400)
     hip.close()
+
+
+def test_a_numpy_subclass_gets_the_interfaces_default_solver(M, O):
+    """A subclass of AbstractMuseProblem that states sample_x_z, logLike_and_grad_z_logLike and grad_theta_logLike in numpy -- and no
+    ẑ_at_θ -- is solved by the interface's default (src/interface.jl:140-166), as in the reference: the funnel's MAP in closed form,
+    the checker's evaluation counts, and a muse() run."""
+    N = 500
+
+    class NumpyFunnel(M.AbstractMuseProblem):
+        def __init__(self, x):
+            self.x = x
+
+        def sample_x_z(self, rng, theta):
+            return O.sample_x_z("funnel", N, rng.seed, rng.sim, np.atleast_1d(theta))
+
+        def logLike_and_grad_z_logLike(self, x, z, theta):
+            iv = np.exp(-np.atleast_1d(theta)[0])
+            return -0.5 * (np.sum((x - z) ** 2) + iv * np.sum(z * z) + N * np.atleast_1d(theta)[0]), (x - z) - iv * z
+
+        def grad_theta_logLike(self, x, z, theta, theta_space=None):
+            return np.array([0.5 * (np.exp(-np.atleast_1d(theta)[0]) * np.sum(z * z) - N)])
+
+        def logPrior_theta(self, theta, theta_space=None):
+            return -0.5 * float(np.sum(np.atleast_1d(theta) ** 2)) / 9.0
+
+        def grad_logPrior_theta(self, theta, theta_space=None):
+            return -np.atleast_1d(theta) / 9.0
+
+        def hess_logPrior_theta(self, theta, theta_space=None):
+            return -np.eye(1) / 9.0
+    x, _ = O.sample_x_z("funnel", N, 3, M.DATA_SIM, [0.5])
+    prob = NumpyFunnel(x)
+    zh, info = prob.zhat_at_theta(x, np.zeros(N), [0.5], 1e-8)
+    zo, io = O.zhat_at_theta("funnel", x, np.zeros(N), [0.5], 1e-8)
+    assert (int(info["iterations"]), int(info["f_calls"]), int(info["status"])) == (io["iterations"], io["f_calls"], io["status"])
+    np.testing.assert_allclose(zh, x / (1 + np.exp(-0.5)), atol=1e-9)
+    res = M.muse(prob, [0.0], rng=4, nsims=30, maxsteps=20, theta_rtol=1e-3, grad_z_logLike_atol=1e-6, get_covariance=True)
+    from test_exact_marginal import exact_scale_family
+    mode, sigma = exact_scale_family(x, 1)
+    assert abs(res.theta[0] - mode[0]) < 4.0 * sigma[0] / np.sqrt(30) + 0.02 and 0.5 < np.sqrt(res.Sigma[0, 0]) / sigma[0] < 2.0
