@@ -44,9 +44,8 @@ class TorchMuseProblem(AbstractMuseProblem):
         """A stream per (master seed, simulation index), never advanced by the caller (src/util.jl:87-92): the generator handed to the
         closure is seeded from the pair, so a simulation's draw depends on nothing else."""
         torch = self._torch
-        seed, sim = (rng.seed, rng.sim) if isinstance(rng, SimRng) else (int(rng), 0)
         gen = torch.Generator(device=self.device)
-        gen.manual_seed((int(seed) * 0x9E3779B97F4A7C15 + int(sim) * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) % (1 << 63))
+        gen.manual_seed(self._stream(rng if isinstance(rng, SimRng) else SimRng(int(rng), 0)))
         with torch.no_grad():
             x, z = self._sample(gen, self._theta(theta))
         return self._t(x), self._t(z)
@@ -101,6 +100,59 @@ class TorchMuseProblem(AbstractMuseProblem):
     def zhat_guess_from_truth(self, x, z, theta):
         return self._torch.zeros_like(self._t(z))
 
+    # -- get_H! by implicit differentiation (src/muse.jl:335-405), every derivative by autograd as the reference takes them by nested AD
+    def implicit_H_batch(self, seed, sim_begin, sim_end, theta0, atol=1e-1, cg_maxiter=100, cg_reltol=1.4901161193847656e-08):
+        """Per simulation H = H1 - dFdθᵀ A⁻¹ dFdθ1: H1 the Jacobian of the score through the DRAW x(θ) at fixed ẑ, dFdθ = ∂θ ∇z logLike,
+        dFdθ1 = ∂θ ∇z logLike(x(θ), ẑ, θ₀), A the Hessian of logLike in z applied by double backward, A⁻¹ by conjugate gradients (reltol
+        sqrt(eps), maxiter 100: IterativeSolvers' defaults).  The draw is differentiated through the closure itself (the generator
+        re-seeded: the same random numbers at every θ), so sample_x_z must be written with differentiable torch operations.
+        Returns (Hs [n, nθ, nθ], CG iteration counts [n, nθ])."""
+        torch = self._torch
+        th0 = self._theta(theta0)
+        nt = th0.numel()
+        Hs, its = [], []
+        jac = torch.autograd.functional.jacobian
+        for sim in range(int(sim_begin), int(sim_end)):
+            rng = SimRng(int(seed), sim)
+            x, z = self.sample_x_z(rng, theta0)
+            zh, _ = self.zhat_at_theta(x, self.zhat_guess_from_truth(x, z, theta0), theta0, atol)
+            zh = zh.detach()
+
+            def x_of(th):          # the draw at th, the simulation's own random numbers
+                gen = torch.Generator(device=self.device)
+                gen.manual_seed(self._stream(rng))
+                return self._sample(gen, th)[0].to(self.dtype)
+
+            def grad_z(xx, zz, th):
+                zz = zz if zz.requires_grad else zz.detach().clone().requires_grad_(True)
+                return torch.autograd.grad(self._logLike(xx, zz, th), zz, create_graph=True)[0]
+
+            def score(xx, th_eval):
+                tt = th_eval.detach().clone().requires_grad_(True)
+                return torch.autograd.grad(self._logLike(xx, zh, tt), tt, create_graph=True)[0]
+            with torch.enable_grad():
+                H1 = jac(lambda th: score(x_of(th), th0), th0).reshape(nt, nt)
+                dF = jac(lambda th: grad_z(x, zh, th), th0).reshape(-1, nt)
+                dF1 = jac(lambda th: grad_z(x_of(th), zh, th0), th0).reshape(-1, nt)
+                zz = zh.clone().requires_grad_(True)
+                g = torch.autograd.grad(self._logLike(x, zz, th0), zz, create_graph=True)[0].reshape(-1)
+
+                def A(w):          # Hessian of logLike in z at the MAP, applied
+                    return torch.autograd.grad(g, zz, w.reshape(zz.shape), retain_graph=True)[0].reshape(-1)
+                cols, n_it = [], []
+                for j in range(nt):
+                    y, k = _cg(lambda w: -A(w), -dF1[:, j].detach(), cg_maxiter, cg_reltol)     # (-A is positive definite at a maximum)
+                    cols.append(y)
+                    n_it.append(k)
+            H = H1.detach() - dF.detach().T @ torch.stack(cols, dim=1)
+            Hs.append(H.cpu().numpy().astype(np.float64))
+            its.append(n_it)
+        return np.array(Hs).reshape(-1, nt, nt), np.array(its, dtype=np.int32).reshape(-1, nt)
+
+    @staticmethod
+    def _stream(rng):
+        return (int(rng.seed) * 0x9E3779B97F4A7C15 + int(rng.sim) * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) % (1 << 63)
+
     # -- prior: the closure, differentiated (the reference: ForwardDiff, src/muse.jl:184,207,539)
     def logPrior_theta(self, theta, theta_space=UnTransformedθ):
         if self._logPrior is None:
@@ -135,6 +187,27 @@ class TorchMuseProblem(AbstractMuseProblem):
         torch = self._torch
         H = torch.autograd.functional.hessian(lambda t: self._logPrior(t), self._theta(t0))
         return H.detach().cpu().numpy().astype(np.float64).reshape(n, n)
+
+
+def _cg(A, b, maxiter, reltol):
+    """Conjugate gradients for A y = b from y = 0 (A symmetric positive definite, given as a function): (y, iterations); stops at
+    |r| <= reltol |b| or after maxiter iterations."""
+    y = b.new_zeros(b.shape)
+    r = b.clone()
+    p = r.clone()
+    rs = float(r.dot(r))
+    stop = (reltol ** 2) * rs
+    k = 0
+    while k < maxiter and rs > stop and rs > 0.0:
+        Ap = A(p)
+        alpha = rs / float(p.dot(Ap))
+        y = y + alpha * p
+        r = r - alpha * Ap
+        rs_new = float(r.dot(r))
+        p = r + (rs_new / rs) * p
+        rs = rs_new
+        k += 1
+    return y, k
 
 
 def _fd_grad(f, t, step=1e-6):

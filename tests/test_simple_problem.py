@@ -210,6 +210,11 @@ def test_closure_problems_with_their_tensors_on_the_gpu(gpu, M):
     sim = M.TorchMuseProblem(None, sample_x_z, logLike, device="cuda")
     x, _ = sim.sample_x_z(M.SimRng(5, M.DATA_SIM), [0.7])
     hip = M.HipMuseProblem(x.cpu().numpy(), model="funnel", ntheta=1, prior=M.GaussianPrior(0.0, 3.0))
+    # get_H! by implicit differentiation: autograd on the device against the HIP engine's closed forms for the same model -- the two
+    # draw different random numbers, so the Monte-Carlo means agree to their scatter
+    Ht, _ = M.TorchMuseProblem(x, sample_x_z, logLike, device="cuda").implicit_H_batch(3, 0, 6, [0.5], atol=1e-8)
+    Hh, _ = hip.implicit_H_batch(3, 0, 64, [0.5], atol=1e-8)
+    assert abs(Ht.mean() / Hh.mean() - 1.0) < 0.15
     ref = M.muse(hip, [0.0], rng=11, nsims=400, maxsteps=30, theta_rtol=1e-4, grad_z_logLike_atol=1e-6, alpha=1.0, get_covariance=True)
     sigma = float(np.sqrt(ref.Sigma[0, 0]))
     assert abs(float(res.theta[0]) - float(ref.theta[0])) < 4.0 * sigma * np.sqrt(1 / 60 + 1 / 400)
@@ -254,3 +259,40 @@ def test_a_numpy_subclass_gets_the_interfaces_default_solver(M, O):
     from test_exact_marginal import exact_scale_family
     mode, sigma = exact_scale_family(x, 1)
     assert abs(res.theta[0] - mode[0]) < 4.0 * sigma[0] / np.sqrt(30) + 0.02 and 0.5 < np.sqrt(res.Sigma[0, 0]) / sigma[0] < 2.0
+
+
+def test_implicit_differentiation_H_by_autograd(M):
+    """get_H!(implicit_diff=true) (src/muse.jl:335-405) for closure problems, every derivative by autograd: against the
+    finite-difference branch on the same simulations (tight MAPs), for the funnel -- whose per-simulation H is known in closed form,
+    -1/2 e^-θ/(1+e^-θ)^2 ... summed: compared with the finite differences only -- and for the dense mixing model."""
+    sample_x_z, logLike = funnel_closures(400, 2)
+    prob = M.TorchMuseProblem(None, sample_x_z, logLike)
+    theta = np.array([0.3, -0.4])
+    Hs, its = prob.implicit_H_batch(9, 0, 3, theta, atol=1e-10)
+    assert Hs.shape == (3, 2, 2) and its.shape == (3, 2) and np.all(its >= 1) and np.all(np.abs(Hs[:, 0, 1]) < 1e-10)
+    for s in range(3):
+        x, z = prob.sample_x_z(M.SimRng(9, s), theta)
+        zfid, _ = prob.zhat_at_theta(x, torch.zeros_like(z), theta, 1e-12)
+        Hfd = np.empty((2, 2))
+        for j in range(2):
+            gs = []
+            for sign in (+1, -1):
+                th = theta.copy()
+                th[j] += sign * 1e-4
+                xs, _ = prob.sample_x_z(M.SimRng(9, s), th)
+                zh, _ = prob.zhat_at_theta(xs, zfid, theta, 1e-12)
+                gs.append(prob.grad_theta_logLike(xs, zh, theta))
+            Hfd[:, j] = (gs[0] - gs[1]) / 2e-4
+        np.testing.assert_allclose(Hs[s], Hfd, rtol=1e-6, atol=1e-6 * np.abs(Hfd).max())
+    # through the driver, next to the finite-difference branch; and the dense model
+    A, sx, ll = mixing_problem(M, "cpu")
+    pm = M.TorchMuseProblem(None, sx, ll)
+    x, _ = pm.sample_x_z(M.SimRng(1, M.DATA_SIM), [0.4])
+    pm = M.TorchMuseProblem(x, sx, ll, logPrior=gaussian_prior(3.0))
+    res = M.muse(pm, [0.0], rng=3, nsims=30, maxsteps=15, theta_rtol=1e-3, grad_z_logLike_atol=1e-6)
+    M.get_H_(res, pm, nsims=8, implicit_diff=True)
+    Himp = res.H.copy()
+    assert len(res.metadata["implicit_diff_cg_hists"]) == 8
+    res.Hs, res.H = [], None
+    M.get_H_(res, pm, nsims=8, grad_z_logLike_atol=1e-8)
+    np.testing.assert_allclose(Himp, res.H, rtol=0.03)
