@@ -125,6 +125,14 @@ def run_funnel(M, device, N=2000, nsims=60):
 
 def test_funnel_as_closures_against_the_exact_posterior(M):
     run_funnel(M, "cpu")
+    # ... and in single precision (the reference's problems may be Float32, src/turing.jl:188; the HIP engine is fp64 only)
+    from test_exact_marginal import exact_scale_family
+    sample_x_z, logLike = funnel_closures(2000, 1)
+    x, _ = M.TorchMuseProblem(None, sample_x_z, logLike, dtype=torch.float32).sample_x_z(M.SimRng(5, M.DATA_SIM), [0.7])
+    prob = M.TorchMuseProblem(x, sample_x_z, logLike, logPrior=gaussian_prior(3.0), dtype=torch.float32)
+    res = M.muse(prob, [0.0], rng=11, nsims=40, maxsteps=20, theta_rtol=1e-3, grad_z_logLike_atol=1e-3, get_covariance=True)
+    mode, sigma = exact_scale_family(x.double().numpy(), 1)
+    assert x.dtype == torch.float32 and abs(res.theta[0] - mode[0]) < 4.0 * sigma[0] / np.sqrt(40) + 0.01
 
 
 def mixing_problem(M, device, n=24, m=40, seed=2):
