@@ -1546,8 +1546,15 @@ static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_o
     //   60.9 / 53.9, 75.1 / 68.4;  N = 512: 23.6 / 16.2, 26.5 / 20.3, 27.7 / 23.4, 31.6 / 35.3
     // and at 100 sims (one problem per worker) the loop kernel leads for every count (N = 10^4 x 8: 34.5 / 32.0).
     // (round 4, before: 53 / 50, 75 / 79, 89 / 97, 100 / 113 at N = 10^4)
+    // Round 6 (tools/runloop_bench.py, 512 sims, five to eight components, host loop / loop kernel per iteration of a 30-iteration call):
+    // in the all-register placement of 512 < N <= 4096 (the loop kernel fills the register file: one workgroup per compute unit, two or
+    // three problems per worker at 512 sims) 68.2 / 59.4 (N = 2048 x 8), 67.6 / 56.7 (2048 x 5), 70.7 / 63.0 (1000 x 8), 72.7 / 59.6
+    // (4096 x 6), and a tie at four problems per worker (N = 4096 x 8, 1000 sims: 101.5 / 103.0): the loop kernel up to three problems
+    // per worker there.  N = 10^4 (x and g in LDS, two problems per worker at 512 sims) stays as it was: 77.7 / 76.8 (5), 75.4 / 74.4
+    // (6), 77.4 / 80.8 (8).
     const bool any_nt = c->sw.loop_any_ntheta;   // tuning aid / tests: the loop kernel whatever ntheta
-    if (r.grid_max < 2 || (nt > 4 && !any_nt && nlocal > r.grid_max - 1)) return false;
+    const int64_t per_worker = pl == P_R512x4 ? 3 : 1;
+    if (r.grid_max < 2 || (nt > 4 && !any_nt && nlocal > per_worker * (r.grid_max - 1))) return false;
     if (shape_out) *shape_out = shape;
     if (max_grid_out) *max_grid_out = r.grid_max;
     return true;

@@ -526,3 +526,23 @@ def test_element_split_hand_offs_under_uneven_load(gpu, M, O, split):
     assert np.array_equal(g2[::3], g[::3])        # from zero again: the same path, the same bits
     np.testing.assert_allclose(g2, g, rtol=1e-9)
     prob.close()
+
+
+@pytest.mark.gpu
+def test_routing_of_five_to_eight_components_between_the_two_native_loops(gpu, M, monkeypatch, capfd):
+    """muse_run_device's own routing (no MUSE_DEBUG_LOOP_ANY_NTHETA): with five to eight components the loop kernel runs where it was
+    measured faster -- one problem per worker, and up to three in the all-register placement of 512 < N <= 4096 -- and the host loop
+    elsewhere (N = 10^4 with two problems per worker); the same bits either way."""
+    monkeypatch.delenv("MUSE_DEBUG_LOOP_ANY_NTHETA", raising=False)
+    for N, nth, nsims, device in ((2048, 8, 512, True), (4096, 6, 700, True), (4096, 8, 1000, False), (10000, 8, 512, False), (10000, 8, 200, True), (10000, 4, 512, True)):
+        x = np.sin(0.3 * np.arange(N)) + 0.5 * np.cos(1.7 * np.arange(N))
+        prob = M.HipMuseProblem(x, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
+        kw = dict(nsims=nsims, maxsteps=3, theta_rtol=0.0, atol=1e-2, alpha=0.7)
+        b = prob.run_muse(3, [0.2] * nth, device_loop=False, **kw)
+        capfd.readouterr()
+        prob.debug_flags(M.HipMuseProblem.DEBUG_RUN_TIMING)
+        a = prob.run_muse(3, [0.2] * nth, device_loop=True, **kw)
+        prob.debug_flags(0)
+        assert ("[muse_run_device] launch call" in capfd.readouterr().err) == device, (N, nth, nsims)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and a[4].tobytes() == b[4].tobytes()
+        prob.close()
