@@ -1555,6 +1555,10 @@ static bool loop_usable(muse_ctx* c, int S, int64_t nlocal, LaunchShape* shape_o
     const bool any_nt = c->sw.loop_any_ntheta;   // tuning aid / tests: the loop kernel whatever ntheta
     const int64_t per_worker = pl == P_R512x4 ? 3 : 1;
     if (r.grid_max < 2 || (nt > 4 && !any_nt && nlocal > per_worker * (r.grid_max - 1))) return false;
+    // ... and with three or four components and MANY problems per worker the map kernel's tickets beat the loop kernel's static deal
+    // (N = 10^4, host loop / loop kernel: 4 components 104.6 / 106.6 at 1000 sims, 153.6 / 152.9 at 1500, 192.3 / 211.2 at 2000; 3
+    // components 101.7 / 96.6 at 1000, 193.4 / 199.5 at 2000; 1-2 components: the loop kernel at every count measured, to 5000 sims)
+    if (pl == P_R512x10 && nt >= 3 && !any_nt && nlocal > 6 * (int64_t)(r.grid_max - 1)) return false;
     if (shape_out) *shape_out = shape;
     if (max_grid_out) *max_grid_out = r.grid_max;
     return true;

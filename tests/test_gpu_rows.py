@@ -534,7 +534,7 @@ def test_routing_of_five_to_eight_components_between_the_two_native_loops(gpu, M
     measured faster -- one problem per worker, and up to three in the all-register placement of 512 < N <= 4096 -- and the host loop
     elsewhere (N = 10^4 with two problems per worker); the same bits either way."""
     monkeypatch.delenv("MUSE_DEBUG_LOOP_ANY_NTHETA", raising=False)
-    for N, nth, nsims, device in ((2048, 8, 512, True), (4096, 6, 700, True), (4096, 8, 1000, False), (10000, 8, 512, False), (10000, 8, 200, True), (10000, 4, 512, True)):
+    for N, nth, nsims, device in ((2048, 8, 512, True), (4096, 6, 700, True), (4096, 8, 1000, False), (10000, 8, 512, False), (10000, 8, 200, True), (10000, 4, 512, True), (10000, 4, 1900, False), (10000, 2, 1900, True)):
         x = np.sin(0.3 * np.arange(N)) + 0.5 * np.cos(1.7 * np.arange(N))
         prob = M.HipMuseProblem(x, model="funnel", ntheta=nth, prior=M.GaussianPrior(0.0, 3.0))
         kw = dict(nsims=nsims, maxsteps=3, theta_rtol=0.0, atol=1e-2, alpha=0.7)
