@@ -270,9 +270,10 @@ int muse_run(muse_ctx* ctx, uint64_t seed, const double* theta0, const muse_run_
  * step, the history record and the convergence test for itself from the same bits; the next theta never leaves the
  * chip.  (exp(theta/2), exp(-theta) are a fixed sequence of IEEE operations on host and device, and the score moments one
  * fixed 64-leaf summation tree, for this reason.)  The loop kernel runs where it is the faster loop: the register/LDS-resident
- * placements (N <= 10 000, no element split) with up to four theta components, or at most one element per workgroup; everything
- * else (more elements AND five to eight components, the streaming placements, score blocks beyond the step's LDS arrays: nsims *
- * ntheta above ~19 000) runs muse_run's loop instead -- the same bits.
+ * placements (N <= 10 000, no element split) with up to four theta components (three or four: up to six elements per workgroup at
+ * N > 4096), or five to eight components and at most one element per workgroup (three for 512 < N <= 4096); everything else (the
+ * streaming placements, score blocks beyond the step's LDS arrays: nsims * ntheta above ~19 000, a loop kernel whose private segment
+ * exceeds 256 bytes per lane -- a user's model header can do that) runs muse_run's loop instead -- the same bits.
  * REQUIREMENT: every workgroup of the loop kernel must be resident at once (they meet once per iteration); the grid is sized from an
  * occupancy query that assumes the GPU is this process's.  On a GPU that something else is using they may not be: every wait inside
  * the kernel is bounded (4 s), the call then returns MUSE_ERR_HIP ("not all resident") -- once: the context remembers it and its later
