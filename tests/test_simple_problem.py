@@ -304,3 +304,30 @@ def test_implicit_differentiation_H_by_autograd(M):
     res.Hs, res.H = [], None
     M.get_H_(res, pm, nsims=8, grad_z_logLike_atol=1e-8)
     np.testing.assert_allclose(Himp, res.H, rtol=0.03)
+
+
+def test_solver_against_the_checker_on_random_problems(O):
+    """optim.lbfgs and the checker's zhat_at_theta on the SAME objective (the checker's own logLike_and_grad_z: identical floats, so
+    every decision of the line search must fall the same way): random models / sizes / parameters / tolerances / starts -- equal
+    iteration and evaluation counts, status, and the same MAP."""
+    from museinference_jl_amd import optim
+    rng = np.random.default_rng(3)
+    longest = 0
+    for case in range(80):
+        model = str(rng.choice(["funnel", "noise", "smooth"]))
+        N = int(rng.integers(8, 1200))
+        nth = 1 if model == "noise" else min(int(rng.integers(1, 5)), N)
+        theta = rng.uniform(-2, 2, size=nth)
+        atol = float(rng.choice([1e-2, 1e-5, 1e-8]))
+        x, z = O.sample_x_z(model, N, int(rng.integers(1, 1 << 40)), int(rng.integers(0, 100)), theta)
+        z0 = np.zeros(N) if rng.random() < 0.5 else z
+
+        def fg(zz):
+            f, g = O.logLike_and_grad_z(model, x, zz.numpy(), theta)
+            return -f, -torch.as_tensor(g)
+        zh, info = optim.lbfgs(fg, torch.as_tensor(z0), atol)
+        zo, io = O.zhat_at_theta(model, x, z0, theta, atol)
+        assert (info["iterations"], info["f_calls"], info["status"]) == (io["iterations"], io["f_calls"], io["status"]), (case, model, N, info, io)
+        np.testing.assert_allclose(zh.numpy(), zo, rtol=0, atol=1e-9)
+        longest = max(longest, io["iterations"])
+    assert longest >= 20        # (the stencil model's solves: real line searches and a wrapping history)
