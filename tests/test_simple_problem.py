@@ -91,6 +91,10 @@ def test_solver_edge_cases():
     assert info["status"] == optim.STATUS_NONFINITE and info["iterations"] == 0
     rosen = lambda z: ((1 - z[0]) ** 2 + 100 * (z[1] - z[0] ** 2) ** 2,
                        torch.stack([-2 * (1 - z[0]) - 400 * z[0] * (z[1] - z[0] ** 2), 200 * (z[1] - z[0] ** 2)]))
+    # Optim.jl's documented run of `optimize(f, g!, [0.0, 0.0], LBFGS())` on this function prints Iterations: 24, f(x) calls: 67
+    # (tests/test_oracle.py holds the checker to the same two counters; quoted from memory, see there)
+    z, info = optim.lbfgs(rosen, torch.tensor([0.0, 0.0], dtype=torch.float64), 1e-8)
+    assert (info["iterations"], info["f_calls"], info["status"]) == (24, 67, optim.STATUS_G_CONVERGED)
     z, info = optim.lbfgs(rosen, torch.tensor([-1.2, 1.0], dtype=torch.float64), 1e-10)
     assert info["status"] == optim.STATUS_G_CONVERGED and 10 < info["iterations"] < 60
     np.testing.assert_allclose(z.numpy(), [1.0, 1.0], atol=1e-8)
